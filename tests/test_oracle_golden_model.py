@@ -1,0 +1,151 @@
+"""Pin oracle/tgn_oracle.py (fp32 numpy, hand-derived backward) against the reference's torch modules + autograd."""
+from collections import defaultdict
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import tgn_oracle as T
+from oracle.neighbor_finder import OracleNeighborFinder, build_adjacency
+
+RTOL = 1e-4     # north_star bar; observed restatement error is 1e-7..1e-6
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-12)
+
+
+def test_g4_time_encode_bit_exact_argument():
+    g = load_golden("g4_modules")
+    y = T.time_encode(g["te_t"], g["te_w"], g["te_b"])
+    # the fp32 FMA argument is exact; cos implementations may differ by an ulp
+    assert np.abs(y - g["te_y"]).max() < 5e-7
+    gw, gb = T.time_encode_backward(g["te_t"], g["te_w"], g["te_b"], g["te_gy"])
+    assert relerr(gw, g["te_gw"].reshape(-1)) < 1e-5 and relerr(gb, g["te_gb"]) < 1e-5
+
+
+def test_fmaf_single_rounding():
+    rs = np.random.RandomState(0)
+    a = rs.randint(0, 1 << 24, 100000).astype(np.float32)
+    b = (10 ** -rs.uniform(0, 9, 100000)).astype(np.float32)
+    c = rs.randn(100000).astype(np.float32)
+    from fractions import Fraction
+    got = T.fmaf(a, b, c)
+    for i in range(0, 100000, 997):
+        exact = Fraction(float(a[i])) * Fraction(float(b[i])) + Fraction(float(c[i]))
+        lo = np.float32(float(exact))        # python float() of a Fraction is correctly rounded to f64; then one more rounding
+        # brute-force the correctly rounded f32: nearest of the two f32 neighbours of the exact value
+        cands = [np.nextafter(lo, np.float32(-np.inf)), lo, np.nextafter(lo, np.float32(np.inf))]
+        best = min(cands, key=lambda v: abs(Fraction(float(v)) - exact))
+        assert got[i] == best
+
+
+def test_g4_gru():
+    g = load_golden("g4_modules")
+    hn, cache = T.gru_cell(g["gru_x"], g["gru_h"], g["gru_weight_ih"], g["gru_weight_hh"], g["gru_bias_ih"], g["gru_bias_hh"])
+    assert relerr(hn, g["gru_hn"]) < 1e-5
+    gr = T.gru_cell_backward(cache, g["gru_ghn"], g["gru_weight_ih"], g["gru_weight_hh"])
+    for k, v in gr.items():
+        assert relerr(v, g["gru_g_" + k]) < 1e-5, k
+
+
+def _att_params(g):
+    p = "att_p_"
+    return dict(Wq=g[p + "multi_head_target.q_proj_weight"], Wk=g[p + "multi_head_target.k_proj_weight"],
+                Wv=g[p + "multi_head_target.v_proj_weight"], b_in=g[p + "multi_head_target.in_proj_bias"],
+                Wo=g[p + "multi_head_target.out_proj.weight"], bo=g[p + "multi_head_target.out_proj.bias"],
+                W1=g[p + "merger.fc1.weight"], b1=g[p + "merger.fc1.bias"], W2=g[p + "merger.fc2.weight"], b2=g[p + "merger.fc2.bias"])
+
+
+def test_g4_attention_forward_backward():
+    g = load_golden("g4_modules")
+    p = _att_params(g)
+    H, D = int(g["H"]), int(g["D"])
+    out, c = T.attention_forward(p, g["att_x"], g["att_tq"], g["att_nb"], g["att_ef"], g["att_tn"], g["att_mask"], H)
+    assert relerr(out, g["att_out"]) < 1e-5
+    # rows with no valid neighbour: zero attention output -> MergeLayer([0 | x])
+    inv = g["att_mask"].all(1)
+    assert inv.sum() == 8
+    grads, dx, dtq, dnb, dte = T.attention_backward(p, c, g["att_go"], H, D)
+    assert relerr(dx, g["att_gx"]) < 1e-5 and relerr(dnb, g["att_gnb"]) < 1e-5
+    assert relerr(dte, g["att_gtn"]) < 1e-5 and relerr(dtq, g["att_gtq"]) < 1e-5
+    for k, name in T._LAYER_KEYS.items():
+        assert relerr(grads[k], g["att_g_" + name]) < 1e-5, name
+
+
+def _load_state(g, pre, tgn, use_mem):
+    P = {}
+    for k in g.files:
+        if k.startswith(pre + "sd_"):
+            name = k[len(pre + "sd_"):]
+            if name in ("memory.memory", "memory.last_update") or "layer_norm" in name:
+                continue
+            P[name] = g[k]
+    tgn.P = {k: v.astype(np.float32) for k, v in P.items()}
+    if use_mem:
+        tgn.memory = g[pre + "sd_memory.memory"].copy()
+        tgn.last_update = g[pre + "sd_memory.last_update"].copy()
+        tgn.messages = defaultdict(list)
+        tab, mt, cnt = g[pre + "msg_tab"], g[pre + "msg_t"], g[pre + "msg_cnt"]
+        for nid in np.nonzero(cnt)[0]:
+            tgn.messages[int(nid)] = [(tab[nid], mt[nid])]
+
+
+@pytest.mark.parametrize("tag", ["L1_mem", "L2_mem", "L2_nomem_uniform", "L1_mem_p"])
+def test_g5_full_step(tag):
+    g = load_golden("g5_step_" + tag)
+    L, H, K = int(g["L"]), int(g["H"]), int(g["K"])
+    use_mem, uniform, path = bool(g["use_memory"]), bool(g["uniform"]), str(g["path"])
+    nf = OracleNeighborFinder(*build_adjacency(g["src_all"], g["dst_all"], g["eidx_all"], g["ts_all"]), uniform=uniform)
+    tgn = T.OracleTGN(nf, g["node_features"], g["edge_features"], {}, L, H, use_memory=use_mem)
+    for step in g["recorded_steps"]:
+        pre = "s%d_" % step
+        _load_state(g, pre, tgn, use_mem)                           # re-inject reference state at every step
+        draws = None
+        if uniform:
+            draws = [g[pre + "draws%d" % j] for j in range(3 if L == 2 else 1)]
+        sb, db, tb, eb, neg = g[pre + "src"], g[pre + "dst"], g[pre + "ts"], g[pre + "eidx"], g[pre + "neg"]
+        B = len(sb)
+        if path == "p":
+            se, de, pe, ne = tgn.compute_temporal_embeddings_p(sb, db, g[pre + "ppos"], neg.flatten(), tb, eb, K, draws=draws)
+        else:
+            se, de, ne = tgn.compute_temporal_embeddings(sb, db, neg.flatten(), tb, eb, K, draws=draws)
+            pe = de
+        for got, key in ((se, "emb_src"), (de, "emb_dst"), (pe, "emb_pos"), (ne, "emb_neg")):
+            assert relerr(got, g[pre + key]) < RTOL, (tag, step, key, relerr(got, g[pre + key]))
+        loss, cache = T.bpr_loss(se, pe.reshape(B, 1, -1), ne.reshape(B, 3, -1))
+        assert abs(loss - g[pre + "loss"]) < 1e-5 * max(1.0, abs(g[pre + "loss"]))
+        d_src, d_pos, d_neg = T.bpr_loss_backward(cache)
+        assert relerr(d_src, g[pre + "gemb_src"]) < RTOL and relerr(d_neg.reshape(-1, d_src.shape[1]), g[pre + "gemb_neg"]) < RTOL
+        d_dst = np.zeros_like(d_src)
+        if path == "p":
+            d_emb = np.concatenate([d_src, d_dst, d_pos.reshape(B, -1), d_neg.reshape(3 * B, -1)])
+        else:
+            d_emb = np.concatenate([d_src, d_pos.reshape(B, -1), d_neg.reshape(3 * B, -1)])
+        grads = tgn.backward(d_emb)
+        worst = 0.0
+        for k in g.files:
+            if k.startswith(pre + "grad_"):
+                name = k[len(pre + "grad_"):]
+                if "layer_norm" in name or name.startswith("memory."):
+                    continue
+                ref = g[k]
+                got = grads[name].reshape(ref.shape)
+                if np.abs(ref).max() == 0:
+                    assert np.abs(got).max() < 1e-7, name
+                    continue
+                e = relerr(got, ref)
+                worst = max(worst, e)
+                assert e < 5e-4, (tag, step, name, e)
+        if use_mem:
+            assert relerr(tgn.memory, g[pre + "after_memory"]) < RTOL
+            assert np.array_equal(tgn.last_update, g[pre + "after_last_update"])
+            tab, mt, has = tgn.pending_table()
+            assert np.array_equal(has, g[pre + "after_msg_cnt"] > 0)
+            assert relerr(tab, g[pre + "after_msg_tab"]) < RTOL
+            assert np.array_equal(mt, g[pre + "after_msg_t"])
+            # per-node list lengths (all messages of a node come from one batch)
+            cnt = np.array([len(tgn.messages.get(i, [])) for i in range(tgn.n_nodes)])
+            touched = np.zeros(tgn.n_nodes, bool); touched[np.concatenate([sb, db])] = True
+            assert np.array_equal(cnt[touched], g[pre + "after_msg_cnt"][touched])
