@@ -1,0 +1,205 @@
+/*
+ * pfotgn.h - C ABI of the MI355X-native TGN-recommender training path.
+ *
+ * Drop-in boundary for the hot path of youngandbin/PfoTGNRec (reference is pure
+ * Python; citations are file:line under /root/reference).  Every entry point takes
+ * plain DEVICE pointers (unless marked host), sizes and a hipStream_t passed as
+ * void*; no torch / C++ types cross this boundary.  All kernels are gfx950 HIP.
+ *
+ * Conventions
+ *   - return value: 0 = ok, <0 = error (pfo_last_error() gives the message, per thread)
+ *   - node / edge ids on device are int32 (node 0 and edge 0 are padding)
+ *   - all floating-point tensors are fp32 row-major unless stated (timestamps fp64)
+ *   - nothing here allocates, frees or synchronises: callers own every buffer
+ */
+#ifndef PFOTGN_H
+#define PFOTGN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFO_OK 0
+#define PFO_ERR_INVALID (-1)
+#define PFO_ERR_HIP (-2)
+
+#define PFO_MAX_NEIGHBORS 64 /* K: one wavefront lane per neighbour slot */
+#define PFO_MAX_LAYERS 4
+#define PFO_MAX_HEADS 8
+
+int pfo_abi_version(void);
+const char* pfo_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  temporal neighbour lookup over a time-sorted CSR.
+ * Replaces NeighborFinder.find_before + get_temporal_neighbor (utils/utils.py:150-219).
+ *
+ *   indptr  i64[n_nodes+1]; adj_nbr i32[nnz]; adj_eidx i32[nnz]; adj_ts f64[nnz] (per node ascending,
+ *   ties in edge order - what utils/utils.py:139 `sorted(key=ts)` yields).
+ *   Query i = (q_nodes[i], q_ts[i]); entries with ts STRICTLY < q_ts qualify (searchsorted side='left').
+ *   mode 0: most-recent K, right-aligned, left-padded with (0,0,0.0)              (:206-218)
+ *   mode 1: uniform with INJECTED draws  draws i64[n_q,K] in [0, #qualifying)     (:194)
+ *   mode 2: uniform with counter-based Philox draws (seed, stream offset)
+ *   uniform modes re-sort each row by f32 time, STABLE (tie policy SURVEY App. A-9)   (:201-204)
+ *   K == 0 is treated as one all-padding column by the host mirror (:175); here K >= 1.
+ * Outputs (any may be NULL): out_nbr/out_eidx i32[n_q,K], out_et f32[n_q,K] (edge time cast to f32),
+ *   out_dt f32[n_q,K] = f32( q_ts - f64(out_et) )  (embedding_module.py:133-135).
+ * Frontier expansion (optional, next_nodes != NULL): writes the next recursion level
+ *   next_nodes[0:n_q] = q_nodes, next_nodes[n_q + i*K + j] = nbr[i][j]; next_ts (optional) likewise, q_ts[i] repeated
+ *   (embedding_module.py:115,141-145: neighbours are evaluated at the ROOT's timestamp).
+ */
+int pfo_tnbr_sample(const int64_t* indptr, const int32_t* adj_nbr, const int32_t* adj_eidx, const double* adj_ts,
+                    int64_t n_nodes, const int32_t* q_nodes, const double* q_ts, int64_t n_q, int32_t K,
+                    int32_t mode, const int64_t* draws, uint64_t seed, uint64_t offset,
+                    int32_t* out_nbr, int32_t* out_eidx, float* out_et, float* out_dt,
+                    int32_t* next_nodes, double* next_ts, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Candidate-negative draw.  Replaces RandEdgeSampler.sample (utils/utils.py:86-114).
+ *   item_avail u8[n_items]: 1 if the item occurs among the train destinations (np.unique(dst_list), :73)
+ *   port_idx i32[B,port_stride] 0-based item indices, port_len i32[B] (the '' entry is already dropped, :76)
+ *   out i32[B,size] = item NODE ids (index + upper_u + 1), drawn without replacement from
+ *   avail \ portfolio when that set has >= size members, otherwise with replacement (:99-111).
+ *   RNG: Philox(seed, offset + interaction) - semantics-level parity only.
+ */
+int pfo_neg_draw(const uint8_t* item_avail, int32_t n_items, const int32_t* port_idx, const int32_t* port_len,
+                 int32_t port_stride, int64_t B, int32_t size, int32_t upper_u, uint64_t seed, uint64_t offset,
+                 int32_t* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  mean-variance-efficient rank fusion.  Replaces the inline block main.py:209-304.
+ *   returns f64[n_days,n_items,n_ret]: log-returns log(p[t+1]/p[t]) (main.py:218,226-227; n_ret = 29)
+ *   day_idx i32[B]; cand i32[B,n_cand] item NODE ids, column 0 = true destination (main.py:207)
+ *   y_mv = (mu/gamma - 0.5*mean_j cov_ij)/cov_ii, or (mu/gamma)/var_i for an empty portfolio (main.py:243-271)
+ *   invest_rank = average-tie rank of y_mv; tgn_rank = n..1; new = lam*invest + (1-lam)*tgn (main.py:282-286)
+ *   order = stable ascending argsort of new, reversed (tie policy SURVEY App. A-9; main.py:289)
+ *   p_pos i32[B,n_pos] = first n_pos of order, p_neg i32[B,n_neg] = last n_neg (main.py:291-292), as node ids.
+ *   y_out f64[B,n_cand] and rank_out f64[B,n_cand] (new_rank) are optional diagnostics.
+ */
+int pfo_mv_select(const double* returns, int32_t n_days, int32_t n_items, int32_t n_ret, const int32_t* day_idx,
+                  const int32_t* cand, int32_t n_cand, const int32_t* port_idx, const int32_t* port_len,
+                  int32_t port_stride, int64_t B, int32_t upper_u, double gamma, double lambda_mv,
+                  int32_t n_pos, int32_t n_neg, int32_t* p_pos, int32_t* p_neg, double* y_out, double* rank_out,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * TimeEncode forward: out[i,d] = cos(fma(t[i], w[d], b[d]))   (model/time_encoding.py:17-25;
+ * single fp32 FMA then a full-range cosine - SURVEY §7 hard part 1).
+ */
+int pfo_time_encode(const float* t, int64_t n, const float* w, const float* b, int32_t D, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense fp32 contraction on the matrix cores (v_mfma_f32_16x16x4_f32), exposed for tests.
+ *   C[M,N] = A[M,K] * op(B) + bias,  op(B) = B[N,K]^T (b_kmajor = 0, the nn.Linear weight layout)
+ *                                    or      B[K,N]   (b_kmajor = 1)
+ *   a_kmajor = 1 reads A as [K,M] (used for weight gradients dW = dY^T X).
+ */
+int pfo_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb, int32_t b_kmajor,
+                 float* C, int64_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, int32_t relu,
+                 float* workspace, int64_t workspace_floats, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BPR loss, forward + gradient in one pass (main.py:321-337 / 364-381):
+ *   loss = -mean_b log sigmoid( mean_k( s_b.p_b - s_b.n_bk ) )       (sigma of the MEAN difference)
+ * emb f32[R,D] holds the roots in the reference's order: [src B | dst B | (p_pos B*n_pos) | neg B*n_neg];
+ * pos_off = row offset of the positives block (B for the baseline path where the positive is dst,
+ * 2B for the `ours` path), neg_off = row offset of the negatives block.  n_pos must be 1 (main.py:33).
+ * loss_out f32[1]; d_emb f32[R,D] receives scale * dloss/demb (rows not involved are zeroed).
+ */
+int pfo_bpr_loss(const float* emb, int64_t B, int32_t D, int64_t pos_off, int64_t neg_off, int32_t n_neg,
+                 int64_t R, float scale, float* loss_out, float* d_emb, float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Adam step over a flat parameter buffer (torch.optim.Adam defaults, main.py:123,389).
+ */
+int pfo_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, int32_t step, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The TGN step (model/tgn.py:102-378 + modules/).  One POD config, one flat parameter buffer,
+ * caller-owned state tables and workspace.
+ */
+typedef struct pfo_tgn_config {
+  int32_t n_nodes;      /* incl. padding node 0 */
+  int32_t n_edges_p1;   /* rows of edge_feat (E+1) */
+  int32_t D;            /* memory = node-feature = time dim (tgn.py:43-54); must be a multiple of 4 */
+  int32_t Ef;           /* edge-feature dim (multiple of 4) */
+  int32_t n_layers;     /* L */
+  int32_t n_heads;      /* H, divides 2D */
+  int32_t use_memory;   /* 0 = TGAT (main.py:70-74) */
+  int32_t max_roots;    /* capacity R the workspace is sized for */
+  int32_t max_neighbors;/* capacity K */
+  int32_t max_batch;    /* capacity B (positives = 2B) */
+} pfo_tgn_config;
+
+/* flat parameter layout (element offsets into the fp32 parameter / gradient buffers) */
+typedef struct pfo_tgn_layer_layout {
+  int64_t wq, wk, wv, b_in, wo, bo, w1, b1, w2, b2; /* attention_models.{l}: MHA in/out proj + MergeLayer */
+} pfo_tgn_layer_layout;
+typedef struct pfo_tgn_layout {
+  int64_t time_w, time_b;                   /* time_encoder.w.{weight,bias} */
+  int64_t gru_w_ih, gru_w_hh, gru_b_ih, gru_b_hh; /* memory_updater.memory_updater.* (-1 without memory) */
+  pfo_tgn_layer_layout layer[PFO_MAX_LAYERS];
+  int64_t total;
+} pfo_tgn_layout;
+
+int pfo_tgn_param_layout(const pfo_tgn_config* cfg, pfo_tgn_layout* out);
+/* bytes of scratch pfo_tgn_forward/backward need for (cfg.max_roots, cfg.max_neighbors) */
+int64_t pfo_tgn_workspace_bytes(const pfo_tgn_config* cfg);
+
+/* device-resident model state; all caller-owned */
+typedef struct pfo_tgn_state {
+  const int64_t* indptr; const int32_t* adj_nbr; const int32_t* adj_eidx; const double* adj_ts; /* CSR (K1) */
+  const float* node_feat;   /* [n_nodes,D]  tgn.py:35 */
+  const float* edge_feat;   /* [E+1,Ef] z-scored, tgn.py:38-41 */
+  float* memory;            /* [n_nodes,D]  modules/memory.py:28 */
+  float* last_update;       /* [n_nodes]    modules/memory.py:30 */
+  float* msg_table;         /* [n_nodes,3D+Ef] last pending raw message per node */
+  float* msg_time;          /* [n_nodes] */
+  uint8_t* has_msg;         /* [n_nodes] */
+  const float* params;      /* flat, pfo_tgn_layout */
+} pfo_tgn_state;
+
+typedef struct pfo_tgn_batch {
+  const int32_t* roots;     /* [R] = [src | dst | (p_pos) | neg]   tgn.py:121 / :235 */
+  const double* root_ts;    /* [R] timestamps, negatives repeat their interaction's time (tgn.py:123-124,238-239) */
+  int32_t R, K;
+  int32_t uniform;          /* 0 most-recent, 1 injected draws, 2 Philox */
+  const int64_t* const* draws; /* HOST array of n_layers device pointers (level L..1), mode 1 only */
+  uint64_t seed, offset;
+  float dropout_p;          /* attention-weight dropout, 0 in eval / parity mode (temporal_attention.py:28-32) */
+  int32_t training;         /* keep what backward needs */
+  const int32_t* extra_nodes; /* [n_extra] nodes whose lazily-updated memory is needed although they are not
+                                 embedded here: data-parallel ranks pass the GLOBAL batch's positives so that
+                                 pfo_tgn_update_state can persist all of them; may be NULL */
+  int32_t n_extra;
+} pfo_tgn_batch;
+
+/* Lazy memory update for touched nodes (tgn.py:251, memory_updater.py:35-53) + L-layer temporal graph
+ * attention (embedding_module.py:76-175, temporal_attention.py:34-90).  emb_out f32[R,D]. */
+int pfo_tgn_forward(const pfo_tgn_config* cfg, const pfo_tgn_state* st, const pfo_tgn_batch* batch,
+                    void* workspace, float* emb_out, void* stream);
+/* Gradients of everything pfo_tgn_forward (training=1) computed, given d_emb f32[R,D]; ACCUMULATES into grad (flat). */
+int pfo_tgn_backward(const pfo_tgn_config* cfg, const pfo_tgn_state* st, const pfo_tgn_batch* batch,
+                     void* workspace, const float* d_emb, float* grad, void* stream);
+/* Persist memory for the positives, clear their pending messages, build and store the new raw messages with
+ * last-wins semantics (tgn.py:290-317, memory_updater.py:18-33, memory.py:35-37,73-75, tgn.py:357-378).
+ * src/dst i32[B], ts f64[B], eidx i32[B]; needs the workspace of the forward call that preceded it. */
+int pfo_tgn_update_state(const pfo_tgn_config* cfg, const pfo_tgn_state* st, const int32_t* src, const int32_t* dst,
+                         const double* ts, const int32_t* eidx, int32_t B, void* workspace, void* stream);
+
+/* diagnostics for tests: copies of internals of the last forward (device pointers into the workspace) */
+typedef struct pfo_tgn_debug {
+  const int32_t* n_touched;  /* [1] */
+  const int32_t* touched_ids;/* [n_touched] */
+  const float* h0_table;     /* [n_touched,D] layer-0 features memory'+node_feat (embedding_module.py:98) */
+  const int32_t* slot;       /* [n_nodes] */
+} pfo_tgn_debug;
+int pfo_tgn_debug_views(const pfo_tgn_config* cfg, void* workspace, pfo_tgn_debug* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFOTGN_H */

@@ -1,2 +1,16 @@
-"""MI355X-native TGN-recommender training path (drop-in for youngandbin/PfoTGNRec's hot path)."""
+"""MI355X-native TGN-recommender training path (drop-in for youngandbin/PfoTGNRec's hot path).
+
+Public surface mirrors the reference's: ``TGN`` (model/tgn.py), ``NeighborFinder`` /
+``get_neighbor_finder`` / ``RandEdgeSampler`` (utils/utils.py), ``Data`` (utils/data.py), ``Memory``
+(modules/memory.py), plus the MV sampler that main.py keeps inline (``MVSampler``).
+"""
 __version__ = "0.1.0"
+
+from .data import Data, compute_time_statistics  # noqa: F401
+from .neighbor_finder import NeighborFinder, get_neighbor_finder  # noqa: F401
+from .rand_edge_sampler import RandEdgeSampler, DeviceNegativeSampler  # noqa: F401
+from .mv_sampler import MVSampler  # noqa: F401
+from .memory import Memory  # noqa: F401
+from .tgn import TGN  # noqa: F401
+from .optim import FusedAdam  # noqa: F401
+from .functional import bpr_loss, time_encode  # noqa: F401

@@ -1,0 +1,121 @@
+"""ctypes binding of libpfotgn.so (the C ABI declared in include/pfotgn.h).
+
+There is no CPU fallback: if the library is missing, loading raises; if no HIP device is present,
+every compute entry raises ``RuntimeError`` before anything is launched.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpfotgn.so")
+
+c_i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+_VP = C.c_void_p
+
+MAX_LAYERS = 4
+
+
+class TgnConfig(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("n_edges_p1", C.c_int32), ("D", C.c_int32), ("Ef", C.c_int32),
+                ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("use_memory", C.c_int32), ("max_roots", C.c_int32),
+                ("max_neighbors", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class TgnLayerLayout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("wq", "wk", "wv", "b_in", "wo", "bo", "w1", "b1", "w2", "b2")]
+
+
+class TgnLayout(C.Structure):
+    _fields_ = [("time_w", C.c_int64), ("time_b", C.c_int64), ("gru_w_ih", C.c_int64), ("gru_w_hh", C.c_int64),
+                ("gru_b_ih", C.c_int64), ("gru_b_hh", C.c_int64), ("layer", TgnLayerLayout * MAX_LAYERS),
+                ("total", C.c_int64)]
+
+
+class TgnState(C.Structure):
+    _fields_ = [(n, _VP) for n in ("indptr", "adj_nbr", "adj_eidx", "adj_ts", "node_feat", "edge_feat", "memory",
+                                   "last_update", "msg_table", "msg_time", "has_msg", "params")]
+
+
+class TgnBatch(C.Structure):
+    _fields_ = [("roots", _VP), ("root_ts", _VP), ("R", C.c_int32), ("K", C.c_int32), ("uniform", C.c_int32),
+                ("draws", C.POINTER(_VP)), ("seed", C.c_uint64), ("offset", C.c_uint64), ("dropout_p", C.c_float),
+                ("training", C.c_int32), ("extra_nodes", _VP), ("n_extra", C.c_int32)]
+
+
+class TgnDebug(C.Structure):
+    _fields_ = [(n, _VP) for n in ("n_touched", "touched_ids", "h0_table", "slot")]
+
+
+# name -> (restype, argtypes); every symbol of include/pfotgn.h
+PROTOTYPES = {
+    "pfo_abi_version": (C.c_int, []),
+    "pfo_last_error": (C.c_char_p, []),
+    "pfo_tnbr_sample": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP, _VP, C.c_int64, C.c_int32, C.c_int32, _VP,
+                                  C.c_uint64, C.c_uint64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "pfo_neg_draw": (C.c_int, [_VP, C.c_int32, _VP, _VP, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_uint64,
+                               C.c_uint64, _VP, _VP]),
+    "pfo_mv_select": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, C.c_int32, _VP, _VP, C.c_int32,
+                                C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, _VP, _VP, _VP,
+                                _VP, _VP]),
+    "pfo_time_encode": (C.c_int, [_VP, C.c_int64, _VP, _VP, C.c_int32, _VP, _VP]),
+    "pfo_gemm_f32": (C.c_int, [_VP, C.c_int64, C.c_int32, _VP, C.c_int64, C.c_int32, _VP, C.c_int64, _VP, C.c_int32,
+                               C.c_int32, C.c_int32, C.c_int32, _VP, C.c_int64, _VP]),
+    "pfo_bpr_loss": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_float, _VP,
+                               _VP, _VP, _VP]),
+    "pfo_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
+                                _VP]),
+    "pfo_tgn_param_layout": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnLayout)]),
+    "pfo_tgn_workspace_bytes": (C.c_int64, [C.POINTER(TgnConfig)]),
+    "pfo_tgn_forward": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP]),
+    "pfo_tgn_backward": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP, _VP]),
+    "pfo_tgn_update_state": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), _VP, _VP, _VP, _VP, C.c_int32, _VP,
+                                       _VP]),
+    "pfo_tgn_debug_views": (C.c_int, [C.POINTER(TgnConfig), _VP, C.POINTER(TgnDebug)]),
+}
+
+_lib = None
+
+
+class PfoError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library (raises if it has not been built: run ``python -m pfotgnrec_amd.build``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PfoError("libpfotgn.so not found at %s - build it with `python -m pfotgnrec_amd.build` "
+                           "(there is no CPU fallback)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise PfoError("%s failed (%d): %s" % (name, rc, lib.pfo_last_error().decode()))
+
+
+def require_gpu(device=None):
+    import torch
+    if not torch.cuda.is_available():
+        raise PfoError("a HIP device (MI355X) is required: the hot path has no CPU implementation")
+    if device is not None and torch.device(device).type != "cuda":
+        raise PfoError("tensors must live on a HIP device, got %s" % device)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

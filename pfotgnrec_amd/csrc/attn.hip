@@ -1,0 +1,362 @@
+// Neighbour-tile temporal attention (K4/K5 neighbour side).
+//
+// One wavefront per instance; the 64 lanes stride the feature dimension so every neighbour row is
+// read as contiguous 256-byte pieces (rows of the layer-0 table are L2/Infinity-Cache resident).
+// Keys are never materialised: key_j = [gathered row | edge feature | cos(fma(dt, w, b))] is formed
+// in registers, used for the score, folded into the running context by an online softmax, and
+// recomputed in the backward (the reference's [N,K,C] key tensor is 1.4 GB at C2).
+// The K/V projections are folded: the kernel consumes qk_h = Wk_h^T Q_h and emits
+// ctx_h = sum_j a_jh key_j; both projections become plain GEMMs on [N, C] operands.
+#include "attn.hpp"
+#include <algorithm>
+
+struct AttnDev {
+  int N, K, D, Ef, H, dh;
+  const float* QK; const float* nbr_tab; int64_t nbr_ld; const int32_t* nbr_row; int64_t nbr_row_base;
+  const int32_t* nbr_ids; const float* edge_feat; const int32_t* eidx; const float* dt; const float* tw; const float* tb;
+  float scale, dropout_p; uint64_t seed, offset;
+  float* ctx; float* attw; float* ssum; uint8_t* inv;
+  const float* dctx; const float* dO; const float* bv; float* dQK; float* d_nbr; int64_t d_nbr_ld; float* dtime_part;
+};
+
+// dropout keep-bits for slot `lane` of instance n: bit h = keep for head h (H <= 4)
+__device__ __forceinline__ unsigned attn_keep_bits(uint64_t seed, uint64_t offset, int64_t n, int lane, float p) {
+  if (p <= 0.f) return 0xFu;
+  const pfo_u4 r = pfo_philox(seed, (uint64_t)n * 64ull + (uint64_t)lane, offset);
+  const uint32_t thr = (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f);
+  return (r.x >= thr ? 1u : 0u) | (r.y >= thr ? 2u : 0u) | (r.z >= thr ? 4u : 0u) | (r.w >= thr ? 8u : 0u);
+}
+
+template <int NR, int H>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+  if (n >= a.N) return;
+  const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef;
+
+  float tw[NR], tb[NR];
+  float qn[H][NR], qt[H][NR], qe[H];
+  const float* qk = a.QK + n * H * C;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int c = lane + 64 * r;
+    tw[r] = c < D ? a.tw[c] : 0.f;
+    tb[r] = c < D ? a.tb[c] : 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      qn[h][r] = c < D ? qk[h * C + c] : 0.f;
+      qt[h][r] = c < D ? qk[h * C + D + Ef + c] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) qe[h] = lane < Ef ? qk[h * C + D + lane] : 0.f;
+
+  const int myid = lane < K ? a.nbr_ids[n * K + lane] : 0;
+  const unsigned long long valid = __ballot(lane < K && myid != 0);
+  float* ctx = a.ctx + n * H * C;
+  if (valid == 0ull) {
+    // no valid neighbour: the reference attends to padded slot 0 and then zero-fills the attention
+    // output (temporal_attention.py:60-65,84), so nothing computed here is ever observed
+    if (lane == 0) a.inv[n] = 1;
+    for (int c = lane; c < H * C; c += 64) ctx[c] = 0.f;
+    for (int c = lane; c < H * K; c += 64) a.attw[n * H * K + c] = 0.f;
+    if (a.ssum && lane < H) a.ssum[n * H + lane] = 0.f;
+    return;
+  }
+  if (lane == 0) a.inv[n] = 0;
+
+  const unsigned keep = attn_keep_bits(a.seed, a.offset, n, lane, a.dropout_p);
+  const float keep_scale = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
+
+  float m[H], l[H], ld[H], my_s[H];
+  float an[H][NR], at[H][NR], ae[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    m[h] = -INFINITY; l[h] = 0.f; ld[h] = 0.f; my_s[h] = -INFINITY; ae[h] = 0.f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { an[h][r] = 0.f; at[h][r] = 0.f; }
+  }
+
+  for (int j = 0; j < K; ++j) {
+    if (!((valid >> j) & 1ull)) continue;
+    const int64_t slot = n * K + j;
+    const int64_t row = a.nbr_row ? (int64_t)a.nbr_row[slot] : a.nbr_row_base + slot;
+    const int e = a.eidx[slot];
+    const float dtv = a.dt[slot];
+    const unsigned kb = __shfl(keep, j, 64);
+    float kn[NR], kt[NR];
+    const float* src = a.nbr_tab + row * a.nbr_ld;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int c = lane + 64 * r;
+      kn[r] = c < D ? src[c] : 0.f;
+      kt[r] = c < D ? pfo_cosf(pfo_time_arg(dtv, tw[r], tb[r])) : 0.f;
+    }
+    const float ke = lane < Ef ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float part = ke * qe[h];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) part = fmaf(kn[r], qn[h][r], fmaf(kt[r], qt[h][r], part));
+      const float s = pfo_wave_sum(part) * a.scale;
+      if (lane == j) my_s[h] = s;
+      const float mn = fmaxf(m[h], s);
+      const float corr = expf(m[h] - mn);
+      const float p = expf(s - mn);
+      const float pd = ((kb >> h) & 1u) ? p * keep_scale : 0.f;
+      l[h] = fmaf(l[h], corr, p);
+      ld[h] = fmaf(ld[h], corr, pd);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        an[h][r] = fmaf(an[h][r], corr, pd * kn[r]);
+        at[h][r] = fmaf(at[h][r], corr, pd * kt[r]);
+      }
+      ae[h] = fmaf(ae[h], corr, pd * ke);
+      m[h] = mn;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const float il = 1.f / l[h];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int c = lane + 64 * r;
+      if (c < D) {
+        ctx[h * C + c] = an[h][r] * il;
+        ctx[h * C + D + Ef + c] = at[h][r] * il;
+      }
+    }
+    if (lane < Ef) ctx[h * C + D + lane] = ae[h] * il;
+    if (lane < K) a.attw[(n * H + h) * K + lane] = ((valid >> lane) & 1ull) ? expf(my_s[h] - m[h]) * il : 0.f;
+    if (a.ssum && lane == 0) a.ssum[n * H + h] = ld[h] * il;
+  }
+}
+
+#define ATTN_BWD_MAX_BLOCKS 2048
+int pfo_attn_bwd_max_parts() { return ATTN_BWD_MAX_BLOCKS; }
+
+template <int NR, int H>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
+  __shared__ float s_red[4][2][NR * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef;
+  const bool direct = (a.nbr_row == nullptr);          // neighbour rows are consecutive (layers >= 2)
+  const bool wdirect = direct && a.d_nbr != nullptr;     // ... and their gradients are written, not accumulated
+  float tw[NR], tb[NR], dw[NR], db[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int c = lane + 64 * r;
+    tw[r] = c < D ? a.tw[c] : 0.f;
+    tb[r] = c < D ? a.tb[c] : 0.f;
+    dw[r] = 0.f; db[r] = 0.f;
+  }
+  const float keep_scale = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
+
+  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < a.N; n += (int64_t)gridDim.x * 4) {
+    float* dqk_out = a.dQK + n * H * C;
+    const int myid = lane < K ? a.nbr_ids[n * K + lane] : 0;
+    const unsigned long long valid = __ballot(lane < K && myid != 0);
+    if (valid == 0ull) {
+      for (int c = lane; c < H * C; c += 64) dqk_out[c] = 0.f;
+      if (wdirect)
+        for (int j = 0; j < K; ++j) {
+          float* dst = a.d_nbr + (a.nbr_row_base + n * K + j) * a.d_nbr_ld;
+          for (int c = lane; c < D; c += 64) dst[c] = 0.f;
+        }
+      continue;
+    }
+    float qn[H][NR], qt[H][NR], qe[H], gn[H][NR], gt[H][NR], ge[H], t[H], dsb[H];
+    float dqn[H][NR], dqt[H][NR], dqe[H];
+    const float* qk = a.QK + n * H * C;
+    const float* dc = a.dctx + n * H * C;
+    const float* cx = a.ctx + n * H * C;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float part = 0.f;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int c = lane + 64 * r;
+        const bool ok = c < D;
+        qn[h][r] = ok ? qk[h * C + c] : 0.f;
+        qt[h][r] = ok ? qk[h * C + D + Ef + c] : 0.f;
+        gn[h][r] = ok ? dc[h * C + c] : 0.f;
+        gt[h][r] = ok ? dc[h * C + D + Ef + c] : 0.f;
+        if (ok) part = fmaf(gn[h][r], cx[h * C + c], fmaf(gt[h][r], cx[h * C + D + Ef + c], part));
+        dqn[h][r] = 0.f; dqt[h][r] = 0.f;
+      }
+      qe[h] = lane < Ef ? qk[h * C + D + lane] : 0.f;
+      ge[h] = lane < Ef ? dc[h * C + D + lane] : 0.f;
+      if (lane < Ef) part = fmaf(ge[h], cx[h * C + D + lane], part);
+      dqe[h] = 0.f;
+      // delta_h = sum_j a_jh * da_jh = dctx_h . ctx_h (+ d ssum_h * ssum_h under dropout)
+      t[h] = pfo_wave_sum(part);
+      dsb[h] = 0.f;
+      if (a.dropout_p > 0.f) {
+        float pb = 0.f;
+        for (int c = lane; c < a.dh; c += 64) pb = fmaf(a.dO[n * H * a.dh + h * a.dh + c], a.bv[h * a.dh + c], pb);
+        dsb[h] = pfo_wave_sum(pb);
+        t[h] = fmaf(dsb[h], a.ssum[n * H + h], t[h]);
+      }
+    }
+    const unsigned keep = attn_keep_bits(a.seed, a.offset, n, lane, a.dropout_p);
+    float my_a[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) my_a[h] = lane < K ? a.attw[(n * H + h) * K + lane] : 0.f;
+
+    for (int j = 0; j < K; ++j) {
+      const int64_t slot = n * K + j;
+      if (!((valid >> j) & 1ull)) {
+        if (wdirect) {
+          float* dst = a.d_nbr + (a.nbr_row_base + slot) * a.d_nbr_ld;
+          for (int c = lane; c < D; c += 64) dst[c] = 0.f;
+        }
+        continue;
+      }
+      const int64_t row = direct ? a.nbr_row_base + slot : (int64_t)a.nbr_row[slot];
+      const int e = a.eidx[slot];
+      const float dtv = a.dt[slot];
+      const unsigned kb = __shfl(keep, j, 64);
+      float kn[NR], kt[NR], ks[NR];
+      const float* src = a.nbr_tab + row * a.nbr_ld;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int c = lane + 64 * r;
+        kn[r] = c < D ? src[c] : 0.f;
+        float sv = 0.f, cv = 0.f;
+        if (c < D) pfo_sincosf(pfo_time_arg(dtv, tw[r], tb[r]), sv, cv);
+        kt[r] = cv;
+        ks[r] = sv;
+      }
+      const float ke = lane < Ef ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
+      float cA[H], cB[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float part = ke * ge[h];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) part = fmaf(kn[r], gn[h][r], fmaf(kt[r], gt[h][r], part));
+        const float ks_h = ((kb >> h) & 1u) ? keep_scale : 0.f;
+        const float da = (pfo_wave_sum(part) + dsb[h]) * ks_h;      // d loss / d a_jh (through dropout)
+        const float aj = __shfl(my_a[h], j, 64);
+        const float dscore = aj * (da - t[h]);                       // softmax backward
+        cA[h] = aj * ks_h;                                           // a'_jh multiplies dctx_h
+        cB[h] = dscore * a.scale;                                    // multiplies qk_h
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          dqn[h][r] = fmaf(cB[h], kn[r], dqn[h][r]);
+          dqt[h][r] = fmaf(cB[h], kt[r], dqt[h][r]);
+        }
+        dqe[h] = fmaf(cB[h], ke, dqe[h]);
+      }
+      float* dst = a.d_nbr ? a.d_nbr + row * a.d_nbr_ld : nullptr;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int c = lane + 64 * r;
+        float dkn = 0.f, dkt = 0.f;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          dkn = fmaf(cA[h], gn[h][r], fmaf(cB[h], qn[h][r], dkn));
+          dkt = fmaf(cA[h], gt[h][r], fmaf(cB[h], qt[h][r], dkt));
+        }
+        if (c < D) {
+          if (dst) {
+            if (direct) dst[c] = dkn; else atomicAdd(dst + c, dkn);
+          }
+          const float gsin = -ks[r] * dkt;          // d/d(arg) cos(arg) = -sin(arg)
+          dw[r] = fmaf(gsin, dtv, dw[r]);
+          db[r] += gsin;
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int c = lane + 64 * r;
+        if (c < D) {
+          dqk_out[h * C + c] = dqn[h][r];
+          dqk_out[h * C + D + Ef + c] = dqt[h][r];
+        }
+      }
+      if (lane < Ef) dqk_out[h * C + D + lane] = dqe[h];
+    }
+  }
+  // time-encoder partials: fold the four wavefronts, one slab row per workgroup (deterministic)
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    s_red[wave][0][lane + 64 * r] = dw[r];
+    s_red[wave][1][lane + 64 * r] = db[r];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += 256) {
+    const int which = c / D, cc = c - which * D;
+    const float v = s_red[0][which][cc] + s_red[1][which][cc] + s_red[2][which][cc] + s_red[3][which][cc];
+    a.dtime_part[(int64_t)blockIdx.x * 2 * D + c] = v;
+  }
+}
+
+static void to_dev(const PfoAttn& a, AttnDev& d) {
+  d.N = a.N; d.K = a.K; d.D = a.D; d.Ef = a.Ef; d.H = a.H; d.dh = a.dh;
+  d.QK = a.QK; d.nbr_tab = a.nbr_tab; d.nbr_ld = a.nbr_ld; d.nbr_row = a.nbr_row; d.nbr_row_base = a.nbr_row_base;
+  d.nbr_ids = a.nbr_ids; d.edge_feat = a.edge_feat; d.eidx = a.eidx; d.dt = a.dt; d.tw = a.tw; d.tb = a.tb;
+  d.scale = a.scale; d.dropout_p = a.dropout_p; d.seed = a.seed; d.offset = a.offset;
+  d.ctx = a.ctx; d.attw = a.attw; d.ssum = a.ssum; d.inv = a.inv;
+  d.dctx = a.dctx; d.dO = a.dO; d.bv = a.bv; d.dQK = a.dQK; d.d_nbr = a.d_nbr; d.d_nbr_ld = a.d_nbr_ld;
+  d.dtime_part = a.dtime_part;
+}
+
+static int check_common(const PfoAttn& a) {
+  PFO_REQUIRE(a.N > 0 && a.K >= 1 && a.K <= PFO_MAX_NEIGHBORS, "bad N / K");
+  PFO_REQUIRE(a.D >= 1 && a.D <= 256, "D must be <= 256");
+  PFO_REQUIRE(a.Ef >= 0 && a.Ef <= 64, "Ef must be <= 64");
+  PFO_REQUIRE(a.H == 1 || a.H == 2 || a.H == 4, "n_heads must be 1, 2 or 4");
+  PFO_REQUIRE(a.QK && a.nbr_tab && a.nbr_ids && a.eidx && a.dt && a.tw && a.tb && a.ctx && a.attw && a.inv, "null input");
+  PFO_REQUIRE(a.Ef == 0 || a.edge_feat, "null edge features");
+  PFO_REQUIRE(a.dropout_p >= 0.f && a.dropout_p < 1.f, "dropout must be in [0, 1)");
+  PFO_REQUIRE(a.dropout_p == 0.f || a.ssum, "dropout needs the ssum buffer");
+  return PFO_OK;
+}
+
+#define ATTN_DISPATCH(KERNEL, grid)                                                                           \
+  {                                                                                                           \
+    const int NRv = (a.D + 63) / 64;                                                                          \
+    const dim3 g((unsigned)(grid)), b(256);                                                                   \
+    bool done = true;                                                                                         \
+    switch (NRv * 8 + a.H) {                                                                                  \
+      case 1 * 8 + 1: hipLaunchKernelGGL((KERNEL<1, 1>), g, b, 0, stream, d); break;                          \
+      case 1 * 8 + 2: hipLaunchKernelGGL((KERNEL<1, 2>), g, b, 0, stream, d); break;                          \
+      case 1 * 8 + 4: hipLaunchKernelGGL((KERNEL<1, 4>), g, b, 0, stream, d); break;                          \
+      case 2 * 8 + 1: hipLaunchKernelGGL((KERNEL<2, 1>), g, b, 0, stream, d); break;                          \
+      case 2 * 8 + 2: hipLaunchKernelGGL((KERNEL<2, 2>), g, b, 0, stream, d); break;                          \
+      case 2 * 8 + 4: hipLaunchKernelGGL((KERNEL<2, 4>), g, b, 0, stream, d); break;                          \
+      case 3 * 8 + 1: hipLaunchKernelGGL((KERNEL<3, 1>), g, b, 0, stream, d); break;                          \
+      case 3 * 8 + 2: hipLaunchKernelGGL((KERNEL<3, 2>), g, b, 0, stream, d); break;                          \
+      case 3 * 8 + 4: hipLaunchKernelGGL((KERNEL<3, 4>), g, b, 0, stream, d); break;                          \
+      case 4 * 8 + 1: hipLaunchKernelGGL((KERNEL<4, 1>), g, b, 0, stream, d); break;                          \
+      case 4 * 8 + 2: hipLaunchKernelGGL((KERNEL<4, 2>), g, b, 0, stream, d); break;                          \
+      case 4 * 8 + 4: hipLaunchKernelGGL((KERNEL<4, 4>), g, b, 0, stream, d); break;                          \
+      default: done = false;                                                                                  \
+    }                                                                                                         \
+    PFO_REQUIRE(done, "unsupported (D, H) combination");                                                      \
+  }
+
+int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream) {
+  if (int rc = check_common(a)) return rc;
+  AttnDev d;
+  to_dev(a, d);
+  ATTN_DISPATCH(attn_fwd_kernel, pfo_ceil_div(a.N, 4));
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
+  if (int rc = check_common(a)) return rc;
+  PFO_REQUIRE(a.dctx && a.dQK && a.dtime_part, "null backward buffers");
+  PFO_REQUIRE(a.dropout_p == 0.f || (a.dO && a.bv && a.dh > 0), "dropout backward needs dO and bv");
+  AttnDev d;
+  to_dev(a, d);
+  const int grid = (int)std::min<int64_t>(ATTN_BWD_MAX_BLOCKS, pfo_ceil_div(a.N, 4));
+  ATTN_DISPATCH(attn_bwd_kernel, grid);
+  PFO_LAUNCH_CHECK();
+  if (n_parts) *n_parts = grid;
+  return PFO_OK;
+}

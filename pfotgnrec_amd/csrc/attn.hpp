@@ -1,0 +1,43 @@
+// Internal interface of the neighbour-tile attention kernels (attn.hip).
+#pragma once
+#include "common.hpp"
+
+// One attention layer's neighbour side for N instances with K neighbour slots each.
+// key_j = [ nbr_tab[row_j] (D) | edge_feat[eidx_j] (Ef) | cos(fma(dt_j, w, b)) (D) ]   (temporal_attention.py:52)
+// scores use the FOLDED query-key vector qk_h = Wk_h^T Q_h: score_jh = scale * qk_h . key_j
+struct PfoAttn {
+  int N = 0, K = 0, D = 0, Ef = 0, H = 0;
+  const float* QK = nullptr;        // [N, H*C], C = 2D+Ef
+  const float* nbr_tab = nullptr;   // rows of D floats
+  int64_t nbr_ld = 0;
+  const int32_t* nbr_row = nullptr; // [N*K] row of nbr_tab per slot, or null: row = nbr_row_base + n*K + j
+  int64_t nbr_row_base = 0;
+  const int32_t* nbr_ids = nullptr; // [N*K] node ids; slot is padding iff id == 0 (embedding_module.py:154)
+  const float* edge_feat = nullptr; // [E+1, Ef]
+  const int32_t* eidx = nullptr;    // [N*K]
+  const float* dt = nullptr;        // [N*K]
+  const float* tw = nullptr;        // time-encoder weight [D]
+  const float* tb = nullptr;        // time-encoder bias [D]
+  float scale = 1.f;
+  float dropout_p = 0.f;
+  uint64_t seed = 0, offset = 0;
+  // forward outputs / backward inputs
+  float* ctx = nullptr;             // [N, H*C]  sum_j a'_jh key_j
+  float* attw = nullptr;            // [N, H, K] softmax probabilities before dropout (0 on padding)
+  float* ssum = nullptr;            // [N, H]    sum_j a'_jh (only when dropout_p > 0)
+  uint8_t* inv = nullptr;           // [N]       1 = no valid neighbour (temporal_attention.py:60)
+  // backward
+  const float* dctx = nullptr;      // [N, H*C]
+  const float* dO = nullptr;        // [N, H*dh] (dropout only: d ssum_h = dO_h . bv_h)
+  const float* bv = nullptr;        // [H*dh]
+  int dh = 0;
+  float* dQK = nullptr;             // [N, H*C]
+  float* d_nbr = nullptr;           // rows of D floats: direct rows (nbr_row == null) or atomically added rows
+  int64_t d_nbr_ld = 0;
+  float* dtime_part = nullptr;      // [grid, 2*D] per-workgroup partial (dw | db) of the time encoder
+};
+
+int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream);
+// returns the number of workgroups (rows of dtime_part written) in *n_parts
+int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream);
+int pfo_attn_bwd_max_parts();

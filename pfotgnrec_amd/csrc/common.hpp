@@ -1,0 +1,98 @@
+// Shared host/device helpers for the gfx950 kernels.  Wave size is 64 everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/pfotgn.h"
+
+#define PFO_WAVE 64
+
+void pfo_set_error(const char* fmt, ...);
+
+#define PFO_REQUIRE(cond, msg)                                    \
+  do {                                                            \
+    if (!(cond)) {                                                \
+      pfo_set_error("%s: %s", __func__, msg);                     \
+      return PFO_ERR_INVALID;                                     \
+    }                                                             \
+  } while (0)
+
+#define PFO_LAUNCH_CHECK()                                                        \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      pfo_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__));   \
+      return PFO_ERR_HIP;                                                         \
+    }                                                                             \
+  } while (0)
+
+static inline int64_t pfo_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t pfo_align_up(int64_t a, int64_t b) { return pfo_ceil_div(a, b) * b; }
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------------------------
+// sin/cos of an fp32 argument of any magnitude (time-encoder arguments reach 1e7 and beyond):
+// range reduction in fp64 against a two-term pi/2 (exact to ~1e-16 * |x|), fp32 minimax
+// polynomials on [-pi/4, pi/4].  ~1 ulp; far inside the 1e-4 parity bar and much cheaper than
+// the generic Payne-Hanek path.
+__device__ __forceinline__ void pfo_sincosf(float x, float& s, float& c) {
+  const double xd = (double)x;
+  const double kd = rint(xd * 0.63661977236758134308);
+  double r = fma(-kd, 1.57079632679489655800e+00, xd);
+  r = fma(-kd, 6.12323399573676603587e-17, r);
+  const int q = (int)((long long)kd & 3);
+  const float rf = (float)r;
+  const float r2 = rf * rf;
+  const float sp = fmaf(rf * r2, fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), rf);
+  const float cp = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                        fmaf(r2, -0.5f, 1.0f));
+  const float ss = (q & 1) ? cp : sp;
+  const float cc = (q & 1) ? sp : cp;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+}
+
+__device__ __forceinline__ float pfo_cosf(float x) {
+  float s, c;
+  pfo_sincosf(x, s, c);
+  return c;
+}
+
+// TimeEncode element: one fp32 FMA, then cosine (model/time_encoding.py:23; SURVEY §7 hard part 1)
+__device__ __forceinline__ float pfo_time_arg(float t, float w, float b) { return __builtin_fmaf(t, w, b); }
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator
+struct pfo_u4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ pfo_u4 pfo_philox(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return pfo_u4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ uint32_t pfo_u4_get(const pfo_u4& v, int i) {
+  return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+
+__device__ __forceinline__ float pfo_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float pfo_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+#endif  // __HIPCC__

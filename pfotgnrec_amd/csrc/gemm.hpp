@@ -1,0 +1,38 @@
+// Internal interface of the fp32 MFMA contraction (gemm.hip).
+#pragma once
+#include "common.hpp"
+
+// C[M,N] = epilogue( sum over up to two K-concatenated sources  A_s[M,K_s] * op(B_s) )
+//   A_s row-major [M,K_s] (a_kmajor=0, optional row gather a_idx) or [K_s,M] (a_kmajor=1)
+//   B_s [N,K_s] (b_kmajor=0, nn.Linear layout) or [K_s,N] (b_kmajor=1, optional k-row gather b_idx)
+// epilogue order: + bias[n]*row_scale[m]  ->  row_zero  ->  relu  ->  * (relu_src>0)  ->  (+= C)
+struct PfoGemm {
+  const float* A[2] = {nullptr, nullptr};
+  int64_t lda[2] = {0, 0};
+  const int32_t* a_idx[2] = {nullptr, nullptr};
+  const float* B[2] = {nullptr, nullptr};
+  int64_t ldb[2] = {0, 0};
+  const int32_t* b_idx = nullptr;   // k-major B only: gathers the k rows of source 0
+  int K[2] = {0, 0};
+  float* C = nullptr;
+  int64_t ldc = 0;
+  const float* bias = nullptr;
+  const float* row_scale = nullptr; int64_t rs_ld = 1;
+  const uint8_t* row_zero = nullptr;
+  const float* relu_src = nullptr; int64_t relu_ld = 0;
+  int M = 0, N = 0;
+  const int32_t* m_dev = nullptr;   // device-side row count (rows M for row-major A, extent K for k-major A)
+  int relu = 0, accumulate = 0;
+  int a_kmajor = 0, b_kmajor = 0;
+  // batch (grid.z), element strides
+  int batch = 1;
+  int64_t a_bs[2] = {0, 0}, b_bs[2] = {0, 0}, c_bs = 0, bias_bs = 0, rs_bs = 0;
+  // split-K for a_kmajor && b_kmajor (weight gradients): partial slabs in `slabs`, then reduced into C
+  float* slabs = nullptr; int64_t slab_floats = 0;
+};
+
+int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream);
+// out[n] (+)= sum_m X[m,n] * (scale ? scale[m*scale_ld] : 1); rows limited by m_dev when given
+int pfo_colsum_launch(const float* X, int64_t ldx, int M, int N, const float* scale, int64_t scale_ld,
+                      const int32_t* m_dev, float* out, int accumulate, float* scratch, hipStream_t stream);
+int64_t pfo_colsum_scratch_floats(int N);

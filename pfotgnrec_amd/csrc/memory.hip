@@ -1,0 +1,303 @@
+// Memory-side kernels: which nodes does this step read (touched-set compaction), the GRU gate
+// math around the two MFMA contractions, and the persist / raw-message store that closes a step.
+//
+// Layout decision: the reference's defaultdict of per-node message lists becomes
+// a dense table msg_table[n_nodes, 3D+Ef] + msg_time[n_nodes] + has_msg[n_nodes]; "last" aggregation
+// (message_aggregator.py:38-55) is a last-index-wins scatter.  The lazy update of tgn.py:251 runs the
+// GRU over EVERY node with a pending message (P -> n_nodes); only rows that this step actually reads
+// can influence its outputs, so the GRU is applied to the compacted set of touched nodes instead.
+#include "memory.hpp"
+#include <algorithm>
+
+#define SCAN_BLOCK 1024
+
+__global__ void touch_mark_kernel(const int32_t* __restrict__ nodes0, int64_t n0, int n_nodes, int32_t* __restrict__ slot) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0; i += (int64_t)gridDim.x * blockDim.x) {
+    const int v = nodes0[i];
+    if (v >= 0 && v < n_nodes) slot[v] = 1;
+  }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_count_kernel(const int32_t* __restrict__ slot, int n_nodes,
+                                                                int32_t* __restrict__ block_counts) {
+  __shared__ int s_cnt[SCAN_BLOCK / 64];
+  const int v = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  const bool f = v < n_nodes && slot[v] != 0;
+  const unsigned long long bal = __ballot(f);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < SCAN_BLOCK / 64; ++w) t += s_cnt[w];
+    block_counts[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(int32_t* __restrict__ block_counts, int n_blocks,
+                                                           int32_t* __restrict__ n_touched) {
+  // exclusive scan of block_counts in place, by one workgroup, 1024 entries per sweep
+  __shared__ int s_w[16];
+  __shared__ int s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = 0; base < n_blocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < n_blocks ? block_counts[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_w[w];
+    const int carry = s_carry;
+    if (i < n_blocks) block_counts[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = carry + woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_touched = s_carry;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_scatter_kernel(int32_t* __restrict__ slot, int n_nodes,
+                                                                  const int32_t* __restrict__ block_offsets,
+                                                                  int32_t* __restrict__ touched_ids) {
+  __shared__ int s_cnt[SCAN_BLOCK / 64];
+  const int v = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool f = v < n_nodes && slot[v] != 0;
+  const unsigned long long bal = __ballot(f);
+  if (lane == 0) s_cnt[wave] = __popcll(bal);
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wave; ++w) woff += s_cnt[w];
+  const int pos = block_offsets[blockIdx.x] + woff + __popcll(bal & ((1ull << lane) - 1ull));
+  if (v < n_nodes) {
+    slot[v] = f ? pos : -1;
+    if (f) touched_ids[pos] = v;
+  }
+}
+
+int64_t pfo_compact_scratch_ints(int n_nodes) { return pfo_ceil_div(n_nodes, SCAN_BLOCK) + 8; }
+
+int pfo_touch_compact_launch(const int32_t* nodes0, int64_t n0, const int32_t* extra, int64_t n_extra, int n_nodes,
+                             int32_t* slot, int32_t* touched_ids, int32_t* n_touched, int32_t* scratch,
+                             hipStream_t stream) {
+  PFO_REQUIRE(nodes0 && slot && touched_ids && n_touched && scratch && n0 > 0 && n_nodes > 0, "bad arguments");
+  hipError_t e = hipMemsetAsync(slot, 0, (size_t)n_nodes * sizeof(int32_t), stream);
+  PFO_REQUIRE(e == hipSuccess, "memset failed");
+  const int nb = (int)pfo_ceil_div(n_nodes, SCAN_BLOCK);
+  const int mb = (int)std::min<int64_t>(2048, pfo_ceil_div(n0, 256));
+  hipLaunchKernelGGL(touch_mark_kernel, dim3(mb), dim3(256), 0, stream, nodes0, n0, n_nodes, slot);
+  if (extra && n_extra > 0) {
+    const int eb = (int)std::min<int64_t>(2048, pfo_ceil_div(n_extra, 256));
+    hipLaunchKernelGGL(touch_mark_kernel, dim3(eb), dim3(256), 0, stream, extra, n_extra, n_nodes, slot);
+  }
+  hipLaunchKernelGGL(scan_count_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, slot, n_nodes, scratch);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, scratch, nb, n_touched);
+  hipLaunchKernelGGL(scan_scatter_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, slot, n_nodes, scratch, touched_ids);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+__global__ void remap_kernel(const int32_t* __restrict__ nodes0, int64_t n0, const int32_t* __restrict__ slot,
+                             int32_t* __restrict__ idx0) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0; i += (int64_t)gridDim.x * blockDim.x)
+    idx0[i] = slot[nodes0[i]];
+}
+
+int pfo_remap_launch(const int32_t* nodes0, int64_t n0, const int32_t* slot, int32_t* idx0, hipStream_t stream) {
+  const int mb = (int)std::min<int64_t>(2048, pfo_ceil_div(n0, 256));
+  hipLaunchKernelGGL(remap_kernel, dim3(mb), dim3(256), 0, stream, nodes0, n0, slot, idx0);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void pack_rows_kernel(const float* __restrict__ msg_table, int M, const float* __restrict__ memory, int D,
+                                 const uint8_t* __restrict__ has_msg, const int32_t* __restrict__ touched_ids,
+                                 const int32_t* __restrict__ n_touched, float* __restrict__ msg_rows,
+                                 float* __restrict__ h_rows, uint8_t* __restrict__ hm) {
+  const int lane = threadIdx.x & 63;
+  const int nt = *n_touched;
+  for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < nt; s += (gridDim.x * blockDim.x) >> 6) {
+    const int id = touched_ids[s];
+    const float4* src = reinterpret_cast<const float4*>(msg_table + (int64_t)id * M);
+    float4* dst = reinterpret_cast<float4*>(msg_rows + (int64_t)s * M);
+    for (int c = lane; c < M / 4; c += 64) dst[c] = src[c];
+    const float4* hs = reinterpret_cast<const float4*>(memory + (int64_t)id * D);
+    float4* hd = reinterpret_cast<float4*>(h_rows + (int64_t)s * D);
+    for (int c = lane; c < D / 4; c += 64) hd[c] = hs[c];
+    if (lane == 0) hm[s] = has_msg[id];
+  }
+}
+
+int pfo_pack_rows_launch(const float* msg_table, int M, const float* memory, int D, const uint8_t* has_msg,
+                         const int32_t* touched_ids, const int32_t* n_touched, int cap, float* msg_rows, float* h_rows,
+                         uint8_t* hm, hipStream_t stream) {
+  PFO_REQUIRE((M % 4) == 0 && (D % 4) == 0, "row lengths must be multiples of 4");
+  const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div(cap, 4));
+  hipLaunchKernelGGL(pack_rows_kernel, dim3(nb), dim3(256), 0, stream, msg_table, M, memory, D, has_msg, touched_ids,
+                     n_touched, msg_rows, h_rows, hm);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+__global__ void gru_gates_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+                                     const float* __restrict__ h_rows, const float* __restrict__ node_feat,
+                                     const uint8_t* __restrict__ hm, const int32_t* __restrict__ touched_ids,
+                                     const int32_t* __restrict__ n_touched, int D, float* __restrict__ upd_mem,
+                                     float* __restrict__ h0_tab) {
+  const int64_t total = (int64_t)(*n_touched) * D;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int s = (int)(e / D), d = (int)(e - (int64_t)s * D);
+    const int id = touched_ids[s];
+    const float h = h_rows[e];
+    float hn = h;
+    if (hm[s]) {
+      const float* gis = gi + (int64_t)s * 3 * D;
+      const float* ghs = gh + (int64_t)s * 3 * D;
+      const float r = sigmoidf_acc(gis[d] + ghs[d]);
+      const float z = sigmoidf_acc(gis[D + d] + ghs[D + d]);
+      const float nn = tanhf(gis[2 * D + d] + r * ghs[2 * D + d]);
+      hn = (1.f - z) * nn + z * h;
+    }
+    upd_mem[e] = hn;
+    h0_tab[e] = hn + node_feat[(int64_t)id * D + d];
+  }
+}
+
+int pfo_gru_gates_fwd_launch(const float* gi, const float* gh, const float* h_rows, const float* node_feat,
+                             const uint8_t* hm, const int32_t* touched_ids, const int32_t* n_touched, int cap, int D,
+                             float* upd_mem, float* h0_tab, hipStream_t stream) {
+  const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div((int64_t)cap * D, 256));
+  hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(nb), dim3(256), 0, stream, gi, gh, h_rows, node_feat, hm,
+                     touched_ids, n_touched, D, upd_mem, h0_tab);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+__global__ void gru_gates_bwd_kernel(float* __restrict__ gi, float* __restrict__ gh, const float* __restrict__ h_rows,
+                                     const uint8_t* __restrict__ hm, const int32_t* __restrict__ n_touched, int D,
+                                     const float* __restrict__ d_h0) {
+  const int64_t total = (int64_t)(*n_touched) * D;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int s = (int)(e / D), d = (int)(e - (int64_t)s * D);
+    float* gis = gi + (int64_t)s * 3 * D;
+    float* ghs = gh + (int64_t)s * 3 * D;
+    float dpr = 0.f, dpz = 0.f, dpn = 0.f, dpnr = 0.f;
+    if (hm[s]) {
+      const float h = h_rows[e];
+      const float ghn = ghs[2 * D + d];
+      const float r = sigmoidf_acc(gis[d] + ghs[d]);
+      const float z = sigmoidf_acc(gis[D + d] + ghs[D + d]);
+      const float nn = tanhf(gis[2 * D + d] + r * ghn);
+      const float dh = d_h0[e];
+      const float dn = dh * (1.f - z);
+      const float dz = dh * (h - nn);
+      dpn = dn * (1.f - nn * nn);
+      const float dr = dpn * ghn;
+      dpr = dr * r * (1.f - r);
+      dpz = dz * z * (1.f - z);
+      dpnr = dpn * r;
+    }
+    gis[d] = dpr; gis[D + d] = dpz; gis[2 * D + d] = dpn;
+    ghs[d] = dpr; ghs[D + d] = dpz; ghs[2 * D + d] = dpnr;
+  }
+}
+
+int pfo_gru_gates_bwd_launch(float* gi, float* gh, const float* h_rows, const uint8_t* hm, const int32_t* n_touched,
+                             int cap, int D, const float* d_h0, hipStream_t stream) {
+  const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div((int64_t)cap * D, 256));
+  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(nb), dim3(256), 0, stream, gi, gh, h_rows, hm, n_touched, D, d_h0);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// persist (tgn.py:295 -> memory_updater.py:18-33): the positives' lazily updated rows become the
+// stored memory; last_update takes the consumed message's time.  Duplicates write equal values.
+__global__ void persist_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int B,
+                               const int32_t* __restrict__ slot, const float* __restrict__ upd_mem,
+                               const uint8_t* __restrict__ has_msg, const float* __restrict__ msg_time,
+                               float* __restrict__ memory, float* __restrict__ last_update, int D) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= 2 * B) return;
+  const int id = wave < B ? src[wave] : dst[wave - B];
+  if (!has_msg[id]) return;
+  const int s = slot[id];
+  if (s < 0) return;
+  for (int d = lane; d < D; d += 64) memory[(int64_t)id * D + d] = upd_mem[(int64_t)s * D + d];
+  if (lane == 0) last_update[id] = msg_time[id];
+}
+
+int pfo_persist_launch(const int32_t* src, const int32_t* dst, int B, const int32_t* slot, const float* upd_mem,
+                       const uint8_t* has_msg, const float* msg_time, float* memory, float* last_update, int D,
+                       hipStream_t stream) {
+  hipLaunchKernelGGL(persist_kernel, dim3((unsigned)pfo_ceil_div(2 * B, 4)), dim3(256), 0, stream, src, dst, B, slot,
+                     upd_mem, has_msg, msg_time, memory, last_update, D);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+// raw messages (tgn.py:357-378): event e = side*B + i; append order is all source-side messages in
+// batch order, then all destination-side ones, so "last" == the largest e that names the node.
+__global__ void msg_winner_init_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int B,
+                                       int32_t* __restrict__ winner) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * B) return;
+  winner[e < B ? src[e] : dst[e - B]] = -1;
+}
+__global__ void msg_winner_max_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int B,
+                                      int32_t* __restrict__ winner) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * B) return;
+  atomicMax(&winner[e < B ? src[e] : dst[e - B]], e);
+}
+__global__ void msg_write_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                 const double* __restrict__ ts, const int32_t* __restrict__ eidx, int B,
+                                 const float* __restrict__ memory, const float* __restrict__ last_update,
+                                 const float* __restrict__ edge_feat, const float* __restrict__ tw,
+                                 const float* __restrict__ tb, int D, int Ef, float* __restrict__ msg_table,
+                                 float* __restrict__ msg_time, uint8_t* __restrict__ has_msg,
+                                 const int32_t* __restrict__ winner) {
+  const int e = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (e >= 2 * B) return;
+  const int i = e < B ? e : e - B;
+  const int X = e < B ? src[i] : dst[i];
+  const int O = e < B ? dst[i] : src[i];
+  if (winner[X] != e) return;
+  const int M = 3 * D + Ef;
+  float* out = msg_table + (int64_t)X * M;
+  const float t = (float)ts[i];                       // tgn.py:359
+  const float delta = t - last_update[X];             // tgn.py:367 (fp32)
+  for (int d = lane; d < D; d += 64) {
+    out[d] = memory[(int64_t)X * D + d];
+    out[D + d] = memory[(int64_t)O * D + d];
+    out[2 * D + Ef + d] = pfo_cosf(pfo_time_arg(delta, tw[d], tb[d]));
+  }
+  if (lane < Ef) out[2 * D + lane] = edge_feat[(int64_t)eidx[i] * Ef + lane];
+  if (lane == 0) {
+    msg_time[X] = t;
+    has_msg[X] = 1;
+  }
+}
+
+int pfo_msg_store_launch(const int32_t* src, const int32_t* dst, const double* ts, const int32_t* eidx, int B,
+                         const float* memory, const float* last_update, const float* edge_feat, const float* tw,
+                         const float* tb, int D, int Ef, float* msg_table, float* msg_time, uint8_t* has_msg,
+                         int32_t* winner, hipStream_t stream) {
+  const unsigned nb = (unsigned)pfo_ceil_div(2 * B, 256);
+  hipLaunchKernelGGL(msg_winner_init_kernel, dim3(nb), dim3(256), 0, stream, src, dst, B, winner);
+  hipLaunchKernelGGL(msg_winner_max_kernel, dim3(nb), dim3(256), 0, stream, src, dst, B, winner);
+  hipLaunchKernelGGL(msg_write_kernel, dim3((unsigned)pfo_ceil_div(2 * B, 4)), dim3(256), 0, stream, src, dst, ts, eidx,
+                     B, memory, last_update, edge_feat, tw, tb, D, Ef, msg_table, msg_time, has_msg, winner);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}

@@ -1,0 +1,43 @@
+// Internal interface of the memory-side kernels (memory.hip) and small ops (misc.hip).
+#pragma once
+#include "common.hpp"
+
+// --- touched-node compaction: slot[v] = rank of v among the nodes referenced this step, -1 otherwise
+int64_t pfo_compact_scratch_ints(int n_nodes);
+int pfo_touch_compact_launch(const int32_t* nodes0, int64_t n0, const int32_t* extra, int64_t n_extra, int n_nodes,
+                             int32_t* slot, int32_t* touched_ids, int32_t* n_touched, int32_t* scratch,
+                             hipStream_t stream);
+// packs the rows backward still needs after the state update overwrites them:
+//   msg_rows[s] = msg_table[id], h_rows[s] = memory[id], hm[s] = has_msg[id]   (id = touched_ids[s])
+int pfo_pack_rows_launch(const float* msg_table, int M, const float* memory, int D, const uint8_t* has_msg,
+                         const int32_t* touched_ids, const int32_t* n_touched, int cap, float* msg_rows, float* h_rows,
+                         uint8_t* hm, hipStream_t stream);
+int pfo_remap_launch(const int32_t* nodes0, int64_t n0, const int32_t* slot, int32_t* idx0, hipStream_t stream);
+
+// --- GRU gates (memory_updater.py:60; torch.nn.GRUCell gate order r, z, n)
+// forward: per touched slot s (id = touched_ids[s]): h' = hm[s] ? GRU(gi[s], gh[s], h_rows[s]) : h_rows[s];
+//          upd_mem[s] = h'; h0_tab[s] = h' + node_feat[id]          (embedding_module.py:98)
+int pfo_gru_gates_fwd_launch(const float* gi, const float* gh, const float* h_rows, const float* node_feat,
+                             const uint8_t* hm, const int32_t* touched_ids, const int32_t* n_touched, int cap, int D,
+                             float* upd_mem, float* h0_tab, hipStream_t stream);
+// backward: overwrites gi/gh with d gi / d gh given d h' = d_h0[s] (zeros where no message was applied)
+int pfo_gru_gates_bwd_launch(float* gi, float* gh, const float* h_rows, const uint8_t* hm, const int32_t* n_touched,
+                             int cap, int D, const float* d_h0, hipStream_t stream);
+
+// --- state update (tgn.py:290-317)
+int pfo_persist_launch(const int32_t* src, const int32_t* dst, int B, const int32_t* slot, const float* upd_mem,
+                       const uint8_t* has_msg, const float* msg_time, float* memory, float* last_update, int D,
+                       hipStream_t stream);
+int pfo_msg_store_launch(const int32_t* src, const int32_t* dst, const double* ts, const int32_t* eidx, int B,
+                         const float* memory, const float* last_update, const float* edge_feat, const float* tw,
+                         const float* tb, int D, int Ef, float* msg_table, float* msg_time, uint8_t* has_msg,
+                         int32_t* winner, hipStream_t stream);
+
+// --- small ops (misc.hip)
+int pfo_scatter_add_rows_launch(const float* src, int64_t ld_src, const int32_t* idx, int64_t n_rows, int D, float* dst,
+                                int64_t ld_dst, hipStream_t stream);
+// cq = Wq[:, D:2D] cos(b) + bq folded query bias: backward of that term
+//   gq[E] = colsum(dQ);  d bq += gq;  d Wq[:, D:] += gq (x) cosb;  d tb += -sin(tb) * (Wq[:, D:]^T gq)
+int pfo_cq_backward_launch(const float* gq, const float* Wq, const float* tb, int D, float* d_bq, float* d_Wq,
+                           float* d_tb, hipStream_t stream);
+int pfo_fold_parts_launch(const float* parts, int n_parts, int n, float* out, int accumulate, hipStream_t stream);

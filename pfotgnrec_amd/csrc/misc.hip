@@ -1,0 +1,186 @@
+// Error plumbing and the small element-wise kernels of the step: TimeEncode, BPR loss, Adam,
+// row scatter-add, the folded query-bias backward, partial-slab folds.
+#include "memory.hpp"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void pfo_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* pfo_last_error(void) { return g_err; }
+extern "C" int pfo_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------------------------
+__global__ void time_encode_kernel(const float* __restrict__ t, int64_t n, const float* __restrict__ w,
+                                   const float* __restrict__ b, int D, float* __restrict__ out) {
+  const int64_t total = n * D;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / D;
+    const int d = (int)(e - i * D);
+    out[e] = pfo_cosf(pfo_time_arg(t[i], w[d], b[d]));
+  }
+}
+extern "C" int pfo_time_encode(const float* t, int64_t n, const float* w, const float* b, int32_t D, float* out,
+                               void* stream) {
+  PFO_REQUIRE(n >= 0 && D > 0, "bad sizes");
+  if (n == 0) return PFO_OK;
+  PFO_REQUIRE(t && w && b && out, "null input");
+  const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div(n * D, 256));
+  hipLaunchKernelGGL(time_encode_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, t, n, w, b, (int)D, out);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BPR (main.py:321-337): one wavefront per interaction
+__global__ void bpr_kernel(const float* __restrict__ emb, int64_t B, int D, int64_t pos_off, int64_t neg_off, int n_neg,
+                           float scale, float* __restrict__ loss_part, float* __restrict__ d_emb) {
+  const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const float* s = emb + b * D;
+  const float* p = emb + (pos_off + b) * D;
+  float pos = 0.f;
+  for (int d = lane; d < D; d += 64) pos = fmaf(s[d], p[d], pos);
+  pos = pfo_wave_sum(pos);
+  float dsum = 0.f;
+  for (int k = 0; k < n_neg; ++k) {
+    const float* nk = emb + (neg_off + b * n_neg + k) * D;
+    float ns = 0.f;
+    for (int d = lane; d < D; d += 64) ns = fmaf(s[d], nk[d], ns);
+    dsum += pos - pfo_wave_sum(ns);                              // score_diff (main.py:334)
+  }
+  const float dm = dsum / (float)n_neg;                          // mean over negatives (main.py:335)
+  const float sg = 1.f / (1.f + expf(-dm));
+  if (lane == 0) loss_part[b] = -logf(sg);                       // log(sigmoid(.)) (main.py:336)
+  if (d_emb) {
+    const float ddm = -(1.f - sg) / (float)B * scale;
+    const float dneg = -ddm / (float)n_neg;
+    for (int d = lane; d < D; d += 64) {
+      float acc = ddm * p[d];
+      const float sd = s[d];
+      for (int k = 0; k < n_neg; ++k) {
+        const int64_t r = (neg_off + b * n_neg + k) * D + d;
+        acc = fmaf(dneg, emb[r], acc);
+        d_emb[r] = dneg * sd;
+      }
+      d_emb[b * D + d] = acc;
+      d_emb[(pos_off + b) * D + d] = ddm * sd;
+    }
+  }
+}
+__global__ void bpr_mean_kernel(const float* __restrict__ loss_part, int64_t B, float* __restrict__ loss_out) {
+  // single wavefront, fixed order: deterministic
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < B; i += 64) s += loss_part[i];
+  s = pfo_wave_sum(s);
+  if (threadIdx.x == 0) *loss_out = s / (float)B;
+}
+extern "C" int pfo_bpr_loss(const float* emb, int64_t B, int32_t D, int64_t pos_off, int64_t neg_off, int32_t n_neg,
+                            int64_t R, float scale, float* loss_out, float* d_emb, float* workspace, void* stream) {
+  PFO_REQUIRE(emb && loss_out && workspace, "null input");
+  PFO_REQUIRE(B > 0 && D > 0 && n_neg > 0, "bad sizes");
+  PFO_REQUIRE(pos_off >= B && pos_off + B <= R && neg_off + B * n_neg <= R && neg_off >= pos_off + B, "bad offsets");
+  hipStream_t s = (hipStream_t)stream;
+  if (d_emb) {
+    hipError_t e = hipMemsetAsync(d_emb, 0, (size_t)R * D * sizeof(float), s);
+    PFO_REQUIRE(e == hipSuccess, "memset failed");
+  }
+  hipLaunchKernelGGL(bpr_kernel, dim3((unsigned)pfo_ceil_div(B, 4)), dim3(256), 0, s, emb, B, (int)D, pos_off, neg_off,
+                     (int)n_neg, scale, workspace, d_emb);
+  hipLaunchKernelGGL(bpr_mean_kernel, dim3(1), dim3(64), 0, s, workspace, B, loss_out);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam, amsgrad off, weight_decay 0)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);            // lerp form used by torch
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+extern "C" int pfo_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                             float beta1, float beta2, float eps, int32_t step, void* stream) {
+  PFO_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const int nb = (int)std::min<int64_t>(2048, pfo_ceil_div(n, 256));
+  hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                     beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void scatter_add_rows_kernel(const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ idx,
+                                        int64_t n_rows, int D, float* __restrict__ dst, int64_t ld_dst) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < n_rows;
+       r += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const int t = idx[r];
+    if (t < 0) continue;
+    for (int d = lane; d < D; d += 64) atomicAdd(dst + (int64_t)t * ld_dst + d, src[r * ld_src + d]);
+  }
+}
+int pfo_scatter_add_rows_launch(const float* src, int64_t ld_src, const int32_t* idx, int64_t n_rows, int D, float* dst,
+                                int64_t ld_dst, hipStream_t stream) {
+  const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div(n_rows, 4));
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(nb), dim3(256), 0, stream, src, ld_src, idx, n_rows, D, dst, ld_dst);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+// one workgroup per time dimension d: d Wq[:, D+d] += gq * cos(b_d);  d tb[d] += -sin(b_d) * sum_e Wq[e, D+d] gq[e]
+__global__ __launch_bounds__(256) void cq_backward_kernel(const float* __restrict__ gq, const float* __restrict__ Wq,
+                                                          const float* __restrict__ tb, int D, float* __restrict__ d_bq,
+                                                          float* __restrict__ d_Wq, float* __restrict__ d_tb) {
+  __shared__ float s_part[4];
+  const int d = blockIdx.x, E = 2 * D;
+  float sb, cb;
+  pfo_sincosf(tb[d], sb, cb);                                     // query time feature is cos(fma(0, w, b)) = cos(b)
+  float part = 0.f;
+  for (int e = threadIdx.x; e < E; e += 256) {
+    const float g = gq[e];
+    d_Wq[(int64_t)e * E + D + d] += g * cb;
+    part = fmaf(Wq[(int64_t)e * E + D + d], g, part);
+    if (d == 0) d_bq[e] += g;
+  }
+  part = pfo_wave_sum(part);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) d_tb[d] += -sb * (s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+int pfo_cq_backward_launch(const float* gq, const float* Wq, const float* tb, int D, float* d_bq, float* d_Wq,
+                           float* d_tb, hipStream_t stream) {
+  hipLaunchKernelGGL(cq_backward_kernel, dim3(D), dim3(256), 0, stream, gq, Wq, tb, D, d_bq, d_Wq, d_tb);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+__global__ void fold_parts_kernel(const float* __restrict__ parts, int n_parts, int n, float* __restrict__ out,
+                                  int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int p = 0; p < n_parts; ++p) s += parts[(int64_t)p * n + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+int pfo_fold_parts_launch(const float* parts, int n_parts, int n, float* out, int accumulate, hipStream_t stream) {
+  hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)pfo_ceil_div(n, 256)), dim3(256), 0, stream, parts, n_parts, n, out,
+                     accumulate);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}

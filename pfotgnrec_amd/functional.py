@@ -1,0 +1,47 @@
+"""Autograd-facing wrappers of the small native ops (BPR loss, TimeEncode)."""
+import torch
+
+from . import _lib
+
+
+class _BprFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, B, pos_off, neg_off, n_neg, scale):
+        _lib.require_gpu(emb.device)
+        emb = emb.contiguous()
+        R, D = emb.shape
+        loss = torch.empty(1, dtype=torch.float32, device=emb.device)
+        d_emb = torch.empty_like(emb)
+        scratch = torch.empty(B, dtype=torch.float32, device=emb.device)
+        _lib.call("pfo_bpr_loss", emb.data_ptr(), B, D, pos_off, neg_off, n_neg, R, float(scale), loss.data_ptr(),
+                  d_emb.data_ptr(), scratch.data_ptr(), _lib.stream_ptr())
+        ctx.save_for_backward(d_emb)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_emb,) = ctx.saved_tensors
+        return d_emb * g, None, None, None, None, None
+
+
+def bpr_loss(emb, batch, n_neg, pos_block=1, grad_scale=1.0):
+    """BPR loss of main.py:321-337 / 364-381 on the root-ordered embedding matrix of ``TGN.embed_device``.
+
+    emb [R,D] = [src B | dst B | (p_pos B) | neg B*n_neg]; ``pos_block`` = 1 when the positive is the destination
+    (baseline path), 2 when it is the p_pos block (``ours`` path).  ``grad_scale`` multiplies the gradient only
+    (1/world_size under data parallelism so that summed gradients equal the global-batch mean).
+    """
+    pos_off = pos_block * batch
+    neg_off = (pos_block + 1) * batch
+    return _BprFn.apply(emb, batch, pos_off, neg_off, n_neg, grad_scale)
+
+
+def time_encode(t, weight, bias):
+    """cos(fma(t, w, b)) (model/time_encoding.py:17-25), forward only; t f32[...], returns [..., D]."""
+    _lib.require_gpu(t.device)
+    t = t.contiguous().float()
+    D = bias.shape[0]
+    out = torch.empty(t.shape + (D,), dtype=torch.float32, device=t.device)
+    _lib.call("pfo_time_encode", t.data_ptr(), t.numel(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
+              D, out.data_ptr(), _lib.stream_ptr())
+    return out

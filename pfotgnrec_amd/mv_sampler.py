@@ -1,0 +1,72 @@
+"""Mean-variance-efficient positive/negative selection - the inline block main.py:190-304 as a
+callable over the HIP kernel ``pfo_mv_select``.
+
+Setup (host, once): prices ``[day, item, 30]`` -> log-returns ``[day, item, 29]`` with the same
+``np.log(p[1:] / p[:-1])`` the reference applies per interaction (main.py:218,226-227), uploaded as
+fp64.  Per batch everything runs on the GPU: y_mv per candidate, average-tie ranks, lambda blend,
+canonical ordering (stable argsort reversed), top-p / bottom-q selection.
+"""
+import numpy as np
+
+from . import _lib
+
+
+def log_returns(prices):
+    prices = np.asarray(prices, np.float64)
+    return np.ascontiguousarray(np.log(prices[:, :, 1:] / prices[:, :, :-1]))
+
+
+def prices_from_time_feature(time_feature, map_item_id):
+    """The reference's ``time_feature[day_key][stock_code] -> 30 prices`` dict -> (sorted day keys, f64[day,item,30])."""
+    days = sorted(time_feature.keys())
+    n_items = len(map_item_id)
+    first = next(iter(time_feature[days[0]].values()))
+    arr = np.ones((len(days), n_items, len(first)), np.float64)
+    for d, key in enumerate(days):
+        for code, p in time_feature[key].items():
+            if code in map_item_id:
+                arr[d, map_item_id[code]] = p
+    return days, arr
+
+
+class MVSampler:
+    def __init__(self, prices, upper_u, device, gamma=2.0, lambda_mv=0.5, p_pos_num=1, p_neg_num=3, day_of=None):
+        import torch
+        _lib.require_gpu(device)
+        self.device = torch.device(device)
+        ret = log_returns(prices)
+        self.n_days, self.n_items, self.n_ret = ret.shape
+        self.returns = torch.from_numpy(ret).to(self.device)
+        self.upper_u = int(upper_u)
+        self.gamma, self.lambda_mv = float(gamma), float(lambda_mv)
+        self.p_pos_num, self.p_neg_num = int(p_pos_num), int(p_neg_num)
+        self.day_of = day_of
+
+    def select_device(self, day_idx, cand, port_idx, port_len, want_scores=False):
+        """day_idx i32[B]; cand i32[B,1+C] item node ids (col 0 = destination); port_idx i32[B,W]; port_len i32[B]."""
+        import torch
+        B, n_c = cand.shape
+        W = port_idx.shape[1] if port_idx.dim() == 2 else 0
+        p_pos = torch.empty((B, self.p_pos_num), dtype=torch.int32, device=self.device)
+        p_neg = torch.empty((B, self.p_neg_num), dtype=torch.int32, device=self.device)
+        y = torch.empty((B, n_c), dtype=torch.float64, device=self.device) if want_scores else None
+        nr = torch.empty((B, n_c), dtype=torch.float64, device=self.device) if want_scores else None
+        _lib.call("pfo_mv_select", _lib.ptr(self.returns), self.n_days, self.n_items, self.n_ret, _lib.ptr(day_idx),
+                  _lib.ptr(cand), n_c, _lib.ptr(port_idx), _lib.ptr(port_len), W, B, self.upper_u, self.gamma,
+                  self.lambda_mv, self.p_pos_num, self.p_neg_num, _lib.ptr(p_pos), _lib.ptr(p_neg), _lib.ptr(y),
+                  _lib.ptr(nr), _lib.stream_ptr())
+        return (p_pos, p_neg, y, nr) if want_scores else (p_pos, p_neg)
+
+    def select(self, destinations_batch, negatives_batch, timestamps_batch, port_idx, port_len, want_scores=False):
+        """Host-array entry mirroring main.py:207-304: returns flat i64 ``p_pos_batch`` / ``p_neg_batch`` node ids."""
+        import torch
+        dst = np.asarray(destinations_batch, np.int64).reshape(-1, 1)
+        cand = np.concatenate([dst, np.asarray(negatives_batch, np.int64)], 1).astype(np.int32)   # main.py:207
+        day = np.asarray(self.day_of(timestamps_batch), np.int64).astype(np.int32)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        out = self.select_device(t(day), t(cand), t(np.asarray(port_idx, np.int32)), t(np.asarray(port_len, np.int32)),
+                                 want_scores)
+        res = [o.cpu().numpy() for o in out]
+        res[0] = res[0].astype(np.int64).reshape(-1)
+        res[1] = res[1].astype(np.int64).reshape(-1)
+        return tuple(res)

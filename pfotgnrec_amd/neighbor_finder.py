@@ -1,0 +1,121 @@
+"""Temporal neighbour finder - host mirror of the reference's ``NeighborFinder`` /
+``get_neighbor_finder`` (utils/utils.py:117-219) over the HIP lookup kernel ``pfo_tnbr_sample``.
+
+The adjacency is a time-sorted CSR (``indptr i64[n+1]``, ``nbr i32``, ``eidx i32``, ``ts f64``)
+built once on the host and kept resident in HBM; every lookup runs on the GPU.  There is no CPU
+lookup path.
+"""
+import numpy as np
+
+from . import _lib
+
+
+def build_csr(sources, destinations, edge_idxs, timestamps, max_node_idx=None):
+    """Per-node adjacency, stable-sorted by timestamp (utils/utils.py:117-142).
+
+    Each edge contributes ``(dst, eidx, ts)`` to its source's row and ``(src, eidx, ts)`` to its
+    destination's row, in edge order; rows are sorted by timestamp with ties keeping that order
+    (the reference uses Python's stable ``sorted``).  One stable lexsort by (owner, ts) does it.
+    """
+    sources = np.asarray(sources, np.int64)
+    destinations = np.asarray(destinations, np.int64)
+    edge_idxs = np.asarray(edge_idxs, np.int64)
+    timestamps = np.asarray(timestamps, np.float64)
+    if not (len(sources) == len(destinations) == len(edge_idxs) == len(timestamps)):
+        raise ValueError("sources, destinations, edge_idxs and timestamps must have equal length")
+    if max_node_idx is None:
+        max_node_idx = int(max(sources.max(), destinations.max())) if len(sources) else 0
+    E = len(sources)
+    owner = np.empty(2 * E, np.int64)
+    other = np.empty(2 * E, np.int64)
+    owner[0::2], owner[1::2] = sources, destinations
+    other[0::2], other[1::2] = destinations, sources
+    eid = np.repeat(edge_idxs, 2)
+    ts = np.repeat(timestamps, 2)
+    order = np.lexsort((ts, owner))
+    counts = np.bincount(owner, minlength=max_node_idx + 1)
+    indptr = np.zeros(max_node_idx + 2, np.int64)
+    np.cumsum(counts, out=indptr[1:])
+    if E and (other.max() >= 2 ** 31 or eid.max() >= 2 ** 31):
+        raise ValueError("node / edge ids must fit in int32")
+    return indptr, other[order].astype(np.int32), eid[order].astype(np.int32), ts[order]
+
+
+class NeighborFinder:
+    """Drop-in for utils/utils.py:130.  ``adj_list`` is the reference's list of per-node
+    ``[(neighbor, edge_idx, timestamp), ...]`` lists; ``from_arrays`` skips that detour."""
+
+    def __init__(self, adj_list=None, uniform=False, seed=None, _csr=None):
+        if _csr is None:
+            owner, nbr, eidx, ts = [], [], [], []
+            for node, lst in enumerate(adj_list):
+                lst = sorted(lst, key=lambda x: x[2])
+                owner.extend([node] * len(lst))
+                nbr.extend(x[0] for x in lst)
+                eidx.extend(x[1] for x in lst)
+                ts.extend(x[2] for x in lst)
+            counts = np.bincount(np.asarray(owner, np.int64), minlength=len(adj_list))
+            indptr = np.zeros(len(adj_list) + 1, np.int64)
+            np.cumsum(counts, out=indptr[1:])
+            _csr = (indptr, np.asarray(nbr, np.int32), np.asarray(eidx, np.int32), np.asarray(ts, np.float64))
+        self.indptr, self.nbr, self.eidx, self.ts = _csr
+        self.n_nodes = len(self.indptr) - 1
+        self.uniform = uniform
+        self.seed = 0 if seed is None else int(seed)
+        self._calls = 0
+        self._dev = {}
+
+    @classmethod
+    def from_arrays(cls, sources, destinations, edge_idxs, timestamps, uniform=False, max_node_idx=None, seed=None):
+        return cls(uniform=uniform, seed=seed, _csr=build_csr(sources, destinations, edge_idxs, timestamps, max_node_idx))
+
+    def device_arrays(self, device):
+        """CSR tensors resident on ``device`` (uploaded once)."""
+        import torch
+        key = str(device)
+        if key not in self._dev:
+            _lib.require_gpu(device)
+            self._dev[key] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device)
+                                   for a in (self.indptr, self.nbr, self.eidx, self.ts))
+        return self._dev[key]
+
+    def next_stream_offset(self):
+        self._calls += 1
+        return self._calls << 20
+
+    def get_temporal_neighbor(self, source_nodes, timestamps, n_neighbors=20, draws=None, device=None):
+        """utils/utils.py:163-219 -> (neighbors i32[N,K], edge_idxs i32[N,K], edge_times f32[N,K]) numpy.
+
+        Most-recent mode is index-exact with the reference.  Uniform mode draws with Philox unless
+        ``draws`` (i64[N,K] positions into each query's history, the reference's ``sampled_idx``) is given.
+        """
+        import torch
+        assert len(source_nodes) == len(timestamps)
+        _lib.require_gpu(device)
+        device = torch.device("cuda") if device is None else torch.device(device)
+        N = len(source_nodes)
+        K = n_neighbors if n_neighbors > 0 else 1
+        if n_neighbors <= 0 or N == 0:                      # utils.py:175: one all-padding column
+            return (np.zeros((N, K), np.int32), np.zeros((N, K), np.int32), np.zeros((N, K), np.float32))
+        indptr, nbr, eidx, ts = self.device_arrays(device)
+        q_nodes = torch.from_numpy(np.ascontiguousarray(source_nodes, dtype=np.int64).astype(np.int32)).to(device)
+        q_ts = torch.from_numpy(np.ascontiguousarray(timestamps, dtype=np.float64)).to(device)
+        o_nbr = torch.empty((N, K), dtype=torch.int32, device=device)
+        o_eidx = torch.empty((N, K), dtype=torch.int32, device=device)
+        o_et = torch.empty((N, K), dtype=torch.float32, device=device)
+        mode, d_draws = 0, None
+        if self.uniform:
+            mode = 2
+            if draws is not None:
+                mode = 1
+                d_draws = torch.from_numpy(np.ascontiguousarray(draws, dtype=np.int64)).to(device)
+        _lib.call("pfo_tnbr_sample", _lib.ptr(indptr), _lib.ptr(nbr), _lib.ptr(eidx), _lib.ptr(ts), self.n_nodes,
+                  _lib.ptr(q_nodes), _lib.ptr(q_ts), N, K, mode, _lib.ptr(d_draws), self.seed, self.next_stream_offset(),
+                  _lib.ptr(o_nbr), _lib.ptr(o_eidx), _lib.ptr(o_et), None, None, None, _lib.stream_ptr())
+        return o_nbr.cpu().numpy(), o_eidx.cpu().numpy(), o_et.cpu().numpy()
+
+
+def get_neighbor_finder(data, uniform, max_node_idx=None):
+    """utils/utils.py:117-127."""
+    return NeighborFinder.from_arrays(data.sources, data.destinations, data.edge_idxs, data.timestamps,
+                                      uniform=uniform, max_node_idx=max_node_idx)

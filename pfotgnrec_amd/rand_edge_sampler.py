@@ -1,0 +1,87 @@
+"""Candidate-negative draw - host mirror of ``RandEdgeSampler`` (utils/utils.py:65-114) over the
+HIP kernel ``pfo_neg_draw``.  Draws are Philox-based: the SET semantics of the reference are kept
+(never an item of the user's portfolio, only items seen among the train destinations, without
+replacement when enough are available), the MT19937 stream is not.
+"""
+import numpy as np
+
+from . import _lib
+
+_AVAIL_CACHE = {}
+_GLOBAL_CALLS = [0]
+
+
+def item_availability(dst_list, upper_u, n_items):
+    """u8[n_items]: 1 where the item occurs in ``dst_list`` (np.unique(dst_list), utils/utils.py:73)."""
+    avail = np.zeros(n_items, np.uint8)
+    idx = np.asarray(dst_list, np.int64) - (upper_u + 1)
+    idx = idx[(idx >= 0) & (idx < n_items)]
+    avail[idx] = 1
+    return avail
+
+
+def pack_portfolios(portfolio_list, map_item_id, width=None):
+    """List of stock-code lists -> (i32[B,width] item indices padded with -1, i32[B] lengths); '' dropped (:76)."""
+    rows = [[map_item_id[c] for c in sub if c] for sub in portfolio_list]
+    if width is None:
+        width = max(1, max((len(r) for r in rows), default=1))
+    out = np.full((len(rows), width), -1, np.int32)
+    lens = np.zeros(len(rows), np.int32)
+    for i, r in enumerate(rows):
+        out[i, :len(r)] = r
+        lens[i] = len(r)
+    return out, lens
+
+
+class DeviceNegativeSampler:
+    """Device-resident form: availability bitmap uploaded once, portfolios passed as packed tensors."""
+
+    def __init__(self, item_avail, upper_u, device, seed=0):
+        import torch
+        _lib.require_gpu(device)
+        self.device = torch.device(device)
+        self.n_items = len(item_avail)
+        self.upper_u = int(upper_u)
+        self.avail = torch.from_numpy(np.ascontiguousarray(item_avail, np.uint8)).to(self.device)
+        self.seed = int(seed)
+
+    def sample(self, port_idx, port_len, size, offset):
+        """port_idx i32[B,W], port_len i32[B] device tensors -> i32[B,size] item node ids (device)."""
+        import torch
+        B = port_len.shape[0]
+        W = port_idx.shape[1] if port_idx.dim() == 2 else 0
+        out = torch.empty((B, size), dtype=torch.int32, device=self.device)
+        _lib.call("pfo_neg_draw", _lib.ptr(self.avail), self.n_items, _lib.ptr(port_idx), _lib.ptr(port_len), W, B,
+                  size, self.upper_u, self.seed, int(offset), _lib.ptr(out), _lib.stream_ptr())
+        return out
+
+
+class RandEdgeSampler:
+    """Drop-in for utils/utils.py:65 (constructed per batch by main.py:194,347 / evaluation.py:88)."""
+
+    def __init__(self, src_list, dst_list, portfolio_list, upper_u, map_item_id, seed=None, device=None):
+        self.src_list = src_list
+        self.upper_u = int(upper_u)
+        self.n_items = len(map_item_id)
+        key = (id(dst_list), len(dst_list), self.upper_u, self.n_items)
+        if key not in _AVAIL_CACHE:                    # the reference re-runs np.unique every batch; same result
+            _AVAIL_CACHE.clear()
+            _AVAIL_CACHE[key] = item_availability(dst_list, self.upper_u, self.n_items)
+        self.item_avail = _AVAIL_CACHE[key]
+        self.port_idx, self.port_len = pack_portfolios(portfolio_list, map_item_id)
+        self.seed = seed
+        self.device = device
+
+    def sample(self, size):
+        import torch
+        _lib.require_gpu(self.device)
+        device = torch.device("cuda") if self.device is None else torch.device(self.device)
+        if self.seed is None:                          # training: a fresh stream every call (utils.py:105,111)
+            _GLOBAL_CALLS[0] += 1
+            seed, offset = 0x5EED, _GLOBAL_CALLS[0] << 24
+        else:                                          # evaluation: same negatives on every run (utils.py:82-84)
+            seed, offset = int(self.seed), 0
+        dev = DeviceNegativeSampler(self.item_avail, self.upper_u, device, seed)
+        pi = torch.from_numpy(self.port_idx).to(device)
+        pl = torch.from_numpy(self.port_len).to(device)
+        return dev.sample(pi, pl, size, offset).cpu().numpy().astype(np.int64)

@@ -1,0 +1,408 @@
+"""TGN facade - drop-in for the reference's ``model/tgn.py`` on the training path.
+
+Same constructor and the same two entry points ``main.py`` / ``evaluation.py`` use
+(``compute_temporal_embeddings`` tgn.py:219, ``compute_temporal_embeddings_p`` tgn.py:102), same
+parameter names in ``state_dict()``; underneath, one flat fp32 parameter buffer in HBM and three
+native calls per step (``pfo_tgn_forward`` / ``pfo_tgn_update_state`` / ``pfo_tgn_backward``).
+PyTorch supplies device memory, the autograd hand-off and the optimizer interface - no torch op
+runs on the hot path.  Without a HIP device every compute method raises; there is no CPU path.
+
+Supported (what the training path of main.py:106-121 selects): ``embedding_module_type =
+"graph_attention"``, ``message_function = "identity"``, ``aggregator_type = "last"``,
+``memory_updater_type = "gru"``, ``use_memory`` True (TGN / ours) or False (TGAT, main.py:70-74).
+Other enum values raise ``ValueError`` like the reference's factories do for unknown names.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .memory import Memory
+
+
+class _Holder(nn.Module):
+    """Bare container used to reproduce the reference's parameter names."""
+
+
+def _normalise_edge_features(edge_features):
+    # tgn.py:38-41: fp32 z-score per column, the padding row 0 included
+    ef = np.asarray(edge_features).astype(np.float32)
+    ef -= ef.mean(axis=0)
+    ef /= ef.std(axis=0)
+    return ef.astype(np.float32)
+
+
+class _Call:
+    """Everything one forward/backward pair of native calls needs to agree on."""
+    __slots__ = ("roots", "root_ts", "R", "K", "mode", "draws", "draw_ptrs", "seed", "offset", "dropout_p", "training",
+                 "extra", "batch_struct")
+
+
+class _EmbedFn(torch.autograd.Function):
+    """Autograd bridge: forward = native forward (+ state update), backward = native backward.
+
+    Parameter gradients are accumulated by the native call straight into the flat gradient buffer
+    that every ``p.grad`` is a view of, so ``None`` is returned for the parameter inputs.
+    """
+
+    @staticmethod
+    def forward(ctx, tgn, call, post, *params):
+        emb = tgn._native_forward(call)
+        if post is not None:
+            post()
+        ctx.tgn, ctx.call, ctx.n_params = tgn, call, len(params)
+        return emb
+
+    @staticmethod
+    def backward(ctx, d_emb):
+        ctx.tgn._native_backward(ctx.call, d_emb.contiguous())
+        return (None, None, None) + (None,) * ctx.n_params
+
+
+class TGN(nn.Module):
+    def __init__(self, neighbor_finder, node_features, edge_features, device, n_layers=2, n_heads=2, dropout=0.1,
+                 use_memory=False, memory_update_at_start=True, message_dimension=100, memory_dimension=500,
+                 embedding_module_type="graph_attention", message_function="mlp", mean_time_shift_src=0,
+                 std_time_shift_src=1, mean_time_shift_dst=0, std_time_shift_dst=1, n_neighbors=None,
+                 aggregator_type="last", memory_updater_type="gru", use_destination_embedding_in_message=False,
+                 use_source_embedding_in_message=False, dyrep=False):
+        super().__init__()
+        if embedding_module_type != "graph_attention":
+            raise ValueError("Embedding Module {} not supported".format(embedding_module_type))
+        if use_memory:
+            if message_function != "identity":
+                raise ValueError("Message function {} not supported (identity only)".format(message_function))
+            if aggregator_type != "last":
+                raise ValueError("Message aggregator {} not implemented".format(aggregator_type))
+            if memory_updater_type != "gru":
+                raise ValueError("Memory updater {} not supported (gru only)".format(memory_updater_type))
+            if not memory_update_at_start:
+                raise ValueError("memory_update_at_start=False is not supported")
+        if dyrep or use_destination_embedding_in_message or use_source_embedding_in_message:
+            raise ValueError("dyrep / embedding-in-message variants are not supported")
+
+        self.device = torch.device(device)
+        self.n_layers, self.n_heads, self.dropout = int(n_layers), int(n_heads), float(dropout)
+        self.use_memory = bool(use_memory)
+        self.memory_update_at_start = True
+        self.n_neighbors = n_neighbors
+        self.embedding_module_type = embedding_module_type
+        self.dyrep = False
+        self.mean_time_shift_src, self.std_time_shift_src = mean_time_shift_src, std_time_shift_src
+        self.mean_time_shift_dst, self.std_time_shift_dst = mean_time_shift_dst, std_time_shift_dst
+
+        self.node_raw_features = torch.from_numpy(np.asarray(node_features).astype(np.float32)).to(self.device).contiguous()
+        self.edge_raw_features = torch.from_numpy(_normalise_edge_features(edge_features)).to(self.device).contiguous()
+        self.n_nodes, self.n_node_features = self.node_raw_features.shape
+        self.n_edge_features = self.edge_raw_features.shape[1]
+        self.embedding_dimension = self.n_node_features
+        D, Ef = self.n_node_features, self.n_edge_features
+        if self.use_memory and memory_dimension != D:
+            raise ValueError("memory_dimension must equal the node-feature dimension (embedding_module.py:98)")
+        self.memory_dimension = D
+
+        self._cfg = _lib.TgnConfig(self.n_nodes, self.edge_raw_features.shape[0], D, Ef, self.n_layers, self.n_heads,
+                                   int(self.use_memory), 1, 1, 1)
+        self._layout = _lib.TgnLayout()
+        _lib.call("pfo_tgn_param_layout", ctypes.byref(self._cfg), ctypes.byref(self._layout))
+        self._flat = torch.zeros(self._layout.total, dtype=torch.float32, device=self.device)
+        self._flat_grad = None
+        self._views = []          # (parameter, offset, numel, shape)
+        self._ws = None
+        self._ws_caps = (0, 0, 0)
+        self._step = 0
+        self.seed = 0
+        self.dp_rank, self.dp_world = 0, 1
+
+        E, C, M = 2 * D, 2 * D + Ef, 3 * D + Ef
+        lay = self._layout
+        self.time_encoder = _Holder()
+        self.time_encoder.dimension = D
+        self.time_encoder.w = _Holder()
+        self._register(self.time_encoder.w, "weight", lay.time_w, (D, 1))
+        self._register(self.time_encoder.w, "bias", lay.time_b, (D,))
+
+        self.memory = None
+        if self.use_memory:
+            self.memory = Memory(n_nodes=self.n_nodes, memory_dimension=D, input_dimension=M, message_dimension=M,
+                                 device=self.device)
+            self.memory_updater = _Holder()
+            self.memory_updater.layer_norm = nn.LayerNorm(D).to(self.device)     # constructed, never applied (memory_updater.py:14)
+            self.memory_updater.memory_updater = _Holder()
+            gru = self.memory_updater.memory_updater
+            self._register(gru, "weight_ih", lay.gru_w_ih, (3 * D, M))
+            self._register(gru, "weight_hh", lay.gru_w_hh, (3 * D, D))
+            self._register(gru, "bias_ih", lay.gru_b_ih, (3 * D,))
+            self._register(gru, "bias_hh", lay.gru_b_hh, (3 * D,))
+
+        self.embedding_module = _Holder()
+        self.embedding_module.neighbor_finder = neighbor_finder       # main.py:427 assigns this attribute directly
+        self.embedding_module.attention_models = nn.ModuleList()
+        for l in range(self.n_layers):
+            q = lay.layer[l]
+            att = _Holder()
+            att.multi_head_target = _Holder()
+            mha = att.multi_head_target
+            self._register(mha, "q_proj_weight", q.wq, (E, E))
+            self._register(mha, "k_proj_weight", q.wk, (E, C))
+            self._register(mha, "v_proj_weight", q.wv, (E, C))
+            self._register(mha, "in_proj_bias", q.b_in, (3 * E,))
+            mha.out_proj = _Holder()
+            self._register(mha.out_proj, "weight", q.wo, (E, E))
+            self._register(mha.out_proj, "bias", q.bo, (E,))
+            att.merger = _Holder()
+            att.merger.fc1, att.merger.fc2 = _Holder(), _Holder()
+            self._register(att.merger.fc1, "weight", q.w1, (D, E + D))
+            self._register(att.merger.fc1, "bias", q.b1, (D,))
+            self._register(att.merger.fc2, "weight", q.w2, (D, D))
+            self._register(att.merger.fc2, "bias", q.b2, (D,))
+            self.embedding_module.attention_models.append(att)
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------ parameters
+    def _register(self, module, name, offset, shape):
+        n = int(np.prod(shape))
+        p = nn.Parameter(self._flat[offset:offset + n].view(shape))
+        module.register_parameter(name, p)
+        self._views.append((p, int(offset), n, tuple(shape)))
+
+    def reset_parameters(self):
+        """The reference's initialisers: TimeEncode (time_encoding.py:13-15), nn.GRUCell, nn.MultiheadAttention
+        (xavier-uniform in-projections, zero biases), MergeLayer xavier-normal (utils.py:11-12)."""
+        D = self.n_node_features
+        with torch.no_grad():
+            te = self.time_encoder.w
+            te.weight.copy_(torch.from_numpy((1 / 10 ** np.linspace(0, 9, D)).astype(np.float32)).reshape(D, 1))
+            te.bias.zero_()
+            if self.use_memory:
+                k = 1.0 / math.sqrt(D)
+                for p in self.memory_updater.memory_updater.parameters():
+                    p.uniform_(-k, k)
+            for att in self.embedding_module.attention_models:
+                mha = att.multi_head_target
+                for w in (mha.q_proj_weight, mha.k_proj_weight, mha.v_proj_weight):
+                    nn.init.xavier_uniform_(w)
+                mha.in_proj_bias.zero_()
+                nn.init.kaiming_uniform_(mha.out_proj.weight, a=math.sqrt(5))
+                mha.out_proj.bias.zero_()
+                for fc in (att.merger.fc1, att.merger.fc2):
+                    nn.init.xavier_normal_(fc.weight)
+                    bound = 1.0 / math.sqrt(fc.weight.shape[1])
+                    fc.bias.uniform_(-bound, bound)
+
+    def hot_parameters(self):
+        return [v[0] for v in self._views]
+
+    @property
+    def flat_parameters(self):
+        return self._flat
+
+    @property
+    def flat_grad(self):
+        return self._flat_grad
+
+    def _apply(self, fn, recurse=True):
+        new_flat = fn(self._flat)
+        if new_flat.dtype != torch.float32:
+            raise TypeError("the native path is fp32 only (1e-4 parity bar)")
+        self._flat = new_flat.contiguous()
+        self._flat_grad = None
+        for p, off, n, shape in self._views:
+            p.data = self._flat[off:off + n].view(shape)
+            p.grad = None
+        self.node_raw_features = fn(self.node_raw_features).contiguous()
+        self.edge_raw_features = fn(self.edge_raw_features).contiguous()
+        if self.use_memory:
+            mem = self.memory
+            with torch.no_grad():
+                mem.memory.data = fn(mem.memory.data)
+                mem.last_update.data = fn(mem.last_update.data)
+            mem.msg_table, mem.msg_time, mem.has_msg = fn(mem.msg_table), fn(mem.msg_time), mem.has_msg.to(self._flat.device)
+            mem.device = self._flat.device
+            self.memory_updater.layer_norm._apply(fn)
+        self.device = self._flat.device
+        self._ws = None
+        return self
+
+    # ------------------------------------------------------------------ neighbour finder plumbing
+    @property
+    def neighbor_finder(self):
+        return self.embedding_module.neighbor_finder
+
+    @neighbor_finder.setter
+    def neighbor_finder(self, nf):
+        self.embedding_module.neighbor_finder = nf
+
+    def set_neighbor_finder(self, neighbor_finder):
+        """tgn.py:380-382."""
+        self.embedding_module.neighbor_finder = neighbor_finder
+
+    def set_data_parallel(self, rank, world_size):
+        """Edge-batch data parallelism: this rank embeds interactions [rank*B/W, (rank+1)*B/W)."""
+        self.dp_rank, self.dp_world = int(rank), int(world_size)
+
+    # ------------------------------------------------------------------ native plumbing
+    def _ensure_workspace(self, R, K, B):
+        cr, ck, cb = self._ws_caps
+        if self._ws is None or R > cr or K > ck or B > cb:
+            cr, ck, cb = max(cr, R), max(ck, K), max(cb, B)
+            self._cfg.max_roots, self._cfg.max_neighbors, self._cfg.max_batch = cr, ck, cb
+            nbytes = _lib.load().pfo_tgn_workspace_bytes(ctypes.byref(self._cfg))
+            if nbytes < 0:
+                raise _lib.PfoError("pfo_tgn_workspace_bytes: %s" % _lib.load().pfo_last_error().decode())
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_caps = (cr, ck, cb)
+        return self._ws
+
+    def _state_struct(self):
+        indptr, nbr, eidx, ts = self.neighbor_finder.device_arrays(self.device)
+        self._keepalive = (indptr, nbr, eidx, ts)
+        mem = self.memory
+        return _lib.TgnState(indptr.data_ptr(), nbr.data_ptr(), eidx.data_ptr(), ts.data_ptr(),
+                             self.node_raw_features.data_ptr(), self.edge_raw_features.data_ptr(),
+                             mem.memory.data_ptr() if mem is not None else None,
+                             mem.last_update.data_ptr() if mem is not None else None,
+                             mem.msg_table.data_ptr() if mem is not None else None,
+                             mem.msg_time.data_ptr() if mem is not None else None,
+                             mem.has_msg.data_ptr() if mem is not None else None, self._flat.data_ptr())
+
+    def _make_call(self, roots, root_ts, K, draws, training, extra):
+        c = _Call()
+        c.roots, c.root_ts, c.R, c.K = roots, root_ts, int(roots.shape[0]), int(K)
+        uniform = bool(getattr(self.neighbor_finder, "uniform", False))
+        c.mode = 0 if not uniform else (1 if draws is not None else 2)
+        c.draws = draws
+        c.draw_ptrs = None
+        if draws is not None:
+            if len(draws) != self.n_layers:
+                raise ValueError("uniform mode with injected draws needs one index tensor per layer")
+            c.draw_ptrs = (ctypes.c_void_p * self.n_layers)(*[d.data_ptr() for d in draws])
+        self._step += 1
+        c.seed = self.seed + getattr(self.neighbor_finder, "seed", 0)
+        c.offset = self._step << 36
+        c.training = int(training)
+        c.dropout_p = self.dropout if training else 0.0
+        c.extra = extra
+        c.batch_struct = _lib.TgnBatch(roots.data_ptr(), root_ts.data_ptr(), c.R, c.K, c.mode,
+                                       ctypes.cast(c.draw_ptrs, ctypes.POINTER(ctypes.c_void_p)) if c.draw_ptrs else None,
+                                       c.seed, c.offset, c.dropout_p, c.training,
+                                       extra.data_ptr() if extra is not None else None,
+                                       int(extra.shape[0]) if extra is not None else 0)
+        return c
+
+    def _native_forward(self, call):
+        _lib.require_gpu(self.device)
+        ws = self._ensure_workspace(call.R, call.K, self._cur_batch)
+        st = self._state_struct()
+        emb = torch.empty((call.R, self.n_node_features), dtype=torch.float32, device=self.device)
+        _lib.call("pfo_tgn_forward", ctypes.byref(self._cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
+                  ws.data_ptr(), emb.data_ptr(), _lib.stream_ptr())
+        return emb
+
+    def _attach_grads(self):
+        if self._flat_grad is None:
+            self._flat_grad = torch.zeros_like(self._flat)
+        if any(p.grad is None for p, _, _, _ in self._views):
+            self._flat_grad.zero_()
+            for p, off, n, shape in self._views:
+                p.grad = self._flat_grad[off:off + n].view(shape)
+
+    def _native_backward(self, call, d_emb):
+        self._attach_grads()
+        st = self._state_struct()
+        _lib.call("pfo_tgn_backward", ctypes.byref(self._cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
+                  self._ws.data_ptr(), d_emb.data_ptr(), self._flat_grad.data_ptr(), _lib.stream_ptr())
+
+    def _native_update_state(self, src, dst, ts, eidx):
+        st = self._state_struct()
+        _lib.call("pfo_tgn_update_state", ctypes.byref(self._cfg), ctypes.byref(st), src.data_ptr(), dst.data_ptr(),
+                  ts.data_ptr(), eidx.data_ptr(), int(src.shape[0]), self._ws.data_ptr(), _lib.stream_ptr())
+
+    # ------------------------------------------------------------------ the step
+    def embed_device(self, src, dst, extra_roots, extra_repeat, edge_times, edge_idxs, n_neighbors, draws=None):
+        """Device-resident core of both reference entry points.
+
+        src/dst i32[B], edge_times f64[B], edge_idxs i32[B], extra_roots: list of i32 tensors [B*r_k] (negatives /
+        p_pos / p_neg, row-major per interaction) with repeat counts ``extra_repeat``; all on ``self.device``.
+        Returns the embedding matrix [R, D] in the order [src | dst | extra...] for THIS rank's shard of the batch,
+        and performs the memory persist + raw-message store for the whole batch (tgn.py:290-317).
+        """
+        _lib.require_gpu(self.device)
+        B = int(src.shape[0])
+        K = int(n_neighbors)
+        lo, hi = 0, B
+        if self.dp_world > 1:
+            per = (B + self.dp_world - 1) // self.dp_world
+            lo, hi = min(B, self.dp_rank * per), min(B, (self.dp_rank + 1) * per)
+        parts, ts_parts = [src[lo:hi], dst[lo:hi]], [edge_times[lo:hi], edge_times[lo:hi]]
+        for t, r in zip(extra_roots, extra_repeat):
+            parts.append(t.view(B, r)[lo:hi].reshape(-1))
+            ts_parts.append(edge_times[lo:hi].repeat_interleave(r))          # tgn.py:123-124 / 238-239
+        roots = torch.cat(parts).contiguous()
+        root_ts = torch.cat(ts_parts).contiguous()
+        if K <= 0:                       # utils.py:175: a single all-padding column
+            K, root_ts = 1, torch.full_like(root_ts, -1.0)
+        training = self.training and torch.is_grad_enabled()
+        extra = torch.cat([src, dst]).contiguous() if (self.use_memory and self.dp_world > 1) else None
+        call = self._make_call(roots, root_ts, K, draws, training, extra)
+        self._cur_batch = B
+        post = None
+        if self.use_memory:
+            post = lambda: self._native_update_state(src, dst, edge_times, edge_idxs)
+        if training:
+            emb = _EmbedFn.apply(self, call, post, *self.hot_parameters())
+        else:
+            emb = self._native_forward(call)
+            if post is not None:
+                post()
+        return emb, hi - lo
+
+    def _to_dev(self, a, dtype):
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=dtype)).to(self.device)
+
+    def compute_temporal_embeddings(self, source_nodes, destination_nodes, p_neg_nodes, edge_times, edge_idxs,
+                                    n_neighbors=20, draws=None):
+        """tgn.py:219-327.  numpy in (i64, i64, i64 flat row-major, f64, i64), device tensors out:
+        (src_emb [B,D], dst_emb [B,D], neg_emb [B*size,D])."""
+        B = len(source_nodes)
+        size = int(len(p_neg_nodes) / B)                                        # tgn.py:237
+        src, dst = self._to_dev(source_nodes, np.int32), self._to_dev(destination_nodes, np.int32)
+        neg = self._to_dev(p_neg_nodes, np.int32)
+        ts, eidx = self._to_dev(edge_times, np.float64), self._to_dev(edge_idxs, np.int32)
+        emb, b = self.embed_device(src, dst, [neg], [size], ts, eidx, n_neighbors, self._dev_draws(draws))
+        return emb[:b], emb[b:2 * b], emb[2 * b:]
+
+    def compute_temporal_embeddings_p(self, source_nodes, destination_nodes, p_pos_nodes, p_neg_nodes, edge_times,
+                                      edge_idxs, n_neighbors=20, draws=None):
+        """tgn.py:102-217: (src_emb, dst_emb, p_pos_emb [B*p,D], p_neg_emb [B*q,D])."""
+        B = len(source_nodes)
+        n_pos, n_neg = int(p_pos_nodes.shape[0] / B), int(p_neg_nodes.shape[0] / B)   # tgn.py:118-119
+        src, dst = self._to_dev(source_nodes, np.int32), self._to_dev(destination_nodes, np.int32)
+        pp, pn = self._to_dev(p_pos_nodes, np.int32), self._to_dev(p_neg_nodes, np.int32)
+        ts, eidx = self._to_dev(edge_times, np.float64), self._to_dev(edge_idxs, np.int32)
+        emb, b = self.embed_device(src, dst, [pp, pn], [n_pos, n_neg], ts, eidx, n_neighbors, self._dev_draws(draws))
+        return emb[:b], emb[b:2 * b], emb[2 * b:(2 + n_pos) * b], emb[(2 + n_pos) * b:]
+
+    def _dev_draws(self, draws):
+        if draws is None:
+            return None
+        return [self._to_dev(d, np.int64) for d in draws]
+
+    # ------------------------------------------------------------------ introspection for tests
+    def debug_touched(self):
+        """(touched node ids, layer-0 feature table rows) of the last forward (use_memory only)."""
+        dbg = _lib.TgnDebug()
+        _lib.call("pfo_tgn_debug_views", ctypes.byref(self._cfg), self._ws.data_ptr(), ctypes.byref(dbg))
+        base = self._ws.data_ptr()
+
+        def view(ptr, count, dtype):
+            off = ptr - base
+            return self._ws[off:off + count * torch.empty((), dtype=dtype).element_size()].view(dtype)
+        n = int(view(dbg.n_touched, 1, torch.int32).item())
+        ids = view(dbg.touched_ids, n, torch.int32).clone()
+        h0 = view(dbg.h0_table, n * self.n_node_features, torch.float32).view(n, -1).clone()
+        return ids, h0

@@ -1,0 +1,99 @@
+"""CPU tests of the host-side mirrors: CSR build, portfolio packing, state_dict naming, unsupported options."""
+import numpy as np
+import pytest
+
+import pfotgnrec_amd as P
+from pfotgnrec_amd.neighbor_finder import build_csr
+from pfotgnrec_amd.rand_edge_sampler import item_availability, pack_portfolios
+from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph, CONFIGS
+from conftest import load_golden
+from oracle.neighbor_finder import build_adjacency
+
+
+def test_csr_build_matches_oracle_on_golden_graphs():
+    g = load_golden("g1_sampler")
+    for p in ("a", "b"):
+        got = build_csr(g[p + "_src"], g[p + "_dst"], g[p + "_eidx"], g[p + "_ts"])
+        ref = build_adjacency(g[p + "_src"], g[p + "_dst"], g[p + "_eidx"], g[p + "_ts"])
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b)
+        assert got[1].dtype == np.int32 and got[3].dtype == np.float64
+
+
+def test_adj_list_constructor_equals_array_constructor():
+    g = make_graph(SyntheticConfig("t", 30, 8, 300, 8, 1, 4, 2), with_prices=False)
+    d = g.data
+    adj = [[] for _ in range(g.n_nodes)]
+    for s, t, e, ts in zip(d.sources, d.destinations, d.edge_idxs, d.timestamps):       # utils/utils.py:119-125
+        adj[s].append((t, e, ts)); adj[t].append((s, e, ts))
+    a = P.NeighborFinder(adj)
+    b = P.get_neighbor_finder(d, False, max_node_idx=g.n_nodes - 1)
+    for x, y in zip((a.indptr, a.nbr, a.eidx, a.ts), (b.indptr, b.nbr, b.eidx, b.ts)):
+        assert np.array_equal(x, y)
+
+
+def test_portfolio_packing_drops_empty_code():
+    m = {"000001": 0, "000002": 1, "000003": 2}
+    idx, ln = pack_portfolios([[""], ["000003", "000001"], ["000002"]], m)
+    assert ln.tolist() == [0, 2, 1] and idx[1, :2].tolist() == [2, 0] and idx[0, 0] == -1
+    av = item_availability(np.array([12, 10, 10]), 9, 3)
+    assert av.tolist() == [1, 0, 1]
+
+
+def test_state_dict_uses_reference_names():
+    g = make_graph(SyntheticConfig("t", 30, 8, 300, 16, 2, 4, 2), with_prices=False)
+    tgn = P.TGN(P.get_neighbor_finder(g.data, False), g.node_features, g.edge_features, "cpu", n_layers=2, n_heads=2,
+                use_memory=True, memory_dimension=16, message_function="identity")
+    ref = load_golden("g5_step_L2_mem")
+    ref_names = {k[len("s2_sd_"):] for k in ref.files if k.startswith("s2_sd_")}
+    assert ref_names <= set(tgn.state_dict().keys())
+    for k in ref_names:
+        if not k.startswith("memory."):              # memory tables are sized by the graph
+            assert tuple(tgn.state_dict()[k].shape) == ref["s2_sd_" + k].shape, k
+    # parameters are views of ONE flat buffer (single all-reduce, single Adam kernel)
+    flat = tgn.flat_parameters
+    for p in tgn.hot_parameters():
+        assert p.data_ptr() >= flat.data_ptr() and p.data_ptr() < flat.data_ptr() + flat.numel() * 4
+    # time-encoder initialisation (time_encoding.py:13-15)
+    assert np.allclose(tgn.time_encoder.w.weight.detach().numpy().ravel(), 1 / 10 ** np.linspace(0, 9, 16), rtol=1e-6)
+
+
+def test_unsupported_options_raise_like_the_reference_factories():
+    g = make_graph(SyntheticConfig("t", 30, 8, 300, 8, 1, 4, 2), with_prices=False)
+    nf = P.get_neighbor_finder(g.data, False)
+    with pytest.raises(ValueError):
+        P.TGN(nf, g.node_features, g.edge_features, "cpu", embedding_module_type="graph_sum")
+    with pytest.raises(ValueError):
+        P.TGN(nf, g.node_features, g.edge_features, "cpu", use_memory=True, memory_dimension=8, message_function="identity",
+              aggregator_type="mean")
+    with pytest.raises(ValueError):
+        P.TGN(nf, g.node_features, g.edge_features, "cpu", use_memory=True, memory_dimension=8, message_function="identity",
+              memory_updater_type="rnn")
+
+
+def test_neighbor_finder_attribute_paths():
+    """main.py:156/405 use set_neighbor_finder, main.py:427 assigns embedding_module.neighbor_finder directly."""
+    g = make_graph(SyntheticConfig("t", 30, 8, 300, 8, 1, 4, 2), with_prices=False)
+    a, b = P.get_neighbor_finder(g.data, False), P.get_neighbor_finder(g.data, True)
+    tgn = P.TGN(a, g.node_features, g.edge_features, "cpu", n_layers=1, use_memory=False)
+    assert tgn.neighbor_finder is a
+    tgn.set_neighbor_finder(b)
+    assert tgn.neighbor_finder is b and tgn.embedding_module.neighbor_finder is b
+    tgn.embedding_module.neighbor_finder = a
+    assert tgn.neighbor_finder is a
+
+
+def test_time_statistics_match_reference_loop():
+    g = make_graph(SyntheticConfig("t", 30, 8, 500, 8, 1, 4, 2), with_prices=False)
+    d = g.data
+    last_s, last_d, gs, gd = {}, {}, [], []
+    for s, t, ts in zip(d.sources, d.destinations, d.timestamps):                      # utils/data.py:75-99
+        gs.append(ts - last_s.get(s, 0)); gd.append(ts - last_d.get(t, 0)); last_s[s] = ts; last_d[t] = ts
+    got = P.compute_time_statistics(d.sources, d.destinations, d.timestamps)
+    assert np.allclose(got, (np.mean(gs), np.std(gs), np.mean(gd), np.std(gd)))
+
+
+def test_synthetic_configs_match_baseline_json():
+    c2 = CONFIGS["C2"]
+    assert (c2.n_users, c2.n_items, c2.n_edges, c2.dim, c2.n_layers, c2.n_neighbors) == (50000, 500, 1000000, 172, 2, 20)
+    assert CONFIGS["C5"].use_memory is False and CONFIGS["C5"].uniform and CONFIGS["C5"].n_heads == 4
