@@ -199,6 +199,23 @@ typedef struct pfo_tgn_debug {
 } pfo_tgn_debug;
 int pfo_tgn_debug_views(const pfo_tgn_config* cfg, void* workspace, pfo_tgn_debug* out);
 
+/* ------------------------------------------------------------------------------------------
+ * Live per-kernel timing with HIP events on the launch stream (bench.py roofline numbers).
+ * While enabled every launch of the kinds below is bracketed by an event pair; pfo_prof_collect
+ * waits for them and returns, per kind, the summed device time [ms], the summed ALGORITHMIC work
+ * (FLOP for the GEMM kinds, bytes otherwise - DESIGN.md states the per-unit figures) and the launch count.
+ */
+#define PFO_PROF_GEMM_NT 0   /* C = A B^T (+bias...)  forward projections                */
+#define PFO_PROF_GEMM_NN 1   /* C = A B             backward-data, folded key projection */
+#define PFO_PROF_GEMM_TN 2   /* dW = A^T B          weight gradients (split-K + reduce)  */
+#define PFO_PROF_GEMM_DEVM 3 /* GEMMs whose row count lives on the device (GRU): time only */
+#define PFO_PROF_ATTN_FWD 4
+#define PFO_PROF_ATTN_BWD 5
+#define PFO_PROF_SAMPLER 6
+#define PFO_PROF_KINDS 7
+int pfo_prof_enable(int32_t on);
+int pfo_prof_collect(double* ms, double* work, int64_t* count); /* HOST arrays of PFO_PROF_KINDS entries */
+
 #ifdef __cplusplus
 }
 #endif

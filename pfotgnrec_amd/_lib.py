@@ -71,7 +71,22 @@ PROTOTYPES = {
     "pfo_tgn_update_state": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), _VP, _VP, _VP, _VP, C.c_int32, _VP,
                                        _VP]),
     "pfo_tgn_debug_views": (C.c_int, [C.POINTER(TgnConfig), _VP, C.POINTER(TgnDebug)]),
+    "pfo_prof_enable": (C.c_int, [C.c_int32]),
+    "pfo_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
+
+PROF_KINDS = ["gemm_nt", "gemm_nn", "gemm_tn", "gemm_devm", "attn_fwd", "attn_bwd", "sampler"]
+
+
+def prof_enable(on):
+    call("pfo_prof_enable", 1 if on else 0)
+
+
+def prof_collect():
+    n = len(PROF_KINDS)
+    ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
+    call("pfo_prof_collect", ms, work, cnt)
+    return {k: dict(ms=ms[i], work=work[i], count=cnt[i]) for i, k in enumerate(PROF_KINDS)}
 
 _lib = None
 

@@ -16,7 +16,7 @@ struct AttnDev {
   const int32_t* nbr_ids; const float* edge_feat; const int32_t* eidx; const float* dt; const float* tw; const float* tb;
   float scale, dropout_p; uint64_t seed, offset;
   float* ctx; float* attw; float* ssum; uint8_t* inv;
-  const float* dctx; const float* dO; const float* bv; float* dQK; float* d_nbr; int64_t d_nbr_ld; float* dtime_part;
+  const float* dctx; const float* dO; const float* bv; float* dQK; float* d_nbr; int64_t d_nbr_ld; double* dtime_part;
 };
 
 // dropout keep-bits for slot `lane` of instance n: bit h = keep for head h (H <= 4)
@@ -137,18 +137,19 @@ int pfo_attn_bwd_max_parts() { return ATTN_BWD_MAX_BLOCKS; }
 
 template <int NR, int H>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
-  __shared__ float s_red[4][2][NR * 64];
+  __shared__ double s_red[4][2][NR * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef;
   const bool direct = (a.nbr_row == nullptr);          // neighbour rows are consecutive (layers >= 2)
   const bool wdirect = direct && a.d_nbr != nullptr;     // ... and their gradients are written, not accumulated
-  float tw[NR], tb[NR], dw[NR], db[NR];
+  float tw[NR], tb[NR];
+  double dw[NR], db[NR];     // sums of terms scaled by dt ~ 1e7 with heavy cancellation: accumulate in fp64
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int c = lane + 64 * r;
     tw[r] = c < D ? a.tw[c] : 0.f;
     tb[r] = c < D ? a.tb[c] : 0.f;
-    dw[r] = 0.f; db[r] = 0.f;
+    dw[r] = 0.0; db[r] = 0.0;
   }
   const float keep_scale = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
 
@@ -262,8 +263,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
             if (direct) dst[c] = dkn; else atomicAdd(dst + c, dkn);
           }
           const float gsin = -ks[r] * dkt;          // d/d(arg) cos(arg) = -sin(arg)
-          dw[r] = fmaf(gsin, dtv, dw[r]);
-          db[r] += gsin;
+          dw[r] += (double)gsin * (double)dtv;
+          db[r] += (double)gsin;
         }
       }
     }
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
   __syncthreads();
   for (int c = threadIdx.x; c < 2 * D; c += 256) {
     const int which = c / D, cc = c - which * D;
-    const float v = s_red[0][which][cc] + s_red[1][which][cc] + s_red[2][which][cc] + s_red[3][which][cc];
+    const double v = s_red[0][which][cc] + s_red[1][which][cc] + s_red[2][which][cc] + s_red[3][which][cc];
     a.dtime_part[(int64_t)blockIdx.x * 2 * D + c] = v;
   }
 }
@@ -343,8 +344,13 @@ int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream) {
   if (int rc = check_common(a)) return rc;
   AttnDev d;
   to_dev(a, d);
+  // algorithmic bytes per instance: K gathered rows + edge feature + (eidx, dt, id), qk in, ctx + weights out
+  const double C = 2.0 * a.D + a.Ef;
+  const double bytes = (double)a.N * (a.K * (4.0 * a.D + 4.0 * a.Ef + 12.0) + 2.0 * a.H * C * 4.0 + 4.0 * a.H * a.K);
+  pfo_prof_begin(stream);
   ATTN_DISPATCH(attn_fwd_kernel, pfo_ceil_div(a.N, 4));
   PFO_LAUNCH_CHECK();
+  pfo_prof_end(PFO_PROF_ATTN_FWD, bytes, stream);
   return PFO_OK;
 }
 
@@ -355,8 +361,13 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
   AttnDev d;
   to_dev(a, d);
   const int grid = (int)std::min<int64_t>(ATTN_BWD_MAX_BLOCKS, pfo_ceil_div(a.N, 4));
+  // rows read again + their gradient rows written/added, qk + dctx + ctx in, dqk out
+  const double C = 2.0 * a.D + a.Ef;
+  const double bytes = (double)a.N * (a.K * (8.0 * a.D + 4.0 * a.Ef + 12.0) + 4.0 * a.H * C * 4.0 + 4.0 * a.H * a.K);
+  pfo_prof_begin(stream);
   ATTN_DISPATCH(attn_bwd_kernel, grid);
   PFO_LAUNCH_CHECK();
+  pfo_prof_end(PFO_PROF_ATTN_BWD, bytes, stream);
   if (n_parts) *n_parts = grid;
   return PFO_OK;
 }

@@ -34,7 +34,7 @@ struct PfoAttn {
   float* dQK = nullptr;             // [N, H*C]
   float* d_nbr = nullptr;           // rows of D floats: direct rows (nbr_row == null) or atomically added rows
   int64_t d_nbr_ld = 0;
-  float* dtime_part = nullptr;      // [grid, 2*D] per-workgroup partial (dw | db) of the time encoder
+  double* dtime_part = nullptr;     // [grid, 2*D] per-workgroup fp64 partial (dw | db) of the time encoder
 };
 
 int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream);

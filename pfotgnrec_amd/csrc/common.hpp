@@ -27,6 +27,10 @@ void pfo_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
+// live event timing (misc.hip); no-ops unless pfo_prof_enable(1)
+void pfo_prof_begin(hipStream_t s);
+void pfo_prof_end(int kind, double work, hipStream_t s);
+
 static inline int64_t pfo_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t pfo_align_up(int64_t a, int64_t b) { return pfo_ceil_div(a, b) * b; }
 

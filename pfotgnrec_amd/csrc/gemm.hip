@@ -302,6 +302,9 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
   to_dev(g, d);
   d.a_vec = a_vec ? 1 : 0;
   d.b_vec = b_vec ? 1 : 0;
+  const double flops = 2.0 * g.M * g.N * ((double)g.K[0] + g.K[1]) * g.batch;
+  const int kind = g.m_dev ? PFO_PROF_GEMM_DEVM : (g.a_kmajor ? PFO_PROF_GEMM_TN : (g.b_kmajor ? PFO_PROF_GEMM_NN : PFO_PROF_GEMM_NT));
+  pfo_prof_begin(stream);
   const int tm = (int)pfo_ceil_div(g.M, BM), tn = (int)pfo_ceil_div(g.N, BN);
   if (g.a_kmajor) {
     PFO_REQUIRE(g.K[1] == 0, "k-major A supports one source");
@@ -323,6 +326,7 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, stream, g.slabs, nsplit, chunk, g.m_dev, K, g.M,
                          g.N, g.C, g.ldc, g.accumulate);
       PFO_LAUNCH_CHECK();
+      pfo_prof_end(kind, flops, stream);
       return PFO_OK;
     }
     hipLaunchKernelGGL((gemm_f32_kernel<true, true>), dim3(tm, tn, g.batch), dim3(GEMM_THREADS), 0, stream, d);
@@ -332,6 +336,7 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(tm, tn, g.batch), dim3(GEMM_THREADS), 0, stream, d);
   }
   PFO_LAUNCH_CHECK();
+  pfo_prof_end(kind, flops, stream);
   return PFO_OK;
 }
 

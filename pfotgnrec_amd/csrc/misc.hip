@@ -12,6 +12,57 @@ void pfo_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* pfo_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// event-pair profiler
+#include <vector>
+namespace {
+struct ProfRec { int kind; double work; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t g_pending = nullptr;
+hipEvent_t prof_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+}  // namespace
+void pfo_prof_begin(hipStream_t s) {
+  if (!g_prof_on) return;
+  g_pending = prof_event();
+  if (g_pending) hipEventRecord(g_pending, s);
+}
+void pfo_prof_end(int kind, double work, hipStream_t s) {
+  if (!g_prof_on || !g_pending) return;
+  hipEvent_t b = prof_event();
+  if (!b) return;
+  hipEventRecord(b, s);
+  g_recs.push_back(ProfRec{kind, work, g_pending, b});
+  g_pending = nullptr;
+}
+extern "C" int pfo_prof_enable(int32_t on) {
+  g_prof_on = on != 0;
+  if (g_prof_on) {
+    for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+    g_recs.clear();
+  }
+  return PFO_OK;
+}
+extern "C" int pfo_prof_collect(double* ms, double* work, int64_t* count) {
+  PFO_REQUIRE(ms && work && count, "null output");
+  for (int k = 0; k < PFO_PROF_KINDS; ++k) { ms[k] = 0; work[k] = 0; count[k] = 0; }
+  for (auto& r : g_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) { pfo_set_error("pfo_prof_collect: event sync failed"); return PFO_ERR_HIP; }
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    ms[r.kind] += t; work[r.kind] += r.work; count[r.kind] += 1;
+    g_pool.push_back(r.a); g_pool.push_back(r.b);
+  }
+  g_recs.clear();
+  return PFO_OK;
+}
 extern "C" int pfo_abi_version(void) { return 1; }
 
 // ---------------------------------------------------------------------------------------------
@@ -170,15 +221,15 @@ int pfo_cq_backward_launch(const float* gq, const float* Wq, const float* tb, in
   return PFO_OK;
 }
 
-__global__ void fold_parts_kernel(const float* __restrict__ parts, int n_parts, int n, float* __restrict__ out,
+__global__ void fold_parts_kernel(const double* __restrict__ parts, int n_parts, int n, float* __restrict__ out,
                                   int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
-  float s = 0.f;
+  double s = 0.0;
   for (int p = 0; p < n_parts; ++p) s += parts[(int64_t)p * n + c];
-  out[c] = accumulate ? out[c] + s : s;
+  out[c] = accumulate ? (float)((double)out[c] + s) : (float)s;
 }
-int pfo_fold_parts_launch(const float* parts, int n_parts, int n, float* out, int accumulate, hipStream_t stream) {
+int pfo_fold_parts_launch(const double* parts, int n_parts, int n, float* out, int accumulate, hipStream_t stream) {
   hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)pfo_ceil_div(n, 256)), dim3(256), 0, stream, parts, n_parts, n, out,
                      accumulate);
   PFO_LAUNCH_CHECK();

@@ -158,11 +158,14 @@ extern "C" int pfo_tnbr_sample(const int64_t* indptr, const int32_t* adj_nbr, co
   hipLaunchKernelGGL(tnbr_sample_kernel<M>, dim3((unsigned)blocks), dim3(threads), 0, s, indptr, adj_nbr, adj_eidx, \
                      adj_ts, n_nodes, q_nodes, q_ts, n_q, (int)K, draws, seed, offset, out_nbr, out_eidx, out_et,   \
                      out_dt, next_nodes, next_ts)
+  pfo_prof_begin(s);
   if (mode == 0) LAUNCH(0);
   else if (mode == 1) LAUNCH(1);
   else LAUNCH(2);
 #undef LAUNCH
   PFO_LAUNCH_CHECK();
+  // per query K*(4+4+8) adjacency bytes read + K*12 written (+8 per frontier slot) + ~11 probes + row bounds
+  pfo_prof_end(PFO_PROF_SAMPLER, (double)n_q * (K * 36.0 + 112.0), s);
   return PFO_OK;
 }
 

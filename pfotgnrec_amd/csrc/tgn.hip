@@ -37,7 +37,8 @@ struct Ws {
   LayerWs layer[PFO_MAX_LAYERS + 1];
   float *dh1, *dattn, *dO, *dctx, *dQK, *dQ, *dx1;
   float* dH[PFO_MAX_LAYERS + 1];
-  float *slabs, *colsum, *dtime;
+  float *slabs, *colsum;
+  double* dtime;
   int64_t slab_floats;
   int64_t bytes;
 };
@@ -127,7 +128,7 @@ Ws carve(const pfo_tgn_config* c, void* base) {
   w.slab_floats = SLAB_FLOATS;
   w.slabs = take<float>(p, w.slab_floats);
   w.colsum = take<float>(p, pfo_colsum_scratch_floats(3 * d.D + 2 * d.E + d.M));
-  w.dtime = take<float>(p, (int64_t)pfo_attn_bwd_max_parts() * 2 * d.D);
+  w.dtime = take<double>(p, (int64_t)pfo_attn_bwd_max_parts() * 2 * d.D);
   w.bytes = p - reinterpret_cast<char*>(base);
   return w;
 }
