@@ -33,30 +33,39 @@ struct GemmDev {
   int M, N; const int32_t* m_dev;
   int relu, accumulate;
   int nsplit; int split_chunk;     // k-major split-K
-  int a_vec, b_vec;                // 16-byte loads legal for A / B (else per-element loads)
   int64_t a_bs[2], b_bs[2], c_bs, bias_bs, rs_bs;
 };
 
-// up to four consecutive floats; `nv` of them are inside the matrix.  Vector form when alignment allows.
-__device__ __forceinline__ float4 ld4(const float* p, bool vec, int nv) {
+// four consecutive floats, `nv` (<= 4 used) of them inside the matrix
+template <bool VEC>
+__device__ __forceinline__ float4 ld4(const float* p, int nv) {
   float4 r = float4{0.f, 0.f, 0.f, 0.f};
-  if (nv <= 0) return r;
-  if (vec && nv >= 4) return *reinterpret_cast<const float4*>(p);
-  r.x = p[0];
-  if (nv > 1) r.y = p[1];
-  if (nv > 2) r.z = p[2];
-  if (nv > 3) r.w = p[3];
+  if (VEC) {
+    if (nv > 0) r = *reinterpret_cast<const float4*>(p);
+  } else {
+    if (nv > 0) r.x = p[0];
+    if (nv > 1) r.y = p[1];
+    if (nv > 2) r.z = p[2];
+    if (nv > 3) r.w = p[3];
+  }
   return r;
 }
 
-template <bool A_KM, bool B_KM>
+// Two workgroup shapes, both 256 threads = 4 wavefronts:
+//   BIG   : 128 x 176 output tile, wavefront w owns rows [32w, 32w+32) x all 11 column tiles   (2 x 11 MFMA tiles)
+//   SMALL :  32 x 176 output tile, wavefront w owns all 32 rows x column tiles {w, w+4, w+8}    (2 x 3 MFMA tiles)
+// SMALL exists for the layer-2 launches (M = 2560 rows): 4x the workgroups, so the chip is not left idle.
+template <bool A_KM, bool B_KM, bool SMALL, bool VEC>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p) {
+  constexpr int TBM = SMALL ? 32 : BM;
+  constexpr int NJ = SMALL ? 3 : 11;
+  constexpr int NA = SMALL ? 1 : 4;            // float4 per thread for the A tile
   __shared__ __attribute__((aligned(16))) float As[AS_FLOATS];
   __shared__ __attribute__((aligned(16))) float Bs[BS_FLOATS];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = blockIdx.x * TBM, n0 = blockIdx.y * BN;
   int zb = blockIdx.z, split = 0;
   if (A_KM && p.nsplit > 1) { split = zb % p.nsplit; zb /= p.nsplit; }
 
@@ -72,14 +81,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
     kbeg = split * p.split_chunk;
     kend0 = min(Kext0, kbeg + p.split_chunk);
   }
+  const int wrow = SMALL ? 0 : 32 * wave;      // first tile row of this wavefront
+  const int wcol = SMALL ? 16 * wave : 0;      // first tile column; SMALL strides columns by 64
 
-  f32x4 acc[2][11];
+  f32x4 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 11; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float4 a_reg[4], b_reg[6];
+  float4 a_reg[NA], b_reg[6];
 
   for (int src = 0; src < 2; ++src) {
     const int Ks = (src == 0) ? kend0 : p.K[1];
@@ -90,11 +101,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
     const int64_t lda = p.lda[src], ldb = p.ldb[src];
 
     // per-thread row bases for the row-major layouts (rows are fixed across k-tiles)
-    const float* a_row[4];
-    bool a_ok[4];
+    const float* a_row[NA];
+    bool a_ok[NA];
     if (!A_KM) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NA; ++i) {
         const int row = (tid + 256 * i) >> 3;
         const int gm = m0 + row;
         a_ok[i] = gm < Mlim;
@@ -109,8 +120,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const int f = tid + 256 * i;
-        const int row = f >> 3;
-        const int gn = n0 + row;
+        const int gn = n0 + (f >> 3);
         b_ok[i] = (f < BN * 8) && gn < p.N;
         b_row[i] = Bb + (int64_t)gn * ldb;
       }
@@ -119,24 +129,24 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
     auto load_tile = [&](int k0) {
       if (!A_KM) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
           const int k = k0 + 4 * ((tid + 256 * i) & 7);
-          a_reg[i] = ld4(a_row[i] + k, p.a_vec, a_ok[i] ? Ks - k : 0);
+          a_reg[i] = ld4<VEC>(a_row[i] + k, a_ok[i] ? Ks - k : 0);
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
           const int f = tid + 256 * i;
-          const int k = k0 + (f >> 5);
-          const int m = m0 + 4 * (f & 31);
-          a_reg[i] = ld4(Ab + (int64_t)k * lda + m, p.a_vec, k < Ks ? p.M - m : 0);
+          const int k = k0 + (f / (TBM / 4));
+          const int m = m0 + 4 * (f % (TBM / 4));
+          a_reg[i] = ld4<VEC>(Ab + (int64_t)k * lda + m, k < Ks ? p.M - m : 0);
         }
       }
       if (!B_KM) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
           const int k = k0 + 4 * ((tid + 256 * i) & 7);
-          b_reg[i] = ld4(b_row[i] + k, p.b_vec, b_ok[i] ? Ks - k : 0);
+          b_reg[i] = ld4<VEC>(b_row[i] + k, b_ok[i] ? Ks - k : 0);
         }
       } else {
 #pragma unroll
@@ -148,14 +158,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
           const bool ok = (f < BK * 44) && k < Ks && n < p.N;
           int64_t krow = k;
           if (ok && p.b_idx && src == 0) krow = p.b_idx[k];
-          b_reg[i] = ld4(Bb + krow * ldb + n, p.b_vec, ok ? p.N - n : 0);
+          b_reg[i] = ld4<VEC>(Bb + krow * ldb + n, ok ? p.N - n : 0);
         }
       }
     };
     auto store_tile = [&]() {
       if (!A_KM) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
           const int f = tid + 256 * i;
           float* d = As + (f >> 3) * LDA_RM + 4 * (f & 7);
           *reinterpret_cast<float2*>(d) = float2{a_reg[i].x, a_reg[i].y};
@@ -163,9 +173,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
           const int f = tid + 256 * i;
-          *reinterpret_cast<float4*>(As + (f >> 5) * LDA_KM + 4 * (f & 31)) = a_reg[i];
+          *reinterpret_cast<float4*>(As + (f / (TBM / 4)) * LDA_KM + 4 * (f % (TBM / 4))) = a_reg[i];
         }
       }
       if (!B_KM) {
@@ -189,26 +199,45 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
         }
       }
     };
+    // fragments of k-step s (lane (r, g) holds A[row r][k = 4s + g], B[k = 4s + g][col r])
+    auto load_frags = [&](int s, float (&a)[2], float (&b)[NJ]) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = A_KM ? As[(4 * s + g) * LDA_KM + wrow + 16 * i + r] : As[(wrow + 16 * i + r) * LDA_RM + 4 * s + g];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = wcol + (SMALL ? 64 : 16) * j + r;
+        b[j] = B_KM ? Bs[(4 * s + g) * LDB_KM + col] : Bs[col * LDA_RM + 4 * s + g];
+      }
+    };
+    auto mma = [&](const float (&a)[2], const float (&b)[NJ]) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          if (!SMALL || wcol + 64 * j < BN)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
 
     load_tile(k_first);
     for (int k0 = k_first; k0 < Ks; k0 += BK) {
       __syncthreads();            // previous tile's fragment reads are done
       store_tile();
       __syncthreads();
-      if (k0 + BK < Ks) load_tile(k0 + BK);   // in flight during the MFMAs below
-      const int steps = min(BK / 4, (Ks - k0 + 3) >> 2);
-      for (int s = 0; s < steps; ++s) {
-        float a[2], b[11];
+      if (k0 + BK < Ks) load_tile(k0 + BK);   // global loads in flight during the MFMAs below
+      // 8 k-steps per tile (fewer on the K tail: the guard is wavefront-uniform); fragment reads of the
+      // next step are issued ahead of the MFMAs of the current one.  LDS beyond K holds zeros.
+      const int nsteps = min(BK / 4, (Ks - k0 + 3) >> 2);
+      float a0[2], b0[NJ], a1[2], b1[NJ];
+      load_frags(0, a0, b0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-          a[i] = A_KM ? As[(4 * s + g) * LDA_KM + 32 * wave + 16 * i + r] : As[(32 * wave + 16 * i + r) * LDA_RM + 4 * s + g];
-#pragma unroll
-        for (int j = 0; j < 11; ++j)
-          b[j] = B_KM ? Bs[(4 * s + g) * LDB_KM + 16 * j + r] : Bs[(16 * j + r) * LDA_RM + 4 * s + g];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 11; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int s = 0; s < BK / 4; s += 2) {
+        if (s < nsteps) {
+          load_frags(s + 1, a1, b1);
+          mma(a0, b0);
+          if (s + 2 < BK / 4) load_frags(s + 2, a0, b0);
+          if (s + 1 < nsteps) mma(a1, b1);
+        }
       }
     }
   }
@@ -216,28 +245,28 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
   // epilogue.  C/D layout of 16x16x4: col = lane & 15, row = 4*(lane >> 4) + reg
   float* Cb;
   int64_t ldc;
-  if (A_KM && p.nsplit > 1) {
+  const bool plain = (A_KM && p.nsplit > 1);
+  if (plain) {
     Cb = p.C + ((int64_t)zb * p.nsplit + split) * (int64_t)p.M * p.N;   // C = slab base
     ldc = p.N;
   } else {
     Cb = p.C + zb * p.c_bs;
     ldc = p.ldc;
   }
-  const bool plain = (A_KM && p.nsplit > 1);
   const float* bias = (p.bias && !plain) ? p.bias + zb * p.bias_bs : nullptr;
   const float* rs = (p.row_scale && !plain) ? p.row_scale + zb * p.rs_bs : nullptr;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int row = m0 + 32 * wave + 16 * i + 4 * g + reg;
+      const int row = m0 + wrow + 16 * i + 4 * g + reg;
       if (row >= Mlim) continue;
       const float rscale = rs ? rs[(int64_t)row * p.rs_ld] : 1.f;
       const bool zero = (!plain && p.row_zero) ? (p.row_zero[row] != 0) : false;
 #pragma unroll
-      for (int j = 0; j < 11; ++j) {
-        const int col = n0 + 16 * j + r;
-        if (col >= p.N) continue;
+      for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wcol + (SMALL ? 64 : 16) * j + r;
+        if (col >= p.N || (SMALL && wcol + 64 * j >= BN)) continue;
         float v = acc[i][j][reg];
         if (!plain) {
           if (bias) v = fmaf(bias[col], rscale, v);
@@ -300,18 +329,23 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
   PFO_REQUIRE(!(g.a_kmajor && !g.b_kmajor), "k-major A with row-major B is not instantiated");
   GemmDev d;
   to_dev(g, d);
-  d.a_vec = a_vec ? 1 : 0;
-  d.b_vec = b_vec ? 1 : 0;
+  const bool vec = a_vec && b_vec;
   const double flops = 2.0 * g.M * g.N * ((double)g.K[0] + g.K[1]) * g.batch;
   const int kind = g.m_dev ? PFO_PROF_GEMM_DEVM : (g.a_kmajor ? PFO_PROF_GEMM_TN : (g.b_kmajor ? PFO_PROF_GEMM_NN : PFO_PROF_GEMM_NT));
   pfo_prof_begin(stream);
-  const int tm = (int)pfo_ceil_div(g.M, BM), tn = (int)pfo_ceil_div(g.N, BN);
+  const int tn = (int)pfo_ceil_div(g.N, BN);
+#define GEMM_GO(AK, BK_, SM, grid)                                                                                   \
+  do {                                                                                                                \
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, SM, true>), grid, dim3(GEMM_THREADS), 0, stream, d);        \
+    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, SM, false>), grid, dim3(GEMM_THREADS), 0, stream, d);           \
+  } while (0)
   if (g.a_kmajor) {
+    const int tm = (int)pfo_ceil_div(g.M, BM);
     PFO_REQUIRE(g.K[1] == 0, "k-major A supports one source");
     // weight gradient: few output tiles, long K -> split K over workgroups, deterministic slab reduce
     const int K = g.K[0];
-    int want = (int)pfo_ceil_div(768, (int64_t)tm * tn * g.batch);
-    int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, pfo_ceil_div(K, 2 * BK)));
+    int want = (int)pfo_ceil_div(512, (int64_t)tm * tn * g.batch);
+    int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, pfo_ceil_div(K, 4 * BK)));
     int chunk = (int)pfo_align_up(pfo_ceil_div(K, nsplit), BK);
     nsplit = (int)pfo_ceil_div(K, chunk);
     if (nsplit > 1) {
@@ -319,63 +353,80 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
       PFO_REQUIRE(g.slabs && g.slab_floats >= (int64_t)nsplit * g.M * g.N, "split-K workspace too small");
       PFO_REQUIRE(!g.bias && !g.relu && !g.row_zero && !g.relu_src, "split-K takes no epilogue");
       d.nsplit = nsplit; d.split_chunk = chunk; d.C = g.slabs;
-      hipLaunchKernelGGL((gemm_f32_kernel<true, true>), dim3(tm, tn, nsplit), dim3(GEMM_THREADS), 0, stream, d);
+      GEMM_GO(true, true, false, dim3(tm, tn, nsplit));
       PFO_LAUNCH_CHECK();
       const int64_t total = (int64_t)g.M * g.N;
-      const int rb = (int)std::min<int64_t>(1024, pfo_ceil_div(total, 256));
+      const int rb = (int)std::min<int64_t>(2048, pfo_ceil_div(total, 256));
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, stream, g.slabs, nsplit, chunk, g.m_dev, K, g.M,
                          g.N, g.C, g.ldc, g.accumulate);
       PFO_LAUNCH_CHECK();
       pfo_prof_end(kind, flops, stream);
       return PFO_OK;
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<true, true>), dim3(tm, tn, g.batch), dim3(GEMM_THREADS), 0, stream, d);
-  } else if (g.b_kmajor) {
-    hipLaunchKernelGGL((gemm_f32_kernel<false, true>), dim3(tm, tn, g.batch), dim3(GEMM_THREADS), 0, stream, d);
+    GEMM_GO(true, true, false, dim3(tm, tn, g.batch));
   } else {
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(tm, tn, g.batch), dim3(GEMM_THREADS), 0, stream, d);
+    // row tiles: 128 rows per workgroup, or 32 when that would leave most of the 256 CUs without work
+    const bool small = (int64_t)pfo_ceil_div(g.M, BM) * tn * g.batch < 512;
+    const int tm = (int)pfo_ceil_div(g.M, small ? 32 : BM);
+    const dim3 grid(tm, tn, g.batch);
+    if (g.b_kmajor) { if (small) GEMM_GO(false, true, true, grid); else GEMM_GO(false, true, false, grid); }
+    else            { if (small) GEMM_GO(false, false, true, grid); else GEMM_GO(false, false, false, grid); }
   }
+#undef GEMM_GO
   PFO_LAUNCH_CHECK();
   pfo_prof_end(kind, flops, stream);
   return PFO_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// column sums (bias gradients): two deterministic stages, 64 row-chunks then a fold
-#define CS_CHUNKS 64
+// column sums (bias gradients): two deterministic stages.  Stage 1: workgroup = 64 columns x 4 row lanes
+// over one of CS_CHUNKS row chunks (coalesced 256-byte row pieces); stage 2 folds the chunk partials.
+#define CS_CHUNKS 256
 __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X, int64_t ldx, int M, int N,
                                                      const float* __restrict__ scale, int64_t scale_ld,
                                                      const int32_t* __restrict__ m_dev, float* __restrict__ part) {
+  __shared__ float s_red[4][64];
   int Mlim = M;
   if (m_dev) Mlim = min(Mlim, *m_dev);
   const int chunk = blockIdx.y;
   const int rows_per = (Mlim + CS_CHUNKS - 1) / CS_CHUNKS;
   const int rbeg = chunk * rows_per, rend = min(Mlim, rbeg + rows_per);
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= N) return;
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int m = rbeg; m < rend; ++m) {
-    const float v = X[(int64_t)m * ldx + col];
-    s += scale ? v * scale[(int64_t)m * scale_ld] : v;
-  }
-  part[(int64_t)chunk * N + col] = s;
+  if (col < N)
+    for (int m = rbeg + rl; m < rend; m += 4) {
+      const float v = X[(int64_t)m * ldx + col];
+      s += scale ? v * scale[(int64_t)m * scale_ld] : v;
+    }
+  s_red[rl][c] = s;
+  __syncthreads();
+  if (rl == 0 && col < N) part[(int64_t)chunk * N + col] = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
 }
-__global__ void colsum_stage2(const float* __restrict__ part, int N, float* __restrict__ out, int accumulate) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= N) return;
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, int N, float* __restrict__ out,
+                                                     int accumulate) {
+  __shared__ float s_red[4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int c = 0; c < CS_CHUNKS; ++c) s += part[(int64_t)c * N + col];
-  out[col] = accumulate ? out[col] + s : s;
+  if (col < N)
+    for (int k = rl; k < CS_CHUNKS; k += 4) s += part[(int64_t)k * N + col];
+  s_red[rl][c] = s;
+  __syncthreads();
+  if (rl == 0 && col < N) {
+    const float t = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
+    out[col] = accumulate ? out[col] + t : t;
+  }
 }
 int64_t pfo_colsum_scratch_floats(int N) { return (int64_t)CS_CHUNKS * N; }
 
 int pfo_colsum_launch(const float* X, int64_t ldx, int M, int N, const float* scale, int64_t scale_ld,
                       const int32_t* m_dev, float* out, int accumulate, float* scratch, hipStream_t stream) {
   PFO_REQUIRE(X && out && scratch && M > 0 && N > 0, "bad arguments");
-  hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)pfo_ceil_div(N, 256), CS_CHUNKS), dim3(256), 0, stream, X, ldx, M, N,
+  hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)pfo_ceil_div(N, 64), CS_CHUNKS), dim3(256), 0, stream, X, ldx, M, N,
                      scale, scale_ld, m_dev, scratch);
   PFO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)pfo_ceil_div(N, 256)), dim3(256), 0, stream, scratch, N, out,
+  hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)pfo_ceil_div(N, 64)), dim3(256), 0, stream, scratch, N, out,
                      accumulate);
   PFO_LAUNCH_CHECK();
   return PFO_OK;

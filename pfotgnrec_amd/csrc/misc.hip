@@ -221,16 +221,26 @@ int pfo_cq_backward_launch(const float* gq, const float* Wq, const float* tb, in
   return PFO_OK;
 }
 
-__global__ void fold_parts_kernel(const double* __restrict__ parts, int n_parts, int n, float* __restrict__ out,
-                                  int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
+// out[c] (+)= sum_p parts[p][c]: workgroup = 16 columns x 16 part lanes, fp64, fixed order (deterministic)
+__global__ __launch_bounds__(256) void fold_parts_kernel(const double* __restrict__ parts, int n_parts, int n,
+                                                         float* __restrict__ out, int accumulate) {
+  __shared__ double s_red[16][16];
+  const int c = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + c;
   double s = 0.0;
-  for (int p = 0; p < n_parts; ++p) s += parts[(int64_t)p * n + c];
-  out[c] = accumulate ? (float)((double)out[c] + s) : (float)s;
+  if (col < n)
+    for (int p = pl; p < n_parts; p += 16) s += parts[(int64_t)p * n + col];
+  s_red[pl][c] = s;
+  __syncthreads();
+  if (pl == 0 && col < n) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += s_red[k][c];
+    out[col] = accumulate ? (float)((double)out[col] + t) : (float)t;
+  }
 }
 int pfo_fold_parts_launch(const double* parts, int n_parts, int n, float* out, int accumulate, hipStream_t stream) {
-  hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)pfo_ceil_div(n, 256)), dim3(256), 0, stream, parts, n_parts, n, out,
+  hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)pfo_ceil_div(n, 16)), dim3(256), 0, stream, parts, n_parts, n, out,
                      accumulate);
   PFO_LAUNCH_CHECK();
   return PFO_OK;

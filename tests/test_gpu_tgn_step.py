@@ -129,7 +129,7 @@ def test_step_against_oracle(D, H, L, K, use_mem, uniform):
         if uniform:
             # draw positions on the host so that both sides see the same neighbourhoods
             R = 5 * B
-            sizes = [R * (1 + K) ** (L - 1 - i) for i in range(L)]          # level L, L-1, ..., 1
+            sizes = [R * (1 + K) ** i for i in range(L)]                    # level L, L-1, ..., 1
             draws = [rs.randint(0, 1 << 30, size=(n, K)).astype(np.int64) for n in sizes]
         tgn.train(); opt.zero_grad()
         if uniform:
@@ -238,12 +238,14 @@ def test_dropout_training_is_consistent_between_forward_and_backward():
     gnum = p.grad.clone()
     idx = (3, 5)
     eps = 1e-2
-    with torch.no_grad():
-        p[idx] += eps
-        up = (run() * w).sum().item()
-        p[idx] -= 2 * eps
-        dn = (run() * w).sum().item()
-        p[idx] += eps
+    def bump(delta):                      # grad mode stays on for run(): under no_grad dropout is off
+        with torch.no_grad():
+            p[idx] += delta
+    bump(eps)
+    up = (run() * w).sum().item()
+    bump(-2 * eps)
+    dn = (run() * w).sum().item()
+    bump(eps)
     fd = (up - dn) / (2 * eps)
     assert abs(fd - gnum[idx].item()) < 2e-2 * max(1.0, abs(fd)), (fd, gnum[idx].item())
     e1, e2 = run(), run()
