@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpfotgn.so")
+LIB_PATH = os.environ.get("PFOTGN_LIB", os.path.join(_HERE, "lib", "libpfotgn.so"))   # override: kernel A/B builds
 
 c_i32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _VP = C.c_void_p

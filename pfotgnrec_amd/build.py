@@ -27,9 +27,11 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, defines=(), tag=""):
+    """``defines``/``tag`` build an A/B variant (lib/libpfotgn_<tag>.so) next to the default library."""
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "obj" + ("_" + tag if tag else ""))
+    lib = os.path.join(LIBDIR, "libpfotgn%s.so" % ("_" + tag if tag else ""))
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "pfotgn.h"))
@@ -39,7 +41,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         path = os.path.join(CSRC, src)
         if force or _newer(obj, [path] + headers):
-            cmd = [hipcc, "-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-c", path, "-o", obj]
+            cmd = [hipcc, "-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17"] + ["-D" + d for d in defines] + ["-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
@@ -47,13 +49,15 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    if force or _newer(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+    if force or _newer(lib, objs):
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    tag = next((a[6:] for a in sys.argv[1:] if a.startswith("--tag=")), "")
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, defines=defs, tag=tag))

@@ -36,17 +36,37 @@ static inline int64_t pfo_align_up(int64_t a, int64_t b) { return pfo_ceil_div(a
 
 #ifdef __HIPCC__
 // ---------------------------------------------------------------------------------------------
-// sin/cos of an fp32 argument of any magnitude (time-encoder arguments reach 1e7 and beyond):
-// range reduction in fp64 against a two-term pi/2 (exact to ~1e-16 * |x|), fp32 minimax
-// polynomials on [-pi/4, pi/4].  ~1 ulp; far inside the 1e-4 parity bar and much cheaper than
-// the generic Payne-Hanek path.
+// sin/cos of an fp32 argument of any magnitude (time-encoder arguments reach 1.7e7 on the synthetic
+// graphs and beyond on epoch-second data).  The cosine is a pure function of the exactly rounded
+// fp32 argument (SURVEY §7 hard part 1), so the range reduction must be accurate, not "fast-math":
+//   |x| < 2e7 : fp32 only.  k = rint(x * 2/pi) from a two-term product (k < 2^24 stays an exact integer),
+//               r = x - k*pi/2 by three FMAs against a three-term pi/2 (each FMA rounds an O(1) value once);
+//               |error(r)| ~ 1.2e-7, validated against fp64 over +-2e7 (max |cos err| 1.03e-7).
+//   otherwise : the same reduction in fp64 (two-term pi/2), a few times slower, never taken on the benchmark.
+// Then fp32 minimax polynomials on [-pi/4, pi/4] (~1 ulp).
 __device__ __forceinline__ void pfo_sincosf(float x, float& s, float& c) {
-  const double xd = (double)x;
-  const double kd = rint(xd * 0.63661977236758134308);
-  double r = fma(-kd, 1.57079632679489655800e+00, xd);
-  r = fma(-kd, 6.12323399573676603587e-17, r);
-  const int q = (int)((long long)kd & 3);
-  const float rf = (float)r;
+  float rf;
+  int q;
+  if (fabsf(x) < 2.0e7f) {
+    const float C_HI = 0.636619746685028076171875f, C_LO = 2.5682553e-08f;
+    const float P1 = 1.57079637050628662109375f, P2 = -4.37113883e-08f, P3 = -1.71512451e-15f;
+    const float p = x * C_HI;
+    const float e = __builtin_fmaf(x, C_HI, -p);               // exact rounding error of p
+    float kf = rintf(p);
+    const float f = (p - kf) + __builtin_fmaf(x, C_LO, e);     // what p missed, |f| < 1.6
+    kf += rintf(f);
+    float r = __builtin_fmaf(-kf, P1, x);
+    r = __builtin_fmaf(-kf, P2, r);
+    rf = __builtin_fmaf(-kf, P3, r);
+    q = ((int)kf) & 3;
+  } else {
+    const double xd = (double)x;
+    const double kd = rint(xd * 0.63661977236758134308);
+    double r = fma(-kd, 1.57079632679489655800e+00, xd);
+    r = fma(-kd, 6.12323399573676603587e-17, r);
+    q = (int)((long long)kd & 3);
+    rf = (float)r;
+  }
   const float r2 = rf * rf;
   const float sp = fmaf(rf * r2, fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), rf);
   const float cp = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),

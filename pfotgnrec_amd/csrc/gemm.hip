@@ -36,32 +36,41 @@ struct GemmDev {
   int64_t a_bs[2], b_bs[2], c_bs, bias_bs, rs_bs;
 };
 
-// four consecutive floats, `nv` (<= 4 used) of them inside the matrix
+#ifndef GEMM_DBUF
+#define GEMM_DBUF 0      // 1: two LDS buffers, one barrier per k-tile (1 workgroup per CU)
+#endif
+
+// four consecutive floats of which `nv` lie inside the matrix; `safe` is any valid 16-byte aligned address,
+// loaded instead of an out-of-range one so that the load itself needs no branch
 template <bool VEC>
-__device__ __forceinline__ float4 ld4(const float* p, int nv) {
-  float4 r = float4{0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ float4 ld4(const float* p, int nv, const float* safe) {
   if (VEC) {
-    if (nv > 0) r = *reinterpret_cast<const float4*>(p);
+    const float4 v = *reinterpret_cast<const float4*>(nv > 0 ? p : safe);
+    return nv > 0 ? v : float4{0.f, 0.f, 0.f, 0.f};
   } else {
-    if (nv > 0) r.x = p[0];
-    if (nv > 1) r.y = p[1];
-    if (nv > 2) r.z = p[2];
-    if (nv > 3) r.w = p[3];
+    float4 r;
+    r.x = nv > 0 ? p[0] : 0.f;
+    r.y = nv > 1 ? p[1] : 0.f;
+    r.z = nv > 2 ? p[2] : 0.f;
+    r.w = nv > 3 ? p[3] : 0.f;
+    return r;
   }
-  return r;
 }
 
 // Two workgroup shapes, both 256 threads = 4 wavefronts:
 //   BIG   : 128 x 176 output tile, wavefront w owns rows [32w, 32w+32) x all 11 column tiles   (2 x 11 MFMA tiles)
 //   SMALL :  32 x 176 output tile, wavefront w owns all 32 rows x column tiles {w, w+4, w+8}    (2 x 3 MFMA tiles)
 // SMALL exists for the layer-2 launches (M = 2560 rows): 4x the workgroups, so the chip is not left idle.
+// The K loop runs over a flattened list of 32-deep tiles of up to two K-concatenated sources; the global loads of
+// tile t+1 are in flight (registers) while the MFMAs of tile t run from LDS.
 template <bool A_KM, bool B_KM, bool SMALL, bool VEC>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p) {
   constexpr int TBM = SMALL ? 32 : BM;
   constexpr int NJ = SMALL ? 3 : 11;
   constexpr int NA = SMALL ? 1 : 4;            // float4 per thread for the A tile
-  __shared__ __attribute__((aligned(16))) float As[AS_FLOATS];
-  __shared__ __attribute__((aligned(16))) float Bs[BS_FLOATS];
+  constexpr int NBUF = GEMM_DBUF ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float As[NBUF][AS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Bs[NBUF][BS_FLOATS];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -90,154 +99,175 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // flattened tile list
+  const int T0 = kend0 > kbeg ? (kend0 - kbeg + BK - 1) / BK : 0;
+  const int T1 = (p.K[1] > 0 && p.A[1]) ? (p.K[1] + BK - 1) / BK : 0;
+  const int T = T0 + T1;
+
   float4 a_reg[NA], b_reg[6];
+  const float* a_row[NA];
+  const float* b_row[6];
+  bool a_ok[NA], b_ok[6];
+  const float *Ab = nullptr, *Bb = nullptr;
+  int64_t lda = 0, ldb = 0;
+  int Ks = 0, cur_src = -1;
+  const float* safe = p.A[0];
 
-  for (int src = 0; src < 2; ++src) {
-    const int Ks = (src == 0) ? kend0 : p.K[1];
-    const int k_first = (src == 0) ? kbeg : 0;
-    if (Ks <= k_first || p.A[src] == nullptr) continue;
-    const float* Ab = p.A[src] + zb * p.a_bs[src];
-    const float* Bb = p.B[src] + zb * p.b_bs[src];
-    const int64_t lda = p.lda[src], ldb = p.ldb[src];
-
-    // per-thread row bases for the row-major layouts (rows are fixed across k-tiles)
-    const float* a_row[NA];
-    bool a_ok[NA];
+  auto bind_src = [&](int src) {
+    cur_src = src;
+    Ks = (src == 0) ? kend0 : p.K[1];
+    Ab = p.A[src] + zb * p.a_bs[src];
+    Bb = p.B[src] + zb * p.b_bs[src];
+    lda = p.lda[src]; ldb = p.ldb[src];
     if (!A_KM) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const int row = (tid + 256 * i) >> 3;
-        const int gm = m0 + row;
+        const int gm = m0 + ((tid + 256 * i) >> 3);
         a_ok[i] = gm < Mlim;
-        int64_t ridx = gm;
+        int64_t ridx = a_ok[i] ? gm : 0;
         if (a_ok[i] && p.a_idx[src]) ridx = p.a_idx[src][gm];
         a_row[i] = Ab + ridx * lda;
       }
     }
-    const float* b_row[6];
-    bool b_ok[6];
     if (!B_KM) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const int f = tid + 256 * i;
         const int gn = n0 + (f >> 3);
         b_ok[i] = (f < BN * 8) && gn < p.N;
-        b_row[i] = Bb + (int64_t)gn * ldb;
+        b_row[i] = Bb + (int64_t)(b_ok[i] ? gn : 0) * ldb;
       }
     }
-
-    auto load_tile = [&](int k0) {
-      if (!A_KM) {
+  };
+  auto load_tile = [&](int t) {
+    const int src = t < T0 ? 0 : 1;
+    if (src != cur_src) bind_src(src);
+    const int k0 = (src == 0) ? kbeg + t * BK : (t - T0) * BK;
+    if (!A_KM) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-          const int k = k0 + 4 * ((tid + 256 * i) & 7);
-          a_reg[i] = ld4<VEC>(a_row[i] + k, a_ok[i] ? Ks - k : 0);
-        }
-      } else {
+      for (int i = 0; i < NA; ++i) {
+        const int k = k0 + 4 * ((tid + 256 * i) & 7);
+        a_reg[i] = ld4<VEC>(a_row[i] + k, a_ok[i] ? Ks - k : 0, safe);
+      }
+    } else {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-          const int f = tid + 256 * i;
-          const int k = k0 + (f / (TBM / 4));
-          const int m = m0 + 4 * (f % (TBM / 4));
-          a_reg[i] = ld4<VEC>(Ab + (int64_t)k * lda + m, k < Ks ? p.M - m : 0);
+      for (int i = 0; i < NA; ++i) {
+        const int f = tid + 256 * i;
+        const int k = k0 + (f / (TBM / 4));
+        const int m = m0 + 4 * (f % (TBM / 4));
+        a_reg[i] = ld4<VEC>(Ab + (int64_t)k * lda + m, k < Ks ? p.M - m : 0, safe);
+      }
+    }
+    if (!B_KM) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int k = k0 + 4 * ((tid + 256 * i) & 7);
+        b_reg[i] = ld4<VEC>(b_row[i] + k, b_ok[i] ? Ks - k : 0, safe);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int f = tid + 256 * i;
+        const int kr = f / 44;
+        const int k = k0 + kr;
+        const int n = n0 + 4 * (f - kr * 44);
+        const bool ok = (f < BK * 44) && k < Ks && n < p.N;
+        int64_t krow = ok ? k : 0;
+        if (ok && p.b_idx && src == 0) krow = p.b_idx[k];
+        b_reg[i] = ld4<VEC>(Bb + krow * ldb + n, ok ? p.N - n : 0, safe);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* as = As[buf];
+    float* bs = Bs[buf];
+    if (!A_KM) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int f = tid + 256 * i;
+        float* d = as + (f >> 3) * LDA_RM + 4 * (f & 7);
+        *reinterpret_cast<float2*>(d) = float2{a_reg[i].x, a_reg[i].y};
+        *reinterpret_cast<float2*>(d + 2) = float2{a_reg[i].z, a_reg[i].w};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int f = tid + 256 * i;
+        *reinterpret_cast<float4*>(as + (f / (TBM / 4)) * LDA_KM + 4 * (f % (TBM / 4))) = a_reg[i];
+      }
+    }
+    if (!B_KM) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int f = tid + 256 * i;
+        if (f < BN * 8) {
+          float* d = bs + (f >> 3) * LDA_RM + 4 * (f & 7);
+          *reinterpret_cast<float2*>(d) = float2{b_reg[i].x, b_reg[i].y};
+          *reinterpret_cast<float2*>(d + 2) = float2{b_reg[i].z, b_reg[i].w};
         }
       }
-      if (!B_KM) {
+    } else {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const int k = k0 + 4 * ((tid + 256 * i) & 7);
-          b_reg[i] = ld4<VEC>(b_row[i] + k, b_ok[i] ? Ks - k : 0);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const int f = tid + 256 * i;
+      for (int i = 0; i < 6; ++i) {
+        const int f = tid + 256 * i;
+        if (f < BK * 44) {
           const int kr = f / 44;
-          const int k = k0 + kr;
-          const int n = n0 + 4 * (f - kr * 44);
-          const bool ok = (f < BK * 44) && k < Ks && n < p.N;
-          int64_t krow = k;
-          if (ok && p.b_idx && src == 0) krow = p.b_idx[k];
-          b_reg[i] = ld4<VEC>(Bb + krow * ldb + n, ok ? p.N - n : 0);
+          *reinterpret_cast<float4*>(bs + kr * LDB_KM + 4 * (f - kr * 44)) = b_reg[i];
         }
       }
-    };
-    auto store_tile = [&]() {
-      if (!A_KM) {
+    }
+  };
+  // fragments of k-step s (lane (r, g) holds A[row r][k = 4s + g], B[k = 4s + g][col r])
+  auto load_frags = [&](const float* as, const float* bs, int s, float (&a)[2], float (&b)[NJ]) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-          const int f = tid + 256 * i;
-          float* d = As + (f >> 3) * LDA_RM + 4 * (f & 7);
-          *reinterpret_cast<float2*>(d) = float2{a_reg[i].x, a_reg[i].y};
-          *reinterpret_cast<float2*>(d + 2) = float2{a_reg[i].z, a_reg[i].w};
-        }
-      } else {
+    for (int i = 0; i < 2; ++i)
+      a[i] = A_KM ? as[(4 * s + g) * LDA_KM + wrow + 16 * i + r] : as[(wrow + 16 * i + r) * LDA_RM + 4 * s + g];
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-          const int f = tid + 256 * i;
-          *reinterpret_cast<float4*>(As + (f / (TBM / 4)) * LDA_KM + 4 * (f % (TBM / 4))) = a_reg[i];
-        }
-      }
-      if (!B_KM) {
+    for (int j = 0; j < NJ; ++j) {
+      const int col = wcol + (SMALL ? 64 : 16) * j + r;
+      b[j] = B_KM ? bs[(4 * s + g) * LDB_KM + col] : bs[col * LDA_RM + 4 * s + g];
+    }
+  };
+  auto mma = [&](const float (&a)[2], const float (&b)[NJ]) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const int f = tid + 256 * i;
-          if (f < BN * 8) {
-            float* d = Bs + (f >> 3) * LDA_RM + 4 * (f & 7);
-            *reinterpret_cast<float2*>(d) = float2{b_reg[i].x, b_reg[i].y};
-            *reinterpret_cast<float2*>(d + 2) = float2{b_reg[i].z, b_reg[i].w};
-          }
-        }
-      } else {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const int f = tid + 256 * i;
-          if (f < BK * 44) {
-            const int kr = f / 44;
-            *reinterpret_cast<float4*>(Bs + kr * LDB_KM + 4 * (f - kr * 44)) = b_reg[i];
-          }
-        }
-      }
-    };
-    // fragments of k-step s (lane (r, g) holds A[row r][k = 4s + g], B[k = 4s + g][col r])
-    auto load_frags = [&](int s, float (&a)[2], float (&b)[NJ]) {
+      for (int j = 0; j < NJ; ++j)
+        if (!SMALL || wcol + 64 * j < BN)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  };
+  // all 8 k-steps of a tile; LDS beyond K holds zeros, so the K tail needs no guard.  Fragment reads of step
+  // s+1 are issued ahead of the MFMAs of step s.
+  auto compute_tile = [&](int buf) {
+    const float* as = As[buf];
+    const float* bs = Bs[buf];
+    float a0[2], b0[NJ], a1[2], b1[NJ];
+    load_frags(as, bs, 0, a0, b0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        a[i] = A_KM ? As[(4 * s + g) * LDA_KM + wrow + 16 * i + r] : As[(wrow + 16 * i + r) * LDA_RM + 4 * s + g];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int col = wcol + (SMALL ? 64 : 16) * j + r;
-        b[j] = B_KM ? Bs[(4 * s + g) * LDB_KM + col] : Bs[col * LDA_RM + 4 * s + g];
-      }
-    };
-    auto mma = [&](const float (&a)[2], const float (&b)[NJ]) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          if (!SMALL || wcol + 64 * j < BN)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    };
+    for (int s = 0; s < BK / 4; s += 2) {
+      load_frags(as, bs, s + 1, a1, b1);
+      mma(a0, b0);
+      if (s + 2 < BK / 4) load_frags(as, bs, s + 2, a0, b0);
+      mma(a1, b1);
+    }
+  };
 
-    load_tile(k_first);
-    for (int k0 = k_first; k0 < Ks; k0 += BK) {
-      __syncthreads();            // previous tile's fragment reads are done
-      store_tile();
-      __syncthreads();
-      if (k0 + BK < Ks) load_tile(k0 + BK);   // global loads in flight during the MFMAs below
-      // 8 k-steps per tile (fewer on the K tail: the guard is wavefront-uniform); fragment reads of the
-      // next step are issued ahead of the MFMAs of the current one.  LDS beyond K holds zeros.
-      const int nsteps = min(BK / 4, (Ks - k0 + 3) >> 2);
-      float a0[2], b0[NJ], a1[2], b1[NJ];
-      load_frags(0, a0, b0);
-#pragma unroll
-      for (int s = 0; s < BK / 4; s += 2) {
-        if (s < nsteps) {
-          load_frags(s + 1, a1, b1);
-          mma(a0, b0);
-          if (s + 2 < BK / 4) load_frags(s + 2, a0, b0);
-          if (s + 1 < nsteps) mma(a1, b1);
-        }
+  if (T > 0) {
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      const bool more = t + 1 < T;
+      if (more) load_tile(t + 1);                // global loads in flight during the MFMAs below
+      if (GEMM_DBUF) {
+        compute_tile(t & 1);
+        if (more) store_tile((t + 1) & 1);
+        __syncthreads();
+      } else {
+        compute_tile(0);
+        __syncthreads();                         // every wavefront is done reading the tile
+        if (more) store_tile(0);
+        __syncthreads();
       }
     }
   }
