@@ -27,6 +27,16 @@ __device__ __forceinline__ unsigned attn_keep_bits(uint64_t seed, uint64_t offse
   return (r.x >= thr ? 1u : 0u) | (r.y >= thr ? 2u : 0u) | (r.z >= thr ? 4u : 0u) | (r.w >= thr ? 8u : 0u);
 }
 
+// Keys are processed in chunks of KC: all gathers of a chunk are issued back to back (one memory latency per
+// chunk instead of one per key), the chunk's KC*H dot-product butterflies are interleaved (6 dependent shuffle
+// stages per chunk instead of per key), then the online-softmax state is advanced key by key.  Per-slot metadata
+// (row, edge id, dt, validity) is loaded once, one slot per lane, and broadcast with v_readlane.
+#define KC_FWD 5
+#define KC_BWD 4
+
+__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
 template <int NR, int H>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -51,8 +61,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
 #pragma unroll
   for (int h = 0; h < H; ++h) qe[h] = lane < Ef ? qk[h * C + D + lane] : 0.f;
 
-  const int myid = lane < K ? a.nbr_ids[n * K + lane] : 0;
-  const unsigned long long valid = __ballot(lane < K && myid != 0);
+  const int64_t slot0 = n * K;
+  const bool inK = lane < K;
+  const int my_id = inK ? a.nbr_ids[slot0 + lane] : 0;
+  const int my_row = inK ? (a.nbr_row ? a.nbr_row[slot0 + lane] : (int)(a.nbr_row_base + slot0 + lane)) : 0;
+  const int my_e = inK ? a.eidx[slot0 + lane] : 0;
+  const float my_dt = inK ? a.dt[slot0 + lane] : 0.f;
+  const unsigned long long valid = __ballot(inK && my_id != 0);
   float* ctx = a.ctx + n * H * C;
   if (valid == 0ull) {
     // no valid neighbour: the reference attends to padded slot 0 and then zero-fills the attention
@@ -77,42 +92,72 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
     for (int r = 0; r < NR; ++r) { an[h][r] = 0.f; at[h][r] = 0.f; }
   }
 
-  for (int j = 0; j < K; ++j) {
-    if (!((valid >> j) & 1ull)) continue;
-    const int64_t slot = n * K + j;
-    const int64_t row = a.nbr_row ? (int64_t)a.nbr_row[slot] : a.nbr_row_base + slot;
-    const int e = a.eidx[slot];
-    const float dtv = a.dt[slot];
-    const unsigned kb = __shfl(keep, j, 64);
-    float kn[NR], kt[NR];
-    const float* src = a.nbr_tab + row * a.nbr_ld;
+  unsigned long long vm = valid;
+  while (vm) {
+    int js[KC_FWD];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const int c = lane + 64 * r;
-      kn[r] = c < D ? src[c] : 0.f;
-      kt[r] = c < D ? pfo_cosf(pfo_time_arg(dtv, tw[r], tb[r])) : 0.f;
+    for (int c = 0; c < KC_FWD; ++c) {
+      js[c] = vm ? (__ffsll((long long)vm) - 1) : -1;
+      vm &= vm - 1ull;
     }
-    const float ke = lane < Ef ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
+    float kn[KC_FWD][NR], kt[KC_FWD][NR], ke[KC_FWD], dtv[KC_FWD];
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-      float part = ke * qe[h];
-#pragma unroll
-      for (int r = 0; r < NR; ++r) part = fmaf(kn[r], qn[h][r], fmaf(kt[r], qt[h][r], part));
-      const float s = pfo_wave_sum(part) * a.scale;
-      if (lane == j) my_s[h] = s;
-      const float mn = fmaxf(m[h], s);
-      const float corr = expf(m[h] - mn);
-      const float p = expf(s - mn);
-      const float pd = ((kb >> h) & 1u) ? p * keep_scale : 0.f;
-      l[h] = fmaf(l[h], corr, p);
-      ld[h] = fmaf(ld[h], corr, pd);
+    for (int c = 0; c < KC_FWD; ++c) {
+      const int j = js[c] < 0 ? 0 : js[c];
+      const float* src = a.nbr_tab + (int64_t)rl_i(my_row, j) * a.nbr_ld;
+      const int e = rl_i(my_e, j);
+      dtv[c] = rl_f(my_dt, j);
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        an[h][r] = fmaf(an[h][r], corr, pd * kn[r]);
-        at[h][r] = fmaf(at[h][r], corr, pd * kt[r]);
+        const int cc = lane + 64 * r;
+        kn[c][r] = (js[c] >= 0 && cc < D) ? src[cc] : 0.f;
       }
-      ae[h] = fmaf(ae[h], corr, pd * ke);
-      m[h] = mn;
+      ke[c] = (js[c] >= 0 && lane < Ef) ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
+    }
+    float part[KC_FWD][H];
+#pragma unroll
+    for (int c = 0; c < KC_FWD; ++c) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int cc = lane + 64 * r;
+        kt[c][r] = (js[c] >= 0 && cc < D) ? pfo_cosf(pfo_time_arg(dtv[c], tw[r], tb[r])) : 0.f;
+      }
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float pp = ke[c] * qe[h];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) pp = fmaf(kn[c][r], qn[h][r], fmaf(kt[c][r], qt[h][r], pp));
+        part[c][h] = pp;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int c = 0; c < KC_FWD; ++c)
+#pragma unroll
+        for (int h = 0; h < H; ++h) part[c][h] += __shfl_xor(part[c][h], o, 64);
+#pragma unroll
+    for (int c = 0; c < KC_FWD; ++c) {
+      if (js[c] < 0) continue;
+      const unsigned kb = (unsigned)rl_i((int)keep, js[c]);
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float sc = part[c][h] * a.scale;
+        if (lane == js[c]) my_s[h] = sc;
+        const float mn = fmaxf(m[h], sc);
+        const float corr = expf(m[h] - mn);
+        const float pr = expf(sc - mn);
+        const float pd = ((kb >> h) & 1u) ? pr * keep_scale : 0.f;
+        l[h] = fmaf(l[h], corr, pr);
+        ld[h] = fmaf(ld[h], corr, pd);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          an[h][r] = fmaf(an[h][r], corr, pd * kn[c][r]);
+          at[h][r] = fmaf(at[h][r], corr, pd * kt[c][r]);
+        }
+        ae[h] = fmaf(ae[h], corr, pd * ke[c]);
+        m[h] = mn;
+      }
     }
   }
 #pragma unroll
@@ -155,15 +200,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
 
   for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < a.N; n += (int64_t)gridDim.x * 4) {
     float* dqk_out = a.dQK + n * H * C;
-    const int myid = lane < K ? a.nbr_ids[n * K + lane] : 0;
-    const unsigned long long valid = __ballot(lane < K && myid != 0);
+    const int64_t slot0 = n * K;
+    const bool inK = lane < K;
+    const int my_id = inK ? a.nbr_ids[slot0 + lane] : 0;
+    const int my_row = inK ? (direct ? (int)(a.nbr_row_base + slot0 + lane) : a.nbr_row[slot0 + lane]) : 0;
+    const int my_e = inK ? a.eidx[slot0 + lane] : 0;
+    const float my_dt = inK ? a.dt[slot0 + lane] : 0.f;
+    const unsigned long long valid = __ballot(inK && my_id != 0);
+    if (wdirect) {
+      // padded slots own a gradient row too (the buffer is reused every step): zero it
+      unsigned long long im = ~valid & (K >= 64 ? ~0ull : ((1ull << K) - 1ull));
+      while (im) {
+        const int j = __ffsll((long long)im) - 1;
+        im &= im - 1ull;
+        float* dst = a.d_nbr + (a.nbr_row_base + slot0 + j) * a.d_nbr_ld;
+        for (int c = lane; c < D; c += 64) dst[c] = 0.f;
+      }
+    }
     if (valid == 0ull) {
       for (int c = lane; c < H * C; c += 64) dqk_out[c] = 0.f;
-      if (wdirect)
-        for (int j = 0; j < K; ++j) {
-          float* dst = a.d_nbr + (a.nbr_row_base + n * K + j) * a.d_nbr_ld;
-          for (int c = lane; c < D; c += 64) dst[c] = 0.f;
-        }
       continue;
     }
     float qn[H][NR], qt[H][NR], qe[H], gn[H][NR], gt[H][NR], ge[H], t[H], dsb[H];
@@ -189,82 +244,118 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
       ge[h] = lane < Ef ? dc[h * C + D + lane] : 0.f;
       if (lane < Ef) part = fmaf(ge[h], cx[h * C + D + lane], part);
       dqe[h] = 0.f;
-      // delta_h = sum_j a_jh * da_jh = dctx_h . ctx_h (+ d ssum_h * ssum_h under dropout)
-      t[h] = pfo_wave_sum(part);
+      t[h] = part;
       dsb[h] = 0.f;
       if (a.dropout_p > 0.f) {
         float pb = 0.f;
         for (int c = lane; c < a.dh; c += 64) pb = fmaf(a.dO[n * H * a.dh + h * a.dh + c], a.bv[h * a.dh + c], pb);
-        dsb[h] = pfo_wave_sum(pb);
-        t[h] = fmaf(dsb[h], a.ssum[n * H + h], t[h]);
+        dsb[h] = pb;
       }
     }
+    // delta_h = sum_j a_jh * da_jh = dctx_h . ctx_h (+ d ssum_h * ssum_h under dropout); interleaved butterflies
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        t[h] += __shfl_xor(t[h], o, 64);
+        if (a.dropout_p > 0.f) dsb[h] += __shfl_xor(dsb[h], o, 64);
+      }
+    if (a.dropout_p > 0.f)
+#pragma unroll
+      for (int h = 0; h < H; ++h) t[h] = fmaf(dsb[h], a.ssum[n * H + h], t[h]);
+
     const unsigned keep = attn_keep_bits(a.seed, a.offset, n, lane, a.dropout_p);
     float my_a[H];
 #pragma unroll
-    for (int h = 0; h < H; ++h) my_a[h] = lane < K ? a.attw[(n * H + h) * K + lane] : 0.f;
+    for (int h = 0; h < H; ++h) my_a[h] = inK ? a.attw[(n * H + h) * K + lane] : 0.f;
 
-    for (int j = 0; j < K; ++j) {
-      const int64_t slot = n * K + j;
-      if (!((valid >> j) & 1ull)) {
-        if (wdirect) {
-          float* dst = a.d_nbr + (a.nbr_row_base + slot) * a.d_nbr_ld;
-          for (int c = lane; c < D; c += 64) dst[c] = 0.f;
-        }
-        continue;
+    unsigned long long vm = valid;
+    while (vm) {
+      int js[KC_BWD];
+#pragma unroll
+      for (int c = 0; c < KC_BWD; ++c) {
+        js[c] = vm ? (__ffsll((long long)vm) - 1) : -1;
+        vm &= vm - 1ull;
       }
-      const int64_t row = direct ? a.nbr_row_base + slot : (int64_t)a.nbr_row[slot];
-      const int e = a.eidx[slot];
-      const float dtv = a.dt[slot];
-      const unsigned kb = __shfl(keep, j, 64);
-      float kn[NR], kt[NR], ks[NR];
-      const float* src = a.nbr_tab + row * a.nbr_ld;
+      float kn[KC_BWD][NR], kt[KC_BWD][NR], ks[KC_BWD][NR], ke[KC_BWD], dtv[KC_BWD];
+      int rows[KC_BWD];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const int c = lane + 64 * r;
-        kn[r] = c < D ? src[c] : 0.f;
-        float sv = 0.f, cv = 0.f;
-        if (c < D) pfo_sincosf(pfo_time_arg(dtv, tw[r], tb[r]), sv, cv);
-        kt[r] = cv;
-        ks[r] = sv;
-      }
-      const float ke = lane < Ef ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
-      float cA[H], cB[H];
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        float part = ke * ge[h];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) part = fmaf(kn[r], gn[h][r], fmaf(kt[r], gt[h][r], part));
-        const float ks_h = ((kb >> h) & 1u) ? keep_scale : 0.f;
-        const float da = (pfo_wave_sum(part) + dsb[h]) * ks_h;      // d loss / d a_jh (through dropout)
-        const float aj = __shfl(my_a[h], j, 64);
-        const float dscore = aj * (da - t[h]);                       // softmax backward
-        cA[h] = aj * ks_h;                                           // a'_jh multiplies dctx_h
-        cB[h] = dscore * a.scale;                                    // multiplies qk_h
+      for (int c = 0; c < KC_BWD; ++c) {
+        const int j = js[c] < 0 ? 0 : js[c];
+        rows[c] = rl_i(my_row, j);
+        const float* src = a.nbr_tab + (int64_t)rows[c] * a.nbr_ld;
+        const int e = rl_i(my_e, j);
+        dtv[c] = rl_f(my_dt, j);
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-          dqn[h][r] = fmaf(cB[h], kn[r], dqn[h][r]);
-          dqt[h][r] = fmaf(cB[h], kt[r], dqt[h][r]);
+          const int cc = lane + 64 * r;
+          kn[c][r] = (js[c] >= 0 && cc < D) ? src[cc] : 0.f;
         }
-        dqe[h] = fmaf(cB[h], ke, dqe[h]);
+        ke[c] = (js[c] >= 0 && lane < Ef) ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
       }
-      float* dst = a.d_nbr ? a.d_nbr + row * a.d_nbr_ld : nullptr;
+      float part[KC_BWD][H];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const int c = lane + 64 * r;
-        float dkn = 0.f, dkt = 0.f;
+      for (int c = 0; c < KC_BWD; ++c) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int cc = lane + 64 * r;
+          float sv = 0.f, cv = 0.f;
+          if (js[c] >= 0 && cc < D) pfo_sincosf(pfo_time_arg(dtv[c], tw[r], tb[r]), sv, cv);
+          kt[c][r] = cv;
+          ks[c][r] = sv;
+        }
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-          dkn = fmaf(cA[h], gn[h][r], fmaf(cB[h], qn[h][r], dkn));
-          dkt = fmaf(cA[h], gt[h][r], fmaf(cB[h], qt[h][r], dkt));
+          float pp = ke[c] * ge[h];
+#pragma unroll
+          for (int r = 0; r < NR; ++r) pp = fmaf(kn[c][r], gn[h][r], fmaf(kt[c][r], gt[h][r], pp));
+          part[c][h] = pp;
         }
-        if (c < D) {
-          if (dst) {
-            if (direct) dst[c] = dkn; else atomicAdd(dst + c, dkn);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int c = 0; c < KC_BWD; ++c)
+#pragma unroll
+          for (int h = 0; h < H; ++h) part[c][h] += __shfl_xor(part[c][h], o, 64);
+#pragma unroll
+      for (int c = 0; c < KC_BWD; ++c) {
+        if (js[c] < 0) continue;
+        const unsigned kb = (unsigned)rl_i((int)keep, js[c]);
+        float cA[H], cB[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const float ks_h = ((kb >> h) & 1u) ? keep_scale : 0.f;
+          const float da = (part[c][h] + dsb[h]) * ks_h;               // d loss / d a_jh (through dropout)
+          const float aj = rl_f(my_a[h], js[c]);
+          const float dscore = aj * (da - t[h]);                       // softmax backward
+          cA[h] = aj * ks_h;                                           // a'_jh multiplies dctx_h
+          cB[h] = dscore * a.scale;                                    // multiplies qk_h
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            dqn[h][r] = fmaf(cB[h], kn[c][r], dqn[h][r]);
+            dqt[h][r] = fmaf(cB[h], kt[c][r], dqt[h][r]);
           }
-          const float gsin = -ks[r] * dkt;          // d/d(arg) cos(arg) = -sin(arg)
-          dw[r] += (double)gsin * (double)dtv;
-          db[r] += (double)gsin;
+          dqe[h] = fmaf(cB[h], ke[c], dqe[h]);
+        }
+        float* dst = a.d_nbr ? a.d_nbr + (int64_t)rows[c] * a.d_nbr_ld : nullptr;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int cc = lane + 64 * r;
+          float dkn = 0.f, dkt = 0.f;
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            dkn = fmaf(cA[h], gn[h][r], fmaf(cB[h], qn[h][r], dkn));
+            dkt = fmaf(cA[h], gt[h][r], fmaf(cB[h], qt[h][r], dkt));
+          }
+          if (cc < D) {
+            if (dst) {
+              if (direct) dst[cc] = dkn; else atomicAdd(dst + cc, dkn);
+            }
+            const float gsin = -ks[c][r] * dkt;          // d/d(arg) cos(arg) = -sin(arg)
+            dw[r] += (double)gsin * (double)dtv[c];
+            db[r] += (double)gsin;
+          }
         }
       }
     }

@@ -44,7 +44,18 @@ static inline int64_t pfo_align_up(int64_t a, int64_t b) { return pfo_ceil_div(a
 //               |error(r)| ~ 1.2e-7, validated against fp64 over +-2e7 (max |cos err| 1.03e-7).
 //   otherwise : the same reduction in fp64 (two-term pi/2), a few times slower, never taken on the benchmark.
 // Then fp32 minimax polynomials on [-pi/4, pi/4] (~1 ulp).
+// slow path kept out of line so that it stays a real (almost never taken) branch instead of being if-converted
+__device__ __attribute__((noinline)) float pfo_reduce_f64(float x, int* quadrant) {
+  const double xd = (double)x;
+  const double kd = rint(xd * 0.63661977236758134308);
+  double r = fma(-kd, 1.57079632679489655800e+00, xd);
+  r = fma(-kd, 6.12323399573676603587e-17, r);
+  *quadrant = (int)((long long)kd & 3);
+  return (float)r;
+}
+
 __device__ __forceinline__ void pfo_sincosf(float x, float& s, float& c) {
+#pragma clang fp contract(off)   // p below is reused as a ROUNDED product: no implicit FMA formation in this function
   float rf;
   int q;
   if (fabsf(x) < 2.0e7f) {
@@ -54,18 +65,13 @@ __device__ __forceinline__ void pfo_sincosf(float x, float& s, float& c) {
     const float e = __builtin_fmaf(x, C_HI, -p);               // exact rounding error of p
     float kf = rintf(p);
     const float f = (p - kf) + __builtin_fmaf(x, C_LO, e);     // what p missed, |f| < 1.6
-    kf += rintf(f);
+    kf = kf + rintf(f);
     float r = __builtin_fmaf(-kf, P1, x);
     r = __builtin_fmaf(-kf, P2, r);
     rf = __builtin_fmaf(-kf, P3, r);
     q = ((int)kf) & 3;
   } else {
-    const double xd = (double)x;
-    const double kd = rint(xd * 0.63661977236758134308);
-    double r = fma(-kd, 1.57079632679489655800e+00, xd);
-    r = fma(-kd, 6.12323399573676603587e-17, r);
-    q = (int)((long long)kd & 3);
-    rf = (float)r;
+    rf = pfo_reduce_f64(x, &q);
   }
   const float r2 = rf * rf;
   const float sp = fmaf(rf * r2, fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), rf);
