@@ -47,6 +47,26 @@ def parse():
     return ap.parse_args()
 
 
+PMC_KERNEL = {"gemm_nt": "void gemm_f32_kernel<false, false, false, true>",
+              "gemm_nn": "void gemm_f32_kernel<false, true, false, true>",
+              "gemm_tn": "void gemm_f32_kernel<true, true, false, true>",
+              "attn_fwd": "void attn_fwd_kernel<3, 2>", "attn_bwd": "void attn_bwd_kernel<3, 2>"}
+
+
+def pmc_traffic(family):
+    """HBM bytes per launch of the family's kernel from the newest committed PMC pass (profiles/r*_summary.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs, (2*FETCH + WRITE)*1024 on gfx950); None if not profiled."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_summary.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["pmc"]["kernels"].get(PMC_KERNEL.get(family, ""))
+        return int(k["hbm_bytes_per_launch_corrected"]) if k else None
+    except Exception:
+        return None
+
+
 def steady_state_init(tgn, rs):
     """Every node holds a pending message and a non-zero memory, the state the reference reaches a few
     hundred batches into an epoch (#pending == #seen nodes -> n)."""
@@ -210,6 +230,7 @@ def main():
             achieved = v["work"] / v["count"] / per_launch_s / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}
+        roof["traffic"] = pmc_traffic(dom)
         roof["kernel"] = dom
         roof["avg_launch_us"] = round(per_launch_s * 1e6, 2)
         roof["launches"] = int(v["count"])

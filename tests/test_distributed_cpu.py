@@ -1,0 +1,77 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel plumbing: shard bounds, the single flat-gradient
+all-reduce, parameter broadcast, and the arithmetic identity the scheme rests on - shard gradients of the BPR
+mean loss, pre-scaled by 1/world and summed, equal the full-batch gradient (checked with the oracle's backward)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from pfotgnrec_amd.distributed import init_from_env, shard_bounds, allreduce_flat_grad, broadcast_parameters
+    from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+    from oracle import tgn_oracle as T
+    from oracle.neighbor_finder import OracleNeighborFinder, build_adjacency
+    r, w, _ = init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    # parameter broadcast: replicas start identical
+    flat = torch.full((1000,), float(rank + 1))
+    broadcast_parameters(flat, world)
+    assert torch.all(flat == 1.0)
+    # shard gradient of the global-batch mean loss
+    cfg = SyntheticConfig("dp", 60, 10, 900, 8, 1, 4, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    onf = OracleNeighborFinder(*build_adjacency(d.sources, d.destinations, d.edge_idxs, d.timestamps))
+    P = T.init_params(8, 4, 1, seed=3)
+    B, s = 16, 500
+    sb, db, tb, eb = d.sources[s:s + B], d.destinations[s:s + B], d.timestamps[s:s + B], d.edge_idxs[s:s + B]
+    neg = np.random.RandomState(0).randint(61, 71, size=B * 3)
+
+    def grads(lo, hi, scale):
+        ref = T.OracleTGN(onf, g.node_features, g.edge_features, P, 1, 2, use_memory=True)
+        for v in range(1, g.n_nodes):
+            ref.messages[v] = [(np.full(28, 0.01 * v, np.float32), np.float32(0))]
+        b = hi - lo
+        se, de, ne = ref.compute_temporal_embeddings(sb[lo:hi], db[lo:hi], neg[3 * lo:3 * hi], tb[lo:hi], eb[lo:hi], 4)
+        _, cache = T.bpr_loss(se, de.reshape(b, 1, -1), ne.reshape(b, 3, -1))
+        ds, dp, dn = T.bpr_loss_backward(cache)
+        gr = ref.backward(np.concatenate([ds, dp.reshape(b, -1), dn.reshape(3 * b, -1)]) * scale)
+        return np.concatenate([gr[k].ravel() for k in sorted(gr)])
+    lo, hi = shard_bounds(B, rank, world)
+    assert (lo, hi) == (rank * B // world, (rank + 1) * B // world)
+    local = torch.from_numpy(grads(lo, hi, 1.0 / world).astype(np.float32))
+    allreduce_flat_grad(local, world)                               # the step's ONE collective
+    full = grads(0, B, 1.0)
+    err = np.abs(local.numpy() - full).max() / (np.abs(full).max() + 1e-12)
+    ret[rank] = float(err)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_equals_single_rank():
+    port = 29600 + (os.getpid() % 200)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert len(ret) == 2
+    for r in (0, 1):
+        assert ret[r] < 1e-5, ret[r]        # fp32 summation-order tolerance
+
+
+def test_shard_bounds_cover_batch_exactly():
+    from pfotgnrec_amd.distributed import shard_bounds
+    for B in (1, 7, 512, 4096):
+        for W in (1, 2, 3, 8):
+            segs = [shard_bounds(B, r, W) for r in range(W)]
+            assert segs[0][0] == 0 and segs[-1][1] == B
+            for a, b in zip(segs, segs[1:]):
+                assert a[1] == b[0]
