@@ -10,6 +10,8 @@
 // fragment read conflict-free for the two 32-lane halves of ds_read_b32.
 #include "gemm.hpp"
 #include <algorithm>
+#include <string.h>
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -34,8 +36,17 @@ struct GemmDev {
   int relu, accumulate;
   int nsplit; int split_chunk;     // k-major split-K
   int64_t a_bs[2], b_bs[2], c_bs, bias_bs, rs_bs;
+  int n_real;                      // columns of B that exist in memory; column n_real (if < N) is the bias column
+  const float* ones_scale; int64_t os_ld;   // value of the bias column per k row (null: 1.0)
+  float* slab_base;                // split-K: this problem's slab region
+  int dyn_chunk;                   // split-K chunk = f(device-side K) instead of split_chunk
 };
 
+static bool aligned4(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+#ifndef GEMM_EXP
+#define GEMM_EXP 0       // timing-only ablations (wrong results): 1 = no global loads / LDS stores after the first tile, 2 = no MFMA,
+#endif                   //                                          3 = no barriers + no reloads
 #ifndef GEMM_DBUF
 #define GEMM_DBUF 0      // 1: two LDS buffers, one barrier per k-tile (1 workgroup per CU)
 #endif
@@ -64,7 +75,7 @@ __device__ __forceinline__ float4 ld4(const float* p, int nv, const float* safe)
 // The K loop runs over a flattened list of 32-deep tiles of up to two K-concatenated sources; the global loads of
 // tile t+1 are in flight (registers) while the MFMAs of tile t run from LDS.
 template <bool A_KM, bool B_KM, bool SMALL, bool VEC>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p) {
+__device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const int by, int zb, const int split_in) {
   constexpr int TBM = SMALL ? 32 : BM;
   constexpr int NJ = SMALL ? 3 : 11;
   constexpr int NA = SMALL ? 1 : 4;            // float4 per thread for the A tile
@@ -74,9 +85,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * TBM, n0 = blockIdx.y * BN;
-  int zb = blockIdx.z, split = 0;
-  if (A_KM && p.nsplit > 1) { split = zb % p.nsplit; zb /= p.nsplit; }
+  const int m0 = bx * TBM, n0 = by * BN;
+  const int split = split_in;
 
   int Mlim = p.M;
   int Kext0 = p.K[0];
@@ -87,8 +97,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
   if (!A_KM && m0 >= Mlim) return;
   int kbeg = 0, kend0 = Kext0;
   if (A_KM && p.nsplit > 1) {
-    kbeg = split * p.split_chunk;
-    kend0 = min(Kext0, kbeg + p.split_chunk);
+    // with a device-side K bound (GRU rows) the chunks are cut from the ACTUAL extent so every split has work
+    const int chunk = p.dyn_chunk ? ((Kext0 + p.nsplit - 1) / p.nsplit + BK - 1) / BK * BK : p.split_chunk;
+    kbeg = split * chunk;
+    kend0 = min(Kext0, kbeg + chunk);
   }
   const int wrow = SMALL ? 0 : 32 * wave;      // first tile row of this wavefront
   const int wcol = SMALL ? 16 * wave : 0;      // first tile column; SMALL strides columns by 64
@@ -174,7 +186,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
         const bool ok = (f < BK * 44) && k < Ks && n < p.N;
         int64_t krow = ok ? k : 0;
         if (ok && p.b_idx && src == 0) krow = p.b_idx[k];
-        b_reg[i] = ld4<VEC>(Bb + krow * ldb + n, ok ? p.N - n : 0, safe);
+        b_reg[i] = ld4<VEC>(Bb + krow * ldb + n, ok ? p.n_real - n : 0, safe);
+        if (A_KM && ok && p.n_real < p.N) {
+          // bias column: dW's extra column accumulates sum_k dY[k][m] * (scale[k] or 1)
+          const int e = p.n_real - n;
+          if (e >= 0 && e < 4) {
+            const float one = p.ones_scale ? p.ones_scale[(int64_t)k * p.os_ld] : 1.f;
+            if (e == 0) b_reg[i].x = one; else if (e == 1) b_reg[i].y = one; else if (e == 2) b_reg[i].z = one; else b_reg[i].w = one;
+          }
+        }
       }
     }
   };
@@ -228,9 +248,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
       b[j] = B_KM ? bs[(4 * s + g) * LDB_KM + col] : bs[col * LDA_RM + 4 * s + g];
     }
   };
+  // a wavefront whose 16-row strip lies entirely beyond M issues no MFMAs for it (172-row weight-gradient tiles:
+  // the matrix pipe of its SIMD is left to the co-resident workgroup)
+  const bool strip_on[2] = {m0 + wrow < p.M, m0 + wrow + 16 < p.M};
   auto mma = [&](const float (&a)[2], const float (&b)[NJ]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
+      if (strip_on[i])
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
         if (!SMALL || wcol + 64 * j < BN)
@@ -257,17 +281,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
     store_tile(0);
     __syncthreads();
     for (int t = 0; t < T; ++t) {
-      const bool more = t + 1 < T;
+      const bool more = (GEMM_EXP == 1 || GEMM_EXP == 3) ? false : (t + 1 < T);
       if (more) load_tile(t + 1);                // global loads in flight during the MFMAs below
       if (GEMM_DBUF) {
         compute_tile(t & 1);
         if (more) store_tile((t + 1) & 1);
         __syncthreads();
       } else {
-        compute_tile(0);
-        __syncthreads();                         // every wavefront is done reading the tile
+        if (GEMM_EXP != 2) compute_tile(0);
+        if (GEMM_EXP != 3) __syncthreads();      // every wavefront is done reading the tile
         if (more) store_tile(0);
-        __syncthreads();
+        if (GEMM_EXP != 3) __syncthreads();
       }
     }
   }
@@ -277,7 +301,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
   int64_t ldc;
   const bool plain = (A_KM && p.nsplit > 1);
   if (plain) {
-    Cb = p.C + ((int64_t)zb * p.nsplit + split) * (int64_t)p.M * p.N;   // C = slab base
+    Cb = p.slab_base + ((int64_t)zb * p.nsplit + split) * (int64_t)p.M * p.N;
     ldc = p.N;
   } else {
     Cb = p.C + zb * p.c_bs;
@@ -311,6 +335,126 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
   }
 }
 
+template <bool A_KM, bool B_KM, bool SMALL, bool VEC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p) {
+  int zb = blockIdx.z, split = 0;
+  if (A_KM && p.nsplit > 1) { split = zb % p.nsplit; zb /= p.nsplit; }
+  gemm_tile<A_KM, B_KM, SMALL, VEC>(p, blockIdx.x, blockIdx.y, zb, split);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped weight gradients: every dW (+ bias gradient as one extra column) of a layer in ONE launch.
+// All problems share the K extent (the layer's instance rows); K is split into `nsplit` chunks, each
+// workgroup writes a partial slab tile, one grouped reduce folds the slabs into the gradient buffers.
+#define TN_MAX_PROBLEMS 16
+struct TnProbDev {
+  const float* A; int64_t lda; const float* B; int64_t ldb; const int32_t* b_idx;
+  const float* ones_scale; int64_t os_ld;
+  float* C; int64_t ldc; float* bias_out; int bias_accumulate;
+  int M, N_real, N;          // N = N_real + (bias_out ? 1 : 0)
+  int tile_begin, tn;        // first flattened tile, column tiles
+  int64_t slab_off;          // floats
+};
+struct TnGroupDev {
+  TnProbDev p[TN_MAX_PROBLEMS];
+  int n, K, nsplit, chunk, total_tiles;
+  const int32_t* k_dev;
+  float* slabs;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_group_kernel(const TnGroupDev g) {
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < TN_MAX_PROBLEMS; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.p[i].tile_begin) q = i;
+  const TnProbDev& pr = g.p[q];
+  const int t = blockIdx.x - pr.tile_begin;
+  GemmDev d;
+  d.A[0] = pr.A; d.A[1] = nullptr; d.lda[0] = pr.lda; d.lda[1] = 0; d.a_idx[0] = d.a_idx[1] = nullptr;
+  d.B[0] = pr.B; d.B[1] = nullptr; d.ldb[0] = pr.ldb; d.ldb[1] = 0; d.b_idx = pr.b_idx;
+  d.K[0] = g.K; d.K[1] = 0;
+  d.C = nullptr; d.ldc = 0; d.bias = nullptr; d.row_scale = nullptr; d.rs_ld = 0; d.row_zero = nullptr;
+  d.relu_src = nullptr; d.relu_ld = 0; d.M = pr.M; d.N = pr.N; d.m_dev = g.k_dev; d.relu = 0; d.accumulate = 0;
+  d.nsplit = 2;                      // any value > 1: selects the slab epilogue; the real split index comes from blockIdx.y
+  d.split_chunk = g.chunk;
+  d.a_bs[0] = d.a_bs[1] = d.b_bs[0] = d.b_bs[1] = d.c_bs = d.bias_bs = d.rs_bs = 0;
+  d.n_real = pr.N_real; d.ones_scale = pr.ones_scale; d.os_ld = pr.os_ld;
+  // slab region of this problem: [nsplit][M][N]; gemm_tile indexes it as (zb * nsplit + split) with zb = 0
+  d.slab_base = g.slabs + pr.slab_off - (int64_t)0;
+  d.nsplit = g.nsplit > 1 ? g.nsplit : 2;
+  d.dyn_chunk = (g.k_dev != nullptr && g.nsplit > 1) ? 1 : 0;
+  gemm_tile<true, true, false, VEC>(d, t / pr.tn, t % pr.tn, 0, blockIdx.y);
+}
+
+__global__ __launch_bounds__(256) void tn_group_reduce_kernel(const TnGroupDev g) {
+  int K = g.K;
+  if (g.k_dev) K = min(K, *g.k_dev);
+  int chunk = g.chunk;
+  if (g.k_dev && g.nsplit > 1) chunk = ((K + g.nsplit - 1) / g.nsplit + BK - 1) / BK * BK;   // same rule as gemm_tile
+  int nz = chunk > 0 ? (K + chunk - 1) / chunk : 0;
+  nz = min(nz, g.nsplit);
+  for (int q = 0; q < g.n; ++q) {
+    const TnProbDev& pr = g.p[q];
+    const int64_t total = (int64_t)pr.M * pr.N;
+    const float* slab = g.slabs + pr.slab_off;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+      float s = 0.f;
+      for (int z = 0; z < nz; ++z) s += slab[(int64_t)z * total + e];
+      const int m = (int)(e / pr.N), n = (int)(e - (int64_t)m * pr.N);
+      if (n < pr.N_real) {
+        float* o = pr.C + (int64_t)m * pr.ldc + n;
+        *o += s;
+      } else {
+        pr.bias_out[m] = pr.bias_accumulate ? pr.bias_out[m] + s : s;
+      }
+    }
+  }
+}
+
+int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int32_t* k_dev, float* slabs,
+                             int64_t slab_floats, hipStream_t stream) {
+  PFO_REQUIRE(n >= 1 && n <= TN_MAX_PROBLEMS && K > 0 && probs && slabs, "bad arguments");
+  TnGroupDev g;
+  memset(&g, 0, sizeof(g));
+  bool vec = true;
+  int tiles = 0;
+  int64_t per_split = 0;
+  for (int i = 0; i < n; ++i) {
+    const PfoTnProblem& s = probs[i];
+    PFO_REQUIRE(s.A && s.B && s.C && s.M > 0 && s.N > 0, "bad problem");
+    TnProbDev& d = g.p[i];
+    d.A = s.A; d.lda = s.lda; d.B = s.B; d.ldb = s.ldb; d.b_idx = s.b_idx;
+    d.ones_scale = s.ones_scale; d.os_ld = s.os_ld; d.C = s.C; d.ldc = s.ldc;
+    d.bias_out = s.bias_out; d.bias_accumulate = s.bias_accumulate;
+    d.M = s.M; d.N_real = s.N; d.N = s.N + (s.bias_out ? 1 : 0);
+    d.tn = (int)pfo_ceil_div(d.N, BN);
+    d.tile_begin = tiles;
+    tiles += (int)pfo_ceil_div(d.M, BM) * d.tn;
+    d.slab_off = per_split;            // scaled by nsplit below
+    per_split += (int64_t)d.M * d.N;
+    vec = vec && aligned4(s.A) && aligned4(s.B) && (s.lda % 4) == 0 && (s.ldb % 4) == 0 && (s.M % 4) == 0 && (s.N % 4) == 0;
+  }
+  // one full round of resident workgroups (2 per CU x 256 CUs), never a nearly empty second one
+  int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(512 / std::max(1, tiles), pfo_ceil_div(K, 4 * BK)));
+  int chunk = (int)pfo_align_up(pfo_ceil_div(K, nsplit), BK);
+  nsplit = (int)pfo_ceil_div(K, chunk);
+  PFO_REQUIRE(slab_floats >= per_split * nsplit, "split-K workspace too small");
+  for (int i = 0; i < n; ++i) g.p[i].slab_off *= nsplit;
+  g.n = n; g.K = K; g.nsplit = nsplit; g.chunk = chunk; g.total_tiles = tiles; g.k_dev = k_dev; g.slabs = slabs;
+  double flops = 0;
+  for (int i = 0; i < n; ++i) flops += 2.0 * probs[i].M * probs[i].N * (double)K;
+  pfo_prof_begin(stream);
+  if (vec) hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
+  else hipLaunchKernelGGL(gemm_tn_group_kernel<false>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
+  PFO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tn_group_reduce_kernel, dim3((unsigned)std::min<int64_t>(1024, pfo_ceil_div(per_split, 256))), dim3(256), 0,
+                     stream, g);
+  PFO_LAUNCH_CHECK();
+  pfo_prof_end(k_dev ? PFO_PROF_GEMM_DEVM : PFO_PROF_GEMM_TN, flops, stream);
+  return PFO_OK;
+}
+
 // sums the split-K slabs: out[m, n] (+)= sum_z slab[z][m][n]
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int nsplit, int split_chunk,
                                      const int32_t* __restrict__ k_dev, int Kfull, int M, int N, float* __restrict__ out,
@@ -340,9 +484,9 @@ static void to_dev(const PfoGemm& g, GemmDev& d) {
   d.relu_src = g.relu_src; d.relu_ld = g.relu_ld; d.M = g.M; d.N = g.N; d.m_dev = g.m_dev;
   d.relu = g.relu; d.accumulate = g.accumulate; d.nsplit = 1; d.split_chunk = 0;
   d.c_bs = g.c_bs; d.bias_bs = g.bias_bs; d.rs_bs = g.rs_bs;
+  d.n_real = g.N; d.ones_scale = nullptr; d.os_ld = 0; d.slab_base = g.slabs; d.dyn_chunk = 0;
 }
 
-static bool aligned4(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
   PFO_REQUIRE(g.M > 0 && g.N > 0 && g.K[0] > 0 && g.batch >= 1, "bad sizes");
@@ -396,7 +540,8 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
     GEMM_GO(true, true, false, dim3(tm, tn, g.batch));
   } else {
     // row tiles: 128 rows per workgroup, or 32 when that would leave most of the 256 CUs without work
-    const bool small = (int64_t)pfo_ceil_div(g.M, BM) * tn * g.batch < 512;
+    static const int force_small = getenv("PFO_GEMM_FORCE_SMALL") ? atoi(getenv("PFO_GEMM_FORCE_SMALL")) : 0;   // A/B switch
+    const bool small = force_small == 1 || (force_small != 2 && (int64_t)pfo_ceil_div(g.M, BM) * tn * g.batch < 400);
     const int tm = (int)pfo_ceil_div(g.M, small ? 32 : BM);
     const dim3 grid(tm, tn, g.batch);
     if (g.b_kmajor) { if (small) GEMM_GO(false, true, true, grid); else GEMM_GO(false, true, false, grid); }

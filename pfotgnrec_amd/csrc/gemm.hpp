@@ -32,6 +32,20 @@ struct PfoGemm {
 };
 
 int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream);
+
+// One weight gradient dW[M,N] += A[K,M]^T B[K,N] (A = dY, B = X, both row-major over the K instance rows) with an
+// optional bias gradient bias_out[M] (+)= sum_k A[k][m] * (ones_scale ? ones_scale[k*os_ld] : 1) carried as column N.
+struct PfoTnProblem {
+  const float* A = nullptr; int64_t lda = 0;
+  const float* B = nullptr; int64_t ldb = 0; const int32_t* b_idx = nullptr;
+  int M = 0, N = 0;
+  float* C = nullptr; int64_t ldc = 0;
+  float* bias_out = nullptr; int bias_accumulate = 1;
+  const float* ones_scale = nullptr; int64_t os_ld = 0;
+};
+// all problems share the K extent (and its optional device-side bound); one GEMM launch + one reduce launch
+int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int32_t* k_dev, float* slabs,
+                             int64_t slab_floats, hipStream_t stream);
 // out[n] (+)= sum_m X[m,n] * (scale ? scale[m*scale_ld] : 1); rows limited by m_dev when given
 int pfo_colsum_launch(const float* X, int64_t ldx, int M, int N, const float* scale, int64_t scale_ld,
                       const int32_t* m_dev, float* out, int accumulate, float* scratch, hipStream_t stream);

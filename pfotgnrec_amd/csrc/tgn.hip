@@ -415,18 +415,27 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     const int32_t* x_idx = (l == 1) ? idx0 : nullptr;
     float* dx = (l == 1) ? w.dx1 : w.dH[l - 1];              // rows [0, N) of the previous level's gradient
 
+    // Data gradients first (a chain of GEMMs + the attention core); every weight / bias gradient of the layer is
+    // then taken in ONE grouped split-K launch (bias gradients ride along as an extra column).
+    PfoTnProblem tn[16];
+    int ntn = 0;
+    auto add_tn = [&](const float* A, int64_t lda, const float* B, int64_t ldb, const int32_t* b_idx, int M_, int N_, float* C,
+                      int64_t ldc, float* bias_out) -> PfoTnProblem& {
+      PfoTnProblem& q = tn[ntn++];
+      q = PfoTnProblem();
+      q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.b_idx = b_idx; q.M = M_; q.N = N_; q.C = C; q.ldc = ldc; q.bias_out = bias_out;
+      return q;
+    };
     // fc2 (utils.py:17)
-    RUN(pfo_gemm_launch(g_tn(dOut, D, lw.h1, D, nullptr, g.w2, D, D, D, N, w), s));
-    RUN(pfo_colsum_launch(dOut, D, N, D, nullptr, 0, nullptr, g.b2, 1, w.colsum, s));
+    add_tn(dOut, D, lw.h1, D, nullptr, D, D, g.w2, D, g.b2);
     {
       PfoGemm q = g_nn(dOut, D, p.w2, D, w.dh1, D, N, D, D);
       q.relu_src = lw.h1; q.relu_ld = D;                     // ReLU backward
       RUN(pfo_gemm_launch(q, s));
     }
     // fc1 on [attn_out | x]
-    RUN(pfo_gemm_launch(g_tn(w.dh1, D, lw.attn_out, E, nullptr, g.w1, E + D, D, E, N, w), s));
-    RUN(pfo_gemm_launch(g_tn(w.dh1, D, xA, D, x_idx, g.w1 + E, E + D, D, D, N, w), s));
-    RUN(pfo_colsum_launch(w.dh1, D, N, D, nullptr, 0, nullptr, g.b1, 1, w.colsum, s));
+    add_tn(w.dh1, D, lw.attn_out, E, nullptr, D, E, g.w1, E + D, g.b1);
+    add_tn(w.dh1, D, xA, D, x_idx, D, D, g.w1 + E, E + D, nullptr);
     {
       PfoGemm q = g_nn(w.dh1, D, p.w1, E + D, w.dattn, E, N, E, D);
       q.row_zero = lw.inv;                                   // zero-filled rows pass no gradient (temporal_attention.py:84)
@@ -434,16 +443,13 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     }
     RUN(pfo_gemm_launch(g_nn(w.dh1, D, p.w1 + E, E + D, dx, D, N, D, D), s));
     // out_proj
-    RUN(pfo_gemm_launch(g_tn(w.dattn, E, lw.O, E, nullptr, g.wo, E, E, E, N, w), s));
-    RUN(pfo_colsum_launch(w.dattn, E, N, E, nullptr, 0, nullptr, g.bo, 1, w.colsum, s));
+    add_tn(w.dattn, E, lw.O, E, nullptr, E, E, g.wo, E, g.bo);
     RUN(pfo_gemm_launch(g_nn(w.dattn, E, p.wo, E, w.dO, E, N, E, E), s));
-    // folded value projection
+    // folded value projection: d bv_h = sum_n ssum_h[n] dO_h[n] (ssum == 1 without dropout)
     for (int h = 0; h < H; ++h) {
-      RUN(pfo_gemm_launch(g_tn(w.dO + h * dh, E, lw.ctx + h * C, (int64_t)H * C, nullptr, g.wv + (int64_t)h * dh * C, C, dh,
-                               C, N, w),
-                          s));
-      RUN(pfo_colsum_launch(w.dO + h * dh, E, N, dh, b->dropout_p > 0.f ? lw.ssum + h : nullptr, H, nullptr,
-                            g.b_in + 2 * E + h * dh, 1, w.colsum, s));
+      PfoTnProblem& q = add_tn(w.dO + h * dh, E, lw.ctx + h * C, (int64_t)H * C, nullptr, dh, C, g.wv + (int64_t)h * dh * C, C,
+                               g.b_in + 2 * E + h * dh);
+      if (b->dropout_p > 0.f) { q.ones_scale = lw.ssum + h; q.os_ld = H; }
     }
     {
       PfoGemm q = g_nn(w.dO, E, p.wv, C, w.dctx, (int64_t)H * C, N, C, dh);
@@ -467,25 +473,23 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     int n_parts = 0;
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
     RUN(pfo_fold_parts_launch(w.dtime, n_parts, 2 * D, G.tw, 1, s));      // time_w and time_b are adjacent in the layout
-    // folded key projection
+    // folded key projection (the key bias has an exactly zero gradient: it cancels in the softmax)
     for (int h = 0; h < H; ++h)
-      RUN(pfo_gemm_launch(g_tn(lw.Q + h * dh, E, w.dQK + h * C, (int64_t)H * C, nullptr, g.wk + (int64_t)h * dh * C, C, dh, C,
-                               N, w),
-                          s));
+      add_tn(lw.Q + h * dh, E, w.dQK + h * C, (int64_t)H * C, nullptr, dh, C, g.wk + (int64_t)h * dh * C, C, nullptr);
     {
       PfoGemm q = g_nt(w.dQK, (int64_t)H * C, nullptr, p.wk, C, w.dQ, E, N, dh, C, nullptr);
       q.batch = H; q.a_bs[0] = C; q.b_bs[0] = (int64_t)dh * C; q.c_bs = dh;
       RUN(pfo_gemm_launch(q, s));
     }
-    // query projection (x part + folded bias)
-    RUN(pfo_gemm_launch(g_tn(w.dQ, E, xA, D, x_idx, g.wq, E, E, D, N, w), s));
-    RUN(pfo_colsum_launch(w.dQ, E, N, E, nullptr, 0, nullptr, w.gq, 0, w.colsum, s));
-    RUN(pfo_cq_backward_launch(w.gq, p.wq, P.tb, D, g.b_in, g.wq, G.tb, s));
+    // query projection (x part); its bias column is gq = colsum(dQ), consumed by the folded-bias backward
+    add_tn(w.dQ, E, xA, D, x_idx, E, D, g.wq, E, w.gq).bias_accumulate = 0;
     {
       PfoGemm q = g_nn(w.dQ, E, p.wq, E, dx, D, N, D, E);
       q.accumulate = 1;
       RUN(pfo_gemm_launch(q, s));
     }
+    RUN(pfo_gemm_tn_group_launch(tn, ntn, N, nullptr, w.slabs, w.slab_floats, s));
+    RUN(pfo_cq_backward_launch(w.gq, p.wq, P.tb, D, g.b_in, g.wq, G.tb, s));
     if (l == 1 && c->use_memory) RUN(pfo_scatter_add_rows_launch(w.dx1, D, idx0, N, D, w.d_h0, D, s));
   }
 
@@ -493,17 +497,13 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
   if (c->use_memory) {
     RUN(pfo_gru_gates_bwd_launch(w.gi, w.gh, w.h_rows, w.hm, w.n_touched, capP, D, w.d_h0, s));
     {
-      PfoGemm q = g_tn(w.gi, 3 * D, w.msg_rows, d.M, nullptr, G.w_ih, d.M, 3 * D, d.M, capP, w);
-      q.m_dev = w.n_touched;
-      RUN(pfo_gemm_launch(q, s));
+      PfoTnProblem gp[2];
+      gp[0].A = w.gi; gp[0].lda = 3 * D; gp[0].B = w.msg_rows; gp[0].ldb = d.M; gp[0].M = 3 * D; gp[0].N = d.M;
+      gp[0].C = G.w_ih; gp[0].ldc = d.M; gp[0].bias_out = G.b_ih;
+      gp[1].A = w.gh; gp[1].lda = 3 * D; gp[1].B = w.h_rows; gp[1].ldb = D; gp[1].M = 3 * D; gp[1].N = D;
+      gp[1].C = G.w_hh; gp[1].ldc = D; gp[1].bias_out = G.b_hh;
+      RUN(pfo_gemm_tn_group_launch(gp, 2, capP, w.n_touched, w.slabs, w.slab_floats, s));
     }
-    {
-      PfoGemm q = g_tn(w.gh, 3 * D, w.h_rows, D, nullptr, G.w_hh, D, 3 * D, D, capP, w);
-      q.m_dev = w.n_touched;
-      RUN(pfo_gemm_launch(q, s));
-    }
-    RUN(pfo_colsum_launch(w.gi, 3 * D, capP, 3 * D, nullptr, 0, w.n_touched, G.b_ih, 1, w.colsum, s));
-    RUN(pfo_colsum_launch(w.gh, 3 * D, capP, 3 * D, nullptr, 0, w.n_touched, G.b_hh, 1, w.colsum, s));
   }
   return PFO_OK;
 }
