@@ -135,6 +135,8 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if os.environ.get("PFO_FORCE_DEVICE") is not None:      # test hook: several ranks on one GPU
+        local = int(os.environ["PFO_FORCE_DEVICE"])
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
