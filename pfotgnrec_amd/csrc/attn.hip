@@ -11,12 +11,12 @@
 #include <algorithm>
 
 struct AttnDev {
-  int N, K, D, Ef, H, dh;
+  int N, K, D, Ef, H, Cp;
   const float* QK; const float* nbr_tab; int64_t nbr_ld; const int32_t* nbr_row; int64_t nbr_row_base;
   const int32_t* nbr_ids; const float* edge_feat; const int32_t* eidx; const float* dt; const float* tw; const float* tb;
   float scale, dropout_p; uint64_t seed, offset;
-  float* ctx; float* attw; float* ssum; uint8_t* inv;
-  const float* dctx; const float* dO; const float* bv; float* dQK; float* d_nbr; int64_t d_nbr_ld; double* dtime_part;
+  float* ctx; float* attw; uint8_t* inv;
+  const float* dctx; float* dQK; float* d_nbr; int64_t d_nbr_ld; double* dtime_part;
 };
 
 // dropout keep-bits for slot `lane` of instance n: bit h = keep for head h (H <= 4)
@@ -42,11 +42,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t n = (int64_t)blockIdx.x * 4 + wave;
   if (n >= a.N) return;
-  const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef;
+  const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef, Cp = a.Cp;   // Cp: per-head row stride (C + 2 extra columns, padded)
 
   float tw[NR], tb[NR];
   float qn[H][NR], qt[H][NR], qe[H];
-  const float* qk = a.QK + n * H * C;
+  const float* qk = a.QK + n * H * Cp;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int c = lane + 64 * r;
@@ -54,12 +54,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
     tb[r] = c < D ? a.tb[c] : 0.f;
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      qn[h][r] = c < D ? qk[h * C + c] : 0.f;
-      qt[h][r] = c < D ? qk[h * C + D + Ef + c] : 0.f;
+      qn[h][r] = c < D ? qk[h * Cp + c] : 0.f;
+      qt[h][r] = c < D ? qk[h * Cp + D + Ef + c] : 0.f;
     }
   }
 #pragma unroll
-  for (int h = 0; h < H; ++h) qe[h] = lane < Ef ? qk[h * C + D + lane] : 0.f;
+  for (int h = 0; h < H; ++h) qe[h] = lane < Ef ? qk[h * Cp + D + lane] : 0.f;
 
   const int64_t slot0 = n * K;
   const bool inK = lane < K;
@@ -68,14 +68,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
   const int my_e = inK ? a.eidx[slot0 + lane] : 0;
   const float my_dt = inK ? a.dt[slot0 + lane] : 0.f;
   const unsigned long long valid = __ballot(inK && my_id != 0);
-  float* ctx = a.ctx + n * H * C;
+  float* ctx = a.ctx + n * H * Cp;
   if (valid == 0ull) {
     // no valid neighbour: the reference attends to padded slot 0 and then zero-fills the attention
     // output (temporal_attention.py:60-65,84), so nothing computed here is ever observed
     if (lane == 0) a.inv[n] = 1;
-    for (int c = lane; c < H * C; c += 64) ctx[c] = 0.f;
+    for (int c = lane; c < H * Cp; c += 64) ctx[c] = 0.f;        // includes the Σa' and valid-flag columns
     for (int c = lane; c < H * K; c += 64) a.attw[n * H * K + c] = 0.f;
-    if (a.ssum && lane < H) a.ssum[n * H + lane] = 0.f;
     return;
   }
   if (lane == 0) a.inv[n] = 0;
@@ -167,13 +166,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
     for (int r = 0; r < NR; ++r) {
       const int c = lane + 64 * r;
       if (c < D) {
-        ctx[h * C + c] = an[h][r] * il;
-        ctx[h * C + D + Ef + c] = at[h][r] * il;
+        ctx[h * Cp + c] = an[h][r] * il;
+        ctx[h * Cp + D + Ef + c] = at[h][r] * il;
       }
     }
-    if (lane < Ef) ctx[h * C + D + lane] = ae[h] * il;
+    if (lane < Ef) ctx[h * Cp + D + lane] = ae[h] * il;
     if (lane < K) a.attw[(n * H + h) * K + lane] = ((valid >> lane) & 1ull) ? expf(my_s[h] - m[h]) * il : 0.f;
-    if (a.ssum && lane == 0) a.ssum[n * H + h] = ld[h] * il;
+    // extra columns consumed by the merged value/out/fc1 projection: C = Σ_j a'_jh (multiplies the folded value
+    // bias), C+1 = 1 on head 0 (multiplies the folded out_proj bias; absent on rows without a valid neighbour)
+    if (lane < Cp - C) ctx[h * Cp + C + lane] = lane == 0 ? ld[h] * il : ((lane == 1 && h == 0) ? 1.f : 0.f);
   }
 }
 
@@ -184,7 +185,7 @@ template <int NR, int H>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
   __shared__ double s_red[4][2][NR * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef;
+  const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef, Cp = a.Cp;
   const bool direct = (a.nbr_row == nullptr);          // neighbour rows are consecutive (layers >= 2)
   const bool wdirect = direct && a.d_nbr != nullptr;     // ... and their gradients are written, not accumulated
   float tw[NR], tb[NR];
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
   const float keep_scale = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
 
   for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < a.N; n += (int64_t)gridDim.x * 4) {
-    float* dqk_out = a.dQK + n * H * C;
+    float* dqk_out = a.dQK + n * H * Cp;
     const int64_t slot0 = n * K;
     const bool inK = lane < K;
     const int my_id = inK ? a.nbr_ids[slot0 + lane] : 0;
@@ -218,14 +219,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
       }
     }
     if (valid == 0ull) {
-      for (int c = lane; c < H * C; c += 64) dqk_out[c] = 0.f;
+      for (int c = lane; c < H * Cp; c += 64) dqk_out[c] = 0.f;
       continue;
     }
     float qn[H][NR], qt[H][NR], qe[H], gn[H][NR], gt[H][NR], ge[H], t[H], dsb[H];
     float dqn[H][NR], dqt[H][NR], dqe[H];
-    const float* qk = a.QK + n * H * C;
-    const float* dc = a.dctx + n * H * C;
-    const float* cx = a.ctx + n * H * C;
+    const float* qk = a.QK + n * H * Cp;
+    const float* dc = a.dctx + n * H * Cp;
+    const float* cx = a.ctx + n * H * Cp;
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       float part = 0.f;
@@ -233,36 +234,27 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
       for (int r = 0; r < NR; ++r) {
         const int c = lane + 64 * r;
         const bool ok = c < D;
-        qn[h][r] = ok ? qk[h * C + c] : 0.f;
-        qt[h][r] = ok ? qk[h * C + D + Ef + c] : 0.f;
-        gn[h][r] = ok ? dc[h * C + c] : 0.f;
-        gt[h][r] = ok ? dc[h * C + D + Ef + c] : 0.f;
-        if (ok) part = fmaf(gn[h][r], cx[h * C + c], fmaf(gt[h][r], cx[h * C + D + Ef + c], part));
+        qn[h][r] = ok ? qk[h * Cp + c] : 0.f;
+        qt[h][r] = ok ? qk[h * Cp + D + Ef + c] : 0.f;
+        gn[h][r] = ok ? dc[h * Cp + c] : 0.f;
+        gt[h][r] = ok ? dc[h * Cp + D + Ef + c] : 0.f;
+        if (ok) part = fmaf(gn[h][r], cx[h * Cp + c], fmaf(gt[h][r], cx[h * Cp + D + Ef + c], part));
         dqn[h][r] = 0.f; dqt[h][r] = 0.f;
       }
-      qe[h] = lane < Ef ? qk[h * C + D + lane] : 0.f;
-      ge[h] = lane < Ef ? dc[h * C + D + lane] : 0.f;
-      if (lane < Ef) part = fmaf(ge[h], cx[h * C + D + lane], part);
+      qe[h] = lane < Ef ? qk[h * Cp + D + lane] : 0.f;
+      ge[h] = lane < Ef ? dc[h * Cp + D + lane] : 0.f;
+      if (lane < Ef) part = fmaf(ge[h], cx[h * Cp + D + lane], part);
       dqe[h] = 0.f;
       t[h] = part;
-      dsb[h] = 0.f;
-      if (a.dropout_p > 0.f) {
-        float pb = 0.f;
-        for (int c = lane; c < a.dh; c += 64) pb = fmaf(a.dO[n * H * a.dh + h * a.dh + c], a.bv[h * a.dh + c], pb);
-        dsb[h] = pb;
-      }
+      dsb[h] = dc[h * Cp + C];          // d loss / d (Σ_j a'_jh): the gradient of the context's extra column
     }
-    // delta_h = sum_j a_jh * da_jh = dctx_h . ctx_h (+ d ssum_h * ssum_h under dropout); interleaved butterflies
+    // delta_h = sum_j a_jh * da_jh = dctx_h . ctx_h + d(Σa')_h * (Σa')_h; interleaved butterflies
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-      for (int h = 0; h < H; ++h) {
-        t[h] += __shfl_xor(t[h], o, 64);
-        if (a.dropout_p > 0.f) dsb[h] += __shfl_xor(dsb[h], o, 64);
-      }
-    if (a.dropout_p > 0.f)
+      for (int h = 0; h < H; ++h) t[h] += __shfl_xor(t[h], o, 64);
 #pragma unroll
-      for (int h = 0; h < H; ++h) t[h] = fmaf(dsb[h], a.ssum[n * H + h], t[h]);
+    for (int h = 0; h < H; ++h) t[h] = fmaf(dsb[h], cx[h * Cp + C], t[h]);
 
     const unsigned keep = attn_keep_bits(a.seed, a.offset, n, lane, a.dropout_p);
     float my_a[H];
@@ -365,11 +357,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
       for (int r = 0; r < NR; ++r) {
         const int c = lane + 64 * r;
         if (c < D) {
-          dqk_out[h * C + c] = dqn[h][r];
-          dqk_out[h * C + D + Ef + c] = dqt[h][r];
+          dqk_out[h * Cp + c] = dqn[h][r];
+          dqk_out[h * Cp + D + Ef + c] = dqt[h][r];
         }
       }
-      if (lane < Ef) dqk_out[h * C + D + lane] = dqe[h];
+      if (lane < Ef) dqk_out[h * Cp + D + lane] = dqe[h];
+      if (lane < Cp - C) dqk_out[h * Cp + C + lane] = 0.f;      // padding columns feed GEMMs: keep them finite
     }
   }
   // time-encoder partials: fold the four wavefronts, one slab row per workgroup (deterministic)
@@ -387,12 +380,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
 }
 
 static void to_dev(const PfoAttn& a, AttnDev& d) {
-  d.N = a.N; d.K = a.K; d.D = a.D; d.Ef = a.Ef; d.H = a.H; d.dh = a.dh;
+  d.N = a.N; d.K = a.K; d.D = a.D; d.Ef = a.Ef; d.H = a.H; d.Cp = a.Cp;
   d.QK = a.QK; d.nbr_tab = a.nbr_tab; d.nbr_ld = a.nbr_ld; d.nbr_row = a.nbr_row; d.nbr_row_base = a.nbr_row_base;
   d.nbr_ids = a.nbr_ids; d.edge_feat = a.edge_feat; d.eidx = a.eidx; d.dt = a.dt; d.tw = a.tw; d.tb = a.tb;
   d.scale = a.scale; d.dropout_p = a.dropout_p; d.seed = a.seed; d.offset = a.offset;
-  d.ctx = a.ctx; d.attw = a.attw; d.ssum = a.ssum; d.inv = a.inv;
-  d.dctx = a.dctx; d.dO = a.dO; d.bv = a.bv; d.dQK = a.dQK; d.d_nbr = a.d_nbr; d.d_nbr_ld = a.d_nbr_ld;
+  d.ctx = a.ctx; d.attw = a.attw; d.inv = a.inv;
+  d.dctx = a.dctx; d.dQK = a.dQK; d.d_nbr = a.d_nbr; d.d_nbr_ld = a.d_nbr_ld;
   d.dtime_part = a.dtime_part;
 }
 
@@ -404,7 +397,7 @@ static int check_common(const PfoAttn& a) {
   PFO_REQUIRE(a.QK && a.nbr_tab && a.nbr_ids && a.eidx && a.dt && a.tw && a.tb && a.ctx && a.attw && a.inv, "null input");
   PFO_REQUIRE(a.Ef == 0 || a.edge_feat, "null edge features");
   PFO_REQUIRE(a.dropout_p >= 0.f && a.dropout_p < 1.f, "dropout must be in [0, 1)");
-  PFO_REQUIRE(a.dropout_p == 0.f || a.ssum, "dropout needs the ssum buffer");
+  PFO_REQUIRE(a.Cp >= 2 * a.D + a.Ef + 2 && (a.Cp % 4) == 0, "Cp must hold C + 2 columns and be a multiple of 4");
   return PFO_OK;
 }
 
@@ -448,7 +441,6 @@ int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream) {
 int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
   if (int rc = check_common(a)) return rc;
   PFO_REQUIRE(a.dctx && a.dQK && a.dtime_part, "null backward buffers");
-  PFO_REQUIRE(a.dropout_p == 0.f || (a.dO && a.bv && a.dh > 0), "dropout backward needs dO and bv");
   AttnDev d;
   to_dev(a, d);
   const int grid = (int)std::min<int64_t>(ATTN_BWD_MAX_BLOCKS, pfo_ceil_div(a.N, 4));

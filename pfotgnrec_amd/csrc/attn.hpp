@@ -7,7 +7,9 @@
 // scores use the FOLDED query-key vector qk_h = Wk_h^T Q_h: score_jh = scale * qk_h . key_j
 struct PfoAttn {
   int N = 0, K = 0, D = 0, Ef = 0, H = 0;
-  const float* QK = nullptr;        // [N, H*C], C = 2D+Ef
+  int Cp = 0;                       // per-head row stride of QK / ctx / dctx / dQK: C = 2D+Ef feature columns, column C =
+                                    // sum_j a'_jh, column C+1 = valid flag on head 0, zero padding up to a multiple of 4
+  const float* QK = nullptr;        // [N, H*Cp]
   const float* nbr_tab = nullptr;   // rows of D floats
   int64_t nbr_ld = 0;
   const int32_t* nbr_row = nullptr; // [N*K] row of nbr_tab per slot, or null: row = nbr_row_base + n*K + j
@@ -22,16 +24,12 @@ struct PfoAttn {
   float dropout_p = 0.f;
   uint64_t seed = 0, offset = 0;
   // forward outputs / backward inputs
-  float* ctx = nullptr;             // [N, H*C]  sum_j a'_jh key_j
+  float* ctx = nullptr;             // [N, H*Cp] sum_j a'_jh key_j (+ the two extra columns)
   float* attw = nullptr;            // [N, H, K] softmax probabilities before dropout (0 on padding)
-  float* ssum = nullptr;            // [N, H]    sum_j a'_jh (only when dropout_p > 0)
   uint8_t* inv = nullptr;           // [N]       1 = no valid neighbour (temporal_attention.py:60)
   // backward
-  const float* dctx = nullptr;      // [N, H*C]
-  const float* dO = nullptr;        // [N, H*dh] (dropout only: d ssum_h = dO_h . bv_h)
-  const float* bv = nullptr;        // [H*dh]
-  int dh = 0;
-  float* dQK = nullptr;             // [N, H*C]
+  const float* dctx = nullptr;      // [N, H*Cp]
+  float* dQK = nullptr;             // [N, H*Cp]
   float* d_nbr = nullptr;           // rows of D floats: direct rows (nbr_row == null) or atomically added rows
   int64_t d_nbr_ld = 0;
   double* dtime_part = nullptr;     // [grid, 2*D] per-workgroup fp64 partial (dw | db) of the time encoder

@@ -44,6 +44,9 @@ struct GemmDev {
 
 static bool aligned4(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+#ifndef PFO_DEFAULT_TILE
+#define PFO_DEFAULT_TILE 0
+#endif
 #ifndef GEMM_EXP
 #define GEMM_EXP 0       // timing-only ablations (wrong results): 1 = no global loads / LDS stores after the first tile, 2 = no MFMA,
 #endif                   //                                          3 = no barriers + no reloads
@@ -74,14 +77,17 @@ __device__ __forceinline__ float4 ld4(const float* p, int nv, const float* safe)
 // SMALL exists for the layer-2 launches (M = 2560 rows): 4x the workgroups, so the chip is not left idle.
 // The K loop runs over a flattened list of 32-deep tiles of up to two K-concatenated sources; the global loads of
 // tile t+1 are in flight (registers) while the MFMAs of tile t run from LDS.
-template <bool A_KM, bool B_KM, bool SMALL, bool VEC>
-__device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const int by, int zb, const int split_in) {
-  constexpr int TBM = SMALL ? 32 : BM;
+template <bool A_KM, bool B_KM, int TILE, bool VEC>
+__device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const int by, int zb, const int split_in,
+                                          float* __restrict__ lds_a, float* __restrict__ lds_b) {
+  constexpr bool SMALL = (TILE == 1), MED = (TILE == 2);
+  constexpr int TBM = SMALL ? 32 : (MED ? 64 : BM);
   constexpr int NJ = SMALL ? 3 : 11;
-  constexpr int NA = SMALL ? 1 : 4;            // float4 per thread for the A tile
-  constexpr int NBUF = GEMM_DBUF ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) float As[NBUF][AS_FLOATS];
-  __shared__ __attribute__((aligned(16))) float Bs[NBUF][BS_FLOATS];
+  constexpr int NI = MED ? 1 : 2;              // 16-row strips per wavefront
+  constexpr int NA = TBM / 32;                 // float4 per thread for the A tile
+  constexpr int LDAK = MED ? 80 : LDA_KM;      // k-major A row stride, = 16 mod 32
+  float* const As[2] = {lds_a, lds_a + AS_FLOATS};   // second buffer only exists with GEMM_DBUF
+  float* const Bs[2] = {lds_b, lds_b + BS_FLOATS};
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -102,12 +108,12 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
     kbeg = split * chunk;
     kend0 = min(Kext0, kbeg + chunk);
   }
-  const int wrow = SMALL ? 0 : 32 * wave;      // first tile row of this wavefront
+  const int wrow = SMALL ? 0 : (MED ? 16 * wave : 32 * wave);      // first tile row of this wavefront
   const int wcol = SMALL ? 16 * wave : 0;      // first tile column; SMALL strides columns by 64
 
-  f32x4 acc[2][NJ];
+  f32x4 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -213,7 +219,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int f = tid + 256 * i;
-        *reinterpret_cast<float4*>(as + (f / (TBM / 4)) * LDA_KM + 4 * (f % (TBM / 4))) = a_reg[i];
+        *reinterpret_cast<float4*>(as + (f / (TBM / 4)) * LDAK + 4 * (f % (TBM / 4))) = a_reg[i];
       }
     }
     if (!B_KM) {
@@ -238,10 +244,10 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
     }
   };
   // fragments of k-step s (lane (r, g) holds A[row r][k = 4s + g], B[k = 4s + g][col r])
-  auto load_frags = [&](const float* as, const float* bs, int s, float (&a)[2], float (&b)[NJ]) {
+  auto load_frags = [&](const float* as, const float* bs, int s, float (&a)[NI], float (&b)[NJ]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      a[i] = A_KM ? as[(4 * s + g) * LDA_KM + wrow + 16 * i + r] : as[(wrow + 16 * i + r) * LDA_RM + 4 * s + g];
+    for (int i = 0; i < NI; ++i)
+      a[i] = A_KM ? as[(4 * s + g) * LDAK + wrow + 16 * i + r] : as[(wrow + 16 * i + r) * LDA_RM + 4 * s + g];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int col = wcol + (SMALL ? 64 : 16) * j + r;
@@ -251,9 +257,9 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
   // a wavefront whose 16-row strip lies entirely beyond M issues no MFMAs for it (172-row weight-gradient tiles:
   // the matrix pipe of its SIMD is left to the co-resident workgroup)
   const bool strip_on[2] = {m0 + wrow < p.M, m0 + wrow + 16 < p.M};
-  auto mma = [&](const float (&a)[2], const float (&b)[NJ]) {
+  auto mma = [&](const float (&a)[NI], const float (&b)[NJ]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
       if (strip_on[i])
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
@@ -265,7 +271,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
   auto compute_tile = [&](int buf) {
     const float* as = As[buf];
     const float* bs = Bs[buf];
-    float a0[2], b0[NJ], a1[2], b1[NJ];
+    float a0[NI], b0[NJ], a1[NI], b1[NJ];
     load_frags(as, bs, 0, a0, b0);
 #pragma unroll
     for (int s = 0; s < BK / 4; s += 2) {
@@ -310,7 +316,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
   const float* bias = (p.bias && !plain) ? p.bias + zb * p.bias_bs : nullptr;
   const float* rs = (p.row_scale && !plain) ? p.row_scale + zb * p.rs_bs : nullptr;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NI; ++i) {
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int row = m0 + wrow + 16 * i + 4 * g + reg;
@@ -323,11 +329,11 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
         if (col >= p.N || (SMALL && wcol + 64 * j >= BN)) continue;
         float v = acc[i][j][reg];
         if (!plain) {
+          if (p.accumulate) v += Cb[(int64_t)row * ldc + col];
           if (bias) v = fmaf(bias[col], rscale, v);
           if (zero) v = 0.f;
           if (p.relu) v = fmaxf(v, 0.f);
           if (p.relu_src) v = (p.relu_src[(int64_t)row * p.relu_ld + col] > 0.f) ? v : 0.f;
-          if (p.accumulate) v += Cb[(int64_t)row * ldc + col];
         }
         Cb[(int64_t)row * ldc + col] = v;
       }
@@ -335,11 +341,66 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
   }
 }
 
-template <bool A_KM, bool B_KM, bool SMALL, bool VEC>
+#define GEMM_LDS_DECL                                                                    \
+  __shared__ __attribute__((aligned(16))) float lds_a[(GEMM_DBUF ? 2 : 1) * AS_FLOATS]; \
+  __shared__ __attribute__((aligned(16))) float lds_b[(GEMM_DBUF ? 2 : 1) * BS_FLOATS]
+
+template <bool A_KM, bool B_KM, int TILE, bool VEC>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p) {
+  GEMM_LDS_DECL;
   int zb = blockIdx.z, split = 0;
   if (A_KM && p.nsplit > 1) { split = zb % p.nsplit; zb /= p.nsplit; }
-  gemm_tile<A_KM, B_KM, SMALL, VEC>(p, blockIdx.x, blockIdx.y, zb, split);
+  gemm_tile<A_KM, B_KM, TILE, VEC>(p, blockIdx.x, blockIdx.y, zb, split, lds_a, lds_b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Several SMALL independent contractions in one launch (the composite-weight products of a layer and their
+// gradient chain: each is far too small to fill the chip or to amortise a launch).  32-row tiles; the operand
+// layout is a per-problem switch (wavefront-uniform).
+#define MULTI_MAX 10
+struct MultiDev {
+  GemmDev p[MULTI_MAX];
+  int layout[MULTI_MAX];      // a_kmajor * 2 + b_kmajor
+  int tile_begin[MULTI_MAX];  // first flattened tile of each problem
+  int tm[MULTI_MAX], tn[MULTI_MAX];
+  int n;
+};
+template <bool VEC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_multi_kernel(const MultiDev g) {
+  GEMM_LDS_DECL;
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < MULTI_MAX; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.tile_begin[i]) q = i;
+  int t = blockIdx.x - g.tile_begin[q];
+  const int per_batch = g.tm[q] * g.tn[q];
+  const int zb = t / per_batch;
+  t -= zb * per_batch;
+  const int bx = t / g.tn[q], by = t % g.tn[q];
+  const GemmDev& p = g.p[q];
+  switch (g.layout[q]) {
+    case 0: gemm_tile<false, false, 1, VEC>(p, bx, by, zb, 0, lds_a, lds_b); break;
+    case 1: gemm_tile<false, true, 1, VEC>(p, bx, by, zb, 0, lds_a, lds_b); break;
+    case 2: gemm_tile<true, false, 1, VEC>(p, bx, by, zb, 0, lds_a, lds_b); break;
+    default: gemm_tile<true, true, 1, VEC>(p, bx, by, zb, 0, lds_a, lds_b); break;
+  }
+}
+
+// out[m, n] (+)= u[m] * v[n]
+__global__ void rank1_kernel(const float* __restrict__ u, int64_t ldu, const float* __restrict__ v, int64_t ldv, int M, int N,
+                             float* __restrict__ out, int64_t ldo) {
+  const int64_t total = (int64_t)M * N;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(e / N), n = (int)(e - (int64_t)m * N);
+    out[(int64_t)m * ldo + n] += u[(int64_t)m * ldu] * v[(int64_t)n * ldv];
+  }
+}
+int pfo_rank1_launch(const float* u, int64_t ldu, const float* v, int64_t ldv, int M, int N, float* out, int64_t ldo,
+                     hipStream_t stream) {
+  const int nb = (int)std::min<int64_t>(512, pfo_ceil_div((int64_t)M * N, 256));
+  hipLaunchKernelGGL(rank1_kernel, dim3(nb), dim3(256), 0, stream, u, ldu, v, ldv, M, N, out, ldo);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -350,7 +411,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
 struct TnProbDev {
   const float* A; int64_t lda; const float* B; int64_t ldb; const int32_t* b_idx;
   const float* ones_scale; int64_t os_ld;
-  float* C; int64_t ldc; float* bias_out; int bias_accumulate;
+  float* C; int64_t ldc; float* bias_out; int bias_accumulate, c_accumulate;
   int M, N_real, N;          // N = N_real + (bias_out ? 1 : 0)
   int tile_begin, tn;        // first flattened tile, column tiles
   int64_t slab_off;          // floats
@@ -364,6 +425,7 @@ struct TnGroupDev {
 
 template <bool VEC>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_group_kernel(const TnGroupDev g) {
+  GEMM_LDS_DECL;
   int q = 0;
 #pragma unroll
   for (int i = 1; i < TN_MAX_PROBLEMS; ++i)
@@ -384,7 +446,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_group_kernel(const TnGro
   d.slab_base = g.slabs + pr.slab_off - (int64_t)0;
   d.nsplit = g.nsplit > 1 ? g.nsplit : 2;
   d.dyn_chunk = (g.k_dev != nullptr && g.nsplit > 1) ? 1 : 0;
-  gemm_tile<true, true, false, VEC>(d, t / pr.tn, t % pr.tn, 0, blockIdx.y);
+  gemm_tile<true, true, 0, VEC>(d, t / pr.tn, t % pr.tn, 0, blockIdx.y, lds_a, lds_b);
 }
 
 __global__ __launch_bounds__(256) void tn_group_reduce_kernel(const TnGroupDev g) {
@@ -404,7 +466,7 @@ __global__ __launch_bounds__(256) void tn_group_reduce_kernel(const TnGroupDev g
       const int m = (int)(e / pr.N), n = (int)(e - (int64_t)m * pr.N);
       if (n < pr.N_real) {
         float* o = pr.C + (int64_t)m * pr.ldc + n;
-        *o += s;
+        *o = pr.c_accumulate ? *o + s : s;
       } else {
         pr.bias_out[m] = pr.bias_accumulate ? pr.bias_out[m] + s : s;
       }
@@ -426,7 +488,7 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
     TnProbDev& d = g.p[i];
     d.A = s.A; d.lda = s.lda; d.B = s.B; d.ldb = s.ldb; d.b_idx = s.b_idx;
     d.ones_scale = s.ones_scale; d.os_ld = s.os_ld; d.C = s.C; d.ldc = s.ldc;
-    d.bias_out = s.bias_out; d.bias_accumulate = s.bias_accumulate;
+    d.bias_out = s.bias_out; d.bias_accumulate = s.bias_accumulate; d.c_accumulate = s.c_accumulate;
     d.M = s.M; d.N_real = s.N; d.N = s.N + (s.bias_out ? 1 : 0);
     d.tn = (int)pfo_ceil_div(d.N, BN);
     d.tile_begin = tiles;
@@ -500,7 +562,6 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
     b_vec = b_vec && aligned4(g.B[s]) && (g.ldb[s] % 4) == 0 && (g.b_bs[s] % 4) == 0 &&
             (g.b_kmajor ? (g.N % 4) == 0 : (g.K[s] % 4) == 0);
   }
-  PFO_REQUIRE(!(g.a_kmajor && !g.b_kmajor), "k-major A with row-major B is not instantiated");
   GemmDev d;
   to_dev(g, d);
   const bool vec = a_vec && b_vec;
@@ -522,12 +583,13 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
     int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(want, pfo_ceil_div(K, 4 * BK)));
     int chunk = (int)pfo_align_up(pfo_ceil_div(K, nsplit), BK);
     nsplit = (int)pfo_ceil_div(K, chunk);
-    if (nsplit > 1) {
+    if (nsplit > 1 && g.b_kmajor && g.slabs) {
       PFO_REQUIRE(g.batch == 1, "split-K with batch is not supported");
       PFO_REQUIRE(g.slabs && g.slab_floats >= (int64_t)nsplit * g.M * g.N, "split-K workspace too small");
       PFO_REQUIRE(!g.bias && !g.relu && !g.row_zero && !g.relu_src, "split-K takes no epilogue");
       d.nsplit = nsplit; d.split_chunk = chunk; d.C = g.slabs;
-      GEMM_GO(true, true, false, dim3(tm, tn, nsplit));
+      PFO_REQUIRE(g.b_kmajor, "split-K needs k-major B");
+      GEMM_GO(true, true, 0, dim3(tm, tn, nsplit));
       PFO_LAUNCH_CHECK();
       const int64_t total = (int64_t)g.M * g.N;
       const int rb = (int)std::min<int64_t>(2048, pfo_ceil_div(total, 256));
@@ -537,19 +599,65 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
       pfo_prof_end(kind, flops, stream);
       return PFO_OK;
     }
-    GEMM_GO(true, true, false, dim3(tm, tn, g.batch));
+    if (g.b_kmajor) GEMM_GO(true, true, 0, dim3(tm, tn, g.batch)); else GEMM_GO(true, false, 0, dim3(tm, tn, g.batch));
   } else {
-    // row tiles: 128 rows per workgroup, or 32 when that would leave most of the 256 CUs without work
-    static const int force_small = getenv("PFO_GEMM_FORCE_SMALL") ? atoi(getenv("PFO_GEMM_FORCE_SMALL")) : 0;   // A/B switch
-    const bool small = force_small == 1 || (force_small != 2 && (int64_t)pfo_ceil_div(g.M, BM) * tn * g.batch < 400);
-    const int tm = (int)pfo_ceil_div(g.M, small ? 32 : BM);
-    const dim3 grid(tm, tn, g.batch);
-    if (g.b_kmajor) { if (small) GEMM_GO(false, true, true, grid); else GEMM_GO(false, true, false, grid); }
-    else            { if (small) GEMM_GO(false, false, true, grid); else GEMM_GO(false, false, false, grid); }
+    // tile rows per workgroup: 128 (BIG), 64 (MED: finer tail quantisation, 3 workgroups per CU) or 32 (SMALL: the
+    // layer-2 launches, where 128-row tiles would leave most of the 256 CUs without work)
+    static const int force = getenv("PFO_GEMM_TILE") ? atoi(getenv("PFO_GEMM_TILE")) : -1;   // A/B switch: 0 BIG, 1 SMALL, 2 MED
+    const int64_t big_tiles = (int64_t)pfo_ceil_div(g.M, BM) * tn * g.batch;
+    int tile = big_tiles < 400 ? 1 : PFO_DEFAULT_TILE;
+    if (force >= 0) tile = force;
+    const int rows = tile == 1 ? 32 : (tile == 2 ? 64 : BM);
+    const dim3 grid((unsigned)pfo_ceil_div(g.M, rows), tn, g.batch);
+    if (g.b_kmajor) {
+      if (tile == 1) GEMM_GO(false, true, 1, grid); else if (tile == 2) GEMM_GO(false, true, 2, grid); else GEMM_GO(false, true, 0, grid);
+    } else {
+      if (tile == 1) GEMM_GO(false, false, 1, grid); else if (tile == 2) GEMM_GO(false, false, 2, grid); else GEMM_GO(false, false, 0, grid);
+    }
   }
 #undef GEMM_GO
   PFO_LAUNCH_CHECK();
   pfo_prof_end(kind, flops, stream);
+  return PFO_OK;
+}
+
+static bool gemm_vec_ok(const PfoGemm& g) {
+  bool a_vec = true, b_vec = true;
+  for (int s = 0; s < 2; ++s) {
+    if (s == 1 && g.K[1] == 0) continue;
+    a_vec = a_vec && aligned4(g.A[s]) && (g.lda[s] % 4) == 0 && (g.a_bs[s] % 4) == 0 &&
+            (g.a_kmajor ? (g.M % 4) == 0 : (g.K[s] % 4) == 0);
+    b_vec = b_vec && aligned4(g.B[s]) && (g.ldb[s] % 4) == 0 && (g.b_bs[s] % 4) == 0 &&
+            (g.b_kmajor ? (g.N % 4) == 0 : (g.K[s] % 4) == 0);
+  }
+  return a_vec && b_vec;
+}
+
+int pfo_gemm_multi_launch(const PfoGemm* list, int n, hipStream_t stream) {
+  PFO_REQUIRE(list && n >= 1, "bad arguments");
+  for (int base = 0; base < n; base += MULTI_MAX) {
+    const int cnt = std::min(MULTI_MAX, n - base);
+    MultiDev g;
+    memset(&g, 0, sizeof(g));
+    bool vec = true;
+    int tiles = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const PfoGemm& s = list[base + i];
+      PFO_REQUIRE(s.M > 0 && s.N > 0 && s.K[0] > 0 && s.A[0] && s.B[0] && s.C, "bad problem");
+      PFO_REQUIRE(!s.m_dev && !s.slabs, "multi launch takes plain problems only");
+      to_dev(s, g.p[i]);
+      g.layout[i] = (s.a_kmajor ? 2 : 0) + (s.b_kmajor ? 1 : 0);
+      g.tm[i] = (int)pfo_ceil_div(s.M, 32);
+      g.tn[i] = (int)pfo_ceil_div(s.N, BN);
+      g.tile_begin[i] = tiles;
+      tiles += g.tm[i] * g.tn[i] * s.batch;
+      vec = vec && gemm_vec_ok(s);
+    }
+    g.n = cnt;
+    if (vec) hipLaunchKernelGGL(gemm_multi_kernel<true>, dim3(tiles), dim3(GEMM_THREADS), 0, stream, g);
+    else hipLaunchKernelGGL(gemm_multi_kernel<false>, dim3(tiles), dim3(GEMM_THREADS), 0, stream, g);
+    PFO_LAUNCH_CHECK();
+  }
   return PFO_OK;
 }
 

@@ -32,6 +32,11 @@ struct PfoGemm {
 };
 
 int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream);
+// several small plain problems (any operand layouts, no device-side counts, no split-K) in one launch
+int pfo_gemm_multi_launch(const PfoGemm* list, int n, hipStream_t stream);
+// out[m, n] += u[m * ldu] * v[n * ldv]
+int pfo_rank1_launch(const float* u, int64_t ldu, const float* v, int64_t ldv, int M, int N, float* out, int64_t ldo,
+                     hipStream_t stream);
 
 // One weight gradient dW[M,N] += A[K,M]^T B[K,N] (A = dY, B = X, both row-major over the K instance rows) with an
 // optional bias gradient bias_out[M] (+)= sum_k A[k][m] * (ones_scale ? ones_scale[k*os_ld] : 1) carried as column N.
@@ -39,7 +44,7 @@ struct PfoTnProblem {
   const float* A = nullptr; int64_t lda = 0;
   const float* B = nullptr; int64_t ldb = 0; const int32_t* b_idx = nullptr;
   int M = 0, N = 0;
-  float* C = nullptr; int64_t ldc = 0;
+  float* C = nullptr; int64_t ldc = 0; int c_accumulate = 1;
   float* bias_out = nullptr; int bias_accumulate = 1;
   const float* ones_scale = nullptr; int64_t os_ld = 0;
 };

@@ -22,7 +22,8 @@ extern "C" int pfo_tnbr_sample(const int64_t*, const int32_t*, const int32_t*, c
 namespace {
 
 struct LayerWs {
-  float *Q, *QK, *attw, *ssum, *ctx, *O, *attn_out, *h1, *Hout, *cq;
+  float *QK, *attw, *ctx, *h1, *Hout;      // activations kept for backward
+  float *cq, *Wqk, *cqk, *W1oT, *W1ovT;   // per-step composite weights (see the layer comment in pfo_tgn_forward)
   uint8_t* inv;
 };
 struct Ws {
@@ -35,7 +36,8 @@ struct Ws {
   uint8_t* hm;
   float *cosb, *zero, *gq;
   LayerWs layer[PFO_MAX_LAYERS + 1];
-  float *dh1, *dattn, *dO, *dctx, *dQK, *dQ, *dx1;
+  float *dh1, *dctx, *dQK, *dx1;
+  float *dWqk, *gqk, *dW1ovT, *dW1oT;   // gradients of the composite weights (chained back to the parameters)
   float* dH[PFO_MAX_LAYERS + 1];
   float *slabs, *colsum;
   double* dtime;
@@ -44,7 +46,7 @@ struct Ws {
 };
 
 struct Dims {
-  int L, D, Ef, H, E, C, dh, M;
+  int L, D, Ef, H, E, C, Cp, dh, M;
   int64_t ncap[PFO_MAX_LAYERS + 1];
   int64_t capP;
 };
@@ -53,6 +55,7 @@ Dims dims_of(const pfo_tgn_config* c) {
   Dims d;
   d.L = c->n_layers; d.D = c->D; d.Ef = c->Ef; d.H = c->n_heads;
   d.E = 2 * d.D; d.C = 2 * d.D + d.Ef; d.dh = d.E / d.H; d.M = 3 * d.D + d.Ef;
+  d.Cp = (int)pfo_align_up(d.C + 2, 4);   // key columns + (sum of weights) + (valid flag), padded for 16-byte rows
   d.ncap[d.L] = c->max_roots;
   for (int l = d.L; l >= 1; --l) d.ncap[l - 1] = d.ncap[l] * (1 + (int64_t)c->max_neighbors);
   d.capP = std::min<int64_t>(c->n_nodes, d.ncap[0] + 2 * (int64_t)c->max_batch);
@@ -105,26 +108,27 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     const int64_t N = d.ncap[l];
     LayerWs& lw = w.layer[l];
     lw.cq = take<float>(p, d.E);
-    lw.Q = take<float>(p, N * d.E);
-    lw.QK = take<float>(p, N * d.H * d.C);
+    lw.Wqk = take<float>(p, (int64_t)d.H * d.Cp * d.D);
+    lw.cqk = take<float>(p, (int64_t)d.H * d.Cp);
+    lw.W1oT = take<float>(p, (int64_t)d.E * d.D);
+    lw.W1ovT = take<float>(p, (int64_t)d.H * d.Cp * d.D);
+    lw.QK = take<float>(p, N * d.H * d.Cp);
     lw.attw = take<float>(p, N * d.H * Km);
-    lw.ssum = take<float>(p, N * d.H);
     lw.inv = take<uint8_t>(p, N);
-    lw.ctx = take<float>(p, N * d.H * d.C);
-    lw.O = take<float>(p, N * d.E);
-    lw.attn_out = take<float>(p, N * d.E);
+    lw.ctx = take<float>(p, N * d.H * d.Cp);
     lw.h1 = take<float>(p, N * d.D);
     lw.Hout = take<float>(p, N * d.D);
     if (l < d.L) w.dH[l] = take<float>(p, N * d.D);
   }
   const int64_t N1 = d.ncap[1];
   w.dh1 = take<float>(p, N1 * d.D);
-  w.dattn = take<float>(p, N1 * d.E);
-  w.dO = take<float>(p, N1 * d.E);
-  w.dctx = take<float>(p, N1 * d.H * d.C);
-  w.dQK = take<float>(p, N1 * d.H * d.C);
-  w.dQ = take<float>(p, N1 * d.E);
+  w.dctx = take<float>(p, N1 * d.H * d.Cp);
+  w.dQK = take<float>(p, N1 * d.H * d.Cp);
   w.dx1 = take<float>(p, N1 * d.D);
+  w.dWqk = take<float>(p, (int64_t)d.H * d.Cp * d.D);
+  w.gqk = take<float>(p, (int64_t)d.H * d.Cp);
+  w.dW1ovT = take<float>(p, (int64_t)d.H * d.Cp * d.D);
+  w.dW1oT = take<float>(p, (int64_t)d.E * d.D);
   w.slab_floats = SLAB_FLOATS;
   w.slabs = take<float>(p, w.slab_floats);
   w.colsum = take<float>(p, pfo_colsum_scratch_floats(3 * d.D + 2 * d.E + d.M));
@@ -327,7 +331,19 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   PFO_REQUIRE(hipMemsetAsync(w.zero, 0, 64 * sizeof(float), s) == hipSuccess, "memset failed");
   RUN(pfo_time_encode(w.zero, 1, P.tw, P.tb, D, w.cosb, stream));
 
+  // One attention layer = THREE large contractions around the neighbour-tile attention kernel (taken
+  // to its end).  With one query per instance every projection that touches only that instance folds into a
+  // per-step composite weight:
+  //   qk'_h  = Wqk_h x + cqk_h,            Wqk_h  = Wk_h^T Wq_h[:, :D],   cqk_h = Wk_h^T (Wq_h[:, D:] cos(b) + bq_h)
+  //   h1     = relu( sum_h W1ov_h ctx'_h + W1[:, E:] x + b1 ),
+  //            W1ov_h = W1[:, :E] Wo[:, h] Wv_h   (fc1 . out_proj . value projection),
+  //            ctx'_h = [ sum_j a'_jh key_j | sum_j a'_jh | valid ]  - the two extra columns carry the folded value
+  //            bias (W1 Wo_h bv_h, scaled by the post-dropout weight sum) and the folded out_proj bias (W1 bo, only
+  //            on rows that have a valid neighbour: temporal_attention.py:84 zero-fills the others)
+  //   out    = W2 h1 + b2
+  // 0.60 MFLOP per instance instead of 1.13 (and 10.3 un-folded); Q, O and attn_out are never formed.
   const float scale = 1.0f / sqrtf((float)dh);
+  const int Cp = d.Cp, HCp = H * d.Cp;
   for (int l = 1; l <= L; ++l) {
     const int N = (int)n[l];
     const LayerWs& lw = w.layer[l];
@@ -335,42 +351,47 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     const float* xA = (l == 1) ? tab0 : w.layer[l - 1].Hout;
     const int32_t* x_idx = (l == 1) ? idx0 : nullptr;
 
-    // folded query bias cq = Wq[:, D:] cos(b) + bq, then Q = x Wq[:, :D]^T + cq
-    RUN(pfo_gemm_launch(g_nt(w.cosb, D, nullptr, p.wq + D, E, lw.cq, E, 1, E, D, p.b_in), s));
-    RUN(pfo_gemm_launch(g_nt(xA, D, x_idx, p.wq, E, lw.Q, E, N, E, D, lw.cq), s));
-    // folded key projection: qk_h = Wk_h^T Q_h   (Wk_h = rows [h dh, (h+1) dh) of k_proj_weight, a [dh, C] k-major operand)
+    // ---- composite weights (tiny products, two multi-problem launches)
+    PFO_REQUIRE(hipMemsetAsync(lw.Wqk, 0, sizeof(float) * (size_t)HCp * D, s) == hipSuccess, "memset failed");
+    PFO_REQUIRE(hipMemsetAsync(lw.W1ovT, 0, sizeof(float) * (size_t)HCp * D, s) == hipSuccess, "memset failed");
+    PFO_REQUIRE(hipMemsetAsync(lw.cqk, 0, sizeof(float) * (size_t)HCp, s) == hipSuccess, "memset failed");
     {
-      PfoGemm g = g_nn(lw.Q, E, p.wk, C, lw.QK, (int64_t)H * C, N, C, dh);
-      g.batch = H; g.a_bs[0] = dh; g.b_bs[0] = (int64_t)dh * C; g.c_bs = C;
-      RUN(pfo_gemm_launch(g, s));
+      PfoGemm st1[3];
+      st1[0] = g_nt(w.cosb, D, nullptr, p.wq + D, E, lw.cq, E, 1, E, D, p.b_in);            // cq = Wq[:, D:] cos(b) + bq
+      st1[1] = g_nt(p.wo, E, nullptr, p.w1, E + D, lw.W1oT, D, E, D, E, nullptr);           // W1oT = Wo^T W1[:, :E]^T
+      st1[1].a_kmajor = 1;
+      st1[2] = g_nt(p.wk, C, nullptr, p.wq, E, lw.Wqk, D, C, D, dh, nullptr);               // Wqk_h = Wk_h^T Wq_h[:, :D]
+      st1[2].a_kmajor = 1; st1[2].b_kmajor = 1; st1[2].batch = H;
+      st1[2].a_bs[0] = (int64_t)dh * C; st1[2].b_bs[0] = (int64_t)dh * E; st1[2].c_bs = (int64_t)Cp * D;
+      RUN(pfo_gemm_multi_launch(st1, 3, s));
+      PfoGemm st2[4];
+      st2[0] = g_nn(lw.cq, E, p.wk, C, lw.cqk, HCp, 1, C, dh);                               // cqk_h = Wk_h^T cq_h
+      st2[0].batch = H; st2[0].a_bs[0] = dh; st2[0].b_bs[0] = (int64_t)dh * C; st2[0].c_bs = Cp;
+      st2[1] = g_nt(p.wv, C, nullptr, lw.W1oT, D, lw.W1ovT, D, C, D, dh, nullptr);           // W1ovT_h = Wv_h^T W1oT_h
+      st2[1].a_kmajor = 1; st2[1].b_kmajor = 1; st2[1].batch = H;
+      st2[1].a_bs[0] = (int64_t)dh * C; st2[1].b_bs[0] = (int64_t)dh * D; st2[1].c_bs = (int64_t)Cp * D;
+      st2[2] = g_nn(p.b_in + 2 * E, dh, lw.W1oT, D, lw.W1ovT + (int64_t)C * D, D, 1, D, dh); // row C: (W1 Wo_h bv_h)^T
+      st2[2].batch = H; st2[2].a_bs[0] = dh; st2[2].b_bs[0] = (int64_t)dh * D; st2[2].c_bs = (int64_t)Cp * D;
+      st2[3] = g_nt(p.bo, E, nullptr, p.w1, E + D, lw.W1ovT + (int64_t)(C + 1) * D, D, 1, D, E, nullptr);   // row C+1 of head 0: (W1 bo)^T
+      RUN(pfo_gemm_multi_launch(st2, 4, s));
     }
+    // ---- qk' = x Wqk^T + cqk
+    RUN(pfo_gemm_launch(g_nt(xA, D, x_idx, lw.Wqk, D, lw.QK, HCp, N, HCp, D, lw.cqk), s));
     PfoAttn a;
-    a.N = N; a.K = K; a.D = D; a.Ef = Ef; a.H = H; a.dh = dh;
+    a.N = N; a.K = K; a.D = D; a.Ef = Ef; a.H = H; a.Cp = Cp;
     a.QK = lw.QK; a.nbr_tab = xA; a.nbr_ld = D;
     a.nbr_row = (l == 1) ? idx0 + N : nullptr;
     a.nbr_row_base = N;
     a.nbr_ids = w.nodes[l - 1] + N;
     a.edge_feat = st->edge_feat; a.eidx = w.eidx[l]; a.dt = w.dt[l]; a.tw = P.tw; a.tb = P.tb;
     a.scale = scale; a.dropout_p = b->dropout_p; a.seed = b->seed; a.offset = b->offset + 0x51ED0000ull + (uint64_t)l;
-    a.ctx = lw.ctx; a.attw = lw.attw; a.ssum = lw.ssum; a.inv = lw.inv;
+    a.ctx = lw.ctx; a.attw = lw.attw; a.inv = lw.inv;
     RUN(pfo_attn_fwd_launch(a, s));
-    // folded value projection O_h = Wv_h ctx_h + bv_h * sum_j a'_jh
+    // ---- h1 = relu(ctx' W1ovT + x W1[:, E:]^T + b1)   (MergeLayer fc1 with out_proj and the value projection folded in)
+    RUN(pfo_gemm_launch(g_nn(lw.ctx, HCp, lw.W1ovT, D, lw.h1, D, N, D, HCp), s));
     {
-      PfoGemm g = g_nt(lw.ctx, (int64_t)H * C, nullptr, p.wv, C, lw.O, E, N, dh, C, p.b_in + 2 * E);
-      g.batch = H; g.a_bs[0] = C; g.b_bs[0] = (int64_t)dh * C; g.c_bs = dh; g.bias_bs = dh;
-      if (b->dropout_p > 0.f) { g.row_scale = lw.ssum; g.rs_ld = H; g.rs_bs = 1; }
-      RUN(pfo_gemm_launch(g, s));
-    }
-    {
-      PfoGemm g = g_nt(lw.O, E, nullptr, p.wo, E, lw.attn_out, E, N, E, E, p.bo);
-      g.row_zero = lw.inv;                                   // temporal_attention.py:84
-      RUN(pfo_gemm_launch(g, s));
-    }
-    {
-      // MergeLayer fc1 on [attn_out | x] as two K-concatenated sources, ReLU fused (utils.py:14-16)
-      PfoGemm g = g_nt(lw.attn_out, E, nullptr, p.w1, E + D, lw.h1, D, N, D, E, p.b1);
-      g.A[1] = xA; g.lda[1] = D; g.a_idx[1] = x_idx; g.B[1] = p.w1 + E; g.ldb[1] = E + D; g.K[1] = D;
-      g.relu = 1;
+      PfoGemm g = g_nt(xA, D, x_idx, p.w1 + E, E + D, lw.h1, D, N, D, D, p.b1);
+      g.accumulate = 1; g.relu = 1;
       RUN(pfo_gemm_launch(g, s));
     }
     RUN(pfo_gemm_launch(g_nt(lw.h1, D, nullptr, p.w2, D, lw.Hout, D, N, D, D, p.b2), s));
@@ -405,6 +426,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
   if (c->use_memory)
     PFO_REQUIRE(hipMemsetAsync(w.d_h0, 0, (size_t)capP * D * sizeof(float), s) == hipSuccess, "memset failed");
 
+  const int Cp = d.Cp, HCp = H * d.Cp;
   for (int l = L; l >= 1; --l) {
     const int N = (int)n[l];
     const LayerWs& lw = w.layer[l];
@@ -417,80 +439,91 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
 
     // Data gradients first (a chain of GEMMs + the attention core); every weight / bias gradient of the layer is
     // then taken in ONE grouped split-K launch (bias gradients ride along as an extra column).
-    PfoTnProblem tn[16];
-    int ntn = 0;
-    auto add_tn = [&](const float* A, int64_t lda, const float* B, int64_t ldb, const int32_t* b_idx, int M_, int N_, float* C,
-                      int64_t ldc, float* bias_out) -> PfoTnProblem& {
-      PfoTnProblem& q = tn[ntn++];
+    PfoTnProblem tn[4];
+    auto set_tn = [&](PfoTnProblem& q, const float* A, int64_t lda, const float* B, int64_t ldb, const int32_t* b_idx, int M_,
+                      int N_, float* C_, int64_t ldc, float* bias_out) {
       q = PfoTnProblem();
-      q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.b_idx = b_idx; q.M = M_; q.N = N_; q.C = C; q.ldc = ldc; q.bias_out = bias_out;
-      return q;
+      q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.b_idx = b_idx; q.M = M_; q.N = N_; q.C = C_; q.ldc = ldc; q.bias_out = bias_out;
     };
     // fc2 (utils.py:17)
-    add_tn(dOut, D, lw.h1, D, nullptr, D, D, g.w2, D, g.b2);
+    set_tn(tn[0], dOut, D, lw.h1, D, nullptr, D, D, g.w2, D, g.b2);
     {
       PfoGemm q = g_nn(dOut, D, p.w2, D, w.dh1, D, N, D, D);
       q.relu_src = lw.h1; q.relu_ld = D;                     // ReLU backward
       RUN(pfo_gemm_launch(q, s));
     }
-    // fc1 on [attn_out | x]
-    add_tn(w.dh1, D, lw.attn_out, E, nullptr, D, E, g.w1, E + D, g.b1);
-    add_tn(w.dh1, D, xA, D, x_idx, D, D, g.w1 + E, E + D, nullptr);
-    {
-      PfoGemm q = g_nn(w.dh1, D, p.w1, E + D, w.dattn, E, N, E, D);
-      q.row_zero = lw.inv;                                   // zero-filled rows pass no gradient (temporal_attention.py:84)
-      RUN(pfo_gemm_launch(q, s));
-    }
+    // merged fc1: d ctx' = dh1 W1ovT^T, dx = dh1 W1[:, E:]
+    RUN(pfo_gemm_launch(g_nt(w.dh1, D, nullptr, lw.W1ovT, D, w.dctx, HCp, N, HCp, D, nullptr), s));
     RUN(pfo_gemm_launch(g_nn(w.dh1, D, p.w1 + E, E + D, dx, D, N, D, D), s));
-    // out_proj
-    add_tn(w.dattn, E, lw.O, E, nullptr, E, E, g.wo, E, g.bo);
-    RUN(pfo_gemm_launch(g_nn(w.dattn, E, p.wo, E, w.dO, E, N, E, E), s));
-    // folded value projection: d bv_h = sum_n ssum_h[n] dO_h[n] (ssum == 1 without dropout)
-    for (int h = 0; h < H; ++h) {
-      PfoTnProblem& q = add_tn(w.dO + h * dh, E, lw.ctx + h * C, (int64_t)H * C, nullptr, dh, C, g.wv + (int64_t)h * dh * C, C,
-                               g.b_in + 2 * E + h * dh);
-      if (b->dropout_p > 0.f) { q.ones_scale = lw.ssum + h; q.os_ld = H; }
-    }
-    {
-      PfoGemm q = g_nn(w.dO, E, p.wv, C, w.dctx, (int64_t)H * C, N, C, dh);
-      q.batch = H; q.a_bs[0] = dh; q.b_bs[0] = (int64_t)dh * C; q.c_bs = C;
-      RUN(pfo_gemm_launch(q, s));
-    }
+    set_tn(tn[1], lw.ctx, HCp, w.dh1, D, nullptr, HCp, D, w.dW1ovT, D, nullptr);       // dW1ovT = ctx'^T dh1
+    tn[1].c_accumulate = 0;
+    set_tn(tn[2], w.dh1, D, xA, D, x_idx, D, D, g.w1 + E, E + D, g.b1);                // dW1[:, E:], db1
     // attention core
     PfoAttn a;
-    a.N = N; a.K = K; a.D = D; a.Ef = Ef; a.H = H; a.dh = dh;
+    a.N = N; a.K = K; a.D = D; a.Ef = Ef; a.H = H; a.Cp = Cp;
     a.QK = lw.QK; a.nbr_tab = xA; a.nbr_ld = D;
     a.nbr_row = (l == 1) ? idx0 + N : nullptr;
     a.nbr_row_base = N;
     a.nbr_ids = w.nodes[l - 1] + N;
     a.edge_feat = st->edge_feat; a.eidx = w.eidx[l]; a.dt = w.dt[l]; a.tw = P.tw; a.tb = P.tb;
     a.scale = scale; a.dropout_p = b->dropout_p; a.seed = b->seed; a.offset = b->offset + 0x51ED0000ull + (uint64_t)l;
-    a.ctx = lw.ctx; a.attw = lw.attw; a.ssum = lw.ssum; a.inv = lw.inv;
-    a.dctx = w.dctx; a.dO = w.dO; a.bv = p.b_in + 2 * E; a.dQK = w.dQK;
+    a.ctx = lw.ctx; a.attw = lw.attw; a.inv = lw.inv;
+    a.dctx = w.dctx; a.dQK = w.dQK;
     if (l == 1) { a.d_nbr = c->use_memory ? w.d_h0 : nullptr; a.d_nbr_ld = D; }
     else        { a.d_nbr = w.dH[l - 1]; a.d_nbr_ld = D; }
     a.dtime_part = w.dtime;
     int n_parts = 0;
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
     RUN(pfo_fold_parts_launch(w.dtime, n_parts, 2 * D, G.tw, 1, s));      // time_w and time_b are adjacent in the layout
-    // folded key projection (the key bias has an exactly zero gradient: it cancels in the softmax)
-    for (int h = 0; h < H; ++h)
-      add_tn(lw.Q + h * dh, E, w.dQK + h * C, (int64_t)H * C, nullptr, dh, C, g.wk + (int64_t)h * dh * C, C, nullptr);
+    // merged query/key projection: dx += dqk' Wqk, dWqk = dqk'^T x, gqk = colsum(dqk')
     {
-      PfoGemm q = g_nt(w.dQK, (int64_t)H * C, nullptr, p.wk, C, w.dQ, E, N, dh, C, nullptr);
-      q.batch = H; q.a_bs[0] = C; q.b_bs[0] = (int64_t)dh * C; q.c_bs = dh;
-      RUN(pfo_gemm_launch(q, s));
-    }
-    // query projection (x part); its bias column is gq = colsum(dQ), consumed by the folded-bias backward
-    add_tn(w.dQ, E, xA, D, x_idx, E, D, g.wq, E, w.gq).bias_accumulate = 0;
-    {
-      PfoGemm q = g_nn(w.dQ, E, p.wq, E, dx, D, N, D, E);
+      PfoGemm q = g_nn(w.dQK, HCp, lw.Wqk, D, dx, D, N, D, HCp);
       q.accumulate = 1;
       RUN(pfo_gemm_launch(q, s));
     }
-    RUN(pfo_gemm_tn_group_launch(tn, ntn, N, nullptr, w.slabs, w.slab_floats, s));
-    RUN(pfo_cq_backward_launch(w.gq, p.wq, P.tb, D, g.b_in, g.wq, G.tb, s));
+    set_tn(tn[3], w.dQK, HCp, xA, D, x_idx, HCp, D, w.dWqk, D, w.gqk);
+    tn[3].c_accumulate = 0; tn[3].bias_accumulate = 0;
+    RUN(pfo_gemm_tn_group_launch(tn, 4, N, nullptr, w.slabs, w.slab_floats, s));
     if (l == 1 && c->use_memory) RUN(pfo_scatter_add_rows_launch(w.dx1, D, idx0, N, D, w.d_h0, D, s));
+
+    // ---- chain the composite-weight gradients back to the parameters (tiny products)
+    {
+      PfoGemm c1[6];
+      c1[0] = g_nn(p.wv, C, w.dW1ovT, D, w.dW1oT, D, dh, D, C);                          // dW1oT_h = Wv_h dW1ovT_h
+      c1[0].batch = H; c1[0].a_bs[0] = (int64_t)dh * C; c1[0].b_bs[0] = (int64_t)Cp * D; c1[0].c_bs = (int64_t)dh * D;
+      c1[1] = g_nt(lw.W1oT, D, nullptr, w.dW1ovT, D, g.wv, C, dh, C, D, nullptr);          // dWv_h += W1oT_h dW1ovT_h^T
+      c1[1].batch = H; c1[1].a_bs[0] = (int64_t)dh * D; c1[1].b_bs[0] = (int64_t)Cp * D; c1[1].c_bs = (int64_t)dh * C;
+      c1[1].accumulate = 1;
+      c1[2] = g_nt(lw.W1oT, D, nullptr, w.dW1ovT + (int64_t)C * D, D, g.b_in + 2 * E, 1, dh, 1, D, nullptr);   // dbv_h += W1oT_h du_h
+      c1[2].batch = H; c1[2].a_bs[0] = (int64_t)dh * D; c1[2].b_bs[0] = (int64_t)Cp * D; c1[2].c_bs = dh;
+      c1[2].accumulate = 1;
+      c1[3] = g_nt(p.wq, E, nullptr, w.dWqk, D, g.wk, C, dh, C, D, nullptr);               // dWk_h += Wq_h[:, :D] dWqk_h^T
+      c1[3].batch = H; c1[3].a_bs[0] = (int64_t)dh * E; c1[3].b_bs[0] = (int64_t)Cp * D; c1[3].c_bs = (int64_t)dh * C;
+      c1[3].accumulate = 1;
+      c1[4] = g_nn(p.wk, C, w.dWqk, D, g.wq, E, dh, D, C);                                 // dWq_h[:, :D] += Wk_h dWqk_h
+      c1[4].batch = H; c1[4].a_bs[0] = (int64_t)dh * C; c1[4].b_bs[0] = (int64_t)Cp * D; c1[4].c_bs = (int64_t)dh * E;
+      c1[4].accumulate = 1;
+      c1[5] = g_nt(p.wk, C, nullptr, w.gqk, C, w.gq, 1, dh, 1, C, nullptr);                // d cq_h = Wk_h gqk_h
+      c1[5].batch = H; c1[5].a_bs[0] = (int64_t)dh * C; c1[5].b_bs[0] = Cp; c1[5].c_bs = dh;
+      RUN(pfo_gemm_multi_launch(c1, 6, s));
+      for (int h = 0; h < H; ++h) {
+        // W1ovT row C = bv_h^T W1oT_h  and  cqk_h = Wk_h^T cq_h : the outer-product halves of their gradients
+        RUN(pfo_rank1_launch(p.b_in + 2 * E + h * dh, 1, w.dW1ovT + ((int64_t)h * Cp + C) * D, 1, dh, D,
+                             w.dW1oT + (int64_t)h * dh * D, D, s));
+        RUN(pfo_rank1_launch(lw.cq + h * dh, 1, w.gqk + (int64_t)h * Cp, 1, dh, C, g.wk + (int64_t)h * dh * C, C, s));
+      }
+      const float* dc = w.dW1ovT + (int64_t)(C + 1) * D;                                   // gradient of (W1 bo)^T
+      PfoGemm c2[3];
+      c2[0] = g_nt(w.dW1oT, D, nullptr, p.wo, E, g.w1, E + D, D, E, E, nullptr);           // dW1[:, :E] += dW1o Wo^T
+      c2[0].a_kmajor = 1; c2[0].accumulate = 1;
+      c2[1] = g_nt(p.w1, E + D, nullptr, w.dW1oT, D, g.wo, E, E, E, D, nullptr);           // dWo += W1[:, :E]^T dW1o
+      c2[1].a_kmajor = 1; c2[1].accumulate = 1;
+      c2[2] = g_nt(p.w1, E + D, nullptr, dc, D, g.bo, 1, E, 1, D, nullptr);                // dbo += W1[:, :E]^T dc
+      c2[2].a_kmajor = 1; c2[2].accumulate = 1;
+      RUN(pfo_gemm_multi_launch(c2, 3, s));
+      RUN(pfo_rank1_launch(dc, 1, p.bo, 1, D, E, g.w1, E + D, s));                          // dW1[:, :E] += dc (x) bo
+      RUN(pfo_cq_backward_launch(w.gq, p.wq, P.tb, D, g.b_in, g.wq, G.tb, s));              // cq = Wq[:, D:] cos(b) + bq
+    }
   }
 
   // ---- GRU parameters (messages and stored memory are constants: SURVEY App. A-6)
