@@ -143,7 +143,8 @@ def main():
     cfg = CONFIGS[args.config]
     per_gpu = args.batch or cfg.batch
     B = per_gpu * world                                   # weak scaling: global batch grows with the GPU count
-    graph = make_graph(cfg, with_prices=False)
+    ours = cfg.name == "C3"                               # C3 = C2 + MV-efficient sampler (main.py `ours` path)
+    graph = make_graph(cfg, with_prices=ours)
     d = graph.data
     nf = P.get_neighbor_finder(d, uniform=cfg.uniform)
     tgn = P.TGN(nf, graph.node_features, graph.edge_features, dev, n_layers=cfg.n_layers, n_heads=cfg.n_heads,
@@ -163,6 +164,10 @@ def main():
     from pfotgnrec_amd.rand_edge_sampler import item_availability, DeviceNegativeSampler
     sampler = DeviceNegativeSampler(item_availability(d.destinations, graph.upper_u, cfg.n_items), graph.upper_u, dev, seed=1)
     n_neg = 3
+    mvs = None
+    if ours:
+        mvs = P.MVSampler(graph.prices, graph.upper_u, dev, gamma=2.0, lambda_mv=0.5, p_pos_num=1, p_neg_num=3)
+        day_all = t(graph.day_of(d.timestamps), np.int32)
     start = cfg.n_edges // 2                              # neighbourhoods are populated
     n_steps_total = args.warmup + args.steps
     assert start + n_steps_total * B <= cfg.n_edges, "not enough edges for this many steps"
@@ -170,10 +175,18 @@ def main():
     def step(i):
         lo = start + i * B
         sl = slice(lo, lo + B)
-        neg = sampler.sample(port_idx_all[sl], port_len_all[sl], n_neg, offset=i)           # utils.py:86-114
-        emb, b = tgn.embed_device(src_all[sl], dst_all[sl], [neg.reshape(-1)], [n_neg], ts_all[sl], eidx_all[sl],
-                                  cfg.n_neighbors)                                          # tgn.py:219-327
-        loss = P.bpr_loss(emb, b, n_neg, pos_block=1, grad_scale=1.0 / world)               # main.py:364-381
+        if mvs is None:
+            neg = sampler.sample(port_idx_all[sl], port_len_all[sl], n_neg, offset=i)       # utils.py:86-114
+            emb, b = tgn.embed_device(src_all[sl], dst_all[sl], [neg.reshape(-1)], [n_neg], ts_all[sl], eidx_all[sl],
+                                      cfg.n_neighbors)                                      # tgn.py:219-327
+            loss = P.bpr_loss(emb, b, n_neg, pos_block=1, grad_scale=1.0 / world)           # main.py:364-381
+        else:
+            cand_neg = sampler.sample(port_idx_all[sl], port_len_all[sl], 20, offset=i)     # main.py:194-195
+            cand = torch.cat([dst_all[sl].unsqueeze(1), cand_neg], 1).contiguous()          # main.py:207
+            p_pos, p_neg = mvs.select_device(day_all[sl], cand, port_idx_all[sl], port_len_all[sl])   # main.py:209-304
+            emb, b = tgn.embed_device(src_all[sl], dst_all[sl], [p_pos.reshape(-1), p_neg.reshape(-1)], [1, 3], ts_all[sl],
+                                      eidx_all[sl], cfg.n_neighbors)                        # tgn.py:102-217
+            loss = P.bpr_loss(emb, b, n_neg, pos_block=2, grad_scale=1.0 / world)           # main.py:321-337
         loss.backward()                                                                     # main.py:388
         allreduce_flat_grad(tgn.flat_grad, world)
         opt.step()                                                                          # main.py:389
@@ -198,7 +211,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = _lib.prof_collect() if not args.no_prof else None
     _lib.prof_enable(False)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

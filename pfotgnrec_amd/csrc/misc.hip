@@ -2,6 +2,7 @@
 // row scatter-add, the folded query-bias backward, partial-slab folds.
 #include "memory.hpp"
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -176,20 +177,50 @@ extern "C" int pfo_adam_step(float* param, const float* grad, float* exp_avg, fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// dst[idx[r]] += src[r] for whole rows.  Four rows per wavefront iteration: their index and data loads are issued
+// together, then the atomics (one 256-byte piece per instruction).
+template <int MODE>
 __global__ void scatter_add_rows_kernel(const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ idx,
-                                        int64_t n_rows, int D, float* __restrict__ dst, int64_t ld_dst) {
+                                        const int32_t* __restrict__ skip_if_zero, int64_t n_rows, int D,
+                                        float* __restrict__ dst, int64_t ld_dst) {
   const int lane = threadIdx.x & 63;
-  for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < n_rows;
-       r += ((int64_t)gridDim.x * blockDim.x) >> 6) {
-    const int t = idx[r];
-    if (t < 0) continue;
-    for (int d = lane; d < D; d += 64) atomicAdd(dst + (int64_t)t * ld_dst + d, src[r * ld_src + d]);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r0 = wave * 4; r0 < n_rows; r0 += n_waves * 4) {
+    int t[4];
+    float v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = r0 + u;
+      t[u] = r < n_rows ? idx[r] : -1;
+      if (r < n_rows && skip_if_zero && skip_if_zero[r] == 0) t[u] = -1;   // padding node: thousands of rows would hit ONE destination
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int d = lane + 64 * q;
+        v[u][q] = (r < n_rows && d < D) ? src[r * ld_src + d] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (t[u] < 0) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int d = lane + 64 * q;
+        if (d < D) {
+          if (MODE == 0) atomicAdd(dst + (int64_t)t[u] * ld_dst + d, v[u][q]);
+          else dst[(int64_t)t[u] * ld_dst + d] = v[u][q];     // timing experiment only
+        }
+      }
+    }
   }
 }
-int pfo_scatter_add_rows_launch(const float* src, int64_t ld_src, const int32_t* idx, int64_t n_rows, int D, float* dst,
-                                int64_t ld_dst, hipStream_t stream) {
-  const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div(n_rows, 4));
-  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(nb), dim3(256), 0, stream, src, ld_src, idx, n_rows, D, dst, ld_dst);
+int pfo_scatter_add_rows_launch(const float* src, int64_t ld_src, const int32_t* idx, const int32_t* skip_if_zero,
+                                int64_t n_rows, int D, float* dst, int64_t ld_dst, hipStream_t stream) {
+  PFO_REQUIRE(D <= 256, "row length must be <= 256");
+  static const int mode = getenv("PFO_SCATTER_MODE") ? atoi(getenv("PFO_SCATTER_MODE")) : 0;
+  const int nb = (int)std::min<int64_t>(2048, pfo_ceil_div(n_rows, 16));
+  if (mode == 0) hipLaunchKernelGGL(scatter_add_rows_kernel<0>, dim3(nb), dim3(256), 0, stream, src, ld_src, idx, skip_if_zero, n_rows, D, dst, ld_dst);
+  else hipLaunchKernelGGL(scatter_add_rows_kernel<1>, dim3(nb), dim3(256), 0, stream, src, ld_src, idx, skip_if_zero, n_rows, D, dst, ld_dst);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
