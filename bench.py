@@ -41,8 +41,8 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=32, help="interactions per oracle step in the CPU baseline sample")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-batch", type=int, default=512, help="interactions per oracle step in the CPU baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=1, help="timed oracle steps (one more runs first, untimed)")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event bracketing of kernel launches")
     return ap.parse_args()
 
@@ -170,10 +170,11 @@ def main():
         day_all = t(graph.day_of(d.timestamps), np.int32)
     start = cfg.n_edges // 2                              # neighbourhoods are populated
     n_steps_total = args.warmup + args.steps
-    assert start + n_steps_total * B <= cfg.n_edges, "not enough edges for this many steps"
+    span = cfg.n_edges - start - B                          # batches wrap inside the second half of the edge list
+    assert span > 0, "batch larger than the timed half of the graph"
 
     def step(i):
-        lo = start + i * B
+        lo = start + (i * B) % span
         sl = slice(lo, lo + B)
         if mvs is None:
             neg = sampler.sample(port_idx_all[sl], port_len_all[sl], n_neg, offset=i)       # utils.py:86-114
@@ -257,10 +258,16 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         try:
             threads = os.cpu_count() or 1
+            try:                                            # threads the BLAS behind numpy actually uses
+                from threadpoolctl import threadpool_info
+                threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+            except Exception:
+                pass
             v, spent = cpu_baseline(cfg, graph, args.cpu_batch, args.cpu_steps)
             out["cpu_baseline"] = {"value": round(v, 2), "unit": "interactions/s", "cores": threads, "kind": "port",
-                                   "sample": "%d steps of %d interactions of the same workload (oracle/tgn_oracle.py, numpy fp32 "
-                                             "+ BLAS, steady-state memory), %.1f s" % (args.cpu_steps, args.cpu_batch, spent)}
+                                   "sample": "%d step(s) of %d interactions of the same workload after one untimed step "
+                                             "(oracle/tgn_oracle.py: numpy fp32 + BLAS + C fmaf/cosf helper, steady-state "
+                                             "memory), %.1f s timed" % (args.cpu_steps, args.cpu_batch, spent)}
         except Exception as e:  # the baseline never blocks the measurement
             out["cpu_baseline"] = {"value": None, "unit": "interactions/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": "failed: %r" % (e,)}

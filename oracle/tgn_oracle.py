@@ -47,14 +47,49 @@ def fmaf(a, b, c):
     return s.astype(f32)
 
 
+_CLIB = None
+
+
+def _clib():
+    """oracle/_build/liboracle.so (C99 fmaf + cosf, built by `make -C oracle`); None -> numpy emulation."""
+    global _CLIB
+    if _CLIB is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "liboracle.so")
+        _CLIB = False
+        if os.path.exists(path):
+            lib = ctypes.CDLL(path)
+            vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+            lib.oracle_time_encode.argtypes = [vp, i64, vp, vp, i32, vp]
+            lib.oracle_time_encode_bwd.argtypes = [vp, i64, vp, vp, i32, vp, vp, vp]
+            _CLIB = lib
+    return _CLIB or None
+
+
 def time_encode(t, w, b):
     """cos(fma(t, w_d, b_d)); t f32[...]; w [D] (or [D,1]); returns f32[..., D]  (time_encoding.py:17-25)."""
+    lib = _clib()
+    w1, b1 = np.ascontiguousarray(w, f32).reshape(-1), np.ascontiguousarray(b, f32)
+    if lib is not None and len(w1) <= 512:
+        tt = np.ascontiguousarray(t, f32)
+        out = np.empty(tt.shape + (len(w1),), f32)
+        lib.oracle_time_encode(tt.ctypes.data, tt.size, w1.ctypes.data, b1.ctypes.data, len(w1), out.ctypes.data)
+        return out
     t = np.asarray(t, f32)[..., None]
-    return np.cos(fmaf(t, np.asarray(w, f32).reshape(-1), np.asarray(b, f32))).astype(f32)
+    return np.cos(fmaf(t, w1, b1)).astype(f32)
 
 
 def time_encode_backward(t, w, b, g):
     """Grads of sum(g * cos(t*w+b)) w.r.t. w [D] and b [D]."""
+    lib = _clib()
+    w1, b1 = np.ascontiguousarray(w, f32).reshape(-1), np.ascontiguousarray(b, f32)
+    if lib is not None and len(w1) <= 512:
+        tt, gg = np.ascontiguousarray(t, f32), np.ascontiguousarray(g, f32)
+        dw, db = np.empty(len(w1), np.float64), np.empty(len(w1), np.float64)
+        lib.oracle_time_encode_bwd(tt.ctypes.data, tt.size, w1.ctypes.data, b1.ctypes.data, len(w1), gg.ctypes.data,
+                                   dw.ctypes.data, db.ctypes.data)
+        return dw.astype(f32), db.astype(f32)
     t = np.asarray(t, f32)[..., None]
     s = -np.sin(fmaf(t, np.asarray(w, f32).reshape(-1), np.asarray(b, f32))).astype(f32) * g
     D = s.shape[-1]
@@ -108,19 +143,20 @@ def attention_forward(p, x, tq, nbr_feat, ef, te, mask, n_head):
     mask[inv, 0] = False                                               # :65
     bq, bk, bv = p["b_in"][:E], p["b_in"][E:2 * E], p["b_in"][2 * E:]
     Qp = q_in @ p["Wq"].T + bq
-    Kp = key @ p["Wk"].T + bk                                          # [N,K,E]
-    Vp = key @ p["Wv"].T + bv
+    key2 = key.reshape(N * K, -1)                                      # one large GEMM instead of N small ones
+    Kp = (key2 @ p["Wk"].T + bk).reshape(N, K, E)                      # [N,K,E]
+    Vp = (key2 @ p["Wv"].T + bv).reshape(N, K, E)
     dh = E // n_head
     scale = f32(1.0 / np.sqrt(dh))
     Qh = (Qp * scale).reshape(N, n_head, dh)
     Kh = Kp.reshape(N, K, n_head, dh)
     Vh = Vp.reshape(N, K, n_head, dh)
-    scores = np.einsum("nhd,nkhd->nhk", Qh, Kh)
+    scores = np.matmul(Kh.transpose(0, 2, 1, 3), Qh[:, :, :, None])[..., 0]          # [N,H,K] (batched BLAS)
     scores = np.where(mask[:, None, :], -np.inf, scores).astype(f32)
     m = scores.max(-1, keepdims=True)
     e = np.exp(scores - m)
     a = (e / e.sum(-1, keepdims=True)).astype(f32)                     # [N,H,K]
-    Oh = np.einsum("nhk,nkhd->nhd", a, Vh).reshape(N, E)
+    Oh = np.matmul(a[:, :, None, :], Vh.transpose(0, 2, 1, 3))[:, :, 0, :].reshape(N, E)
     attn = Oh @ p["Wo"].T + p["bo"]
     attn[inv] = 0                                                      # :84
     cat = np.concatenate([attn, x], 1)                                 # :88 / utils.py:15
@@ -146,12 +182,12 @@ def attention_backward(p, c, d_out, n_head, D):
     dattn[c["inv"]] = 0
     g["Wo"] = dattn.T @ c["Oh"]; g["bo"] = dattn.sum(0)
     dOh = (dattn @ p["Wo"]).reshape(N, n_head, E // n_head)
-    da = np.einsum("nhd,nkhd->nhk", dOh, c["Vh"])
-    dVh = np.einsum("nhk,nhd->nkhd", c["a"], dOh)
+    da = np.matmul(c["Vh"].transpose(0, 2, 1, 3), dOh[:, :, :, None])[..., 0]
+    dVh = (c["a"].transpose(0, 2, 1)[:, :, :, None] * dOh[:, None, :, :])
     a = c["a"]
     ds = a * (da - (a * da).sum(-1, keepdims=True))                     # softmax backward; masked a == 0
-    dQh = np.einsum("nhk,nkhd->nhd", ds, c["Kh"])
-    dKh = np.einsum("nhk,nhd->nkhd", ds, c["Qh"])
+    dQh = np.matmul(ds[:, :, None, :], c["Kh"].transpose(0, 2, 1, 3))[:, :, 0, :]
+    dKh = (ds.transpose(0, 2, 1)[:, :, :, None] * c["Qh"][:, None, :, :])
     dQp = (dQh * c["scale"]).reshape(N, E)
     dKp = dKh.reshape(N * K, E)
     dVp = dVh.reshape(N * K, E)
