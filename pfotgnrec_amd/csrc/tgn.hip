@@ -24,6 +24,7 @@ namespace {
 struct LayerWs {
   float *QK, *attw, *ctx, *h1, *Hout;      // activations kept for backward
   float *cq, *Wqk, *cqk, *W1oT, *W1ovT;   // per-step composite weights (see the layer comment in pfo_tgn_forward)
+  float *dWqk, *gqk, *dW1ovT, *dW1oT, *gq; // their gradients (per layer: the chain-back runs on the side stream)
   uint8_t* inv;
 };
 struct Ws {
@@ -34,10 +35,9 @@ struct Ws {
   int32_t *slot, *touched, *n_touched, *scan, *idx0, *winner;
   float *gi, *gh, *upd_mem, *h0_tab, *d_h0, *msg_rows, *h_rows;
   uint8_t* hm;
-  float *cosb, *zero, *gq;
+  float *cosb, *zero;
   LayerWs layer[PFO_MAX_LAYERS + 1];
   float *dh1, *dctx, *dQK, *dx1;
-  float *dWqk, *gqk, *dW1ovT, *dW1oT;   // gradients of the composite weights (chained back to the parameters)
   float* dH[PFO_MAX_LAYERS + 1];
   float *slabs, *colsum;
   double* dtime;
@@ -87,7 +87,6 @@ Ws carve(const pfo_tgn_config* c, void* base) {
   }
   w.zero = take<float>(p, 64);
   w.cosb = take<float>(p, d.D);
-  w.gq = take<float>(p, d.E);
   if (c->use_memory) {
     w.slot = take<int32_t>(p, c->n_nodes);
     w.winner = take<int32_t>(p, c->n_nodes);
@@ -112,6 +111,11 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     lw.cqk = take<float>(p, (int64_t)d.H * d.Cp);
     lw.W1oT = take<float>(p, (int64_t)d.E * d.D);
     lw.W1ovT = take<float>(p, (int64_t)d.H * d.Cp * d.D);
+    lw.dWqk = take<float>(p, (int64_t)d.H * d.Cp * d.D);
+    lw.gqk = take<float>(p, (int64_t)d.H * d.Cp);
+    lw.dW1ovT = take<float>(p, (int64_t)d.H * d.Cp * d.D);
+    lw.dW1oT = take<float>(p, (int64_t)d.E * d.D);
+    lw.gq = take<float>(p, d.E);
     lw.QK = take<float>(p, N * d.H * d.Cp);
     lw.attw = take<float>(p, N * d.H * Km);
     lw.inv = take<uint8_t>(p, N);
@@ -125,10 +129,6 @@ Ws carve(const pfo_tgn_config* c, void* base) {
   w.dctx = take<float>(p, N1 * d.H * d.Cp);
   w.dQK = take<float>(p, N1 * d.H * d.Cp);
   w.dx1 = take<float>(p, N1 * d.D);
-  w.dWqk = take<float>(p, (int64_t)d.H * d.Cp * d.D);
-  w.gqk = take<float>(p, (int64_t)d.H * d.Cp);
-  w.dW1ovT = take<float>(p, (int64_t)d.H * d.Cp * d.D);
-  w.dW1oT = take<float>(p, (int64_t)d.E * d.D);
   w.slab_floats = SLAB_FLOATS;
   w.slabs = take<float>(p, w.slab_floats);
   w.colsum = take<float>(p, pfo_colsum_scratch_floats(3 * d.D + 2 * d.E + d.M));
@@ -197,6 +197,27 @@ PfoGemm g_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const int
   g.slabs = w.slabs; g.slab_floats = w.slab_floats;
   return g;
 }
+
+// Internal side stream: the composite-weight products (forward) and their gradient chain (backward) are tiny
+// dependent launches; they run beside the main stream's work and are joined by events where their results are needed.
+struct Side {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, done = nullptr;
+  hipEvent_t layer[PFO_MAX_LAYERS + 1] = {};
+  bool ok = false;
+};
+Side& side() {
+  static Side sd;
+  if (!sd.ok) {
+    bool good = hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.done, hipEventDisableTiming) == hipSuccess;
+    for (int l = 0; l <= PFO_MAX_LAYERS; ++l) good = good && hipEventCreateWithFlags(&sd.layer[l], hipEventDisableTiming) == hipSuccess;
+    sd.ok = good;
+  }
+  return sd;
+}
+#define HIPOK(expr, msg) PFO_REQUIRE((expr) == hipSuccess, msg)
 
 #define RUN(expr)                  \
   do {                             \
@@ -287,6 +308,44 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   bind(lay, st->params, P, d.L, c->use_memory != 0);
   const int L = d.L, D = d.D, Ef = d.Ef, H = d.H, E = d.E, C = d.C, dh = d.dh, K = b->K;
 
+  // ---- composite weights of every layer: on the side stream, beside the sampling / memory phase
+  Side& sd = side();
+  PFO_REQUIRE(sd.ok, "could not create the side stream");
+  hipStream_t ss = sd.s;
+  const int Cp = d.Cp, HCp = H * d.Cp;
+  PFO_REQUIRE(hipMemsetAsync(w.zero, 0, 64 * sizeof(float), s) == hipSuccess, "memset failed");
+  RUN(pfo_time_encode(w.zero, 1, P.tw, P.tb, D, w.cosb, stream));              // cos(fma(0, w, b)) (embedding_module.py:92)
+  HIPOK(hipEventRecord(sd.fork, s), "event record failed");
+  HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
+  for (int l = 1; l <= L; ++l) {
+    const LayerWs& lw = w.layer[l];
+    const auto& p = P.l[l];
+    PFO_REQUIRE(hipMemsetAsync(lw.Wqk, 0, sizeof(float) * (size_t)HCp * D, ss) == hipSuccess, "memset failed");
+    PFO_REQUIRE(hipMemsetAsync(lw.W1ovT, 0, sizeof(float) * (size_t)HCp * D, ss) == hipSuccess, "memset failed");
+    PFO_REQUIRE(hipMemsetAsync(lw.cqk, 0, sizeof(float) * (size_t)HCp, ss) == hipSuccess, "memset failed");
+    {
+      PfoGemm st1[3];
+      st1[0] = g_nt(w.cosb, D, nullptr, p.wq + D, E, lw.cq, E, 1, E, D, p.b_in);            // cq = Wq[:, D:] cos(b) + bq
+      st1[1] = g_nt(p.wo, E, nullptr, p.w1, E + D, lw.W1oT, D, E, D, E, nullptr);           // W1oT = Wo^T W1[:, :E]^T
+      st1[1].a_kmajor = 1;
+      st1[2] = g_nt(p.wk, C, nullptr, p.wq, E, lw.Wqk, D, C, D, dh, nullptr);               // Wqk_h = Wk_h^T Wq_h[:, :D]
+      st1[2].a_kmajor = 1; st1[2].b_kmajor = 1; st1[2].batch = H;
+      st1[2].a_bs[0] = (int64_t)dh * C; st1[2].b_bs[0] = (int64_t)dh * E; st1[2].c_bs = (int64_t)Cp * D;
+      RUN(pfo_gemm_multi_launch(st1, 3, ss));
+      PfoGemm st2[4];
+      st2[0] = g_nn(lw.cq, E, p.wk, C, lw.cqk, HCp, 1, C, dh);                               // cqk_h = Wk_h^T cq_h
+      st2[0].batch = H; st2[0].a_bs[0] = dh; st2[0].b_bs[0] = (int64_t)dh * C; st2[0].c_bs = Cp;
+      st2[1] = g_nt(p.wv, C, nullptr, lw.W1oT, D, lw.W1ovT, D, C, D, dh, nullptr);           // W1ovT_h = Wv_h^T W1oT_h
+      st2[1].a_kmajor = 1; st2[1].b_kmajor = 1; st2[1].batch = H;
+      st2[1].a_bs[0] = (int64_t)dh * C; st2[1].b_bs[0] = (int64_t)dh * D; st2[1].c_bs = (int64_t)Cp * D;
+      st2[2] = g_nn(p.b_in + 2 * E, dh, lw.W1oT, D, lw.W1ovT + (int64_t)C * D, D, 1, D, dh); // row C: (W1 Wo_h bv_h)^T
+      st2[2].batch = H; st2[2].a_bs[0] = dh; st2[2].b_bs[0] = (int64_t)dh * D; st2[2].c_bs = (int64_t)Cp * D;
+      st2[3] = g_nt(p.bo, E, nullptr, p.w1, E + D, lw.W1ovT + (int64_t)(C + 1) * D, D, 1, D, E, nullptr);   // row C+1 of head 0: (W1 bo)^T
+      RUN(pfo_gemm_multi_launch(st2, 4, ss));
+    }
+    HIPOK(hipEventRecord(sd.layer[l], ss), "event record failed");
+  }
+
   // ---- frontier expansion: K1 per level (utils.py:163-219 called from embedding_module.py:125)
   PFO_REQUIRE(hipMemcpyAsync(w.nodes[L], b->roots, (size_t)b->R * sizeof(int32_t), hipMemcpyDeviceToDevice, s) == hipSuccess,
               "copy failed");
@@ -327,10 +386,6 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     idx0 = w.nodes[0];
   }
 
-  // ---- query time feature cos(fma(0, w, b)) (embedding_module.py:92)
-  PFO_REQUIRE(hipMemsetAsync(w.zero, 0, 64 * sizeof(float), s) == hipSuccess, "memset failed");
-  RUN(pfo_time_encode(w.zero, 1, P.tw, P.tb, D, w.cosb, stream));
-
   // One attention layer = THREE large contractions around the neighbour-tile attention kernel (taken
   // to its end).  With one query per instance every projection that touches only that instance folds into a
   // per-step composite weight:
@@ -343,7 +398,6 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   //   out    = W2 h1 + b2
   // 0.60 MFLOP per instance instead of 1.13 (and 10.3 un-folded); Q, O and attn_out are never formed.
   const float scale = 1.0f / sqrtf((float)dh);
-  const int Cp = d.Cp, HCp = H * d.Cp;
   for (int l = 1; l <= L; ++l) {
     const int N = (int)n[l];
     const LayerWs& lw = w.layer[l];
@@ -351,30 +405,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     const float* xA = (l == 1) ? tab0 : w.layer[l - 1].Hout;
     const int32_t* x_idx = (l == 1) ? idx0 : nullptr;
 
-    // ---- composite weights (tiny products, two multi-problem launches)
-    PFO_REQUIRE(hipMemsetAsync(lw.Wqk, 0, sizeof(float) * (size_t)HCp * D, s) == hipSuccess, "memset failed");
-    PFO_REQUIRE(hipMemsetAsync(lw.W1ovT, 0, sizeof(float) * (size_t)HCp * D, s) == hipSuccess, "memset failed");
-    PFO_REQUIRE(hipMemsetAsync(lw.cqk, 0, sizeof(float) * (size_t)HCp, s) == hipSuccess, "memset failed");
-    {
-      PfoGemm st1[3];
-      st1[0] = g_nt(w.cosb, D, nullptr, p.wq + D, E, lw.cq, E, 1, E, D, p.b_in);            // cq = Wq[:, D:] cos(b) + bq
-      st1[1] = g_nt(p.wo, E, nullptr, p.w1, E + D, lw.W1oT, D, E, D, E, nullptr);           // W1oT = Wo^T W1[:, :E]^T
-      st1[1].a_kmajor = 1;
-      st1[2] = g_nt(p.wk, C, nullptr, p.wq, E, lw.Wqk, D, C, D, dh, nullptr);               // Wqk_h = Wk_h^T Wq_h[:, :D]
-      st1[2].a_kmajor = 1; st1[2].b_kmajor = 1; st1[2].batch = H;
-      st1[2].a_bs[0] = (int64_t)dh * C; st1[2].b_bs[0] = (int64_t)dh * E; st1[2].c_bs = (int64_t)Cp * D;
-      RUN(pfo_gemm_multi_launch(st1, 3, s));
-      PfoGemm st2[4];
-      st2[0] = g_nn(lw.cq, E, p.wk, C, lw.cqk, HCp, 1, C, dh);                               // cqk_h = Wk_h^T cq_h
-      st2[0].batch = H; st2[0].a_bs[0] = dh; st2[0].b_bs[0] = (int64_t)dh * C; st2[0].c_bs = Cp;
-      st2[1] = g_nt(p.wv, C, nullptr, lw.W1oT, D, lw.W1ovT, D, C, D, dh, nullptr);           // W1ovT_h = Wv_h^T W1oT_h
-      st2[1].a_kmajor = 1; st2[1].b_kmajor = 1; st2[1].batch = H;
-      st2[1].a_bs[0] = (int64_t)dh * C; st2[1].b_bs[0] = (int64_t)dh * D; st2[1].c_bs = (int64_t)Cp * D;
-      st2[2] = g_nn(p.b_in + 2 * E, dh, lw.W1oT, D, lw.W1ovT + (int64_t)C * D, D, 1, D, dh); // row C: (W1 Wo_h bv_h)^T
-      st2[2].batch = H; st2[2].a_bs[0] = dh; st2[2].b_bs[0] = (int64_t)dh * D; st2[2].c_bs = (int64_t)Cp * D;
-      st2[3] = g_nt(p.bo, E, nullptr, p.w1, E + D, lw.W1ovT + (int64_t)(C + 1) * D, D, 1, D, E, nullptr);   // row C+1 of head 0: (W1 bo)^T
-      RUN(pfo_gemm_multi_launch(st2, 4, s));
-    }
+    HIPOK(hipStreamWaitEvent(s, sd.layer[l], 0), "event wait failed");     // this layer's composite weights are ready
     // ---- qk' = x Wqk^T + cqk
     RUN(pfo_gemm_launch(g_nt(xA, D, x_idx, lw.Wqk, D, lw.QK, HCp, N, HCp, D, lw.cqk), s));
     PfoAttn a;
@@ -427,6 +458,9 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     PFO_REQUIRE(hipMemsetAsync(w.d_h0, 0, (size_t)capP * D * sizeof(float), s) == hipSuccess, "memset failed");
 
   const int Cp = d.Cp, HCp = H * d.Cp;
+  Side& sd = side();
+  PFO_REQUIRE(sd.ok, "could not create the side stream");
+  hipStream_t ss = sd.s;
   for (int l = L; l >= 1; --l) {
     const int N = (int)n[l];
     const LayerWs& lw = w.layer[l];
@@ -455,7 +489,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     // merged fc1: d ctx' = dh1 W1ovT^T, dx = dh1 W1[:, E:]
     RUN(pfo_gemm_launch(g_nt(w.dh1, D, nullptr, lw.W1ovT, D, w.dctx, HCp, N, HCp, D, nullptr), s));
     RUN(pfo_gemm_launch(g_nn(w.dh1, D, p.w1 + E, E + D, dx, D, N, D, D), s));
-    set_tn(tn[1], lw.ctx, HCp, w.dh1, D, nullptr, HCp, D, w.dW1ovT, D, nullptr);       // dW1ovT = ctx'^T dh1
+    set_tn(tn[1], lw.ctx, HCp, w.dh1, D, nullptr, HCp, D, lw.dW1ovT, D, nullptr);       // dW1ovT = ctx'^T dh1
     tn[1].c_accumulate = 0;
     set_tn(tn[2], w.dh1, D, xA, D, x_idx, D, D, g.w1 + E, E + D, g.b1);                // dW1[:, E:], db1
     // attention core
@@ -481,48 +515,49 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       q.accumulate = 1;
       RUN(pfo_gemm_launch(q, s));
     }
-    set_tn(tn[3], w.dQK, HCp, xA, D, x_idx, HCp, D, w.dWqk, D, w.gqk);
+    set_tn(tn[3], w.dQK, HCp, xA, D, x_idx, HCp, D, lw.dWqk, D, lw.gqk);
     tn[3].c_accumulate = 0; tn[3].bias_accumulate = 0;
     RUN(pfo_gemm_tn_group_launch(tn, 4, N, nullptr, w.slabs, w.slab_floats, s));
     if (l == 1 && c->use_memory) RUN(pfo_scatter_add_rows_launch(w.dx1, D, idx0, w.nodes[0], N, D, w.d_h0, D, s));
 
-    // ---- chain the composite-weight gradients back to the parameters (tiny products)
+    // ---- chain the composite-weight gradients back to the parameters (tiny products, side stream)
+    HIPOK(hipEventRecord(sd.layer[l], s), "event record failed");
+    HIPOK(hipStreamWaitEvent(ss, sd.layer[l], 0), "event wait failed");
     {
       PfoGemm c1[6];
-      c1[0] = g_nn(p.wv, C, w.dW1ovT, D, w.dW1oT, D, dh, D, C);                          // dW1oT_h = Wv_h dW1ovT_h
+      c1[0] = g_nn(p.wv, C, lw.dW1ovT, D, lw.dW1oT, D, dh, D, C);                          // dW1oT_h = Wv_h dW1ovT_h
       c1[0].batch = H; c1[0].a_bs[0] = (int64_t)dh * C; c1[0].b_bs[0] = (int64_t)Cp * D; c1[0].c_bs = (int64_t)dh * D;
-      c1[1] = g_nt(lw.W1oT, D, nullptr, w.dW1ovT, D, g.wv, C, dh, C, D, nullptr);          // dWv_h += W1oT_h dW1ovT_h^T
+      c1[1] = g_nt(lw.W1oT, D, nullptr, lw.dW1ovT, D, g.wv, C, dh, C, D, nullptr);          // dWv_h += W1oT_h dW1ovT_h^T
       c1[1].batch = H; c1[1].a_bs[0] = (int64_t)dh * D; c1[1].b_bs[0] = (int64_t)Cp * D; c1[1].c_bs = (int64_t)dh * C;
       c1[1].accumulate = 1;
-      c1[2] = g_nt(lw.W1oT, D, nullptr, w.dW1ovT + (int64_t)C * D, D, g.b_in + 2 * E, 1, dh, 1, D, nullptr);   // dbv_h += W1oT_h du_h
+      c1[2] = g_nt(lw.W1oT, D, nullptr, lw.dW1ovT + (int64_t)C * D, D, g.b_in + 2 * E, 1, dh, 1, D, nullptr);   // dbv_h += W1oT_h du_h
       c1[2].batch = H; c1[2].a_bs[0] = (int64_t)dh * D; c1[2].b_bs[0] = (int64_t)Cp * D; c1[2].c_bs = dh;
       c1[2].accumulate = 1;
-      c1[3] = g_nt(p.wq, E, nullptr, w.dWqk, D, g.wk, C, dh, C, D, nullptr);               // dWk_h += Wq_h[:, :D] dWqk_h^T
+      c1[3] = g_nt(p.wq, E, nullptr, lw.dWqk, D, g.wk, C, dh, C, D, nullptr);               // dWk_h += Wq_h[:, :D] dWqk_h^T
       c1[3].batch = H; c1[3].a_bs[0] = (int64_t)dh * E; c1[3].b_bs[0] = (int64_t)Cp * D; c1[3].c_bs = (int64_t)dh * C;
       c1[3].accumulate = 1;
-      c1[4] = g_nn(p.wk, C, w.dWqk, D, g.wq, E, dh, D, C);                                 // dWq_h[:, :D] += Wk_h dWqk_h
+      c1[4] = g_nn(p.wk, C, lw.dWqk, D, g.wq, E, dh, D, C);                                 // dWq_h[:, :D] += Wk_h dWqk_h
       c1[4].batch = H; c1[4].a_bs[0] = (int64_t)dh * C; c1[4].b_bs[0] = (int64_t)Cp * D; c1[4].c_bs = (int64_t)dh * E;
       c1[4].accumulate = 1;
-      c1[5] = g_nt(p.wk, C, nullptr, w.gqk, C, w.gq, 1, dh, 1, C, nullptr);                // d cq_h = Wk_h gqk_h
+      c1[5] = g_nt(p.wk, C, nullptr, lw.gqk, C, lw.gq, 1, dh, 1, C, nullptr);                // d cq_h = Wk_h gqk_h
       c1[5].batch = H; c1[5].a_bs[0] = (int64_t)dh * C; c1[5].b_bs[0] = Cp; c1[5].c_bs = dh;
-      RUN(pfo_gemm_multi_launch(c1, 6, s));
+      RUN(pfo_gemm_multi_launch(c1, 6, ss));
       for (int h = 0; h < H; ++h) {
         // W1ovT row C = bv_h^T W1oT_h  and  cqk_h = Wk_h^T cq_h : the outer-product halves of their gradients
-        RUN(pfo_rank1_launch(p.b_in + 2 * E + h * dh, 1, w.dW1ovT + ((int64_t)h * Cp + C) * D, 1, dh, D,
-                             w.dW1oT + (int64_t)h * dh * D, D, s));
-        RUN(pfo_rank1_launch(lw.cq + h * dh, 1, w.gqk + (int64_t)h * Cp, 1, dh, C, g.wk + (int64_t)h * dh * C, C, s));
+        RUN(pfo_rank1_launch(p.b_in + 2 * E + h * dh, 1, lw.dW1ovT + ((int64_t)h * Cp + C) * D, 1, dh, D,
+                             lw.dW1oT + (int64_t)h * dh * D, D, ss));
+        RUN(pfo_rank1_launch(lw.cq + h * dh, 1, lw.gqk + (int64_t)h * Cp, 1, dh, C, g.wk + (int64_t)h * dh * C, C, ss));
       }
-      const float* dc = w.dW1ovT + (int64_t)(C + 1) * D;                                   // gradient of (W1 bo)^T
+      const float* dc = lw.dW1ovT + (int64_t)(C + 1) * D;                                   // gradient of (W1 bo)^T
       PfoGemm c2[3];
-      c2[0] = g_nt(w.dW1oT, D, nullptr, p.wo, E, g.w1, E + D, D, E, E, nullptr);           // dW1[:, :E] += dW1o Wo^T
+      c2[0] = g_nt(lw.dW1oT, D, nullptr, p.wo, E, g.w1, E + D, D, E, E, nullptr);           // dW1[:, :E] += dW1o Wo^T
       c2[0].a_kmajor = 1; c2[0].accumulate = 1;
-      c2[1] = g_nt(p.w1, E + D, nullptr, w.dW1oT, D, g.wo, E, E, E, D, nullptr);           // dWo += W1[:, :E]^T dW1o
+      c2[1] = g_nt(p.w1, E + D, nullptr, lw.dW1oT, D, g.wo, E, E, E, D, nullptr);           // dWo += W1[:, :E]^T dW1o
       c2[1].a_kmajor = 1; c2[1].accumulate = 1;
       c2[2] = g_nt(p.w1, E + D, nullptr, dc, D, g.bo, 1, E, 1, D, nullptr);                // dbo += W1[:, :E]^T dc
       c2[2].a_kmajor = 1; c2[2].accumulate = 1;
-      RUN(pfo_gemm_multi_launch(c2, 3, s));
-      RUN(pfo_rank1_launch(dc, 1, p.bo, 1, D, E, g.w1, E + D, s));                          // dW1[:, :E] += dc (x) bo
-      RUN(pfo_cq_backward_launch(w.gq, p.wq, P.tb, D, g.b_in, g.wq, G.tb, s));              // cq = Wq[:, D:] cos(b) + bq
+      RUN(pfo_gemm_multi_launch(c2, 3, ss));
+      RUN(pfo_rank1_launch(dc, 1, p.bo, 1, D, E, g.w1, E + D, ss));                          // dW1[:, :E] += dc (x) bo
     }
   }
 
@@ -538,6 +573,12 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       RUN(pfo_gemm_tn_group_launch(gp, 2, capP, w.n_touched, w.slabs, w.slab_floats, s));
     }
   }
+  // join the side stream; the folded query-bias backward touches the time-encoder bias gradient, which the main
+  // stream's folds also accumulate, so it runs here, after both are done
+  HIPOK(hipEventRecord(sd.done, ss), "event record failed");
+  HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
+  for (int l = 1; l <= L; ++l)
+    RUN(pfo_cq_backward_launch(w.layer[l].gq, P.l[l].wq, P.tb, D, G.l[l].b_in, G.l[l].wq, G.tb, s));   // cq = Wq[:, D:] cos(b) + bq
   return PFO_OK;
 }
 
