@@ -47,9 +47,9 @@ def parse():
     return ap.parse_args()
 
 
-PMC_KERNEL = {"gemm_nt": "void gemm_f32_kernel<false, false, false, true>",
-              "gemm_nn": "void gemm_f32_kernel<false, true, false, true>",
-              "gemm_tn": "void gemm_f32_kernel<true, true, false, true>",
+PMC_KERNEL = {"gemm_nt": "void gemm_f32_kernel<false, false, 0, true>",
+              "gemm_nn": "void gemm_f32_kernel<false, true, 0, true>",
+              "gemm_tn": "void gemm_tn_group_kernel<true>",
               "attn_fwd": "void attn_fwd_kernel<3, 2>", "attn_bwd": "void attn_bwd_kernel<3, 2>"}
 
 
