@@ -112,6 +112,17 @@ int pfo_bpr_loss(const float* emb, int64_t B, int32_t D, int64_t pos_off, int64_
                  int64_t R, float scale, float* loss_out, float* d_emb, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Ranking metrics of evaluation.py:114-145 for one positive per interaction.
+ *   emb f32[R,D] = [src B | dst B | neg B*n_items]; score = src . item (evaluation.py:114-115).
+ *   rank_b = #{ k : score(neg_bk) >= score(dst_b) }  - position of the positive in the descending order of
+ *   concat(pos, neg) with the canonical tie policy (stable ascending argsort reversed, SURVEY App. A-9;
+ *   evaluation.py:138 uses the platform's unstable argsort).
+ *   rank_out i32[B]; hits_out f32[B,3] = recall@{1,3,5}; ndcg_out f32[B,3] = NDCG@{1,3,5} (evaluation.py:11-21).
+ */
+int pfo_rank_metrics(const float* emb, int64_t B, int32_t D, int32_t n_items, int32_t* rank_out, float* hits_out,
+                     float* ndcg_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Adam step over a flat parameter buffer (torch.optim.Adam defaults, main.py:123,389).
  */
 int pfo_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

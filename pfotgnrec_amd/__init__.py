@@ -13,4 +13,4 @@ from .mv_sampler import MVSampler  # noqa: F401
 from .memory import Memory  # noqa: F401
 from .tgn import TGN  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
-from .functional import bpr_loss, time_encode  # noqa: F401
+from .functional import bpr_loss, time_encode, rank_metrics  # noqa: F401

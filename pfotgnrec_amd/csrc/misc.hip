@@ -150,6 +150,45 @@ extern "C" int pfo_bpr_loss(const float* emb, int64_t B, int32_t D, int64_t pos_
 }
 
 // ---------------------------------------------------------------------------------------------
+// evaluation ranking (evaluation.py:114-145): one wavefront per interaction
+__global__ void rank_metrics_kernel(const float* __restrict__ emb, int64_t B, int D, int n_items, int32_t* __restrict__ rank_out,
+                                    float* __restrict__ hits, float* __restrict__ ndcg) {
+  const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const float* s = emb + b * D;
+  const float* p = emb + (B + b) * D;
+  float pos = 0.f;
+  for (int d = lane; d < D; d += 64) pos = fmaf(s[d], p[d], pos);
+  pos = pfo_wave_sum(pos);
+  int rank = 0;
+  for (int k = 0; k < n_items; ++k) {
+    const float* nk = emb + (2 * B + b * (int64_t)n_items + k) * D;
+    float ns = 0.f;
+    for (int d = lane; d < D; d += 64) ns = fmaf(s[d], nk[d], ns);
+    ns = pfo_wave_sum(ns);
+    rank += (ns >= pos) ? 1 : 0;
+  }
+  if (lane == 0) {
+    if (rank_out) rank_out[b] = rank;
+    const int ks[3] = {1, 3, 5};
+    for (int i = 0; i < 3; ++i) {
+      const bool hit = rank < ks[i];
+      if (hits) hits[b * 3 + i] = hit ? 1.f : 0.f;                           // recall@k with one test item
+      if (ndcg) ndcg[b * 3 + i] = hit ? 1.f / log2f((float)rank + 2.f) : 0.f; // idcg = 1
+    }
+  }
+}
+extern "C" int pfo_rank_metrics(const float* emb, int64_t B, int32_t D, int32_t n_items, int32_t* rank_out, float* hits_out,
+                                float* ndcg_out, void* stream) {
+  PFO_REQUIRE(emb && B > 0 && D > 0 && n_items > 0, "bad arguments");
+  hipLaunchKernelGGL(rank_metrics_kernel, dim3((unsigned)pfo_ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, emb, B, (int)D,
+                     (int)n_items, rank_out, hits_out, ndcg_out);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam, amsgrad off, weight_decay 0)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float bc1,

@@ -45,3 +45,19 @@ def time_encode(t, weight, bias):
     _lib.call("pfo_time_encode", t.data_ptr(), t.numel(), weight.contiguous().data_ptr(), bias.contiguous().data_ptr(),
               D, out.data_ptr(), _lib.stream_ptr())
     return out
+
+
+def rank_metrics(emb, batch, n_items):
+    """Ranking part of evaluation.py:114-145 on the device: emb [R,D] = [src B | dst B | neg B*n_items].
+
+    Returns (rank i32[B], recall f32[B,3], ndcg f32[B,3]) for k = 1, 3, 5; rank = number of negatives scoring >= the
+    positive (canonical tie policy)."""
+    _lib.require_gpu(emb.device)
+    emb = emb.contiguous()
+    D = emb.shape[1]
+    rank = torch.empty(batch, dtype=torch.int32, device=emb.device)
+    hits = torch.empty((batch, 3), dtype=torch.float32, device=emb.device)
+    ndcg = torch.empty((batch, 3), dtype=torch.float32, device=emb.device)
+    _lib.call("pfo_rank_metrics", emb.data_ptr(), batch, D, n_items, rank.data_ptr(), hits.data_ptr(), ndcg.data_ptr(),
+              _lib.stream_ptr())
+    return rank, hits, ndcg

@@ -116,6 +116,7 @@ class TGN(nn.Module):
         self._step = 0
         self.seed = 0
         self.dp_rank, self.dp_world = 0, 1
+        self.eval_chunk_roots = 16384     # roots per forward-only pass (evaluation.py scores B*(2+N_ITEMS) roots per batch)
 
         E, C, M = 2 * D, 2 * D + Ef, 3 * D + Ef
         lay = self._layout
@@ -348,17 +349,30 @@ class TGN(nn.Module):
             K, root_ts = 1, torch.full_like(root_ts, -1.0)
         training = self.training and torch.is_grad_enabled()
         extra = torch.cat([src, dst]).contiguous() if (self.use_memory and self.dp_world > 1) else None
-        call = self._make_call(roots, root_ts, K, draws, training, extra)
         self._cur_batch = B
         post = None
         if self.use_memory:
             post = lambda: self._native_update_state(src, dst, edge_times, edge_idxs)
         if training:
+            call = self._make_call(roots, root_ts, K, draws, training, extra)
             emb = _EmbedFn.apply(self, call, post, *self.hot_parameters())
+            return emb, hi - lo
+        # forward only (evaluation.py:94: R = B*(2+N_ITEMS) roots): walk the roots in chunks through the same
+        # kernels; memory is persisted once, after the last chunk, from a pass that covers the positives
+        R, cap = int(roots.shape[0]), int(self.eval_chunk_roots)
+        if R <= cap or draws is not None:
+            emb = self._native_forward(self._make_call(roots, root_ts, K, draws, False, extra))
         else:
-            emb = self._native_forward(call)
-            if post is not None:
-                post()
+            emb = torch.empty((R, self.n_node_features), dtype=torch.float32, device=self.device)
+            pos = torch.cat([src, dst]).contiguous() if self.use_memory else None
+            order = list(range(cap, R, cap)) + [0]                # chunk 0 (holds src|dst) last: its touched set feeds the persist
+            for c0 in order:
+                c1 = min(R, c0 + cap)
+                ex = extra if c0 != 0 or pos is None else (pos if extra is None else extra)
+                call = self._make_call(roots[c0:c1].contiguous(), root_ts[c0:c1].contiguous(), K, None, False, ex)
+                emb[c0:c1] = self._native_forward(call)
+        if post is not None:
+            post()
         return emb, hi - lo
 
     def _to_dev(self, a, dtype):

@@ -260,3 +260,49 @@ def test_dropout_training_is_consistent_between_forward_and_backward():
     assert abs(fd - gnum[idx].item()) < 5e-2 * max(1.0, abs(fd)), (fd, gnum[idx].item())   # fp32 central difference
     e1, e2 = run(), run()
     assert torch.equal(e1, e2)
+
+
+def test_evaluation_fast_path_chunked_roots_and_rank_metrics():
+    """evaluation.py:88-145: every interaction scores ALL items (R = B*(2+N_ITEMS) roots, forward only).  Roots are
+    walked in chunks through the same kernels: identical embeddings and identical memory/message state as one pass;
+    ranking metrics on the device equal the host computation."""
+    torch.manual_seed(3)
+    cfg = SyntheticConfig("ev", 300, 25, 5000, 32, 2, 6, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    B, n_items = 20, cfg.n_items
+    sl = slice(3000, 3000 + B)
+    neg = np.tile(np.arange(cfg.n_users + 1, cfg.n_users + 1 + n_items), B)            # all items for every interaction
+    outs, states = [], []
+    for cap in (1 << 30, 96):
+        torch.manual_seed(3)
+        tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=2, dropout=0.2,
+                    use_memory=True, memory_dimension=32, message_function="identity")
+        tgn.eval_chunk_roots = cap
+        tgn.eval()
+        with torch.no_grad():
+            for warm in (2900, 2950):                                                     # populate memory / messages
+                w = slice(warm, warm + B)
+                tgn.compute_temporal_embeddings(d.sources[w], d.destinations[w], d.destinations[w].repeat(3), d.timestamps[w],
+                                                d.edge_idxs[w], 6)
+            se, de, ne = tgn.compute_temporal_embeddings(d.sources[sl], d.destinations[sl], neg, d.timestamps[sl], d.edge_idxs[sl], 6)
+        outs.append(torch.cat([se, de, ne]))
+        states.append((tgn.memory.memory.clone(), tgn.memory.last_update.clone(), tgn.memory.msg_table.clone(), tgn.memory.has_msg.clone()))
+    assert outs[0].shape[0] == B * (2 + n_items)
+    assert torch.equal(outs[0], outs[1])
+    for a, b in zip(states[0], states[1]):
+        assert torch.equal(a, b)
+    emb = outs[0]
+    rank, hits, ndcg = P.rank_metrics(emb, B, n_items)
+    e = emb.cpu().numpy().astype(np.float64)
+    src, dst, ngs = e[:B], e[B:2 * B], e[2 * B:].reshape(B, n_items, -1)
+    pos = (src * dst).sum(1)
+    negs = np.einsum("bd,bkd->bk", src, ngs)
+    r = rank.cpu().numpy()
+    for b in range(B):
+        margin = np.abs(negs[b] - pos[b]).min()
+        if margin > 1e-5:                                                                 # away from fp32 ties
+            assert r[b] == int((negs[b] >= pos[b]).sum())
+        for i, k in enumerate((1, 3, 5)):
+            assert hits[b, i].item() == float(r[b] < k)
+            assert abs(ndcg[b, i].item() - (1 / np.log2(r[b] + 2) if r[b] < k else 0.0)) < 1e-6
