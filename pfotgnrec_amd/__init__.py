@@ -6,7 +6,7 @@ Public surface mirrors the reference's: ``TGN`` (model/tgn.py), ``NeighborFinder
 """
 __version__ = "0.1.0"
 
-from .data import Data, compute_time_statistics  # noqa: F401
+from .data import Data, compute_time_statistics, get_data  # noqa: F401
 from .neighbor_finder import NeighborFinder, get_neighbor_finder  # noqa: F401
 from .rand_edge_sampler import RandEdgeSampler, DeviceNegativeSampler  # noqa: F401
 from .mv_sampler import MVSampler  # noqa: F401

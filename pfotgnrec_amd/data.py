@@ -41,3 +41,29 @@ def compute_time_statistics(sources, destinations, timestamps):
     g_src = _gaps(sources, timestamps)
     g_dst = _gaps(destinations, timestamps)
     return float(np.mean(g_src)), float(np.std(g_src)), float(np.mean(g_dst)), float(np.std(g_dst))
+
+
+def get_data(dataset_name, period, root="./data"):
+    """Reads the reference's on-disk format and applies its chronological 80/10/10 split (utils/data.py:18-72).
+
+    Files under ``{root}/period_{period}/`` (README.md:45): ``ml_{name}.json`` (records u, i, ts, label, idx, portfolio),
+    ``ml_{name}.npy`` (edge features, row 0 = padding), ``ml_{name}_node.npy`` (node features).
+    Returns (node_features, edge_features, full_data, train_data, val_data, test_data, upper_u) like the reference.
+    """
+    import os
+    import pandas as pd
+    base = os.path.join(root, "period_{}".format(period))
+    graph_df = pd.read_json(os.path.join(base, "ml_{}.json".format(dataset_name)))
+    edge_features = np.load(os.path.join(base, "ml_{}.npy".format(dataset_name)))
+    node_features = np.load(os.path.join(base, "ml_{}_node.npy".format(dataset_name)))
+    val_time, test_time = list(np.quantile(graph_df.ts, [0.8, 0.9]))                       # data.py:28
+    sources, destinations = graph_df.u.values, graph_df.i.values
+    edge_idxs, labels, timestamps = graph_df.idx.values, graph_df.label.values, graph_df.ts.values
+    portfolios = graph_df.portfolio.values
+    full_data = Data(sources, destinations, timestamps, edge_idxs, labels, portfolios)
+    train_mask = timestamps <= val_time                                                    # data.py:50-52
+    val_mask = np.logical_and(timestamps <= test_time, timestamps > val_time)
+    test_mask = timestamps > test_time
+    pick = lambda m: Data(sources[m], destinations[m], timestamps[m], edge_idxs[m], labels[m], portfolios[m])
+    upper_u = graph_df.u.max()                                                             # data.py:59
+    return node_features, edge_features, full_data, pick(train_mask), pick(val_mask), pick(test_mask), upper_u

@@ -249,3 +249,15 @@ def test_fused_adam_matches_torch_adam():
         _lib.call("pfo_adam_step", p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, step,
                   _lib.stream_ptr())
     assert np.abs(p.cpu().numpy() - ref_p.detach().numpy()).max() < 2e-6
+
+
+def test_device_csr_build_equals_host_build():
+    g = load_golden("g1_sampler")
+    from pfotgnrec_amd.neighbor_finder import build_csr
+    for p in ("a", "b"):                                   # b has heavy timestamp ties: the sorts must be stable
+        host = build_csr(g[p + "_src"], g[p + "_dst"], g[p + "_eidx"], g[p + "_ts"])
+        nf = P.NeighborFinder.from_arrays(g[p + "_src"], g[p + "_dst"], g[p + "_eidx"], g[p + "_ts"], device=DEV)
+        for a, b in zip(host, (nf.indptr, nf.nbr, nf.eidx, nf.ts)):
+            assert np.array_equal(a, b)
+    nb, ei, et = nf.get_temporal_neighbor(g["b_q_nodes"], g["b_q_ts"], 4)
+    assert np.array_equal(nb, g["b_K4_nbr"]) and np.array_equal(ei, g["b_K4_eidx"])

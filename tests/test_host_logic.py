@@ -97,3 +97,24 @@ def test_synthetic_configs_match_baseline_json():
     c2 = CONFIGS["C2"]
     assert (c2.n_users, c2.n_items, c2.n_edges, c2.dim, c2.n_layers, c2.n_neighbors) == (50000, 500, 1000000, 172, 2, 20)
     assert CONFIGS["C5"].use_memory is False and CONFIGS["C5"].uniform and CONFIGS["C5"].n_heads == 4
+
+
+def test_get_data_reads_the_reference_file_format(tmp_path):
+    """utils/data.py:18-72 on files written the way utils/preprocess_data.py writes them."""
+    import pandas as pd
+    g = make_graph(SyntheticConfig("t", 40, 8, 600, 8, 1, 4, 2), with_prices=False)
+    d = g.data
+    base = tmp_path / "period_30"
+    base.mkdir()
+    df = pd.DataFrame({"u": d.sources, "i": d.destinations, "ts": d.timestamps, "label": np.zeros(len(d.sources), int),
+                       "idx": d.edge_idxs, "portfolio": list(d.portfolios)})
+    df.to_json(base / "ml_transaction.json")
+    np.save(base / "ml_transaction.npy", g.edge_features)
+    np.save(base / "ml_transaction_node.npy", g.node_features)
+    nf, ef, full, train, val, test, upper_u = P.get_data("transaction", "30", root=str(tmp_path))
+    assert upper_u == d.sources.max() and full.n_interactions == 600
+    assert train.n_interactions + val.n_interactions + test.n_interactions == 600
+    v, t = np.quantile(d.timestamps, [0.8, 0.9])
+    assert train.timestamps.max() <= v < val.timestamps.min() and val.timestamps.max() <= t < test.timestamps.min()
+    assert np.array_equal(full.sources, d.sources) and list(full.portfolios[5]) == list(d.portfolios[5])
+    assert np.array_equal(ef, g.edge_features)
