@@ -101,6 +101,20 @@ int pfo_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, 
                  float* workspace, int64_t workspace_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The same contraction for row-major A, computed on the BF16 matrix cores by a 3-way split of every fp32 operand
+ * (x = x1 + x2 + x3, bf16 pieces with exact residuals; six piece products accumulated in fp32): fp32-level accuracy
+ * (error <= ~2^-22 sum_k |a||b|, the same bound as an fp32 accumulation) at 2.7x the fp32 matrix rate.  This is the
+ * kernel the large launches of pfo_tgn_forward / pfo_tgn_backward use for torch.nn.Linear (utils.py:7-17,
+ * torch.nn.MultiheadAttention in temporal_attention.py:27-31); it is exported so that it can be checked alone.
+ *   workspace: pfo_gemm_bf16x3_workspace_bytes(N, K) bytes, 16-byte aligned (receives the split image of B).
+ *   A 16-byte aligned, lda % 4 == 0, K % 4 == 0.
+ */
+int64_t pfo_gemm_bf16x3_workspace_bytes(int32_t N, int32_t K);
+int pfo_gemm_bf16x3(const float* A, int64_t lda, const float* B, int64_t ldb, int32_t b_kmajor, float* C, int64_t ldc,
+                    const float* bias, int32_t M, int32_t N, int32_t K, int32_t relu, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * BPR loss, forward + gradient in one pass (main.py:321-337 / 364-381):
  *   loss = -mean_b log sigmoid( mean_k( s_b.p_b - s_b.n_bk ) )       (sigma of the MEAN difference)
  * emb f32[R,D] holds the roots in the reference's order: [src B | dst B | (p_pos B*n_pos) | neg B*n_neg];

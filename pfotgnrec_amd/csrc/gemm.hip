@@ -40,12 +40,19 @@ struct GemmDev {
   const float* ones_scale; int64_t os_ld;   // value of the bias column per k row (null: 1.0)
   float* slab_base;                // split-K: this problem's slab region
   int dyn_chunk;                   // split-K chunk = f(device-side K) instead of split_chunk
+  const void* b_img; int b_img_rows;   // pre-split bf16x3 image of B (source 0) and its padded row count
 };
 
 static bool aligned4(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 #ifndef PFO_DEFAULT_TILE
 #define PFO_DEFAULT_TILE 0
+#endif
+#ifndef PFO_DEFAULT_BF16X3
+#define PFO_DEFAULT_BF16X3 1
+#endif
+#ifndef PFO_BX_MIN_TILES
+#define PFO_BX_MIN_TILES 400
 #endif
 #ifndef GEMM_EXP
 #define GEMM_EXP 0       // timing-only ablations (wrong results): 1 = no global loads / LDS stores after the first tile, 2 = no MFMA,
@@ -354,6 +361,264 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp32 contraction on the BF16 matrix cores by a 3-way split ("bf16x3"): x = x1 + x2 + x3 with x1 = hi16(x),
+// x2 = hi16(x - x1), x3 = hi16(x - x1 - x2) (24 mantissa bits in three bf16 pieces, residuals exact), and
+//   a.b ~= a1b1 + (a1b2 + a2b1) + (a2b2 + a1b3 + a3b1)          (dropped terms <= 2^-24 |a||b|)
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  Six bf16 MFMAs (16 cycles each) replace eight fp32 MFMAs
+// (32 cycles each) per 16x16x32 block: 2.7x the matrix rate at fp32-level accuracy (validated against fp64 in
+// tests/test_gpu_kernels.py).  Row-major A and B only (the nn.Linear layout); same tile, staging and epilogue as
+// the fp32 kernel.  LDS image per piece: [row][32 bf16] = 64-byte rows, 16-byte k-chunks XOR-swizzled with
+// f(row >> 2) = {0,3,2,1} so that every ds_read_b128 fragment read covers all 64 banks exactly once.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define BX_A_PIECE (BM * 64)     // bytes per piece of the A tile
+#define BX_B_PIECE (BN * 64)
+
+template <int N, typename F, int I = 0>
+__device__ __forceinline__ void bx_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); bx_for<N, F, I + 1>(static_cast<F&&>(f)); }
+}
+__device__ __forceinline__ int bx_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }   // {0,3,2,1}
+
+__device__ __forceinline__ void bx_split_store(char* base, int piece_bytes, int row, int c4, const float4 v) {
+  // float4 = 4 consecutive k of one row: k = 4*c4 .. 4*c4+3 -> 16-byte chunk c4 >> 1, half c4 & 1
+  const int off = row * 64 + (((c4 >> 1) ^ bx_swz(row)) << 4) + ((c4 & 1) << 3);
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  uint32_t p1[4], p2[4], p3[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t b1 = __float_as_uint(x[e]) & 0xFFFF0000u;
+    const float r1 = x[e] - __uint_as_float(b1);                 // exact
+    const uint32_t b2 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(b2);                   // exact
+    p1[e] = b1; p2[e] = b2; p3[e] = __float_as_uint(r2);
+  }
+  *reinterpret_cast<uint2*>(base + off) = uint2{(p1[1] & 0xFFFF0000u) | (p1[0] >> 16), (p1[3] & 0xFFFF0000u) | (p1[2] >> 16)};
+  *reinterpret_cast<uint2*>(base + piece_bytes + off) =
+      uint2{(p2[1] & 0xFFFF0000u) | (p2[0] >> 16), (p2[3] & 0xFFFF0000u) | (p2[2] >> 16)};
+  *reinterpret_cast<uint2*>(base + 2 * piece_bytes + off) =
+      uint2{(p3[1] & 0xFFFF0000u) | (p3[0] >> 16), (p3[3] & 0xFFFF0000u) | (p3[2] >> 16)};
+}
+
+template <bool BSPLIT>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const GemmDev p) {
+  __shared__ __attribute__((aligned(16))) char lds[3 * BX_A_PIECE + 3 * BX_B_PIECE];
+  char* const As = lds;
+  char* const Bs = lds + 3 * BX_A_PIECE;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int zb = blockIdx.z;
+  int Mlim = p.M;
+  if (p.m_dev) Mlim = min(Mlim, *p.m_dev);
+  if (m0 >= Mlim) return;
+  const int wrow = 32 * wave;
+
+  f32x4 acc[2][11];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 11; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int T0 = (p.K[0] + BK - 1) / BK;
+  const int T1 = (p.K[1] > 0 && p.A[1]) ? (p.K[1] + BK - 1) / BK : 0;
+  const int T = T0 + T1;
+  constexpr int NB = BSPLIT ? 9 : 6;                  // staged 16-byte units of B per thread
+  float4 a_reg[4], b_reg[6];
+  f32x4 i_reg[NB];                                    // (vector type: a struct copy here would pin the array in scratch)
+  const float* a_row[4];
+  const float* b_row[6];
+  bool a_ok[4], b_ok[6];
+  int Ks = 0, cur_src = -1;
+  const float* safe = p.A[0];
+  // pre-split B: tile t, piece q of the rows n0.. is one contiguous BX_B_PIECE-byte run of the image
+  const char* img = BSPLIT ? reinterpret_cast<const char*>(p.b_img) + (int64_t)n0 * 64 : nullptr;
+  const int64_t img_piece = (int64_t)p.b_img_rows * 64;
+
+  auto bind_src = [&](int src) {
+    cur_src = src;
+    Ks = p.K[src];
+    const float* Ab = p.A[src] + zb * p.a_bs[src];
+    const float* Bb = p.B[src] + zb * p.b_bs[src];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gm = m0 + ((tid + 256 * i) >> 3);
+      a_ok[i] = gm < Mlim;
+      int64_t ridx = a_ok[i] ? gm : 0;
+      if (a_ok[i] && p.a_idx[src]) ridx = p.a_idx[src][gm];
+      a_row[i] = Ab + ridx * p.lda[src];
+    }
+    if constexpr (!BSPLIT) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int f = tid + 256 * i;
+        const int gn = n0 + (f >> 3);
+        b_ok[i] = (f < BN * 8) && gn < p.N;
+        b_row[i] = Bb + (int64_t)(b_ok[i] ? gn : 0) * p.ldb[src];
+      }
+    }
+  };
+  auto load_tile = [&](int t) {
+    const int src = t < T0 ? 0 : 1;
+    if (src != cur_src) bind_src(src);
+    const int k0 = (src == 0) ? t * BK : (t - T0) * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + 4 * ((tid + 256 * i) & 7);
+      a_reg[i] = ld4<true>(a_row[i] + k, a_ok[i] ? Ks - k : 0, safe);
+    }
+    if constexpr (BSPLIT) {
+      const char* tile = img + (int64_t)t * 3 * img_piece;
+      // 3 pieces x 704 units of 16 bytes = 8.25 units per thread (tail clamped); piece boundaries fall at units 704, 1408
+      bx_for<9>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        const int unit = min(tid + 256 * u, 3 * (BX_B_PIECE / 16) - 1);
+        const int q = (unit >= 2 * (BX_B_PIECE / 16)) ? 2 : (unit >= BX_B_PIECE / 16 ? 1 : 0);
+        i_reg[u] = *reinterpret_cast<const f32x4*>(tile + q * img_piece + (unit - q * (BX_B_PIECE / 16)) * 16);
+      });
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int k = k0 + 4 * ((tid + 256 * i) & 7);
+        b_reg[i] = ld4<true>(b_row[i] + k, b_ok[i] ? Ks - k : 0, safe);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i;
+      bx_split_store(As, BX_A_PIECE, f >> 3, f & 7, a_reg[i]);
+    }
+    if constexpr (BSPLIT) {
+      bx_for<9>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        const int unit = tid + 256 * u;
+        if (u < 8 || unit < 3 * (BX_B_PIECE / 16)) *reinterpret_cast<f32x4*>(Bs + unit * 16) = i_reg[u];
+      });
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int f = tid + 256 * i;
+        if (f < BN * 8) bx_split_store(Bs, BX_B_PIECE, f >> 3, f & 7, b_reg[i]);
+      }
+    }
+  };
+  const int frag_off = r * 64 + ((g ^ bx_swz(r)) << 4);     // rows of a strip start at multiples of 16: same swizzle
+  const bool strip_on[2] = {m0 + wrow < p.M, m0 + wrow + 16 < p.M};
+  auto compute_tile = [&]() {
+    bf16x8 a[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(As + q * BX_A_PIECE + (wrow + 16 * i) * 64 + frag_off);
+#pragma unroll
+    for (int j = 0; j < 11; ++j) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) b[q] = *reinterpret_cast<const bf16x8*>(Bs + q * BX_B_PIECE + (16 * j) * 64 + frag_off);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (!strip_on[i]) continue;
+        f32x4 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[0], c, 0, 0, 0);   // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+    }
+  };
+
+  if (T > 0) {
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      const bool more = t + 1 < T;
+      if (more) load_tile(t + 1);
+      compute_tile();
+      __syncthreads();
+      if (more) store_tile();
+      __syncthreads();
+    }
+  }
+
+  float* Cb = p.C + zb * p.c_bs;
+  const int64_t ldc = p.ldc;
+  const float* bias = p.bias ? p.bias + zb * p.bias_bs : nullptr;
+  const float* rs = p.row_scale ? p.row_scale + zb * p.rs_bs : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = m0 + wrow + 16 * i + 4 * g + reg;
+      if (row >= Mlim) continue;
+      const float rscale = rs ? rs[(int64_t)row * p.rs_ld] : 1.f;
+      const bool zero = p.row_zero ? (p.row_zero[row] != 0) : false;
+#pragma unroll
+      for (int j = 0; j < 11; ++j) {
+        const int col = n0 + 16 * j + r;
+        if (col >= p.N) continue;
+        float v = acc[i][j][reg];
+        if (p.accumulate) v += Cb[(int64_t)row * ldc + col];
+        if (bias) v = fmaf(bias[col], rscale, v);
+        if (zero) v = 0.f;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.relu_src) v = (p.relu_src[(int64_t)row * p.relu_ld + col] > 0.f) ? v : 0.f;
+        Cb[(int64_t)row * ldc + col] = v;
+      }
+    }
+  }
+}
+
+// Pre-split image of a weight operand for gemm_bf16x3_kernel<true>: [k-tile][piece][row n, padded to BN][64 B],
+// the exact LDS image of the kernel (same swizzle), zero-padded in n and k.  W(n, k) = src[n*ld + k] or, with
+// `trans`, src[k*ld + n] - so a k-major ("NN") operand becomes a row-major one for free.
+struct BimgDev {
+  const float* src[PFO_BIMG_MAX]; int64_t ld[PFO_BIMG_MAX]; int N[PFO_BIMG_MAX], K[PFO_BIMG_MAX], trans[PFO_BIMG_MAX];
+  void* dst[PFO_BIMG_MAX]; int rows[PFO_BIMG_MAX];
+};
+__global__ __launch_bounds__(256) void bimg_kernel(const BimgDev g) {
+  const int z = blockIdx.y;
+  const int N = g.N[z], K = g.K[z], rows = g.rows[z];
+  const int T = (K + 31) / 32;
+  const int64_t total = (int64_t)T * rows * 4;                 // one thread per (tile, row, 16-byte chunk)
+  const float* __restrict__ src = g.src[z];
+  const int64_t ld = g.ld[z];
+  char* dst = reinterpret_cast<char*>(g.dst[z]);
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int t, n, c;
+    if (g.trans[z]) { n = (int)(i % rows); c = (int)((i / rows) & 3); t = (int)(i / (4 * (int64_t)rows)); }
+    else            { c = (int)(i & 3); n = (int)((i >> 2) % rows); t = (int)((i >> 2) / rows); }
+    uint32_t w[3][4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      uint32_t pc[2][3];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = 32 * t + 8 * c + 2 * e2 + h;
+        float x = 0.f;
+        if (n < N && k < K) x = g.trans[z] ? src[(int64_t)k * ld + n] : src[(int64_t)n * ld + k];
+        const uint32_t b1 = __float_as_uint(x) & 0xFFFF0000u;
+        const float r1 = x - __uint_as_float(b1);
+        const uint32_t b2 = __float_as_uint(r1) & 0xFFFF0000u;
+        const float r2 = r1 - __uint_as_float(b2);
+        pc[h][0] = b1; pc[h][1] = b2; pc[h][2] = __float_as_uint(r2);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) w[q][e2] = (pc[1][q] & 0xFFFF0000u) | (pc[0][q] >> 16);
+    }
+    const int64_t off = (int64_t)n * 64 + ((c ^ bx_swz(n)) << 4);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      *reinterpret_cast<uint4*>(dst + ((int64_t)t * 3 + q) * rows * 64 + off) = uint4{w[q][0], w[q][1], w[q][2], w[q][3]};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Several SMALL independent contractions in one launch (the composite-weight products of a layer and their
 // gradient chain: each is far too small to fill the chip or to amortise a launch).  32-row tiles; the operand
 // layout is a per-problem switch (wavefront-uniform).
@@ -547,8 +812,27 @@ static void to_dev(const PfoGemm& g, GemmDev& d) {
   d.relu = g.relu; d.accumulate = g.accumulate; d.nsplit = 1; d.split_chunk = 0;
   d.c_bs = g.c_bs; d.bias_bs = g.bias_bs; d.rs_bs = g.rs_bs;
   d.n_real = g.N; d.ones_scale = nullptr; d.os_ld = 0; d.slab_base = g.slabs; d.dyn_chunk = 0;
+  d.b_img = nullptr; d.b_img_rows = 0;
 }
 
+
+int64_t pfo_bimg_bytes(int N, int K) { return (int64_t)pfo_ceil_div(K, 32) * 3 * pfo_align_up(N, BN) * 64; }
+
+int pfo_bimg_launch(const PfoBimg* list, int n, hipStream_t stream) {
+  PFO_REQUIRE(n >= 1 && n <= PFO_BIMG_MAX, "bad image count");
+  BimgDev d;
+  int64_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    PFO_REQUIRE(list[i].src && list[i].dst && list[i].N > 0 && list[i].K > 0, "bad image problem");
+    PFO_REQUIRE((((uintptr_t)list[i].dst) & 15) == 0, "image must be 16-byte aligned");
+    d.src[i] = list[i].src; d.ld[i] = list[i].ld; d.N[i] = list[i].N; d.K[i] = list[i].K; d.trans[i] = list[i].trans;
+    d.dst[i] = list[i].dst; d.rows[i] = (int)pfo_align_up(list[i].N, BN);
+    most = std::max<int64_t>(most, (int64_t)pfo_ceil_div(list[i].K, 32) * d.rows[i] * 4);
+  }
+  hipLaunchKernelGGL(bimg_kernel, dim3((unsigned)pfo_ceil_div(most, 256), n), dim3(256), 0, stream, d);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
 
 int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
   PFO_REQUIRE(g.M > 0 && g.N > 0 && g.K[0] > 0 && g.batch >= 1, "bad sizes");
@@ -609,7 +893,18 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
     if (force >= 0) tile = force;
     const int rows = tile == 1 ? 32 : (tile == 2 ? 64 : BM);
     const dim3 grid((unsigned)pfo_ceil_div(g.M, rows), tn, g.batch);
-    if (g.b_kmajor) {
+    // bf16x3 split contraction: 1 = when the caller supplies the pre-split image of B, 2 = also for plain row-major
+    // B (split in the kernel), 0 = never (fp32 MFMA everywhere).  A/B switch.
+    static const int bx = getenv("PFO_GEMM_BF16X3") ? atoi(getenv("PFO_GEMM_BF16X3")) : PFO_DEFAULT_BF16X3;
+    static const int bx_min_tiles = getenv("PFO_BX_MIN_TILES") ? atoi(getenv("PFO_BX_MIN_TILES")) : PFO_BX_MIN_TILES;
+    const bool a_rowvec = a_vec && g.batch == 1;
+    if (g.b_img && g.K[1] == 0 && a_rowvec && (g.bx_force || (bx >= 1 && big_tiles >= bx_min_tiles && force < 0))) {
+      d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN);
+      hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0,
+                         stream, d);
+    } else if (bx >= 2 && !g.b_kmajor && tile == 0 && vec) {
+      hipLaunchKernelGGL(gemm_bf16x3_kernel<false>, grid, dim3(GEMM_THREADS), 0, stream, d);
+    } else if (g.b_kmajor) {
       if (tile == 1) GEMM_GO(false, true, 1, grid); else if (tile == 2) GEMM_GO(false, true, 2, grid); else GEMM_GO(false, true, 0, grid);
     } else {
       if (tile == 1) GEMM_GO(false, false, 1, grid); else if (tile == 2) GEMM_GO(false, false, 2, grid); else GEMM_GO(false, false, 0, grid);
@@ -725,5 +1020,23 @@ extern "C" int pfo_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const
   g.a_kmajor = a_kmajor; g.b_kmajor = b_kmajor;
   g.slabs = workspace; g.slab_floats = workspace_floats;
   if (a_kmajor && bias) { pfo_set_error("pfo_gemm_f32: k-major A takes no bias"); return PFO_ERR_INVALID; }
+  return pfo_gemm_launch(g, (hipStream_t)stream);
+}
+
+extern "C" int64_t pfo_gemm_bf16x3_workspace_bytes(int32_t N, int32_t K) { return pfo_bimg_bytes(N, K); }
+
+extern "C" int pfo_gemm_bf16x3(const float* A, int64_t lda, const float* B, int64_t ldb, int32_t b_kmajor, float* C,
+                               int64_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, int32_t relu,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+  PFO_REQUIRE(A && B && C && workspace, "null operand");
+  PFO_REQUIRE(M > 0 && N > 0 && K > 0, "bad sizes");
+  PFO_REQUIRE(workspace_bytes >= pfo_bimg_bytes(N, K), "workspace too small for the image of B");
+  PFO_REQUIRE(aligned4(A) && (lda % 4) == 0 && (K % 4) == 0, "A must be 16-byte aligned with lda and K multiples of 4");
+  PfoBimg im;
+  im.src = B; im.ld = ldb; im.N = N; im.K = K; im.trans = b_kmajor ? 1 : 0; im.dst = workspace;
+  if (int rc = pfo_bimg_launch(&im, 1, (hipStream_t)stream)) return rc;
+  PfoGemm g;
+  g.A[0] = A; g.lda[0] = lda; g.B[0] = B; g.ldb[0] = ldb; g.K[0] = K; g.C = C; g.ldc = ldc; g.bias = bias;
+  g.M = M; g.N = N; g.relu = relu; g.b_kmajor = b_kmajor ? 1 : 0; g.b_img = workspace; g.bx_force = 1;
   return pfo_gemm_launch(g, (hipStream_t)stream);
 }

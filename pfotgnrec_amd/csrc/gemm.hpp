@@ -29,7 +29,19 @@ struct PfoGemm {
   int64_t a_bs[2] = {0, 0}, b_bs[2] = {0, 0}, c_bs = 0, bias_bs = 0, rs_bs = 0;
   // split-K for a_kmajor && b_kmajor (weight gradients): partial slabs in `slabs`, then reduced into C
   float* slabs = nullptr; int64_t slab_floats = 0;
+  // optional pre-split bf16x3 image of op(B) for source 0 (pfo_bimg_launch); used by the large row-major launches
+  const void* b_img = nullptr;
+  int bx_force = 0;                 // take the bf16x3 kernel whatever the launch-size heuristic says (tests)
 };
+
+// Pre-split ("bf16x3") image of a weight operand W(n, k) = src[n*ld + k] (trans = 0) or src[k*ld + n] (trans = 1):
+// three bf16 pieces per element in the LDS layout of the split contraction kernel.  dst needs pfo_bimg_bytes(N, K).
+#define PFO_BIMG_MAX 16
+struct PfoBimg {
+  const float* src = nullptr; int64_t ld = 0; int N = 0, K = 0, trans = 0; void* dst = nullptr;
+};
+int64_t pfo_bimg_bytes(int N, int K);
+int pfo_bimg_launch(const PfoBimg* list, int n, hipStream_t stream);
 
 int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream);
 // several small plain problems (any operand layouts, no device-side counts, no split-K) in one launch

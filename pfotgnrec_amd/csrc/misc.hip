@@ -33,13 +33,13 @@ hipEvent_t prof_event() {
 void pfo_prof_begin(hipStream_t s) {
   if (!g_prof_on) return;
   g_pending = prof_event();
-  if (g_pending) hipEventRecord(g_pending, s);
+  if (g_pending) (void)hipEventRecord(g_pending, s);
 }
 void pfo_prof_end(int kind, double work, hipStream_t s) {
   if (!g_prof_on || !g_pending) return;
   hipEvent_t b = prof_event();
   if (!b) return;
-  hipEventRecord(b, s);
+  (void)hipEventRecord(b, s);
   g_recs.push_back(ProfRec{kind, work, g_pending, b});
   g_pending = nullptr;
 }

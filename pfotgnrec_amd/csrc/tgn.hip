@@ -26,6 +26,8 @@ struct LayerWs {
   float *cq, *Wqk, *cqk, *W1oT, *W1ovT;   // per-step composite weights (see the layer comment in pfo_tgn_forward)
   float *dWqk, *gqk, *dW1ovT, *dW1oT, *gq; // their gradients (per layer: the chain-back runs on the side stream)
   uint8_t* inv;
+  // pre-split bf16x3 images of the weight operands of the large contractions (gemm.hpp PfoBimg): per step, side stream
+  void *iWqk, *iWqkT, *iW1ov, *iW1ovT, *iW1b, *iW1bT, *iW2, *iW2T;
 };
 struct Ws {
   int32_t* nodes[PFO_MAX_LAYERS + 1];
@@ -36,6 +38,7 @@ struct Ws {
   float *gi, *gh, *upd_mem, *h0_tab, *d_h0, *msg_rows, *h_rows;
   uint8_t* hm;
   float *cosb, *zero;
+  void *iWih, *iWhh;
   LayerWs layer[PFO_MAX_LAYERS + 1];
   float *dh1, *dctx, *dQK, *dx1;
   float* dH[PFO_MAX_LAYERS + 1];
@@ -102,6 +105,8 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     w.msg_rows = take<float>(p, d.capP * d.M);
     w.h_rows = take<float>(p, d.capP * d.D);
     w.hm = take<uint8_t>(p, d.capP);
+    w.iWih = take<char>(p, pfo_bimg_bytes(3 * d.D, d.M));
+    w.iWhh = take<char>(p, pfo_bimg_bytes(3 * d.D, d.D));
   }
   for (int l = 1; l <= d.L; ++l) {
     const int64_t N = d.ncap[l];
@@ -116,6 +121,13 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     lw.dW1ovT = take<float>(p, (int64_t)d.H * d.Cp * d.D);
     lw.dW1oT = take<float>(p, (int64_t)d.E * d.D);
     lw.gq = take<float>(p, d.E);
+    {
+      const int HCp = d.H * d.Cp;
+      lw.iWqk = take<char>(p, pfo_bimg_bytes(HCp, d.D));   lw.iWqkT = take<char>(p, pfo_bimg_bytes(d.D, HCp));
+      lw.iW1ovT = take<char>(p, pfo_bimg_bytes(HCp, d.D)); lw.iW1ov = take<char>(p, pfo_bimg_bytes(d.D, HCp));
+      lw.iW1b = take<char>(p, pfo_bimg_bytes(d.D, d.D));   lw.iW1bT = take<char>(p, pfo_bimg_bytes(d.D, d.D));
+      lw.iW2 = take<char>(p, pfo_bimg_bytes(d.D, d.D));    lw.iW2T = take<char>(p, pfo_bimg_bytes(d.D, d.D));
+    }
     lw.QK = take<float>(p, N * d.H * d.Cp);
     lw.attw = take<float>(p, N * d.H * Km);
     lw.inv = take<uint8_t>(p, N);
@@ -342,6 +354,21 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
       st2[2].batch = H; st2[2].a_bs[0] = dh; st2[2].b_bs[0] = (int64_t)dh * D; st2[2].c_bs = (int64_t)Cp * D;
       st2[3] = g_nt(p.bo, E, nullptr, p.w1, E + D, lw.W1ovT + (int64_t)(C + 1) * D, D, 1, D, E, nullptr);   // row C+1 of head 0: (W1 bo)^T
       RUN(pfo_gemm_multi_launch(st2, 4, ss));
+      // bf16x3 images of this layer's weight operands, in both orientations (forward and data-gradient launches)
+      PfoBimg im[10];
+      int ni = 0;
+      auto img = [&](const float* src, int64_t ld, int N_, int K_, int trans, void* dst) {
+        im[ni].src = src; im[ni].ld = ld; im[ni].N = N_; im[ni].K = K_; im[ni].trans = trans; im[ni].dst = dst; ++ni;
+      };
+      img(lw.Wqk, D, HCp, D, 0, lw.iWqk);        img(lw.Wqk, D, D, HCp, 1, lw.iWqkT);
+      img(lw.W1ovT, D, HCp, D, 0, lw.iW1ovT);    img(lw.W1ovT, D, D, HCp, 1, lw.iW1ov);
+      img(p.w1 + E, E + D, D, D, 0, lw.iW1b);    img(p.w1 + E, E + D, D, D, 1, lw.iW1bT);
+      img(p.w2, D, D, D, 0, lw.iW2);             img(p.w2, D, D, D, 1, lw.iW2T);
+      if (l == 1 && c->use_memory) {
+        img(P.w_ih, d.M, 3 * D, d.M, 0, w.iWih);
+        img(P.w_hh, D, 3 * D, D, 0, w.iWhh);
+      }
+      RUN(pfo_bimg_launch(im, ni, ss));
     }
     HIPOK(hipEventRecord(sd.layer[l], ss), "event record failed");
   }
@@ -372,10 +399,10 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     RUN(pfo_pack_rows_launch(st->msg_table, d.M, st->memory, D, st->has_msg, w.touched, w.n_touched, capP, w.msg_rows,
                              w.h_rows, w.hm, s));
     PfoGemm gi = g_nt(w.msg_rows, d.M, nullptr, P.w_ih, d.M, w.gi, 3 * D, capP, 3 * D, d.M, P.b_ih);
-    gi.m_dev = w.n_touched;
+    gi.m_dev = w.n_touched; gi.b_img = w.iWih;
     RUN(pfo_gemm_launch(gi, s));
     PfoGemm gh = g_nt(w.h_rows, D, nullptr, P.w_hh, D, w.gh, 3 * D, capP, 3 * D, D, P.b_hh);
-    gh.m_dev = w.n_touched;
+    gh.m_dev = w.n_touched; gh.b_img = w.iWhh;
     RUN(pfo_gemm_launch(gh, s));
     RUN(pfo_gru_gates_fwd_launch(w.gi, w.gh, w.h_rows, st->node_feat, w.hm, w.touched, w.n_touched, capP, D, w.upd_mem,
                                  w.h0_tab, s));
@@ -407,7 +434,11 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
 
     HIPOK(hipStreamWaitEvent(s, sd.layer[l], 0), "event wait failed");     // this layer's composite weights are ready
     // ---- qk' = x Wqk^T + cqk
-    RUN(pfo_gemm_launch(g_nt(xA, D, x_idx, lw.Wqk, D, lw.QK, HCp, N, HCp, D, lw.cqk), s));
+    {
+      PfoGemm g = g_nt(xA, D, x_idx, lw.Wqk, D, lw.QK, HCp, N, HCp, D, lw.cqk);
+      g.b_img = lw.iWqk;
+      RUN(pfo_gemm_launch(g, s));
+    }
     PfoAttn a;
     a.N = N; a.K = K; a.D = D; a.Ef = Ef; a.H = H; a.Cp = Cp;
     a.QK = lw.QK; a.nbr_tab = xA; a.nbr_ld = D;
@@ -419,13 +450,21 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     a.ctx = lw.ctx; a.attw = lw.attw; a.inv = lw.inv;
     RUN(pfo_attn_fwd_launch(a, s));
     // ---- h1 = relu(ctx' W1ovT + x W1[:, E:]^T + b1)   (MergeLayer fc1 with out_proj and the value projection folded in)
-    RUN(pfo_gemm_launch(g_nn(lw.ctx, HCp, lw.W1ovT, D, lw.h1, D, N, D, HCp), s));
     {
-      PfoGemm g = g_nt(xA, D, x_idx, p.w1 + E, E + D, lw.h1, D, N, D, D, p.b1);
-      g.accumulate = 1; g.relu = 1;
+      PfoGemm g = g_nn(lw.ctx, HCp, lw.W1ovT, D, lw.h1, D, N, D, HCp);
+      g.b_img = lw.iW1ov;
       RUN(pfo_gemm_launch(g, s));
     }
-    RUN(pfo_gemm_launch(g_nt(lw.h1, D, nullptr, p.w2, D, lw.Hout, D, N, D, D, p.b2), s));
+    {
+      PfoGemm g = g_nt(xA, D, x_idx, p.w1 + E, E + D, lw.h1, D, N, D, D, p.b1);
+      g.accumulate = 1; g.relu = 1; g.b_img = lw.iW1b;
+      RUN(pfo_gemm_launch(g, s));
+    }
+    {
+      PfoGemm g = g_nt(lw.h1, D, nullptr, p.w2, D, lw.Hout, D, N, D, D, p.b2);
+      g.b_img = lw.iW2;
+      RUN(pfo_gemm_launch(g, s));
+    }
   }
   PFO_REQUIRE(hipMemcpyAsync(emb_out, w.layer[L].Hout, (size_t)b->R * D * sizeof(float), hipMemcpyDeviceToDevice, s) ==
                   hipSuccess,
@@ -484,11 +523,18 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     {
       PfoGemm q = g_nn(dOut, D, p.w2, D, w.dh1, D, N, D, D);
       q.relu_src = lw.h1; q.relu_ld = D;                     // ReLU backward
+      q.b_img = lw.iW2T;
       RUN(pfo_gemm_launch(q, s));
     }
     // merged fc1: d ctx' = dh1 W1ovT^T, dx = dh1 W1[:, E:]
-    RUN(pfo_gemm_launch(g_nt(w.dh1, D, nullptr, lw.W1ovT, D, w.dctx, HCp, N, HCp, D, nullptr), s));
-    RUN(pfo_gemm_launch(g_nn(w.dh1, D, p.w1 + E, E + D, dx, D, N, D, D), s));
+    {
+      PfoGemm q = g_nt(w.dh1, D, nullptr, lw.W1ovT, D, w.dctx, HCp, N, HCp, D, nullptr);
+      q.b_img = lw.iW1ovT;
+      RUN(pfo_gemm_launch(q, s));
+      q = g_nn(w.dh1, D, p.w1 + E, E + D, dx, D, N, D, D);
+      q.b_img = lw.iW1bT;
+      RUN(pfo_gemm_launch(q, s));
+    }
     set_tn(tn[1], lw.ctx, HCp, w.dh1, D, nullptr, HCp, D, lw.dW1ovT, D, nullptr);       // dW1ovT = ctx'^T dh1
     tn[1].c_accumulate = 0;
     set_tn(tn[2], w.dh1, D, xA, D, x_idx, D, D, g.w1 + E, E + D, g.b1);                // dW1[:, E:], db1
@@ -512,7 +558,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     // merged query/key projection: dx += dqk' Wqk, dWqk = dqk'^T x, gqk = colsum(dqk')
     {
       PfoGemm q = g_nn(w.dQK, HCp, lw.Wqk, D, dx, D, N, D, HCp);
-      q.accumulate = 1;
+      q.accumulate = 1; q.b_img = lw.iWqkT;
       RUN(pfo_gemm_launch(q, s));
     }
     set_tn(tn[3], w.dQK, HCp, xA, D, x_idx, HCp, D, lw.dWqk, D, lw.gqk);

@@ -203,6 +203,40 @@ def test_gemm_nt_and_nn(M, N, K):
     assert np.abs(got - np.maximum(ref - bias, 0)).max() < 2e-5 * np.abs(ref).max() + 1e-5
 
 
+def _gemm_bf16x3(A, B, bias, b_km, relu=0):
+    M, K = A.shape
+    N = B.shape[1] if b_km else B.shape[0]
+    C = torch.full((M, N), float("nan"), device=DEV)
+    nbytes = _lib.load().pfo_gemm_bf16x3_workspace_bytes(N, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    a, b = t(A), t(B)
+    bb = t(bias) if bias is not None else None
+    _lib.call("pfo_gemm_bf16x3", a.data_ptr(), K, b.data_ptr(), B.shape[1], int(b_km), C.data_ptr(), N, _lib.ptr(bb), M, N, K,
+              relu, ws.data_ptr(), nbytes, _lib.stream_ptr())
+    return C.cpu().numpy()
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 344, 172), (300, 348, 172), (257, 696, 172), (129, 172, 516), (64, 64, 32),
+                                   (1000, 516, 520), (130, 86, 348), (77, 348, 88), (4099, 177, 44), (5000, 172, 696)])
+def test_gemm_bf16x3_split_contraction_matches_float64(M, N, K):
+    """fp32 contraction on the bf16 matrix cores (3-way operand split, 6 piece products): fp32-level accuracy.
+    Operands with a wide dynamic range (exponents differ along k) so that dropped low pieces would show."""
+    rs = np.random.RandomState(M + N + K)
+    A = (rs.randn(M, K) * np.exp(2 * rs.randn(M, K))).astype(np.float32)
+    W = (rs.randn(N, K) * np.exp(2 * rs.randn(N, K))).astype(np.float32)
+    bias = rs.randn(N).astype(np.float32)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    mag = np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T + 1.0
+    got = _gemm_bf16x3(A, W, bias, 0)
+    assert (np.abs(got - (ref + bias)) / mag).max() < 4e-6            # an fp32 accumulation over K <= 696 gives ~2e-6
+    got = _gemm_bf16x3(A, np.ascontiguousarray(W.T), None, 1, relu=1)  # k-major weights: image built transposed
+    assert (np.abs(got - np.maximum(ref, 0)) / mag).max() < 4e-6
+    # and it is no worse than the exact-fp32 MFMA kernel on the same operands
+    f32 = _gemm(A, W, bias, 0, 0)
+    bx = _gemm_bf16x3(A, W, bias, 0)
+    assert (np.abs(bx - (ref + bias)) / mag).max() <= 2.0 * (np.abs(f32 - (ref + bias)) / mag).max() + 1e-7
+
+
 @pytest.mark.parametrize("M,N,K", [(172, 172, 3000), (344, 348, 5001), (516, 520, 900), (86, 348, 2049), (344, 172, 40)])
 def test_gemm_weight_gradient_form(M, N, K):
     """dW[M,N] = A[K,M]^T B[K,N] with split-K over workgroups and a deterministic slab reduce"""
