@@ -574,6 +574,178 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16x3 weight gradient tile: C[m][n] = sum_k A[k][m] B[k][n], both operands k-major (k = instance row), so the
+// MFMA fragments (8 consecutive k per lane) are TRANSPOSED reads of the staged tile: ds_read_b64_tr_b16 delivers a
+// 4(k) x 16(m) block column-major, two of them make one 16x16x32 operand.  LDS image per piece: [k 0..31][row of
+// 32-byte slots, one slot = 16 columns], A rows 256 B (8 slots), B rows 512 B (11 slots used); slot j of row k sits
+// at slot (j + pi(k)) mod {8,16}, pi(k) = (k & 3) + 4 * ((k >> 3) & 1): the 8 rows a 32-lane half reads in one
+// instruction ({0..3, 8..11} + 4h + 16 * half) land on 8 different 32-byte bank groups - conflict-free.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define TX_A_ROW 256
+#define TX_B_ROW 512
+#define TX_A_PIECE (BK * TX_A_ROW)
+#define TX_B_PIECE (BK * TX_B_ROW)
+#define TX_LDS_BYTES (3 * TX_A_PIECE + 3 * TX_B_PIECE)
+
+__device__ __forceinline__ int tx_pi(int k) { return (k & 3) + ((k >> 1) & 4); }
+
+// float4 = 4 consecutive columns (m or n) of k-row `k`: 8 bytes of bf16 per piece
+__device__ __forceinline__ void tx_split_store(char* base, int piece_bytes, int row_bytes, int slot_mask, int k, int col,
+                                               const float4 v) {
+  const int off = k * row_bytes + ((((col >> 4) + tx_pi(k)) & slot_mask) << 5) + ((col & 15) << 1);
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  uint32_t p1[4], p2[4], p3[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t b1 = __float_as_uint(x[e]) & 0xFFFF0000u;
+    const float r1 = x[e] - __uint_as_float(b1);
+    const uint32_t b2 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(b2);
+    p1[e] = b1; p2[e] = b2; p3[e] = __float_as_uint(r2);
+  }
+  *reinterpret_cast<uint2*>(base + off) = uint2{(p1[1] & 0xFFFF0000u) | (p1[0] >> 16), (p1[3] & 0xFFFF0000u) | (p1[2] >> 16)};
+  *reinterpret_cast<uint2*>(base + piece_bytes + off) =
+      uint2{(p2[1] & 0xFFFF0000u) | (p2[0] >> 16), (p2[3] & 0xFFFF0000u) | (p2[2] >> 16)};
+  *reinterpret_cast<uint2*>(base + 2 * piece_bytes + off) =
+      uint2{(p3[1] & 0xFFFF0000u) | (p3[0] >> 16), (p3[3] & 0xFFFF0000u) | (p3[2] >> 16)};
+}
+
+__device__ __forceinline__ bf16x8 tx_read(const char* piece, int row_bytes, int slot_mask, int slot, int g, int idx) {
+  // lane (g, idx): block rows 8g + 4h + (idx >> 2), 8 bytes at column quad idx & 3
+  typedef __attribute__((address_space(3))) bf16x4* lds_p;
+  const int k0 = 8 * g + (idx >> 2), k1 = k0 + 4;
+  const char* a0 = piece + k0 * row_bytes + (((slot + tx_pi(k0)) & slot_mask) << 5) + ((idx & 3) << 3);
+  const char* a1 = piece + k1 * row_bytes + (((slot + tx_pi(k1)) & slot_mask) << 5) + ((idx & 3) << 3);
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a1));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// one 128 x 176 tile of a split-K weight gradient into its slab (the grouped launch below); VEC operands only
+__device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by, int split, char* lds) {
+  char* const As = lds;
+  char* const Bs = lds + 3 * TX_A_PIECE;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int m0 = bx * BM, n0 = by * BN;
+  int Kext = p.K[0];
+  if (p.m_dev) Kext = min(Kext, *p.m_dev);
+  const int chunk = p.dyn_chunk ? ((Kext + p.nsplit - 1) / p.nsplit + BK - 1) / BK * BK : p.split_chunk;
+  const int kbeg = split * chunk;
+  const int Ks = min(Kext, kbeg + chunk);
+  const int wrow = 32 * wave;
+
+  f32x4 acc[2][11];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 11; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int T = Ks > kbeg ? (Ks - kbeg + BK - 1) / BK : 0;
+  float4 a_reg[4], b_reg[6];
+  const float* safe = p.A[0];
+  const float* Ab = p.A[0];
+  const float* Bb = p.B[0];
+  const int64_t lda = p.lda[0], ldb = p.ldb[0];
+
+  auto load_tile = [&](int t) {
+    const int k0 = kbeg + t * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i;
+      const int k = k0 + (f >> 5);
+      const int m = m0 + 4 * (f & 31);
+      a_reg[i] = ld4<true>(Ab + (int64_t)k * lda + m, k < Ks ? p.M - m : 0, safe);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int f = tid + 256 * i;
+      const int kr = f / 44;
+      const int k = k0 + kr;
+      const int n = n0 + 4 * (f - kr * 44);
+      const bool ok = (f < BK * 44) && k < Ks && n < p.N;
+      int64_t krow = ok ? k : 0;
+      if (ok && p.b_idx) krow = p.b_idx[k];
+      b_reg[i] = ld4<true>(Bb + krow * ldb + n, ok ? p.n_real - n : 0, safe);
+      if (ok && p.n_real < p.N) {
+        const int e = p.n_real - n;                          // bias column (see gemm_tile)
+        if (e >= 0 && e < 4) {
+          const float one = p.ones_scale ? p.ones_scale[(int64_t)k * p.os_ld] : 1.f;
+          if (e == 0) b_reg[i].x = one; else if (e == 1) b_reg[i].y = one; else if (e == 2) b_reg[i].z = one; else b_reg[i].w = one;
+        }
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i;
+      tx_split_store(As, TX_A_PIECE, TX_A_ROW, 7, f >> 5, 4 * (f & 31), a_reg[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int f = tid + 256 * i;
+      if (f < BK * 44) {
+        const int kr = f / 44;
+        tx_split_store(Bs, TX_B_PIECE, TX_B_ROW, 15, kr, 4 * (f - kr * 44), b_reg[i]);
+      }
+    }
+  };
+  const bool strip_on[2] = {m0 + wrow < p.M, m0 + wrow + 16 < p.M};
+  auto compute_tile = [&]() {
+    bf16x8 a[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a[i][q] = tx_read(As + q * TX_A_PIECE, TX_A_ROW, 7, 2 * wave + i, g, r);
+#pragma unroll
+    for (int j = 0; j < 11; ++j) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) b[q] = tx_read(Bs + q * TX_B_PIECE, TX_B_ROW, 15, j, g, r);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (!strip_on[i]) continue;
+        f32x4 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+    }
+  };
+  if (T > 0) {
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      const bool more = t + 1 < T;
+      if (more) load_tile(t + 1);
+      compute_tile();
+      __syncthreads();
+      if (more) store_tile();
+      __syncthreads();
+    }
+  }
+  float* Cb = p.slab_base + (int64_t)split * (int64_t)p.M * p.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = m0 + wrow + 16 * i + 4 * g + reg;
+      if (row >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 11; ++j) {
+        const int col = n0 + 16 * j + r;
+        if (col < p.N) Cb[(int64_t)row * p.N + col] = acc[i][j][reg];
+      }
+    }
+}
+
 // Pre-split image of a weight operand for gemm_bf16x3_kernel<true>: [k-tile][piece][row n, padded to BN][64 B],
 // the exact LDS image of the kernel (same swizzle), zero-padded in n and k.  W(n, k) = src[n*ld + k] or, with
 // `trans`, src[k*ld + n] - so a k-major ("NN") operand becomes a row-major one for free.
@@ -714,6 +886,25 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_group_kernel(const TnGro
   gemm_tile<true, true, 0, VEC>(d, t / pr.tn, t % pr.tn, 0, blockIdx.y, lds_a, lds_b);
 }
 
+// the same grouped launch on the bf16 matrix cores (3-way split, transposed LDS reads)
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_group_bx_kernel(const TnGroupDev g) {
+  __shared__ __attribute__((aligned(16))) char lds[TX_LDS_BYTES];
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < TN_MAX_PROBLEMS; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.p[i].tile_begin) q = i;
+  const TnProbDev& pr = g.p[q];
+  const int t = blockIdx.x - pr.tile_begin;
+  GemmDev d;
+  d.A[0] = pr.A; d.lda[0] = pr.lda; d.B[0] = pr.B; d.ldb[0] = pr.ldb; d.b_idx = pr.b_idx;
+  d.K[0] = g.K; d.M = pr.M; d.N = pr.N; d.m_dev = g.k_dev;
+  d.split_chunk = g.chunk;
+  d.n_real = pr.N_real; d.ones_scale = pr.ones_scale; d.os_ld = pr.os_ld;
+  d.slab_base = g.slabs + pr.slab_off;
+  d.nsplit = g.nsplit;
+  d.dyn_chunk = (g.k_dev != nullptr && g.nsplit > 1) ? 1 : 0;
+  gemm_tile_tn_bx(d, t / pr.tn, t % pr.tn, blockIdx.y, lds);
+}
 __global__ __launch_bounds__(256) void tn_group_reduce_kernel(const TnGroupDev g) {
   int K = g.K;
   if (g.k_dev) K = min(K, *g.k_dev);
@@ -772,7 +963,9 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
   double flops = 0;
   for (int i = 0; i < n; ++i) flops += 2.0 * probs[i].M * probs[i].N * (double)K;
   pfo_prof_begin(stream);
-  if (vec) hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
+  static const int bx = getenv("PFO_GEMM_BF16X3") ? atoi(getenv("PFO_GEMM_BF16X3")) : PFO_DEFAULT_BF16X3;
+  if (vec && bx >= 1) hipLaunchKernelGGL(gemm_tn_group_bx_kernel, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
+  else if (vec) hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   else hipLaunchKernelGGL(gemm_tn_group_kernel<false>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   PFO_LAUNCH_CHECK();
   hipLaunchKernelGGL(tn_group_reduce_kernel, dim3((unsigned)std::min<int64_t>(1024, pfo_ceil_div(per_split, 256))), dim3(256), 0,
