@@ -38,56 +38,42 @@ static inline int64_t pfo_align_up(int64_t a, int64_t b) { return pfo_ceil_div(a
 // ---------------------------------------------------------------------------------------------
 // sin/cos of an fp32 argument of any magnitude (time-encoder arguments reach 1.7e7 on the synthetic
 // graphs and beyond on epoch-second data).  The cosine is a pure function of the exactly rounded
-// fp32 argument (SURVEY §7 hard part 1), so the range reduction must be accurate, not "fast-math":
-//   |x| < 2e7 : fp32 only.  k = rint(x * 2/pi) from a two-term product (k < 2^24 stays an exact integer),
-//               r = x - k*pi/2 by three FMAs against a three-term pi/2 (each FMA rounds an O(1) value once);
-//               |error(r)| ~ 1.2e-7, validated against fp64 over +-2e7 (max |cos err| 1.03e-7).
-//   otherwise : the same reduction in fp64 (two-term pi/2), a few times slower, never taken on the benchmark.
-// Then fp32 minimax polynomials on [-pi/4, pi/4] (~1 ulp).
+// fp32 argument (SURVEY §7 hard part 1), so the range reduction must be accurate, not "fast-math".
+// The reduction works in REVOLUTIONS, the unit of the hardware v_sin_f32 / v_cos_f32:
+//   |x| < 2e7 : fp32 only.  p = fl(x * C_HI) with C_HI + C_LO = 1/(2 pi) to 48 bits; the rounding error of p is
+//               recovered exactly by one FMA, p - rint(p) is exact (p < 2^22), so
+//               u = (p - rint(p)) + (x * C_LO + err) is x/(2 pi) mod 1 in [-0.5, 0.5] to ~1e-8 revolutions.
+//   otherwise : the same reduction in fp64, a few times slower, never taken on the benchmark.
+// v_sin_f32 / v_cos_f32 on [-0.5, 0.5] revolutions: max |error| 1.25e-7 (tools/probes/hwcos.hip), the same as
+// the minimax polynomials they replace at a third of the instructions (the attention kernels evaluate 172 of
+// these per neighbour: it was their largest VALU item).
 // slow path kept out of line so that it stays a real (almost never taken) branch instead of being if-converted
-__device__ __attribute__((noinline)) float pfo_reduce_f64(float x, int* quadrant) {
+__device__ __attribute__((noinline)) float pfo_revolutions_f64(float x) {
   const double xd = (double)x;
-  const double kd = rint(xd * 0.63661977236758134308);
-  double r = fma(-kd, 1.57079632679489655800e+00, xd);
-  r = fma(-kd, 6.12323399573676603587e-17, r);
-  *quadrant = (int)((long long)kd & 3);
-  return (float)r;
+  const double kd = rint(xd * 0.15915494309189533577);
+  double r = fma(-kd, 6.283185307179586232, xd);            // x - k * 2 pi against a two-term 2 pi (k < 2^53 / 2^53: exact products)
+  r = fma(-kd, 2.4492935982947064e-16, r);
+  return (float)(r * 0.15915494309189533577);
+}
+
+__device__ __forceinline__ float pfo_revolutions(float x) {
+#pragma clang fp contract(off)   // p below is reused as a ROUNDED product: no implicit FMA formation in this function
+  if (fabsf(x) < 2.0e7f) {
+    const float C_HI = 0.15915493667125702f, C_LO = 6.4206382432985265e-09f;
+    const float p = x * C_HI;
+    const float e = __builtin_fmaf(x, C_HI, -p);               // exact rounding error of p
+    return (p - rintf(p)) + __builtin_fmaf(x, C_LO, e);
+  }
+  return pfo_revolutions_f64(x);
 }
 
 __device__ __forceinline__ void pfo_sincosf(float x, float& s, float& c) {
-#pragma clang fp contract(off)   // p below is reused as a ROUNDED product: no implicit FMA formation in this function
-  float rf;
-  int q;
-  if (fabsf(x) < 2.0e7f) {
-    const float C_HI = 0.636619746685028076171875f, C_LO = 2.5682553e-08f;
-    const float P1 = 1.57079637050628662109375f, P2 = -4.37113883e-08f, P3 = -1.71512451e-15f;
-    const float p = x * C_HI;
-    const float e = __builtin_fmaf(x, C_HI, -p);               // exact rounding error of p
-    float kf = rintf(p);
-    const float f = (p - kf) + __builtin_fmaf(x, C_LO, e);     // what p missed, |f| < 1.6
-    kf = kf + rintf(f);
-    float r = __builtin_fmaf(-kf, P1, x);
-    r = __builtin_fmaf(-kf, P2, r);
-    rf = __builtin_fmaf(-kf, P3, r);
-    q = ((int)kf) & 3;
-  } else {
-    rf = pfo_reduce_f64(x, &q);
-  }
-  const float r2 = rf * rf;
-  const float sp = fmaf(rf * r2, fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), rf);
-  const float cp = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
-                        fmaf(r2, -0.5f, 1.0f));
-  const float ss = (q & 1) ? cp : sp;
-  const float cc = (q & 1) ? sp : cp;
-  s = (q & 2) ? -ss : ss;
-  c = ((q + 1) & 2) ? -cc : cc;
+  const float u = pfo_revolutions(x);
+  s = __builtin_amdgcn_sinf(u);
+  c = __builtin_amdgcn_cosf(u);
 }
 
-__device__ __forceinline__ float pfo_cosf(float x) {
-  float s, c;
-  pfo_sincosf(x, s, c);
-  return c;
-}
+__device__ __forceinline__ float pfo_cosf(float x) { return __builtin_amdgcn_cosf(pfo_revolutions(x)); }
 
 // TimeEncode element: one fp32 FMA, then cosine (model/time_encoding.py:23; SURVEY §7 hard part 1)
 __device__ __forceinline__ float pfo_time_arg(float t, float w, float b) { return __builtin_fmaf(t, w, b); }

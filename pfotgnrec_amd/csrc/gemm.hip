@@ -51,6 +51,9 @@ static bool aligned4(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 #ifndef PFO_DEFAULT_BF16X3
 #define PFO_DEFAULT_BF16X3 1
 #endif
+#ifndef BX_EXP
+#define BX_EXP 0      // timing-only ablations of the bf16x3 kernel (wrong results): 1 = first tile only, 2 = no MFMA, 3 = no LDS refill
+#endif
 #ifndef PFO_BX_MIN_TILES
 #define PFO_BX_MIN_TILES 400
 #endif
@@ -512,11 +515,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(As + q * BX_A_PIECE + (wrow + 16 * i) * 64 + frag_off);
-#pragma unroll
-    for (int j = 0; j < 11; ++j) {
-      bf16x8 b[3];
+    // B fragments are double-buffered in registers: the LDS reads of column tile j+1 are in flight during the 12
+    // MFMAs of tile j (with one register set the reads could only issue after those MFMAs, latency fully exposed)
+    auto ldb = [&](bf16x8 (&b)[3], int j) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) b[q] = *reinterpret_cast<const bf16x8*>(Bs + q * BX_B_PIECE + (16 * j) * 64 + frag_off);
+    };
+    auto mma = [&](const bf16x8 (&b)[3], int j) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (!strip_on[i]) continue;
@@ -529,6 +534,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[0], c, 0, 0, 0);
         acc[i][j] = c;
       }
+    };
+    bf16x8 b0[3], b1[3];
+    ldb(b0, 0);
+#pragma unroll
+    for (int j = 0; j < 11; j += 2) {
+      if (j + 1 < 11) ldb(b1, j + 1);
+      mma(b0, j);
+      if (j + 2 < 11) ldb(b0, j + 2);
+      if (j + 1 < 11) mma(b1, j + 1);
     }
   };
 
@@ -537,11 +551,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
     store_tile();
     __syncthreads();
     for (int t = 0; t < T; ++t) {
-      const bool more = t + 1 < T;
+      const bool more = (BX_EXP == 1) ? false : (t + 1 < T);
       if (more) load_tile(t + 1);
-      compute_tile();
+      if (BX_EXP != 2) compute_tile();
       __syncthreads();
-      if (more) store_tile();
+      if (more && BX_EXP != 3) store_tile();
       __syncthreads();
     }
   }
@@ -699,11 +713,11 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int q = 0; q < 3; ++q) a[i][q] = tx_read(As + q * TX_A_PIECE, TX_A_ROW, 7, 2 * wave + i, g, r);
-#pragma unroll
-    for (int j = 0; j < 11; ++j) {
-      bf16x8 b[3];
+    auto ldb = [&](bf16x8 (&b)[3], int j) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) b[q] = tx_read(Bs + q * TX_B_PIECE, TX_B_ROW, 15, j, g, r);
+    };
+    auto mma = [&](const bf16x8 (&b)[3], int j) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (!strip_on[i]) continue;
@@ -716,6 +730,15 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[0], c, 0, 0, 0);
         acc[i][j] = c;
       }
+    };
+    bf16x8 b0[3], b1[3];                      // double-buffered B fragments (see gemm_bf16x3_kernel)
+    ldb(b0, 0);
+#pragma unroll
+    for (int j = 0; j < 11; j += 2) {
+      if (j + 1 < 11) ldb(b1, j + 1);
+      mma(b0, j);
+      if (j + 2 < 11) ldb(b0, j + 2);
+      if (j + 1 < 11) mma(b1, j + 1);
     }
   };
   if (T > 0) {
