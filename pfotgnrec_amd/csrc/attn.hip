@@ -17,6 +17,7 @@ struct AttnDev {
   float scale, dropout_p; uint64_t seed, offset;
   float* ctx; float* attw; uint8_t* inv;
   const float* dctx; float* dQK; float* d_nbr; int64_t d_nbr_ld; double* dtime_part;
+  int abl;      // timing-only ablation switch (PFO_ATTN_ABL): 1 = spread the atomic destinations (wrong results)
 };
 
 // dropout keep-bits for slot `lane` of instance n: bit h = keep for head h (H <= 4)
@@ -31,8 +32,12 @@ __device__ __forceinline__ unsigned attn_keep_bits(uint64_t seed, uint64_t offse
 // chunk instead of one per key), the chunk's KC*H dot-product butterflies are interleaved (6 dependent shuffle
 // stages per chunk instead of per key), then the online-softmax state is advanced key by key.  Per-slot metadata
 // (row, edge id, dt, validity) is loaded once, one slot per lane, and broadcast with v_readlane.
-#define KC_FWD 5
-#define KC_BWD 4
+#ifndef KC_FWD
+#define KC_FWD 4
+#endif
+#ifndef KC_BWD
+#define KC_BWD 2
+#endif
 
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
@@ -130,11 +135,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
       }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
+    for (int c = 0; c < KC_FWD; ++c)
 #pragma unroll
-      for (int c = 0; c < KC_FWD; ++c)
-#pragma unroll
-        for (int h = 0; h < H; ++h) part[c][h] += __shfl_xor(part[c][h], o, 64);
+      for (int h = 0; h < H; ++h) part[c][h] = pfo_wave_sum_scalar(part[c][h]);
 #pragma unroll
     for (int c = 0; c < KC_FWD; ++c) {
       if (js[c] < 0) continue;
@@ -305,11 +308,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
         }
       }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1)
+      for (int c = 0; c < KC_BWD; ++c)
 #pragma unroll
-        for (int c = 0; c < KC_BWD; ++c)
-#pragma unroll
-          for (int h = 0; h < H; ++h) part[c][h] += __shfl_xor(part[c][h], o, 64);
+        for (int h = 0; h < H; ++h) part[c][h] = pfo_wave_sum_scalar(part[c][h]);
 #pragma unroll
       for (int c = 0; c < KC_BWD; ++c) {
         if (js[c] < 0) continue;
@@ -331,6 +332,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
           dqe[h] = fmaf(cB[h], ke[c], dqe[h]);
         }
         float* dst = a.d_nbr ? a.d_nbr + (int64_t)rows[c] * a.d_nbr_ld : nullptr;
+        if (a.abl == 1 && dst) dst = a.d_nbr + (int64_t)((((unsigned)rows[c] * 2654435761u) + (unsigned)n * 40503u) % 8192u) * a.d_nbr_ld;
+        if (a.abl == 2) dst = nullptr;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           const int cc = lane + 64 * r;
@@ -384,6 +387,8 @@ static void to_dev(const PfoAttn& a, AttnDev& d) {
   d.QK = a.QK; d.nbr_tab = a.nbr_tab; d.nbr_ld = a.nbr_ld; d.nbr_row = a.nbr_row; d.nbr_row_base = a.nbr_row_base;
   d.nbr_ids = a.nbr_ids; d.edge_feat = a.edge_feat; d.eidx = a.eidx; d.dt = a.dt; d.tw = a.tw; d.tb = a.tb;
   d.scale = a.scale; d.dropout_p = a.dropout_p; d.seed = a.seed; d.offset = a.offset;
+  static const int abl = getenv("PFO_ATTN_ABL") ? atoi(getenv("PFO_ATTN_ABL")) : 0;
+  d.abl = abl;
   d.ctx = a.ctx; d.attw = a.attw; d.inv = a.inv;
   d.dctx = a.dctx; d.dQK = a.dQK; d.d_nbr = a.d_nbr; d.d_nbr_ld = a.d_nbr_ld;
   d.dtime_part = a.dtime_part;

@@ -101,6 +101,21 @@ __device__ __forceinline__ uint32_t pfo_u4_get(const pfo_u4& v, int i) {
   return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
+// Wave-wide sum delivered as a wave-uniform scalar: 6 DPP adds (quad xor 1/2, row_ror 4/8, row_bcast 15/31) and
+// one v_readlane instead of 6 ds_bpermute round trips through the LDS crossbar.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float pfo_dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float pfo_wave_sum_scalar(float v) {
+  v = pfo_dpp_add<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+  v = pfo_dpp_add<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+  v = pfo_dpp_add<0x124, 0xF>(v);    // row_ror:4
+  v = pfo_dpp_add<0x128, 0xF>(v);    // row_ror:8   -> every lane holds its 16-lane row sum
+  v = pfo_dpp_add<0x142, 0xA>(v);    // row_bcast:15 into rows 1 and 3
+  v = pfo_dpp_add<0x143, 0xC>(v);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float pfo_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -41,4 +41,7 @@ int pfo_scatter_add_rows_launch(const float* src, int64_t ld_src, const int32_t*
 //   gq[E] = colsum(dQ);  d bq += gq;  d Wq[:, D:] += gq (x) cosb;  d tb += -sin(tb) * (Wq[:, D:]^T gq)
 int pfo_cq_backward_launch(const float* gq, const float* Wq, const float* tb, int D, float* d_bq, float* d_Wq,
                            float* d_tb, hipStream_t stream);
-int pfo_fold_parts_launch(const double* parts, int n_parts, int n, float* out, int accumulate, hipStream_t stream);
+// scratch: pfo_fold_parts_scratch_doubles(n) doubles; tickets: 64 ints, zero before the first use (self-resetting)
+int64_t pfo_fold_parts_scratch_doubles(int n);
+int pfo_fold_parts_launch(const double* parts, int n_parts, int n, float* out, int accumulate, double* scratch, int* tickets,
+                          hipStream_t stream);

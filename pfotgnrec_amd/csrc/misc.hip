@@ -291,27 +291,42 @@ int pfo_cq_backward_launch(const float* gq, const float* Wq, const float* tb, in
   return PFO_OK;
 }
 
-// out[c] (+)= sum_p parts[p][c]: workgroup = 16 columns x 16 part lanes, fp64, fixed order (deterministic)
+// out[c] (+)= sum_p parts[p][c] in fp64, fixed summation order (deterministic).  Two levels in ONE launch: workgroup
+// (x, y) folds the parts p = 4y + lane-group (mod 4 * FOLD_SLICES) of 64 columns into slice y of `scratch`, takes a
+// ticket, and the last workgroup of a column block folds the FOLD_SLICES slices in slice order and resets the ticket.
+#define FOLD_SLICES 32
 __global__ __launch_bounds__(256) void fold_parts_kernel(const double* __restrict__ parts, int n_parts, int n,
-                                                         float* __restrict__ out, int accumulate) {
-  __shared__ double s_red[16][16];
-  const int c = threadIdx.x & 15, pl = threadIdx.x >> 4;
-  const int col = blockIdx.x * 16 + c;
+                                                         float* __restrict__ out, int accumulate, double* scratch,
+                                                         int* tickets) {
+  __shared__ double s_red[4][64];
+  __shared__ int s_last;
+  const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
   double s = 0.0;
   if (col < n)
-    for (int p = pl; p < n_parts; p += 16) s += parts[(int64_t)p * n + col];
+    for (int p = blockIdx.y * 4 + pl; p < n_parts; p += 4 * FOLD_SLICES) s += parts[(int64_t)p * n + col];
   s_red[pl][c] = s;
   __syncthreads();
+  if (pl == 0 && col < n) scratch[(int64_t)blockIdx.y * n + col] = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(&tickets[blockIdx.x], 1) == FOLD_SLICES - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
   if (pl == 0 && col < n) {
     double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += s_red[k][c];
+    for (int y = 0; y < FOLD_SLICES; ++y) t += scratch[(int64_t)y * n + col];
     out[col] = accumulate ? (float)((double)out[col] + t) : (float)t;
   }
+  if (threadIdx.x == 0) tickets[blockIdx.x] = 0;
 }
-int pfo_fold_parts_launch(const double* parts, int n_parts, int n, float* out, int accumulate, hipStream_t stream) {
-  hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)pfo_ceil_div(n, 16)), dim3(256), 0, stream, parts, n_parts, n, out,
-                     accumulate);
+int64_t pfo_fold_parts_scratch_doubles(int n) { return (int64_t)FOLD_SLICES * n; }
+int pfo_fold_parts_launch(const double* parts, int n_parts, int n, float* out, int accumulate, double* scratch, int* tickets,
+                          hipStream_t stream) {
+  PFO_REQUIRE(n <= 64 * 64, "too many columns for the ticket array");
+  hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)pfo_ceil_div(n, 64), FOLD_SLICES), dim3(256), 0, stream, parts, n_parts,
+                     n, out, accumulate, scratch, tickets);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

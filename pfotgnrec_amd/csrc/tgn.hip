@@ -43,7 +43,8 @@ struct Ws {
   float *dh1, *dctx, *dQK, *dx1;
   float* dH[PFO_MAX_LAYERS + 1];
   float *slabs, *colsum;
-  double* dtime;
+  double *dtime, *fold_scratch;
+  int32_t* tickets;
   int64_t slab_floats;
   int64_t bytes;
 };
@@ -89,6 +90,7 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     }
   }
   w.zero = take<float>(p, 64);
+  w.tickets = take<int32_t>(p, 64);         // directly behind w.zero: one memset clears both
   w.cosb = take<float>(p, d.D);
   if (c->use_memory) {
     w.slot = take<int32_t>(p, c->n_nodes);
@@ -145,6 +147,7 @@ Ws carve(const pfo_tgn_config* c, void* base) {
   w.slabs = take<float>(p, w.slab_floats);
   w.colsum = take<float>(p, pfo_colsum_scratch_floats(3 * d.D + 2 * d.E + d.M));
   w.dtime = take<double>(p, (int64_t)pfo_attn_bwd_max_parts() * 2 * d.D);
+  w.fold_scratch = take<double>(p, pfo_fold_parts_scratch_doubles(2 * d.D));
   w.bytes = p - reinterpret_cast<char*>(base);
   return w;
 }
@@ -325,7 +328,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   PFO_REQUIRE(sd.ok, "could not create the side stream");
   hipStream_t ss = sd.s;
   const int Cp = d.Cp, HCp = H * d.Cp;
-  PFO_REQUIRE(hipMemsetAsync(w.zero, 0, 64 * sizeof(float), s) == hipSuccess, "memset failed");
+  PFO_REQUIRE(hipMemsetAsync(w.zero, 0, 512, s) == hipSuccess, "memset failed");      // w.zero and w.tickets
   RUN(pfo_time_encode(w.zero, 1, P.tw, P.tb, D, w.cosb, stream));              // cos(fma(0, w, b)) (embedding_module.py:92)
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
@@ -554,7 +557,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     a.dtime_part = w.dtime;
     int n_parts = 0;
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
-    RUN(pfo_fold_parts_launch(w.dtime, n_parts, 2 * D, G.tw, 1, s));      // time_w and time_b are adjacent in the layout
+    RUN(pfo_fold_parts_launch(w.dtime, n_parts, 2 * D, G.tw, 1, w.fold_scratch, w.tickets, s));      // time_w and time_b are adjacent in the layout
     // merged query/key projection: dx += dqk' Wqk, dWqk = dqk'^T x, gqk = colsum(dqk')
     {
       PfoGemm q = g_nn(w.dQK, HCp, lw.Wqk, D, dx, D, N, D, HCp);
