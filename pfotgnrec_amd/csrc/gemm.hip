@@ -526,12 +526,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
       for (int i = 0; i < 2; ++i) {
         if (!strip_on[i]) continue;
         f32x4 c = acc[i][j];
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[0], c, 0, 0, 0);   // smallest terms first
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[0], c, 0, 0, 0);
+        // operands swapped (weights as the MFMA "A" side): the accumulator holds the TRANSPOSED tile, lane (r, g)
+        // owns row r and the four consecutive columns 4g..4g+3 - 16-byte epilogue accesses.  Smallest terms first.
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[2], a[i][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[i][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[i][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][0], c, 0, 0, 0);
         acc[i][j] = c;
       }
     };
@@ -564,25 +566,46 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
   const int64_t ldc = p.ldc;
   const float* bias = p.bias ? p.bias + zb * p.bias_bs : nullptr;
   const float* rs = p.row_scale ? p.row_scale + zb * p.rs_bs : nullptr;
+  const bool n4 = (p.N & 3) == 0 && (ldc & 3) == 0 && (((uintptr_t)Cb) & 15) == 0 &&
+                  (!p.relu_src || ((p.relu_ld & 3) == 0 && (((uintptr_t)p.relu_src) & 15) == 0)) &&
+                  (!bias || (((uintptr_t)bias) & 15) == 0);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    const int row = m0 + wrow + 16 * i + r;
+    if (row >= Mlim) continue;
+    const float rscale = rs ? rs[(int64_t)row * p.rs_ld] : 1.f;
+    const bool zero = p.row_zero ? (p.row_zero[row] != 0) : false;
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int row = m0 + wrow + 16 * i + 4 * g + reg;
-      if (row >= Mlim) continue;
-      const float rscale = rs ? rs[(int64_t)row * p.rs_ld] : 1.f;
-      const bool zero = p.row_zero ? (p.row_zero[row] != 0) : false;
+    for (int j = 0; j < 11; ++j) {
+      const int col = n0 + 16 * j + 4 * g;
+      if (col >= p.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      float* cp = Cb + (int64_t)row * ldc + col;
+      if (n4) {
+        if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(cp); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+        if (bias) {
+          const float4 bv = *reinterpret_cast<const float4*>(bias + col);
+          v[0] = fmaf(bv.x, rscale, v[0]); v[1] = fmaf(bv.y, rscale, v[1]); v[2] = fmaf(bv.z, rscale, v[2]); v[3] = fmaf(bv.w, rscale, v[3]);
+        }
+        if (zero) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+        if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (p.relu_src) {
+          const float4 m = *reinterpret_cast<const float4*>(p.relu_src + (int64_t)row * p.relu_ld + col);
+          v[0] = m.x > 0.f ? v[0] : 0.f; v[1] = m.y > 0.f ? v[1] : 0.f; v[2] = m.z > 0.f ? v[2] : 0.f; v[3] = m.w > 0.f ? v[3] : 0.f;
+        }
+        *reinterpret_cast<float4*>(cp) = float4{v[0], v[1], v[2], v[3]};
+      } else {
 #pragma unroll
-      for (int j = 0; j < 11; ++j) {
-        const int col = n0 + 16 * j + r;
-        if (col >= p.N) continue;
-        float v = acc[i][j][reg];
-        if (p.accumulate) v += Cb[(int64_t)row * ldc + col];
-        if (bias) v = fmaf(bias[col], rscale, v);
-        if (zero) v = 0.f;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.relu_src) v = (p.relu_src[(int64_t)row * p.relu_ld + col] > 0.f) ? v : 0.f;
-        Cb[(int64_t)row * ldc + col] = v;
+        for (int e = 0; e < 4; ++e) {
+          if (col + e >= p.N) continue;
+          float x = v[e];
+          if (p.accumulate) x += cp[e];
+          if (bias) x = fmaf(bias[col + e], rscale, x);
+          if (zero) x = 0.f;
+          if (p.relu) x = fmaxf(x, 0.f);
+          if (p.relu_src) x = (p.relu_src[(int64_t)row * p.relu_ld + col + e] > 0.f) ? x : 0.f;
+          cp[e] = x;
+        }
       }
     }
   }
