@@ -29,6 +29,7 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32)
+MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the sparsity figure is never used)
 
 
 def parse():
@@ -44,10 +45,14 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=512, help="interactions per oracle step in the CPU baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=1, help="timed oracle steps (one more runs first, untimed)")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event bracketing of kernel launches")
+    ap.add_argument("--prof-every", type=int, default=4,
+                    help="bracket the kernel launches of every Nth timed step with HIP events (the brackets cost ~0.2 ms "
+                         "per step at C2, so the roofline sample is taken on a subset of the timed steps)")
     return ap.parse_args()
 
 
-PMC_KERNEL = {"gemm_nt": "void gemm_f32_kernel<false, false, 0, true>",
+PMC_KERNEL = {"gemm_bx": "void gemm_bf16x3_kernel<true>", "gemm_tn_bx": "gemm_tn_group_bx_kernel",
+              "gemm_nt": "void gemm_f32_kernel<false, false, 0, true>",
               "gemm_nn": "void gemm_f32_kernel<false, true, 0, true>",
               "gemm_tn": "void gemm_tn_group_kernel<true>",
               "attn_fwd": "void attn_fwd_kernel<3, 2>", "attn_bwd": "void attn_bwd_kernel<3, 2>"}
@@ -200,11 +205,16 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    if not args.no_prof:
-        _lib.prof_enable(True)
+    n_prof_steps = 0
     t0 = time.perf_counter()
     for i in range(args.warmup, n_steps_total):
+        sampled = (not args.no_prof) and ((i - args.warmup) % max(1, args.prof_every) == 0)
+        if sampled:
+            _lib.prof_enable(True)
+            n_prof_steps += 1
         loss = step(i)
+        if sampled:
+            _lib.prof_enable(False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -233,15 +243,18 @@ def main():
                    "global_batch": B, "parallelism": "dp%d" % world, "dropout": args.dropout, "final_loss": round(final_loss, 5)},
     }
     if prof is not None:
-        # dominant kernel family by device time; GEMM kinds are priced against the fp32 MFMA peak, the rest against HBM
+        # dominant kernel family by device time over the sampled steps.  Contractions on the bf16x3 kernels are priced
+        # against the dense bf16 MFMA peak divided by the six piece products one fp32 product costs; the fp32-MFMA
+        # kernels against the fp32 MFMA peak; the attention / sampling kernels against HBM.
         fam = {k: v for k, v in prof.items() if v["count"] > 0 and v["work"] > 0}
         dom = max(fam, key=lambda k: fam[k]["ms"])
         v = fam[dom]
         per_launch_s = v["ms"] / v["count"] * 1e-3
         if dom.startswith("gemm"):
+            peak = MFMA_BF16_PEAK_TF / 6.0 if dom in ("gemm_bx", "gemm_tn_bx") else MFMA_F32_PEAK_TF
             achieved = v["work"] / v["count"] / per_launch_s / 1e12
-            roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": round(achieved / MFMA_F32_PEAK_TF, 4), "traffic": None}
+            roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": None}
         else:
             achieved = v["work"] / v["count"] / per_launch_s / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -250,9 +263,10 @@ def main():
         roof["kernel"] = dom
         roof["avg_launch_us"] = round(per_launch_s * 1e6, 2)
         roof["launches"] = int(v["count"])
-        roof["families_ms_per_step"] = {k: round(x["ms"] / args.steps, 4) for k, x in prof.items() if x["count"] > 0}
+        roof["sampled_steps"] = n_prof_steps
+        roof["families_ms_per_step"] = {k: round(x["ms"] / max(1, n_prof_steps), 4) for k, x in prof.items() if x["count"] > 0}
         tot = lambda ks: sum(prof[k]["work"] for k in ks) / max(1e-9, sum(prof[k]["ms"] for k in ks) * 1e-3)
-        roof["gemm_all_tflops"] = round(tot(["gemm_nt", "gemm_nn", "gemm_tn"]) / 1e12, 2)
+        roof["gemm_all_tflops"] = round(tot(["gemm_nt", "gemm_nn", "gemm_tn", "gemm_bx", "gemm_tn_bx"]) / 1e12, 2)
         roof["attn_all_gbs"] = round(tot(["attn_fwd", "attn_bwd"]) / 1e9, 1)
         out["roofline"] = roof
     if not args.no_cpu_baseline and world == 1:

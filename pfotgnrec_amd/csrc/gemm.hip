@@ -840,7 +840,7 @@ __global__ __launch_bounds__(256) void bimg_kernel(const BimgDev g) {
 // Several SMALL independent contractions in one launch (the composite-weight products of a layer and their
 // gradient chain: each is far too small to fill the chip or to amortise a launch).  32-row tiles; the operand
 // layout is a per-problem switch (wavefront-uniform).
-#define MULTI_MAX 10
+#define MULTI_MAX PFO_GEMM_MULTI_MAX
 struct MultiDev {
   GemmDev p[MULTI_MAX];
   int layout[MULTI_MAX];      // a_kmajor * 2 + b_kmajor
@@ -1008,16 +1008,18 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
   g.n = n; g.K = K; g.nsplit = nsplit; g.chunk = chunk; g.total_tiles = tiles; g.k_dev = k_dev; g.slabs = slabs;
   double flops = 0;
   for (int i = 0; i < n; ++i) flops += 2.0 * probs[i].M * probs[i].N * (double)K;
-  pfo_prof_begin(stream);
   static const int bx = getenv("PFO_GEMM_BF16X3") ? atoi(getenv("PFO_GEMM_BF16X3")) : PFO_DEFAULT_BF16X3;
-  if (vec && bx >= 1) hipLaunchKernelGGL(gemm_tn_group_bx_kernel, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
+  const bool use_bx = vec && bx >= 1;
+  pfo_prof_begin(stream);
+  if (use_bx) hipLaunchKernelGGL(gemm_tn_group_bx_kernel, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   else if (vec) hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   else hipLaunchKernelGGL(gemm_tn_group_kernel<false>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   PFO_LAUNCH_CHECK();
+  if (use_bx) pfo_prof_end(PFO_PROF_GEMM_TN_BX, flops, stream);        // the GEMM kernel alone
   hipLaunchKernelGGL(tn_group_reduce_kernel, dim3((unsigned)std::min<int64_t>(1024, pfo_ceil_div(per_split, 256))), dim3(256), 0,
                      stream, g);
   PFO_LAUNCH_CHECK();
-  pfo_prof_end(k_dev ? PFO_PROF_GEMM_DEVM : PFO_PROF_GEMM_TN, flops, stream);
+  if (!use_bx) pfo_prof_end(k_dev ? PFO_PROF_GEMM_DEVM : PFO_PROF_GEMM_TN, flops, stream);
   return PFO_OK;
 }
 
@@ -1089,7 +1091,7 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
   to_dev(g, d);
   const bool vec = a_vec && b_vec;
   const double flops = 2.0 * g.M * g.N * ((double)g.K[0] + g.K[1]) * g.batch;
-  const int kind = g.m_dev ? PFO_PROF_GEMM_DEVM : (g.a_kmajor ? PFO_PROF_GEMM_TN : (g.b_kmajor ? PFO_PROF_GEMM_NN : PFO_PROF_GEMM_NT));
+  int kind = g.m_dev ? PFO_PROF_GEMM_DEVM : (g.a_kmajor ? PFO_PROF_GEMM_TN : (g.b_kmajor ? PFO_PROF_GEMM_NN : PFO_PROF_GEMM_NT));
   pfo_prof_begin(stream);
   const int tn = (int)pfo_ceil_div(g.N, BN);
 #define GEMM_GO(AK, BK_, SM, grid)                                                                                   \
@@ -1139,9 +1141,11 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
     const bool a_rowvec = a_vec && g.batch == 1;
     if (g.b_img && g.K[1] == 0 && a_rowvec && (g.bx_force || (bx >= 1 && big_tiles >= bx_min_tiles && force < 0))) {
       d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN);
+      if (!g.m_dev) kind = PFO_PROF_GEMM_BX;       // device-side row counts stay "time only"
       hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0,
                          stream, d);
     } else if (bx >= 2 && !g.b_kmajor && tile == 0 && vec) {
+      kind = PFO_PROF_GEMM_BX;
       hipLaunchKernelGGL(gemm_bf16x3_kernel<false>, grid, dim3(GEMM_THREADS), 0, stream, d);
     } else if (g.b_kmajor) {
       if (tile == 1) GEMM_GO(false, true, 1, grid); else if (tile == 2) GEMM_GO(false, true, 2, grid); else GEMM_GO(false, true, 0, grid);

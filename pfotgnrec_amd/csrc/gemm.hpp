@@ -36,7 +36,7 @@ struct PfoGemm {
 
 // Pre-split ("bf16x3") image of a weight operand W(n, k) = src[n*ld + k] (trans = 0) or src[k*ld + n] (trans = 1):
 // three bf16 pieces per element in the LDS layout of the split contraction kernel.  dst needs pfo_bimg_bytes(N, K).
-#define PFO_BIMG_MAX 16
+#define PFO_BIMG_MAX 24
 struct PfoBimg {
   const float* src = nullptr; int64_t ld = 0; int N = 0, K = 0, trans = 0; void* dst = nullptr;
 };
@@ -45,6 +45,7 @@ int pfo_bimg_launch(const PfoBimg* list, int n, hipStream_t stream);
 
 int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream);
 // several small plain problems (any operand layouts, no device-side counts, no split-K) in one launch
+#define PFO_GEMM_MULTI_MAX 10
 int pfo_gemm_multi_launch(const PfoGemm* list, int n, hipStream_t stream);
 // out[m, n] += u[m * ldu] * v[n * ldv]
 int pfo_rank1_launch(const float* u, int64_t ldu, const float* v, int64_t ldv, int M, int N, float* out, int64_t ldo,

@@ -226,10 +226,12 @@ int pfo_gru_gates_bwd_launch(float* gi, float* gh, const float* h_rows, const ui
 __global__ void persist_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int B,
                                const int32_t* __restrict__ slot, const float* __restrict__ upd_mem,
                                const uint8_t* __restrict__ has_msg, const float* __restrict__ msg_time,
-                               float* __restrict__ memory, float* __restrict__ last_update, int D) {
+                               float* __restrict__ memory, float* __restrict__ last_update, int D,
+                               int32_t* __restrict__ winner) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (wave >= 2 * B) return;
   const int id = wave < B ? src[wave] : dst[wave - B];
+  if (lane == 0) winner[id] = -1;              // reset for the raw-message pass that follows (msg_winner_max_kernel)
   if (!has_msg[id]) return;
   const int s = slot[id];
   if (s < 0) return;
@@ -239,21 +241,15 @@ __global__ void persist_kernel(const int32_t* __restrict__ src, const int32_t* _
 
 int pfo_persist_launch(const int32_t* src, const int32_t* dst, int B, const int32_t* slot, const float* upd_mem,
                        const uint8_t* has_msg, const float* msg_time, float* memory, float* last_update, int D,
-                       hipStream_t stream) {
+                       int32_t* winner, hipStream_t stream) {
   hipLaunchKernelGGL(persist_kernel, dim3((unsigned)pfo_ceil_div(2 * B, 4)), dim3(256), 0, stream, src, dst, B, slot,
-                     upd_mem, has_msg, msg_time, memory, last_update, D);
+                     upd_mem, has_msg, msg_time, memory, last_update, D, winner);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
 
 // raw messages (tgn.py:357-378): event e = side*B + i; append order is all source-side messages in
 // batch order, then all destination-side ones, so "last" == the largest e that names the node.
-__global__ void msg_winner_init_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int B,
-                                       int32_t* __restrict__ winner) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= 2 * B) return;
-  winner[e < B ? src[e] : dst[e - B]] = -1;
-}
 __global__ void msg_winner_max_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int B,
                                       int32_t* __restrict__ winner) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -294,7 +290,6 @@ int pfo_msg_store_launch(const int32_t* src, const int32_t* dst, const double* t
                          const float* tb, int D, int Ef, float* msg_table, float* msg_time, uint8_t* has_msg,
                          int32_t* winner, hipStream_t stream) {
   const unsigned nb = (unsigned)pfo_ceil_div(2 * B, 256);
-  hipLaunchKernelGGL(msg_winner_init_kernel, dim3(nb), dim3(256), 0, stream, src, dst, B, winner);
   hipLaunchKernelGGL(msg_winner_max_kernel, dim3(nb), dim3(256), 0, stream, src, dst, B, winner);
   hipLaunchKernelGGL(msg_write_kernel, dim3((unsigned)pfo_ceil_div(2 * B, 4)), dim3(256), 0, stream, src, dst, ts, eidx,
                      B, memory, last_update, edge_feat, tw, tb, D, Ef, msg_table, msg_time, has_msg, winner);

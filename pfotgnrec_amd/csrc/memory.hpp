@@ -26,7 +26,7 @@ int pfo_gru_gates_bwd_launch(float* gi, float* gh, const float* h_rows, const ui
 
 // --- state update (tgn.py:290-317)
 int pfo_persist_launch(const int32_t* src, const int32_t* dst, int B, const int32_t* slot, const float* upd_mem,
-                       const uint8_t* has_msg, const float* msg_time, float* memory, float* last_update, int D,
+                       const uint8_t* has_msg, const float* msg_time, float* memory, float* last_update, int D, int32_t* winner,
                        hipStream_t stream);
 int pfo_msg_store_launch(const int32_t* src, const int32_t* dst, const double* ts, const int32_t* eidx, int B,
                          const float* memory, const float* last_update, const float* edge_feat, const float* tw,

@@ -44,11 +44,7 @@ void pfo_prof_end(int kind, double work, hipStream_t s) {
   g_pending = nullptr;
 }
 extern "C" int pfo_prof_enable(int32_t on) {
-  g_prof_on = on != 0;
-  if (g_prof_on) {
-    for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
-    g_recs.clear();
-  }
+  g_prof_on = on != 0;         // records accumulate across enable/disable toggles until pfo_prof_collect drains them
   return PFO_OK;
 }
 extern "C" int pfo_prof_collect(double* ms, double* work, int64_t* count) {

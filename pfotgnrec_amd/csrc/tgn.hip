@@ -46,6 +46,7 @@ struct Ws {
   double *dtime, *fold_scratch;
   int32_t* tickets;
   int64_t slab_floats;
+  size_t zero_bytes;
   int64_t bytes;
 };
 
@@ -89,8 +90,16 @@ Ws carve(const pfo_tgn_config* c, void* base) {
       w.dt[l] = take<float>(p, d.ncap[l] * Km);
     }
   }
+  // one memset per step clears [zero | tickets | Wqk, W1ovT, cqk of every layer] (the composites are accumulated into)
   w.zero = take<float>(p, 64);
-  w.tickets = take<int32_t>(p, 64);         // directly behind w.zero: one memset clears both
+  w.tickets = take<int32_t>(p, 64);
+  for (int l = 1; l <= d.L; ++l) {
+    LayerWs& lw = w.layer[l];
+    lw.Wqk = take<float>(p, (int64_t)d.H * d.Cp * d.D);
+    lw.W1ovT = take<float>(p, (int64_t)d.H * d.Cp * d.D);
+    lw.cqk = take<float>(p, (int64_t)d.H * d.Cp);
+  }
+  w.zero_bytes = (size_t)(p - reinterpret_cast<char*>(w.zero));
   w.cosb = take<float>(p, d.D);
   if (c->use_memory) {
     w.slot = take<int32_t>(p, c->n_nodes);
@@ -114,10 +123,7 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     const int64_t N = d.ncap[l];
     LayerWs& lw = w.layer[l];
     lw.cq = take<float>(p, d.E);
-    lw.Wqk = take<float>(p, (int64_t)d.H * d.Cp * d.D);
-    lw.cqk = take<float>(p, (int64_t)d.H * d.Cp);
     lw.W1oT = take<float>(p, (int64_t)d.E * d.D);
-    lw.W1ovT = take<float>(p, (int64_t)d.H * d.Cp * d.D);
     lw.dWqk = take<float>(p, (int64_t)d.H * d.Cp * d.D);
     lw.gqk = take<float>(p, (int64_t)d.H * d.Cp);
     lw.dW1ovT = take<float>(p, (int64_t)d.H * d.Cp * d.D);
@@ -328,63 +334,66 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   PFO_REQUIRE(sd.ok, "could not create the side stream");
   hipStream_t ss = sd.s;
   const int Cp = d.Cp, HCp = H * d.Cp;
-  PFO_REQUIRE(hipMemsetAsync(w.zero, 0, 512, s) == hipSuccess, "memset failed");      // w.zero and w.tickets
-  RUN(pfo_time_encode(w.zero, 1, P.tw, P.tb, D, w.cosb, stream));              // cos(fma(0, w, b)) (embedding_module.py:92)
+  // Everything here depends on the parameters only, so the side stream starts at once (after whatever the main
+  // stream did before this call) and the host enqueues it in six calls: the sampling / compaction launches behind
+  // it are what the main stream is waiting for.  All layers share each launch.
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
-  for (int l = 1; l <= L; ++l) {
-    const LayerWs& lw = w.layer[l];
-    const auto& p = P.l[l];
-    PFO_REQUIRE(hipMemsetAsync(lw.Wqk, 0, sizeof(float) * (size_t)HCp * D, ss) == hipSuccess, "memset failed");
-    PFO_REQUIRE(hipMemsetAsync(lw.W1ovT, 0, sizeof(float) * (size_t)HCp * D, ss) == hipSuccess, "memset failed");
-    PFO_REQUIRE(hipMemsetAsync(lw.cqk, 0, sizeof(float) * (size_t)HCp, ss) == hipSuccess, "memset failed");
-    {
-      PfoGemm st1[3];
-      st1[0] = g_nt(w.cosb, D, nullptr, p.wq + D, E, lw.cq, E, 1, E, D, p.b_in);            // cq = Wq[:, D:] cos(b) + bq
-      st1[1] = g_nt(p.wo, E, nullptr, p.w1, E + D, lw.W1oT, D, E, D, E, nullptr);           // W1oT = Wo^T W1[:, :E]^T
-      st1[1].a_kmajor = 1;
-      st1[2] = g_nt(p.wk, C, nullptr, p.wq, E, lw.Wqk, D, C, D, dh, nullptr);               // Wqk_h = Wk_h^T Wq_h[:, :D]
-      st1[2].a_kmajor = 1; st1[2].b_kmajor = 1; st1[2].batch = H;
-      st1[2].a_bs[0] = (int64_t)dh * C; st1[2].b_bs[0] = (int64_t)dh * E; st1[2].c_bs = (int64_t)Cp * D;
-      RUN(pfo_gemm_multi_launch(st1, 3, ss));
-      PfoGemm st2[4];
-      st2[0] = g_nn(lw.cq, E, p.wk, C, lw.cqk, HCp, 1, C, dh);                               // cqk_h = Wk_h^T cq_h
-      st2[0].batch = H; st2[0].a_bs[0] = dh; st2[0].b_bs[0] = (int64_t)dh * C; st2[0].c_bs = Cp;
-      st2[1] = g_nt(p.wv, C, nullptr, lw.W1oT, D, lw.W1ovT, D, C, D, dh, nullptr);           // W1ovT_h = Wv_h^T W1oT_h
-      st2[1].a_kmajor = 1; st2[1].b_kmajor = 1; st2[1].batch = H;
-      st2[1].a_bs[0] = (int64_t)dh * C; st2[1].b_bs[0] = (int64_t)dh * D; st2[1].c_bs = (int64_t)Cp * D;
-      st2[2] = g_nn(p.b_in + 2 * E, dh, lw.W1oT, D, lw.W1ovT + (int64_t)C * D, D, 1, D, dh); // row C: (W1 Wo_h bv_h)^T
-      st2[2].batch = H; st2[2].a_bs[0] = dh; st2[2].b_bs[0] = (int64_t)dh * D; st2[2].c_bs = (int64_t)Cp * D;
-      st2[3] = g_nt(p.bo, E, nullptr, p.w1, E + D, lw.W1ovT + (int64_t)(C + 1) * D, D, 1, D, E, nullptr);   // row C+1 of head 0: (W1 bo)^T
-      RUN(pfo_gemm_multi_launch(st2, 4, ss));
+  PFO_REQUIRE(hipMemsetAsync(w.zero, 0, w.zero_bytes, ss) == hipSuccess, "memset failed");   // w.zero, w.tickets, Wqk / W1ovT / cqk of every layer
+  RUN(pfo_time_encode(w.zero, 1, P.tw, P.tb, D, w.cosb, ss));                  // cos(fma(0, w, b)) (embedding_module.py:92)
+  {
+    PfoGemm st1[3 * PFO_MAX_LAYERS], st2[4 * PFO_MAX_LAYERS];
+    PfoBimg im[8 * PFO_MAX_LAYERS + 2];
+    int n1 = 0, n2 = 0, ni = 0;
+    auto img = [&](const float* src, int64_t ld, int N_, int K_, int trans, void* dst) {
+      im[ni].src = src; im[ni].ld = ld; im[ni].N = N_; im[ni].K = K_; im[ni].trans = trans; im[ni].dst = dst; ++ni;
+    };
+    for (int l = 1; l <= L; ++l) {
+      const LayerWs& lw = w.layer[l];
+      const auto& p = P.l[l];
+      PfoGemm* a1 = st1 + n1;
+      a1[0] = g_nt(w.cosb, D, nullptr, p.wq + D, E, lw.cq, E, 1, E, D, p.b_in);            // cq = Wq[:, D:] cos(b) + bq
+      a1[1] = g_nt(p.wo, E, nullptr, p.w1, E + D, lw.W1oT, D, E, D, E, nullptr);           // W1oT = Wo^T W1[:, :E]^T
+      a1[1].a_kmajor = 1;
+      a1[2] = g_nt(p.wk, C, nullptr, p.wq, E, lw.Wqk, D, C, D, dh, nullptr);               // Wqk_h = Wk_h^T Wq_h[:, :D]
+      a1[2].a_kmajor = 1; a1[2].b_kmajor = 1; a1[2].batch = H;
+      a1[2].a_bs[0] = (int64_t)dh * C; a1[2].b_bs[0] = (int64_t)dh * E; a1[2].c_bs = (int64_t)Cp * D;
+      n1 += 3;
+      PfoGemm* a2 = st2 + n2;
+      a2[0] = g_nn(lw.cq, E, p.wk, C, lw.cqk, HCp, 1, C, dh);                               // cqk_h = Wk_h^T cq_h
+      a2[0].batch = H; a2[0].a_bs[0] = dh; a2[0].b_bs[0] = (int64_t)dh * C; a2[0].c_bs = Cp;
+      a2[1] = g_nt(p.wv, C, nullptr, lw.W1oT, D, lw.W1ovT, D, C, D, dh, nullptr);           // W1ovT_h = Wv_h^T W1oT_h
+      a2[1].a_kmajor = 1; a2[1].b_kmajor = 1; a2[1].batch = H;
+      a2[1].a_bs[0] = (int64_t)dh * C; a2[1].b_bs[0] = (int64_t)dh * D; a2[1].c_bs = (int64_t)Cp * D;
+      a2[2] = g_nn(p.b_in + 2 * E, dh, lw.W1oT, D, lw.W1ovT + (int64_t)C * D, D, 1, D, dh); // row C: (W1 Wo_h bv_h)^T
+      a2[2].batch = H; a2[2].a_bs[0] = dh; a2[2].b_bs[0] = (int64_t)dh * D; a2[2].c_bs = (int64_t)Cp * D;
+      a2[3] = g_nt(p.bo, E, nullptr, p.w1, E + D, lw.W1ovT + (int64_t)(C + 1) * D, D, 1, D, E, nullptr);   // row C+1 of head 0: (W1 bo)^T
+      n2 += 4;
       // bf16x3 images of this layer's weight operands, in both orientations (forward and data-gradient launches)
-      PfoBimg im[10];
-      int ni = 0;
-      auto img = [&](const float* src, int64_t ld, int N_, int K_, int trans, void* dst) {
-        im[ni].src = src; im[ni].ld = ld; im[ni].N = N_; im[ni].K = K_; im[ni].trans = trans; im[ni].dst = dst; ++ni;
-      };
       img(lw.Wqk, D, HCp, D, 0, lw.iWqk);        img(lw.Wqk, D, D, HCp, 1, lw.iWqkT);
       img(lw.W1ovT, D, HCp, D, 0, lw.iW1ovT);    img(lw.W1ovT, D, D, HCp, 1, lw.iW1ov);
       img(p.w1 + E, E + D, D, D, 0, lw.iW1b);    img(p.w1 + E, E + D, D, D, 1, lw.iW1bT);
       img(p.w2, D, D, D, 0, lw.iW2);             img(p.w2, D, D, D, 1, lw.iW2T);
-      if (l == 1 && c->use_memory) {
-        img(P.w_ih, d.M, 3 * D, d.M, 0, w.iWih);
-        img(P.w_hh, D, 3 * D, D, 0, w.iWhh);
-      }
-      RUN(pfo_bimg_launch(im, ni, ss));
     }
-    HIPOK(hipEventRecord(sd.layer[l], ss), "event record failed");
+    if (c->use_memory) {
+      img(P.w_ih, d.M, 3 * D, d.M, 0, w.iWih);
+      img(P.w_hh, D, 3 * D, D, 0, w.iWhh);
+    }
+    for (int i = 0; i < n1; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(st1 + i, std::min(PFO_GEMM_MULTI_MAX, n1 - i), ss));
+    for (int i = 0; i < n2; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(st2 + i, std::min(PFO_GEMM_MULTI_MAX, n2 - i), ss));
+    for (int i = 0; i < ni; i += PFO_BIMG_MAX) RUN(pfo_bimg_launch(im + i, std::min(PFO_BIMG_MAX, ni - i), ss));
   }
+  HIPOK(hipEventRecord(sd.layer[0], ss), "event record failed");        // composite weights and images of all layers are ready
+  bool composites_awaited = false;
 
   // ---- frontier expansion: K1 per level (utils.py:163-219 called from embedding_module.py:125)
-  PFO_REQUIRE(hipMemcpyAsync(w.nodes[L], b->roots, (size_t)b->R * sizeof(int32_t), hipMemcpyDeviceToDevice, s) == hipSuccess,
-              "copy failed");
-  PFO_REQUIRE(hipMemcpyAsync(w.ts[L], b->root_ts, (size_t)b->R * sizeof(double), hipMemcpyDeviceToDevice, s) == hipSuccess,
-              "copy failed");
   for (int l = L; l >= 1; --l) {
     const int64_t* dr = (b->uniform == 1) ? b->draws[L - l] : nullptr;
     PFO_REQUIRE(b->uniform != 1 || dr, "missing draws for a level");
-    RUN(pfo_tnbr_sample(st->indptr, st->adj_nbr, st->adj_eidx, st->adj_ts, c->n_nodes, w.nodes[l], w.ts[l], n[l], K,
+    // level L reads the caller's roots directly; every level writes [its own nodes | their neighbours] as the next one
+    const int32_t* lvl_nodes = (l == L) ? b->roots : w.nodes[l];
+    const double* lvl_ts = (l == L) ? b->root_ts : w.ts[l];
+    RUN(pfo_tnbr_sample(st->indptr, st->adj_nbr, st->adj_eidx, st->adj_ts, c->n_nodes, lvl_nodes, lvl_ts, n[l], K,
                         b->uniform, dr, b->seed, b->offset + (uint64_t)l * 0x100000000ull, nullptr, w.eidx[l], nullptr,
                         w.dt[l], w.nodes[l - 1], l > 1 ? w.ts[l - 1] : nullptr, stream));
   }
@@ -401,6 +410,8 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
     RUN(pfo_pack_rows_launch(st->msg_table, d.M, st->memory, D, st->has_msg, w.touched, w.n_touched, capP, w.msg_rows,
                              w.h_rows, w.hm, s));
+    HIPOK(hipStreamWaitEvent(s, sd.layer[0], 0), "event wait failed");     // images of W_ih / W_hh (and all composites)
+    composites_awaited = true;
     PfoGemm gi = g_nt(w.msg_rows, d.M, nullptr, P.w_ih, d.M, w.gi, 3 * D, capP, 3 * D, d.M, P.b_ih);
     gi.m_dev = w.n_touched; gi.b_img = w.iWih;
     RUN(pfo_gemm_launch(gi, s));
@@ -435,7 +446,10 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     const float* xA = (l == 1) ? tab0 : w.layer[l - 1].Hout;
     const int32_t* x_idx = (l == 1) ? idx0 : nullptr;
 
-    HIPOK(hipStreamWaitEvent(s, sd.layer[l], 0), "event wait failed");     // this layer's composite weights are ready
+    if (!composites_awaited) {
+      HIPOK(hipStreamWaitEvent(s, sd.layer[0], 0), "event wait failed");   // composite weights are ready
+      composites_awaited = true;
+    }
     // ---- qk' = x Wqk^T + cqk
     {
       PfoGemm g = g_nt(xA, D, x_idx, lw.Wqk, D, lw.QK, HCp, N, HCp, D, lw.cqk);
@@ -464,14 +478,12 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
       RUN(pfo_gemm_launch(g, s));
     }
     {
-      PfoGemm g = g_nt(lw.h1, D, nullptr, p.w2, D, lw.Hout, D, N, D, D, p.b2);
+      // the last layer's rows ARE the requested embeddings (N == R): written in place, no copy
+      PfoGemm g = g_nt(lw.h1, D, nullptr, p.w2, D, l == L ? emb_out : lw.Hout, D, N, D, D, p.b2);
       g.b_img = lw.iW2;
       RUN(pfo_gemm_launch(g, s));
     }
   }
-  PFO_REQUIRE(hipMemcpyAsync(emb_out, w.layer[L].Hout, (size_t)b->R * D * sizeof(float), hipMemcpyDeviceToDevice, s) ==
-                  hipSuccess,
-              "copy failed");
   return PFO_OK;
 }
 
@@ -644,7 +656,7 @@ extern "C" int pfo_tgn_update_state(const pfo_tgn_config* c, const pfo_tgn_state
   RUN(pfo_tgn_param_layout(c, &lay));
   const float* tw = st->params + lay.time_w;
   const float* tb = st->params + lay.time_b;
-  RUN(pfo_persist_launch(src, dst, B, w.slot, w.upd_mem, st->has_msg, st->msg_time, st->memory, st->last_update, c->D, s));
+  RUN(pfo_persist_launch(src, dst, B, w.slot, w.upd_mem, st->has_msg, st->msg_time, st->memory, st->last_update, c->D, w.winner, s));
   RUN(pfo_msg_store_launch(src, dst, ts, eidx, B, st->memory, st->last_update, st->edge_feat, tw, tb, c->D, c->Ef,
                            st->msg_table, st->msg_time, st->has_msg, w.winner, s));
   return PFO_OK;
