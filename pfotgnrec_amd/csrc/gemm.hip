@@ -382,24 +382,70 @@ __device__ __forceinline__ void bx_for(F&& f) {
 }
 __device__ __forceinline__ int bx_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }   // {0,3,2,1}
 
-__device__ __forceinline__ void bx_split_store(char* base, int piece_bytes, int row, int c4, const float4 v) {
-  // float4 = 4 consecutive k of one row: k = 4*c4 .. 4*c4+3 -> 16-byte chunk c4 >> 1, half c4 & 1
-  const int off = row * 64 + (((c4 >> 1) ^ bx_swz(row)) << 4) + ((c4 & 1) << 3);
+// 3-way bf16 split of four fp32 values, packed two per dword (element e in the low half of dword e/2):
+// 4 VALU per value (and, sub, and, sub: the residuals are exact) + one v_perm_b32 per pair and piece
+__device__ __forceinline__ void bx_split4(const float4 v, uint2& o1, uint2& o2, uint2& o3) {
   const float x[4] = {v.x, v.y, v.z, v.w};
   uint32_t p1[4], p2[4], p3[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const uint32_t b1 = __float_as_uint(x[e]) & 0xFFFF0000u;
-    const float r1 = x[e] - __uint_as_float(b1);                 // exact
-    const uint32_t b2 = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(b2);                   // exact
-    p1[e] = b1; p2[e] = b2; p3[e] = __float_as_uint(r2);
+    p1[e] = __float_as_uint(x[e]);
+    const float r1 = x[e] - __uint_as_float(p1[e] & 0xFFFF0000u);                 // exact
+    p2[e] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(p2[e] & 0xFFFF0000u);                   // exact
+    p3[e] = __float_as_uint(r2);
   }
-  *reinterpret_cast<uint2*>(base + off) = uint2{(p1[1] & 0xFFFF0000u) | (p1[0] >> 16), (p1[3] & 0xFFFF0000u) | (p1[2] >> 16)};
-  *reinterpret_cast<uint2*>(base + piece_bytes + off) =
-      uint2{(p2[1] & 0xFFFF0000u) | (p2[0] >> 16), (p2[3] & 0xFFFF0000u) | (p2[2] >> 16)};
-  *reinterpret_cast<uint2*>(base + 2 * piece_bytes + off) =
-      uint2{(p3[1] & 0xFFFF0000u) | (p3[0] >> 16), (p3[3] & 0xFFFF0000u) | (p3[2] >> 16)};
+  constexpr uint32_t HI2 = 0x07060302u;                                            // {hi16(a), hi16(b)} -> a in the upper half
+  o1 = uint2{__builtin_amdgcn_perm(p1[1], p1[0], HI2), __builtin_amdgcn_perm(p1[3], p1[2], HI2)};
+  o2 = uint2{__builtin_amdgcn_perm(p2[1], p2[0], HI2), __builtin_amdgcn_perm(p2[3], p2[2], HI2)};
+  o3 = uint2{__builtin_amdgcn_perm(p3[1], p3[0], HI2), __builtin_amdgcn_perm(p3[3], p3[2], HI2)};
+}
+
+__device__ __forceinline__ void bx_split_store(char* base, int piece_bytes, int row, int c4, const float4 v) {
+  // float4 = 4 consecutive k of one row: k = 4*c4 .. 4*c4+3 -> 16-byte chunk c4 >> 1, half c4 & 1
+  const int off = row * 64 + (((c4 >> 1) ^ bx_swz(row)) << 4) + ((c4 & 1) << 3);
+  uint2 o1, o2, o3;
+  bx_split4(v, o1, o2, o3);
+  *reinterpret_cast<uint2*>(base + off) = o1;
+  *reinterpret_cast<uint2*>(base + piece_bytes + off) = o2;
+  *reinterpret_cast<uint2*>(base + 2 * piece_bytes + off) = o3;
+}
+
+// epilogue of the operand-swapped bf16x3 kernels: four consecutive columns col..col+3 of one output row
+__device__ __forceinline__ void bx_store4(const GemmDev& p, float* Cb, int64_t ldc, const float* bias, float rscale, bool zero,
+                                          bool n4, int row, int col, const f32x4 a) {
+  float v[4] = {a[0], a[1], a[2], a[3]};
+  float* cp = Cb + (int64_t)row * ldc + col;
+  if (n4) {
+    if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(cp); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+    if (bias) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + col);
+      v[0] = fmaf(bv.x, rscale, v[0]); v[1] = fmaf(bv.y, rscale, v[1]); v[2] = fmaf(bv.z, rscale, v[2]); v[3] = fmaf(bv.w, rscale, v[3]);
+    }
+    if (zero) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+    if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    if (p.relu_src) {
+      const float4 m = *reinterpret_cast<const float4*>(p.relu_src + (int64_t)row * p.relu_ld + col);
+      v[0] = m.x > 0.f ? v[0] : 0.f; v[1] = m.y > 0.f ? v[1] : 0.f; v[2] = m.z > 0.f ? v[2] : 0.f; v[3] = m.w > 0.f ? v[3] : 0.f;
+    }
+    *reinterpret_cast<float4*>(cp) = float4{v[0], v[1], v[2], v[3]};
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (col + e >= p.N) continue;
+      float x = v[e];
+      if (p.accumulate) x += cp[e];
+      if (bias) x = fmaf(bias[col + e], rscale, x);
+      if (zero) x = 0.f;
+      if (p.relu) x = fmaxf(x, 0.f);
+      if (p.relu_src) x = (p.relu_src[(int64_t)row * p.relu_ld + col + e] > 0.f) ? x : 0.f;
+      cp[e] = x;
+    }
+  }
+}
+__device__ __forceinline__ bool bx_n4(const GemmDev& p, const float* Cb, int64_t ldc, const float* bias) {
+  return (p.N & 3) == 0 && (ldc & 3) == 0 && (((uintptr_t)Cb) & 15) == 0 &&
+         (!p.relu_src || ((p.relu_ld & 3) == 0 && (((uintptr_t)p.relu_src) & 15) == 0)) && (!bias || (((uintptr_t)bias) & 15) == 0);
 }
 
 template <bool BSPLIT>
@@ -566,9 +612,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
   const int64_t ldc = p.ldc;
   const float* bias = p.bias ? p.bias + zb * p.bias_bs : nullptr;
   const float* rs = p.row_scale ? p.row_scale + zb * p.rs_bs : nullptr;
-  const bool n4 = (p.N & 3) == 0 && (ldc & 3) == 0 && (((uintptr_t)Cb) & 15) == 0 &&
-                  (!p.relu_src || ((p.relu_ld & 3) == 0 && (((uintptr_t)p.relu_src) & 15) == 0)) &&
-                  (!bias || (((uintptr_t)bias) & 15) == 0);
+  const bool n4 = bx_n4(p, Cb, ldc, bias);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = m0 + wrow + 16 * i + r;
@@ -578,35 +622,130 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
 #pragma unroll
     for (int j = 0; j < 11; ++j) {
       const int col = n0 + 16 * j + 4 * g;
-      if (col >= p.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      float* cp = Cb + (int64_t)row * ldc + col;
-      if (n4) {
-        if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(cp); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
-        if (bias) {
-          const float4 bv = *reinterpret_cast<const float4*>(bias + col);
-          v[0] = fmaf(bv.x, rscale, v[0]); v[1] = fmaf(bv.y, rscale, v[1]); v[2] = fmaf(bv.z, rscale, v[2]); v[3] = fmaf(bv.w, rscale, v[3]);
-        }
-        if (zero) { v[0] = v[1] = v[2] = v[3] = 0.f; }
-        if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        if (p.relu_src) {
-          const float4 m = *reinterpret_cast<const float4*>(p.relu_src + (int64_t)row * p.relu_ld + col);
-          v[0] = m.x > 0.f ? v[0] : 0.f; v[1] = m.y > 0.f ? v[1] : 0.f; v[2] = m.z > 0.f ? v[2] : 0.f; v[3] = m.w > 0.f ? v[3] : 0.f;
-        }
-        *reinterpret_cast<float4*>(cp) = float4{v[0], v[1], v[2], v[3]};
-      } else {
+      if (col < p.N) bx_store4(p, Cb, ldc, bias, rscale, zero, n4, row, col, acc[i][j]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same contraction for SHORT operands (the layer-2 launches: a few thousand rows, where 128-row tiles leave most
+// CUs idle and every workgroup is latency-bound): 32 rows x 176 columns per workgroup, wavefront w owns the column
+// tiles w, w+4, w+8 of all 32 rows; two LDS buffers, ONE barrier per k-tile, and two register stages so that the
+// global loads of k-tiles t+2 and t+3 are in flight while tile t is multiplied.  Pre-split B image only.
+#define SK_ROWS 32
+#define SK_A_PIECE (SK_ROWS * 64)
+#define SK_BUF_BYTES (3 * SK_A_PIECE + 3 * BX_B_PIECE)
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const GemmDev p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * SK_BUF_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * SK_ROWS, n0 = blockIdx.y * BN;
+  int Mlim = p.M;
+  if (p.m_dev) Mlim = min(Mlim, *p.m_dev);
+  if (m0 >= Mlim) return;
+  const int T = (p.K[0] + BK - 1) / BK;
+  f32x4 acc[2][3];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (col + e >= p.N) continue;
-          float x = v[e];
-          if (p.accumulate) x += cp[e];
-          if (bias) x = fmaf(bias[col + e], rscale, x);
-          if (zero) x = 0.f;
-          if (p.relu) x = fmaxf(x, 0.f);
-          if (p.relu_src) x = (p.relu_src[(int64_t)row * p.relu_ld + col + e] > 0.f) ? x : 0.f;
-          cp[e] = x;
-        }
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging: one float4 of A (row tid >> 3, k quad tid & 7) and nine 16-byte units of the B image per thread and stage
+  float4 a_st[2];
+  f32x4 i_st[2][9];
+  const int a_r = tid >> 3, a_c4 = tid & 7;
+  const bool a_ok = m0 + a_r < Mlim;
+  int64_t ridx = a_ok ? m0 + a_r : 0;
+  if (a_ok && p.a_idx[0]) ridx = p.a_idx[0][m0 + a_r];
+  const float* a_row = p.A[0] + ridx * p.lda[0];
+  const float* safe = p.A[0];
+  const char* img = reinterpret_cast<const char*>(p.b_img) + (int64_t)n0 * 64;
+  const int64_t img_piece = (int64_t)p.b_img_rows * 64;
+  auto load_global = [&](int t, auto sc) {
+    constexpr int st = decltype(sc)::value;
+    const int k = t * BK + 4 * a_c4;
+    a_st[st] = ld4<true>(a_row + k, a_ok ? p.K[0] - k : 0, safe);
+    const char* tile = img + (int64_t)t * 3 * img_piece;
+    bx_for<9>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const int unit = min(tid + 256 * u, 3 * (BX_B_PIECE / 16) - 1);
+      const int q = (unit >= 2 * (BX_B_PIECE / 16)) ? 2 : (unit >= BX_B_PIECE / 16 ? 1 : 0);
+      i_st[st][u] = *reinterpret_cast<const f32x4*>(tile + q * img_piece + (unit - q * (BX_B_PIECE / 16)) * 16);
+    });
+  };
+  auto store_lds = [&](int buf, auto sc) {
+    constexpr int st = decltype(sc)::value;
+    char* As = lds + buf * SK_BUF_BYTES;
+    char* Bs = As + 3 * SK_A_PIECE;
+    bx_split_store(As, SK_A_PIECE, a_r, a_c4, a_st[st]);
+    bx_for<9>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const int unit = tid + 256 * u;
+      if (u < 8 || unit < 3 * (BX_B_PIECE / 16)) *reinterpret_cast<f32x4*>(Bs + unit * 16) = i_st[st][u];
+    });
+  };
+  const int frag_off = r * 64 + ((g ^ bx_swz(r)) << 4);
+  auto compute = [&](int buf) {
+    const char* As = lds + buf * SK_BUF_BYTES;
+    const char* Bs = As + 3 * SK_A_PIECE;
+    bf16x8 a[2][3], b[3][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(As + q * SK_A_PIECE + (16 * i) * 64 + frag_off);
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int j = min(wave + 4 * jj, 10);                 // wave 3 has no third tile: re-reads tile 10, result unused
+        b[jj][q] = *reinterpret_cast<const bf16x8*>(Bs + q * BX_B_PIECE + (16 * j) * 64 + frag_off);
       }
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
+#pragma unroll
+    for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[jj][PB[t6]], a[i][PA[t6]], acc[i][jj], 0, 0, 0);
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  load_global(0, S0{});
+  if (T > 1) load_global(1, S1{});
+  store_lds(0, S0{});
+  if (T > 2) load_global(2, S0{});
+  __syncthreads();
+  for (int t = 0; t < T; t += 2) {
+    if (t + 1 < T) {                       // tile t in buffer 0; stage 1 holds t+1, stage 0 has t+2 in flight
+      store_lds(1, S1{});
+      if (t + 3 < T) load_global(t + 3, S1{});
+    }
+    compute(0);
+    __syncthreads();
+    if (t + 1 >= T) break;
+    if (t + 2 < T) {                       // tile t+1 in buffer 1; stage 0 holds t+2, stage 1 has t+3 in flight
+      store_lds(0, S0{});
+      if (t + 4 < T) load_global(t + 4, S0{});
+    }
+    compute(1);
+    __syncthreads();
+  }
+  float* Cb = p.C;
+  const int64_t ldc = p.ldc;
+  const bool n4 = bx_n4(p, Cb, ldc, p.bias);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = m0 + 16 * i + r;
+    if (row >= Mlim) continue;
+    const float rscale = p.row_scale ? p.row_scale[(int64_t)row * p.rs_ld] : 1.f;
+    const bool zero = p.row_zero ? (p.row_zero[row] != 0) : false;
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+      const int j = wave + 4 * jj;
+      const int col = n0 + 16 * j + 4 * g;
+      if (j < 11 && col < p.N) bx_store4(p, Cb, ldc, p.bias, rscale, zero, n4, row, col, acc[i][jj]);
     }
   }
 }
@@ -628,24 +767,16 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int tx_pi(int k) { return (k & 3) + ((k >> 1) & 4); }
 
 // float4 = 4 consecutive columns (m or n) of k-row `k`: 8 bytes of bf16 per piece
-__device__ __forceinline__ void tx_split_store(char* base, int piece_bytes, int row_bytes, int slot_mask, int k, int col,
-                                               const float4 v) {
-  const int off = k * row_bytes + ((((col >> 4) + tx_pi(k)) & slot_mask) << 5) + ((col & 15) << 1);
-  const float x[4] = {v.x, v.y, v.z, v.w};
-  uint32_t p1[4], p2[4], p3[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const uint32_t b1 = __float_as_uint(x[e]) & 0xFFFF0000u;
-    const float r1 = x[e] - __uint_as_float(b1);
-    const uint32_t b2 = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(b2);
-    p1[e] = b1; p2[e] = b2; p3[e] = __float_as_uint(r2);
-  }
-  *reinterpret_cast<uint2*>(base + off) = uint2{(p1[1] & 0xFFFF0000u) | (p1[0] >> 16), (p1[3] & 0xFFFF0000u) | (p1[2] >> 16)};
-  *reinterpret_cast<uint2*>(base + piece_bytes + off) =
-      uint2{(p2[1] & 0xFFFF0000u) | (p2[0] >> 16), (p2[3] & 0xFFFF0000u) | (p2[2] >> 16)};
-  *reinterpret_cast<uint2*>(base + 2 * piece_bytes + off) =
-      uint2{(p3[1] & 0xFFFF0000u) | (p3[0] >> 16), (p3[3] & 0xFFFF0000u) | (p3[2] >> 16)};
+__device__ __forceinline__ void tx_split_store(char* base, int piece_bytes, int off, const float4 v) {
+  uint2 o1, o2, o3;
+  bx_split4(v, o1, o2, o3);
+  *reinterpret_cast<uint2*>(base + off) = o1;
+  *reinterpret_cast<uint2*>(base + piece_bytes + off) = o2;
+  *reinterpret_cast<uint2*>(base + 2 * piece_bytes + off) = o3;
+}
+// byte offset of columns col..col+3 of k-row `k` in a transposed-read image
+__device__ __forceinline__ int tx_off(int row_bytes, int slot_mask, int k, int col) {
+  return k * row_bytes + ((((col >> 4) + tx_pi(k)) & slot_mask) << 5) + ((col & 15) << 1);
 }
 
 __device__ __forceinline__ bf16x8 tx_read(const char* piece, int row_bytes, int slot_mask, int slot, int g, int idx) {
@@ -680,54 +811,64 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
 #pragma unroll
     for (int j = 0; j < 11; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int T = Ks > kbeg ? (Ks - kbeg + BK - 1) / BK : 0;
-  float4 a_reg[4], b_reg[6];
   const float* safe = p.A[0];
-  const float* Ab = p.A[0];
-  const float* Bb = p.B[0];
   const int64_t lda = p.lda[0], ldb = p.ldb[0];
+  // per-thread invariants of the staging pass: which (k-row, column quad) of the tile each of the 4 + 6 float4 covers,
+  // where it lands in LDS, and whether it holds the bias column
+  float4 a_reg[4], b_reg[6];
+  const float* a_ptr[4];          // row kbeg + kr of A at this thread's columns; advanced by BK rows per tile
+  int a_kr[4], a_off[4];
+  bool a_col_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = tid + 256 * i;
+    a_kr[i] = f >> 5;
+    const int mc = 4 * (f & 31);
+    a_col_ok[i] = m0 + mc < p.M;                        // M % 4 == 0 (VEC): a quad is all in or all out
+    a_ptr[i] = p.A[0] + (int64_t)(kbeg + a_kr[i]) * lda + m0 + mc;
+    a_off[i] = tx_off(TX_A_ROW, 7, a_kr[i], mc);
+  }
+  int b_kr[6], b_off[6], b_n[6], b_bias_e[6];
+  bool b_live[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int f = tid + 256 * i;
+    b_kr[i] = f / 44;
+    const int nc = 4 * (f - b_kr[i] * 44);
+    b_live[i] = f < BK * 44;
+    b_n[i] = n0 + nc;
+    b_off[i] = tx_off(TX_B_ROW, 15, b_live[i] ? b_kr[i] : 0, nc);
+    const int e = p.n_real - b_n[i];                     // bias column inside this quad?
+    b_bias_e[i] = (p.n_real < p.N && e >= 0 && e < 4) ? e : -1;
+  }
 
   auto load_tile = [&](int t) {
     const int k0 = kbeg + t * BK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int f = tid + 256 * i;
-      const int k = k0 + (f >> 5);
-      const int m = m0 + 4 * (f & 31);
-      a_reg[i] = ld4<true>(Ab + (int64_t)k * lda + m, k < Ks ? p.M - m : 0, safe);
+      const bool ok = a_col_ok[i] && (k0 + a_kr[i] < Ks);
+      a_reg[i] = ld4<true>(a_ptr[i] + (int64_t)t * BK * lda, ok ? 4 : 0, safe);
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const int f = tid + 256 * i;
-      const int kr = f / 44;
-      const int k = k0 + kr;
-      const int n = n0 + 4 * (f - kr * 44);
-      const bool ok = (f < BK * 44) && k < Ks && n < p.N;
+      const int k = k0 + b_kr[i];
+      const bool ok = b_live[i] && k < Ks && b_n[i] < p.N;
       int64_t krow = ok ? k : 0;
       if (ok && p.b_idx) krow = p.b_idx[k];
-      b_reg[i] = ld4<true>(Bb + krow * ldb + n, ok ? p.n_real - n : 0, safe);
-      if (ok && p.n_real < p.N) {
-        const int e = p.n_real - n;                          // bias column (see gemm_tile)
-        if (e >= 0 && e < 4) {
-          const float one = p.ones_scale ? p.ones_scale[(int64_t)k * p.os_ld] : 1.f;
-          if (e == 0) b_reg[i].x = one; else if (e == 1) b_reg[i].y = one; else if (e == 2) b_reg[i].z = one; else b_reg[i].w = one;
-        }
+      b_reg[i] = ld4<true>(p.B[0] + krow * ldb + b_n[i], ok ? p.n_real - b_n[i] : 0, safe);
+      if (b_bias_e[i] >= 0 && ok) {
+        const float one = p.ones_scale ? p.ones_scale[(int64_t)k * p.os_ld] : 1.f;     // bias column (see gemm_tile)
+        const int e = b_bias_e[i];
+        if (e == 0) b_reg[i].x = one; else if (e == 1) b_reg[i].y = one; else if (e == 2) b_reg[i].z = one; else b_reg[i].w = one;
       }
     }
   };
   auto store_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = tid + 256 * i;
-      tx_split_store(As, TX_A_PIECE, TX_A_ROW, 7, f >> 5, 4 * (f & 31), a_reg[i]);
-    }
+    for (int i = 0; i < 4; ++i) tx_split_store(As, TX_A_PIECE, a_off[i], a_reg[i]);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int f = tid + 256 * i;
-      if (f < BK * 44) {
-        const int kr = f / 44;
-        tx_split_store(Bs, TX_B_PIECE, TX_B_ROW, 15, kr, 4 * (f - kr * 44), b_reg[i]);
-      }
-    }
+    for (int i = 0; i < 6; ++i)
+      if (b_live[i]) tx_split_store(Bs, TX_B_PIECE, b_off[i], b_reg[i]);
   };
   const bool strip_on[2] = {m0 + wrow < p.M, m0 + wrow + 16 < p.M};
   auto compute_tile = [&]() {
@@ -769,11 +910,11 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
     store_tile();
     __syncthreads();
     for (int t = 0; t < T; ++t) {
-      const bool more = t + 1 < T;
+      const bool more = (BX_EXP == 1) ? false : (t + 1 < T);
       if (more) load_tile(t + 1);
-      compute_tile();
+      if (BX_EXP != 2) compute_tile();
       __syncthreads();
-      if (more) store_tile();
+      if (more && BX_EXP != 3) store_tile();
       __syncthreads();
     }
   }
@@ -1109,20 +1250,13 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
     int chunk = (int)pfo_align_up(pfo_ceil_div(K, nsplit), BK);
     nsplit = (int)pfo_ceil_div(K, chunk);
     if (nsplit > 1 && g.b_kmajor && g.slabs) {
+      // the weight-gradient form goes through the grouped split-K launch (one problem)
       PFO_REQUIRE(g.batch == 1, "split-K with batch is not supported");
-      PFO_REQUIRE(g.slabs && g.slab_floats >= (int64_t)nsplit * g.M * g.N, "split-K workspace too small");
       PFO_REQUIRE(!g.bias && !g.relu && !g.row_zero && !g.relu_src, "split-K takes no epilogue");
-      d.nsplit = nsplit; d.split_chunk = chunk; d.C = g.slabs;
-      PFO_REQUIRE(g.b_kmajor, "split-K needs k-major B");
-      GEMM_GO(true, true, 0, dim3(tm, tn, nsplit));
-      PFO_LAUNCH_CHECK();
-      const int64_t total = (int64_t)g.M * g.N;
-      const int rb = (int)std::min<int64_t>(2048, pfo_ceil_div(total, 256));
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rb), dim3(256), 0, stream, g.slabs, nsplit, chunk, g.m_dev, K, g.M,
-                         g.N, g.C, g.ldc, g.accumulate);
-      PFO_LAUNCH_CHECK();
-      pfo_prof_end(kind, flops, stream);
-      return PFO_OK;
+      PfoTnProblem q;
+      q.A = g.A[0]; q.lda = g.lda[0]; q.B = g.B[0]; q.ldb = g.ldb[0]; q.b_idx = g.b_idx; q.M = g.M; q.N = g.N;
+      q.C = g.C; q.ldc = g.ldc; q.c_accumulate = g.accumulate;
+      return pfo_gemm_tn_group_launch(&q, 1, K, g.m_dev, g.slabs, g.slab_floats, stream);
     }
     if (g.b_kmajor) GEMM_GO(true, true, 0, dim3(tm, tn, g.batch)); else GEMM_GO(true, false, 0, dim3(tm, tn, g.batch));
   } else {
@@ -1139,7 +1273,12 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
     static const int bx = getenv("PFO_GEMM_BF16X3") ? atoi(getenv("PFO_GEMM_BF16X3")) : PFO_DEFAULT_BF16X3;
     static const int bx_min_tiles = getenv("PFO_BX_MIN_TILES") ? atoi(getenv("PFO_BX_MIN_TILES")) : PFO_BX_MIN_TILES;
     const bool a_rowvec = a_vec && g.batch == 1;
-    if (g.b_img && g.K[1] == 0 && a_rowvec && (g.bx_force || (bx >= 1 && big_tiles >= bx_min_tiles && force < 0))) {
+    static const int sk = getenv("PFO_GEMM_SKINNY") ? atoi(getenv("PFO_GEMM_SKINNY")) : 1;                  // A/B switch
+    if (g.b_img && g.K[1] == 0 && a_rowvec && (g.bx_force == 2 || (bx >= 1 && sk && !g.bx_force && force < 0 && big_tiles < bx_min_tiles))) {
+      d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN);
+      if (!g.m_dev) kind = PFO_PROF_GEMM_BX;
+      hipLaunchKernelGGL(gemm_bx_skinny_kernel, dim3((unsigned)pfo_ceil_div(g.M, SK_ROWS), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
+    } else if (g.b_img && g.K[1] == 0 && a_rowvec && (g.bx_force || (bx >= 1 && big_tiles >= bx_min_tiles && force < 0))) {
       d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN);
       if (!g.m_dev) kind = PFO_PROF_GEMM_BX;       // device-side row counts stay "time only"
       hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0,
@@ -1280,6 +1419,7 @@ extern "C" int pfo_gemm_bf16x3(const float* A, int64_t lda, const float* B, int6
   if (int rc = pfo_bimg_launch(&im, 1, (hipStream_t)stream)) return rc;
   PfoGemm g;
   g.A[0] = A; g.lda[0] = lda; g.B[0] = B; g.ldb[0] = ldb; g.K[0] = K; g.C = C; g.ldc = ldc; g.bias = bias;
-  g.M = M; g.N = N; g.relu = relu; g.b_kmajor = b_kmajor ? 1 : 0; g.b_img = workspace; g.bx_force = 1;
+  g.M = M; g.N = N; g.relu = relu; g.b_kmajor = b_kmajor ? 1 : 0; g.b_img = workspace;
+  g.bx_force = M <= 4096 ? 2 : 1;            // short operands take the 32-row kernel, as in the TGN step
   return pfo_gemm_launch(g, (hipStream_t)stream);
 }

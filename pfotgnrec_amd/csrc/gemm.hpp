@@ -31,7 +31,7 @@ struct PfoGemm {
   float* slabs = nullptr; int64_t slab_floats = 0;
   // optional pre-split bf16x3 image of op(B) for source 0 (pfo_bimg_launch); used by the large row-major launches
   const void* b_img = nullptr;
-  int bx_force = 0;                 // take the bf16x3 kernel whatever the launch-size heuristic says (tests)
+  int bx_force = 0;                 // tests: 1 = the 128-row bf16x3 kernel, 2 = the 32-row one, whatever the heuristic says
 };
 
 // Pre-split ("bf16x3") image of a weight operand W(n, k) = src[n*ld + k] (trans = 0) or src[k*ld + n] (trans = 1):

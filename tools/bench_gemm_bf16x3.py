@@ -18,9 +18,16 @@ for M, N, K, label in SHAPES:
     A = torch.randn(M, K, device=dev) * torch.exp(2 * torch.randn(M, K, device=dev))
     B = torch.randn(N, K, device=dev) * torch.exp(2 * torch.randn(N, K, device=dev))
     C = torch.empty(M, N, device=dev)
-    def run():
-        _lib.call("pfo_gemm_f32", A.data_ptr(), K, 0, B.data_ptr(), K, 0, C.data_ptr(), N, None, M, N, K, 0,
-                  ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+    if os.environ.get("BX_API"):      # the pre-split-image path (includes the ~5 us image kernel of the small weight operand)
+        nbytes = _lib.load().pfo_gemm_bf16x3_workspace_bytes(N, K)
+        iws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        def run():
+            _lib.call("pfo_gemm_bf16x3", A.data_ptr(), K, B.data_ptr(), K, 0, C.data_ptr(), N, None, M, N, K, 0,
+                      iws.data_ptr(), nbytes, _lib.stream_ptr())
+    else:
+        def run():
+            _lib.call("pfo_gemm_f32", A.data_ptr(), K, 0, B.data_ptr(), K, 0, C.data_ptr(), N, None, M, N, K, 0,
+                      ws.data_ptr(), ws.numel(), _lib.stream_ptr())
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
