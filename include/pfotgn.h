@@ -115,6 +115,19 @@ int pfo_gemm_bf16x3(const float* A, int64_t lda, const float* B, int64_t ldb, in
                     int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Root list of one batch shard, the node/timestamp arrays the reference concatenates before compute_embedding
+ * (tgn.py:118-124 for the `ours` path, tgn.py:237-239 for the baseline):
+ *   roots   = [ src[lo:hi] | dst[lo:hi] | groups[0][lo:hi, :] | groups[1][lo:hi, :] ... ]
+ *   root_ts = ts of the interaction each root belongs to (edge_times repeated per group element)
+ * groups[g] i32[B * reps[g]] (device pointers in a HOST array of n_groups <= PFO_MAX_ROOT_GROUPS entries), row-major
+ * per interaction.  roots i32[R], root_ts f64[R], R = (hi - lo) * (2 + sum reps).
+ */
+#define PFO_MAX_ROOT_GROUPS 4
+int pfo_roots_assemble(const int32_t* src, const int32_t* dst, const double* ts, int32_t lo, int32_t hi,
+                       const int32_t* const* groups, const int32_t* reps, int32_t n_groups, int32_t* roots,
+                       double* root_ts, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * BPR loss, forward + gradient in one pass (main.py:321-337 / 364-381):
  *   loss = -mean_b log sigmoid( mean_k( s_b.p_b - s_b.n_bk ) )       (sigma of the MEAN difference)
  * emb f32[R,D] holds the roots in the reference's order: [src B | dst B | (p_pos B*n_pos) | neg B*n_neg];

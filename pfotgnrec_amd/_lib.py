@@ -63,6 +63,8 @@ PROTOTYPES = {
     "pfo_gemm_bf16x3_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
     "pfo_gemm_bf16x3": (C.c_int, [_VP, C.c_int64, _VP, C.c_int64, C.c_int32, _VP, C.c_int64, _VP, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, _VP, C.c_int64, _VP]),
+    "pfo_roots_assemble": (C.c_int, [_VP, _VP, _VP, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32,
+                                     _VP, _VP, _VP]),
     "pfo_bpr_loss": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_float, _VP,
                                _VP, _VP, _VP]),
     "pfo_rank_metrics": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP]),

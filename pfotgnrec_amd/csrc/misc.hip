@@ -326,3 +326,49 @@ int pfo_fold_parts_launch(const double* parts, int n_parts, int n, float* out, i
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Root list of one batch shard (tgn.py:118-124 / 237-239): [src | dst | group 0 | group 1 ...] with the edge time of the
+// interaction each root belongs to; group g holds reps[g] nodes per interaction, row-major.
+struct RootsDev { const int32_t* grp[PFO_MAX_ROOT_GROUPS]; int rep[PFO_MAX_ROOT_GROUPS]; int n_groups; };
+__global__ __launch_bounds__(256) void roots_assemble_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                             const double* __restrict__ ts, int lo, int hi, const RootsDev g,
+                                                             int32_t* __restrict__ roots, double* __restrict__ root_ts) {
+  const int b = hi - lo;
+  int64_t total = 2 * (int64_t)b;
+  for (int q = 0; q < g.n_groups; ++q) total += (int64_t)b * g.rep[q];
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t o = e;
+    int node, i;
+    if (o < b) { i = (int)o; node = src[lo + i]; }
+    else if (o < 2 * (int64_t)b) { i = (int)(o - b); node = dst[lo + i]; }
+    else {
+      o -= 2 * (int64_t)b;
+      int q = 0;
+      while (q + 1 < g.n_groups && o >= (int64_t)b * g.rep[q]) { o -= (int64_t)b * g.rep[q]; ++q; }
+      i = (int)(o / g.rep[q]);
+      node = g.grp[q][(int64_t)(lo + i) * g.rep[q] + (o - (int64_t)i * g.rep[q])];
+    }
+    roots[e] = node;
+    root_ts[e] = ts[lo + i];
+  }
+}
+extern "C" int pfo_roots_assemble(const int32_t* src, const int32_t* dst, const double* ts, int32_t lo, int32_t hi,
+                                  const int32_t* const* groups, const int32_t* reps, int32_t n_groups, int32_t* roots,
+                                  double* root_ts, void* stream) {
+  PFO_REQUIRE(src && dst && ts && roots && root_ts && hi > lo && lo >= 0, "bad arguments");
+  PFO_REQUIRE(n_groups >= 0 && n_groups <= PFO_MAX_ROOT_GROUPS && (n_groups == 0 || (groups && reps)), "bad groups");
+  RootsDev g;
+  memset(&g, 0, sizeof(g));
+  g.n_groups = n_groups;
+  int64_t total = 2 * (int64_t)(hi - lo);
+  for (int q = 0; q < n_groups; ++q) {
+    PFO_REQUIRE(groups[q] && reps[q] >= 1, "bad group");
+    g.grp[q] = groups[q]; g.rep[q] = reps[q];
+    total += (int64_t)(hi - lo) * reps[q];
+  }
+  hipLaunchKernelGGL(roots_assemble_kernel, dim3((unsigned)std::min<int64_t>(1024, pfo_ceil_div(total, 256))), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, ts, lo, hi, g, roots, root_ts);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}

@@ -339,6 +339,14 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   // it are what the main stream is waiting for.  All layers share each launch.
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
+  if (c->use_memory) {
+    // the GRU contractions come first on the main stream: their two weight images get their own launch and event
+    PfoBimg im[2];
+    im[0].src = P.w_ih; im[0].ld = d.M; im[0].N = 3 * D; im[0].K = d.M; im[0].trans = 0; im[0].dst = w.iWih;
+    im[1].src = P.w_hh; im[1].ld = D; im[1].N = 3 * D; im[1].K = D; im[1].trans = 0; im[1].dst = w.iWhh;
+    RUN(pfo_bimg_launch(im, 2, ss));
+    HIPOK(hipEventRecord(sd.done, ss), "event record failed");
+  }
   PFO_REQUIRE(hipMemsetAsync(w.zero, 0, w.zero_bytes, ss) == hipSuccess, "memset failed");   // w.zero, w.tickets, Wqk / W1ovT / cqk of every layer
   RUN(pfo_time_encode(w.zero, 1, P.tw, P.tb, D, w.cosb, ss));                  // cos(fma(0, w, b)) (embedding_module.py:92)
   {
@@ -375,10 +383,6 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
       img(p.w1 + E, E + D, D, D, 0, lw.iW1b);    img(p.w1 + E, E + D, D, D, 1, lw.iW1bT);
       img(p.w2, D, D, D, 0, lw.iW2);             img(p.w2, D, D, D, 1, lw.iW2T);
     }
-    if (c->use_memory) {
-      img(P.w_ih, d.M, 3 * D, d.M, 0, w.iWih);
-      img(P.w_hh, D, 3 * D, D, 0, w.iWhh);
-    }
     for (int i = 0; i < n1; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(st1 + i, std::min(PFO_GEMM_MULTI_MAX, n1 - i), ss));
     for (int i = 0; i < n2; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(st2 + i, std::min(PFO_GEMM_MULTI_MAX, n2 - i), ss));
     for (int i = 0; i < ni; i += PFO_BIMG_MAX) RUN(pfo_bimg_launch(im + i, std::min(PFO_BIMG_MAX, ni - i), ss));
@@ -410,8 +414,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
     RUN(pfo_pack_rows_launch(st->msg_table, d.M, st->memory, D, st->has_msg, w.touched, w.n_touched, capP, w.msg_rows,
                              w.h_rows, w.hm, s));
-    HIPOK(hipStreamWaitEvent(s, sd.layer[0], 0), "event wait failed");     // images of W_ih / W_hh (and all composites)
-    composites_awaited = true;
+    HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");         // images of W_ih / W_hh
     PfoGemm gi = g_nt(w.msg_rows, d.M, nullptr, P.w_ih, d.M, w.gi, 3 * D, capP, 3 * D, d.M, P.b_ih);
     gi.m_dev = w.n_touched; gi.b_img = w.iWih;
     RUN(pfo_gemm_launch(gi, s));

@@ -339,12 +339,17 @@ class TGN(nn.Module):
         if self.dp_world > 1:
             per = (B + self.dp_world - 1) // self.dp_world
             lo, hi = min(B, self.dp_rank * per), min(B, (self.dp_rank + 1) * per)
-        parts, ts_parts = [src[lo:hi], dst[lo:hi]], [edge_times[lo:hi], edge_times[lo:hi]]
-        for t, r in zip(extra_roots, extra_repeat):
-            parts.append(t.view(B, r)[lo:hi].reshape(-1))
-            ts_parts.append(edge_times[lo:hi].repeat_interleave(r))          # tgn.py:123-124 / 238-239
-        roots = torch.cat(parts).contiguous()
-        root_ts = torch.cat(ts_parts).contiguous()
+        # roots = [src | dst | extra groups], root_ts = the interaction's edge time per root (tgn.py:123-124 / 238-239)
+        R = (hi - lo) * (2 + sum(int(r) for r in extra_repeat))
+        roots = torch.empty(R, dtype=torch.int32, device=self.device)
+        root_ts = torch.empty(R, dtype=torch.float64, device=self.device)
+        extra_roots = [t.contiguous() for t in extra_roots]
+        ng = len(extra_roots)
+        gptr = (ctypes.c_void_p * max(1, ng))(*[t.data_ptr() for t in extra_roots])
+        greps = (ctypes.c_int32 * max(1, ng))(*[int(r) for r in extra_repeat])
+        if hi > lo:
+            _lib.call("pfo_roots_assemble", src.data_ptr(), dst.data_ptr(), edge_times.data_ptr(), lo, hi, gptr, greps, ng,
+                      roots.data_ptr(), root_ts.data_ptr(), _lib.stream_ptr())
         if K <= 0:                       # utils.py:175: a single all-padding column
             K, root_ts = 1, torch.full_like(root_ts, -1.0)
         training = self.training and torch.is_grad_enabled()
