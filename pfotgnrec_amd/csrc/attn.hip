@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const int cc = lane + 64 * r;
-        kn[c][r] = (js[c] >= 0 && cc < D) ? src[cc] : 0.f;
+        kn[c][r] = (js[c] >= 0 && (r < NR - 1 || cc < D)) ? src[cc] : 0.f;
       }
       ke[c] = (js[c] >= 0 && lane < Ef) ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
     }
@@ -124,7 +124,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const int cc = lane + 64 * r;
-        kt[c][r] = (js[c] >= 0 && cc < D) ? pfo_cosf(pfo_time_arg(dtv[c], tw[r], tb[r])) : 0.f;
+        // lanes beyond D (last r only) evaluate a harmless cosine and are masked by a select, not a branch
+        const float cv = pfo_cosf(pfo_time_arg(dtv[c], tw[r], tb[r]));
+        kt[c][r] = (js[c] >= 0 && (r < NR - 1 || cc < D)) ? cv : 0.f;
       }
 #pragma unroll
       for (int h = 0; h < H; ++h) {
@@ -184,13 +186,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
 #define ATTN_BWD_MAX_BLOCKS 2048
 int pfo_attn_bwd_max_parts() { return ATTN_BWD_MAX_BLOCKS; }
 
-template <int NR, int H>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
+// DMODE: what happens to the neighbour-row gradients - 0 none (layer 1 without memory: level-0 rows are constants),
+// 1 float atomics into the rows `nbr_row` names (layer 1 over the touched-node table), 2 plain stores (layers >= 2,
+// where every (instance, slot) owns its row).  A template parameter: as a run-time test it cost three scalar branch
+// sequences per key inside the inner loop.
+template <int NR, int H, int DMODE>
+__device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
   __shared__ double s_red[4][2][NR * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef, Cp = a.Cp;
-  const bool direct = (a.nbr_row == nullptr);          // neighbour rows are consecutive (layers >= 2)
-  const bool wdirect = direct && a.d_nbr != nullptr;     // ... and their gradients are written, not accumulated
+  constexpr bool wdirect = (DMODE == 2);                // ... and their gradients are written, not accumulated
+  const bool direct = (a.nbr_row == nullptr);
   float tw[NR], tb[NR];
   double dw[NR], db[NR];     // sums of terms scaled by dt ~ 1e7 with heavy cancellation: accumulate in fp64
 #pragma unroll
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           const int cc = lane + 64 * r;
-          kn[c][r] = (js[c] >= 0 && cc < D) ? src[cc] : 0.f;
+          kn[c][r] = (js[c] >= 0 && (r < NR - 1 || cc < D)) ? src[cc] : 0.f;
         }
         ke[c] = (js[c] >= 0 && lane < Ef) ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
       }
@@ -294,10 +300,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           const int cc = lane + 64 * r;
-          float sv = 0.f, cv = 0.f;
-          if (js[c] >= 0 && cc < D) pfo_sincosf(pfo_time_arg(dtv[c], tw[r], tb[r]), sv, cv);
-          kt[c][r] = cv;
-          ks[c][r] = sv;
+          float sv, cv;
+          pfo_sincosf(pfo_time_arg(dtv[c], tw[r], tb[r]), sv, cv);
+          const bool on = js[c] >= 0 && (r < NR - 1 || cc < D);     // select, not a branch (only the last r can be off)
+          kt[c][r] = on ? cv : 0.f;
+          ks[c][r] = on ? sv : 0.f;
         }
 #pragma unroll
         for (int h = 0; h < H; ++h) {
@@ -331,9 +338,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
           }
           dqe[h] = fmaf(cB[h], ke[c], dqe[h]);
         }
-        float* dst = a.d_nbr ? a.d_nbr + (int64_t)rows[c] * a.d_nbr_ld : nullptr;
-        if (a.abl == 1 && dst) dst = a.d_nbr + (int64_t)((((unsigned)rows[c] * 2654435761u) + (unsigned)n * 40503u) % 8192u) * a.d_nbr_ld;
-        if (a.abl == 2) dst = nullptr;
+        float* dst = (DMODE != 0) ? a.d_nbr + (int64_t)rows[c] * a.d_nbr_ld : nullptr;
+        if (DMODE == 1 && a.abl == 1) dst = a.d_nbr + (int64_t)((((unsigned)rows[c] * 2654435761u) + (unsigned)n * 40503u) % 8192u) * a.d_nbr_ld;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           const int cc = lane + 64 * r;
@@ -343,14 +349,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnDev a) {
             dkn = fmaf(cA[h], gn[h][r], fmaf(cB[h], qn[h][r], dkn));
             dkt = fmaf(cA[h], gt[h][r], fmaf(cB[h], qt[h][r], dkt));
           }
-          if (cc < D) {
-            if (dst) {
-              if (direct) dst[cc] = dkn; else atomicAdd(dst + cc, dkn);
-            }
-            const float gsin = -ks[c][r] * dkt;          // d/d(arg) cos(arg) = -sin(arg)
-            dw[r] += (double)gsin * (double)dtv[c];
-            db[r] += (double)gsin;
+          if (r < NR - 1 || cc < D) {                    // 64 * (NR - 1) < D: only the last r needs the lane test
+            if (DMODE == 2) dst[cc] = dkn;
+            else if (DMODE == 1 && a.abl != 2) atomicAdd(dst + cc, dkn);
           }
+          const float gsin = -ks[c][r] * dkt;            // d/d(arg) cos(arg) = -sin(arg); ks = 0 on lanes beyond D
+          dw[r] += (double)gsin * (double)dtv[c];
+          db[r] += (double)gsin;
         }
       }
     }
@@ -429,6 +434,9 @@ static int check_common(const PfoAttn& a) {
     PFO_REQUIRE(done, "unsupported (D, H) combination");                                                      \
   }
 
+template <int NR, int H> __global__ __launch_bounds__(256, (H <= 2 && NR <= 3) ? 3 : 2) void attn_bwd_kernel_none(const AttnDev a) { attn_bwd_body<NR, H, 0>(a); }
+template <int NR, int H> __global__ __launch_bounds__(256, (H <= 2 && NR <= 3) ? 3 : 2) void attn_bwd_kernel(const AttnDev a) { attn_bwd_body<NR, H, 1>(a); }
+template <int NR, int H> __global__ __launch_bounds__(256, (H <= 2 && NR <= 3) ? 3 : 2) void attn_bwd_kernel_direct(const AttnDev a) { attn_bwd_body<NR, H, 2>(a); }
 int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream) {
   if (int rc = check_common(a)) return rc;
   AttnDev d;
@@ -452,8 +460,11 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
   // rows read again + their gradient rows written/added, qk + dctx + ctx in, dqk out
   const double C = 2.0 * a.D + a.Ef;
   const double bytes = (double)a.N * (a.K * (8.0 * a.D + 4.0 * a.Ef + 12.0) + 4.0 * a.H * C * 4.0 + 4.0 * a.H * a.K);
+  const int dmode = !a.d_nbr ? 0 : (a.nbr_row ? 1 : 2);
   pfo_prof_begin(stream);
-  ATTN_DISPATCH(attn_bwd_kernel, grid);
+  if (dmode == 0) { ATTN_DISPATCH(attn_bwd_kernel_none, grid); }
+  else if (dmode == 1) { ATTN_DISPATCH(attn_bwd_kernel, grid); }
+  else { ATTN_DISPATCH(attn_bwd_kernel_direct, grid); }
   PFO_LAUNCH_CHECK();
   pfo_prof_end(PFO_PROF_ATTN_BWD, bytes, stream);
   if (n_parts) *n_parts = grid;

@@ -56,15 +56,22 @@ __device__ __attribute__((noinline)) float pfo_revolutions_f64(float x) {
   return (float)(r * 0.15915494309189533577);
 }
 
-__device__ __forceinline__ float pfo_revolutions(float x) {
+__device__ __forceinline__ float pfo_revolutions_fast(float x) {
 #pragma clang fp contract(off)   // p below is reused as a ROUNDED product: no implicit FMA formation in this function
-  if (fabsf(x) < 2.0e7f) {
-    const float C_HI = 0.15915493667125702f, C_LO = 6.4206382432985265e-09f;
-    const float p = x * C_HI;
-    const float e = __builtin_fmaf(x, C_HI, -p);               // exact rounding error of p
-    return (p - rintf(p)) + __builtin_fmaf(x, C_LO, e);
+  const float C_HI = 0.15915493667125702f, C_LO = 6.4206382432985265e-09f;
+  const float p = x * C_HI;
+  const float e = __builtin_fmaf(x, C_HI, -p);               // exact rounding error of p
+  return (p - rintf(p)) + __builtin_fmaf(x, C_LO, e);
+}
+// The out-of-range test is taken wave-wide (one scalar branch; a per-lane branch around the call costs a dozen scalar
+// instructions per evaluation in the attention kernels): only a wavefront that holds such a lane runs the fp64 path.
+__device__ __forceinline__ float pfo_revolutions(float x) {
+  const bool big = !(fabsf(x) < 2.0e7f);
+  float u = pfo_revolutions_fast(x);
+  if (__builtin_expect(__ballot(big) != 0ull, 0)) {
+    if (big) u = pfo_revolutions_f64(x);
   }
-  return pfo_revolutions_f64(x);
+  return u;
 }
 
 __device__ __forceinline__ void pfo_sincosf(float x, float& s, float& c) {

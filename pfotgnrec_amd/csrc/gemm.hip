@@ -1104,8 +1104,19 @@ __global__ __launch_bounds__(256) void tn_group_reduce_kernel(const TnGroupDev g
     const int64_t total = (int64_t)pr.M * pr.N;
     const float* slab = g.slabs + pr.slab_off;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-      float s = 0.f;
-      for (int z = 0; z < nz; ++z) s += slab[(int64_t)z * total + e];
+      // eight slab loads in flight per thread; the summation order (z ascending within four interleaved chains, then a
+      // fixed tree) depends on nz only, so the result is reproducible
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int z = 0;
+      for (; z + 8 <= nz; z += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = slab[(int64_t)(z + u) * total + e];
+        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+        s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
+      }
+      for (; z < nz; ++z) s0 += slab[(int64_t)z * total + e];
+      const float s = (s0 + s1) + (s2 + s3);
       const int m = (int)(e / pr.N), n = (int)(e - (int64_t)m * pr.N);
       if (n < pr.N_real) {
         float* o = pr.C + (int64_t)m * pr.ldc + n;
