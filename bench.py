@@ -52,6 +52,7 @@ def parse():
 
 
 PMC_KERNEL = {"gemm_bx": "void gemm_bf16x3_kernel<true>", "gemm_tn_bx": "gemm_tn_group_bx_kernel",
+              "gemm_bx_skinny": "gemm_bx_skinny_kernel",
               "gemm_nt": "void gemm_f32_kernel<false, false, 0, true>",
               "gemm_nn": "void gemm_f32_kernel<false, true, 0, true>",
               "gemm_tn": "void gemm_tn_group_kernel<true>",
@@ -251,7 +252,7 @@ def main():
         v = fam[dom]
         per_launch_s = v["ms"] / v["count"] * 1e-3
         if dom.startswith("gemm"):
-            peak = MFMA_BF16_PEAK_TF / 6.0 if dom in ("gemm_bx", "gemm_tn_bx") else MFMA_F32_PEAK_TF
+            peak = MFMA_BF16_PEAK_TF / 6.0 if dom in ("gemm_bx", "gemm_tn_bx", "gemm_bx_skinny") else MFMA_F32_PEAK_TF
             achieved = v["work"] / v["count"] / per_launch_s / 1e12
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None}
@@ -266,7 +267,7 @@ def main():
         roof["sampled_steps"] = n_prof_steps
         roof["families_ms_per_step"] = {k: round(x["ms"] / max(1, n_prof_steps), 4) for k, x in prof.items() if x["count"] > 0}
         tot = lambda ks: sum(prof[k]["work"] for k in ks) / max(1e-9, sum(prof[k]["ms"] for k in ks) * 1e-3)
-        roof["gemm_all_tflops"] = round(tot(["gemm_nt", "gemm_nn", "gemm_tn", "gemm_bx", "gemm_tn_bx"]) / 1e12, 2)
+        roof["gemm_all_tflops"] = round(tot(["gemm_nt", "gemm_nn", "gemm_tn", "gemm_bx", "gemm_tn_bx", "gemm_bx_skinny"]) / 1e12, 2)
         roof["attn_all_gbs"] = round(tot(["attn_fwd", "attn_bwd"]) / 1e9, 1)
         out["roofline"] = roof
     if not args.no_cpu_baseline and world == 1:

@@ -1287,7 +1287,7 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
     static const int sk = getenv("PFO_GEMM_SKINNY") ? atoi(getenv("PFO_GEMM_SKINNY")) : 1;                  // A/B switch
     if (g.b_img && g.K[1] == 0 && a_rowvec && (g.bx_force == 2 || (bx >= 1 && sk && !g.bx_force && force < 0 && big_tiles < bx_min_tiles))) {
       d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN);
-      if (!g.m_dev) kind = PFO_PROF_GEMM_BX;
+      if (!g.m_dev) kind = PFO_PROF_GEMM_BX_SKINNY;
       hipLaunchKernelGGL(gemm_bx_skinny_kernel, dim3((unsigned)pfo_ceil_div(g.M, SK_ROWS), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
     } else if (g.b_img && g.K[1] == 0 && a_rowvec && (g.bx_force || (bx >= 1 && big_tiles >= bx_min_tiles && force < 0))) {
       d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN);
