@@ -1,0 +1,198 @@
+"""Parity at BASELINE.json's full C2 size (50 000 users x 500 items, 1 M edges, L2 K20 D172 H2, batch 512).
+
+One complete training step against the oracle with every node holding a pending message (the state the large bf16x3
+kernels, the grouped weight gradients and the 12 k-row GRU see in `bench.py`), plus size-independent properties of the
+path: strictly-before / sorted / right-aligned sampling, permutation equivariance and duplicate-root idempotence of the
+embeddings (bitwise in eval mode), linearity of the backward in the upstream gradient, and the memory state machine.
+"""
+import numpy as np
+import pytest
+import torch
+
+import pfotgnrec_amd as P
+from pfotgnrec_amd.synthetic import CONFIGS, make_graph
+from oracle import tgn_oracle as T
+from oracle.neighbor_finder import OracleNeighborFinder, build_adjacency
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RTOL_EMB = 1e-4          # north_star: embeddings within 1e-4 relative
+RTOL_GRAD_L2 = 2e-3      # relative L2 of a parameter gradient (ReLU kinks flip for a handful of the 9 M hidden units)
+RTOL_GRAD_TIME = 5e-3    # time-encoder gradients: sums of terms scaled by dt ~ 1e7 with heavy cancellation
+
+
+def relerr(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def c2():
+    cfg = CONFIGS["C2"]
+    g = make_graph(cfg, with_prices=False)
+    nf = P.get_neighbor_finder(g.data, uniform=False)
+    return cfg, g, nf
+
+
+def _model(cfg, g, nf, seed=3):
+    torch.manual_seed(seed)
+    tgn = P.TGN(nf, g.node_features, g.edge_features, DEV, n_layers=cfg.n_layers, n_heads=cfg.n_heads, dropout=0.0,
+                use_memory=True, memory_dimension=cfg.dim, message_function="identity", n_neighbors=cfg.n_neighbors)
+    with torch.no_grad():
+        tgn.time_encoder.w.bias.normal_(0, 0.3)
+        for att in tgn.embedding_module.attention_models:
+            att.multi_head_target.in_proj_bias.normal_(0, 0.1)
+            att.multi_head_target.out_proj.bias.normal_(0, 0.1)
+    return tgn
+
+
+def _steady_state(tgn, g, cfg, rs):
+    """Every node holds a pending message and a non-zero memory; returns the numpy copies for the oracle."""
+    M = 3 * cfg.dim + cfg.edge_dim
+    msgs = (rs.randn(g.n_nodes, M) * 0.1).astype(np.float32)
+    mem = (rs.randn(g.n_nodes, cfg.dim) * 0.1).astype(np.float32)
+    m = tgn.memory
+    with torch.no_grad():
+        m.memory.copy_(torch.from_numpy(mem))
+        m.msg_table.copy_(torch.from_numpy(msgs))
+        m.msg_time.zero_()
+        m.last_update.zero_()
+        m.has_msg.fill_(1)
+        m.has_msg[0] = 0
+    return msgs, mem
+
+
+def test_full_size_training_step_against_oracle(c2):
+    cfg, g, nf = c2
+    d = g.data
+    tgn = _model(cfg, g, nf)
+    rs = np.random.RandomState(11)
+    msgs, mem = _steady_state(tgn, g, cfg, rs)
+    onf = OracleNeighborFinder(*build_adjacency(d.sources, d.destinations, d.edge_idxs, d.timestamps), uniform=False)
+    names = [k for k in tgn.state_dict() if "layer_norm" not in k and not k.startswith("memory.")]
+    ref = T.OracleTGN(onf, g.node_features, g.edge_features, {k: tgn.state_dict()[k].cpu().numpy() for k in names},
+                      cfg.n_layers, cfg.n_heads, True)
+    for v in range(1, g.n_nodes):
+        ref.messages[v] = [(msgs[v], np.float32(0))]
+    ref.memory = mem.copy()
+
+    B, K = 512, cfg.n_neighbors
+    s = cfg.n_edges // 2
+    sb, db, tb, eb = d.sources[s:s + B], d.destinations[s:s + B], d.timestamps[s:s + B], d.edge_idxs[s:s + B]
+    neg = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * 3)
+    tgn.train()
+    se, de, ne = tgn.compute_temporal_embeddings(sb, db, neg, tb, eb, K)
+    rse, rde, rne = ref.compute_temporal_embeddings(sb, db, neg, tb, eb, K)
+    emb = torch.cat([se, de, ne])
+    remb = np.concatenate([rse, rde, rne])
+    e = relerr(emb.detach().cpu().numpy(), remb)
+    assert e < RTOL_EMB, e
+    loss = P.bpr_loss(emb, B, 3)
+    loss.backward()
+    rl, cache = T.bpr_loss(rse, rde.reshape(B, 1, -1), rne.reshape(B, 3, -1))
+    assert abs(float(loss.detach()) - float(rl)) < 1e-5
+    ds, dp, dn = T.bpr_loss_backward(cache)
+    rgrads = ref.backward(np.concatenate([ds, dp.reshape(B, -1), dn.reshape(3 * B, -1)]))
+    checked = 0
+    for name, p in tgn.named_parameters():
+        if name not in rgrads:
+            continue
+        r = rgrads[name].reshape(p.shape)
+        if np.abs(r).max() < 1e-7:
+            continue
+        got = p.grad.cpu().numpy().astype(np.float64)
+        err = np.linalg.norm(got - r) / (np.linalg.norm(r) + 1e-30)
+        assert err < (RTOL_GRAD_TIME if name.startswith("time_encoder") else RTOL_GRAD_L2), (name, err)
+        checked += 1
+    assert checked >= 20
+    # memory state machine: persisted rows, last_update, pending messages of the positives
+    assert relerr(tgn.memory.memory.cpu().numpy(), ref.memory) < RTOL_EMB
+    assert np.array_equal(tgn.memory.last_update.cpu().numpy(), ref.last_update)
+    tab, mt, has = ref.pending_table()
+    assert np.array_equal(tgn.memory.has_msg.cpu().numpy() > 0, has)
+    pos = np.unique(np.concatenate([sb, db]))
+    assert relerr(tgn.memory.msg_table.cpu().numpy()[pos], tab[pos]) < RTOL_EMB
+    assert np.array_equal(tgn.memory.msg_time.cpu().numpy()[pos], mt[pos])
+
+
+def test_full_size_sampler_invariants(c2):
+    cfg, g, nf = c2
+    d = g.data
+    rs = np.random.RandomState(5)
+    N, K = 60000, cfg.n_neighbors
+    q = rs.randint(0, g.n_nodes, size=N)
+    t = d.timestamps[rs.randint(0, cfg.n_edges, size=N)].astype(np.float64)
+    nbr, eid, et = nf.get_temporal_neighbor(q, t, K)
+    valid = nbr != 0
+    # right-aligned: once a slot is valid every later slot is valid (utils.py:216-218)
+    assert np.all(valid[:, 1:] >= valid[:, :-1])
+    # strictly before the query time (utils.py:158) and ascending in time within a row
+    assert np.all(et[valid] < np.repeat(t[:, None], K, 1)[valid])
+    tt = np.where(valid, et, -np.inf)
+    assert np.all(tt[:, 1:] >= tt[:, :-1])
+    # every returned (neighbour, edge) is an edge incident to the query node, at the returned time
+    e = eid[valid].astype(np.int64) - 1
+    qq = np.repeat(q[:, None], K, 1)[valid]
+    other = np.where(d.sources[e] == qq, d.destinations[e], d.sources[e])
+    assert np.all((d.sources[e] == qq) | (d.destinations[e] == qq))
+    assert np.array_equal(other, nbr[valid])
+    assert np.array_equal(d.timestamps[e].astype(np.float32), et[valid])
+    # padding carries (0, 0, 0.0)
+    assert np.all(eid[~valid] == 0) and np.all(et[~valid] == 0)
+    # a sample of rows against the host restatement, bit-exact
+    onf = OracleNeighborFinder(*build_adjacency(d.sources, d.destinations, d.edge_idxs, d.timestamps), uniform=False)
+    sel = rs.choice(N, 3000, replace=False)
+    rn, re_, rt = onf.get_temporal_neighbor(q[sel], t[sel], K)
+    assert np.array_equal(rn, nbr[sel]) and np.array_equal(re_, eid[sel]) and np.array_equal(rt, et[sel])
+
+
+def test_full_size_embedding_properties(c2):
+    """Eval mode (no dropout): outputs are a pure function of (root, time): permuting the batch permutes the rows
+    bitwise, duplicated roots get identical rows, and the backward is linear in the upstream gradient."""
+    cfg, g, nf = c2
+    d = g.data
+    tgn = _model(cfg, g, nf, seed=4)
+    rs = np.random.RandomState(2)
+    _steady_state(tgn, g, cfg, rs)
+    B, K = 512, cfg.n_neighbors
+    s = cfg.n_edges // 2 + 4096
+    sb, db, tb, eb = d.sources[s:s + B], d.destinations[s:s + B], d.timestamps[s:s + B], d.edge_idxs[s:s + B]
+    neg = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * 3)
+    neg[3:6] = neg[0:3]                        # interaction 1 reuses interaction 0's negatives ...
+    tb = tb.copy(); tb[1] = tb[0]              # ... at the same time: duplicate (node, time) roots
+    snap = (tgn.memory.memory.clone(), tgn.memory.last_update.clone(), tgn.memory.msg_table.clone(),
+            tgn.memory.msg_time.clone(), tgn.memory.has_msg.clone())
+
+    def restore():
+        with torch.no_grad():
+            tgn.memory.memory.copy_(snap[0]); tgn.memory.last_update.copy_(snap[1]); tgn.memory.msg_table.copy_(snap[2])
+            tgn.memory.msg_time.copy_(snap[3]); tgn.memory.has_msg.copy_(snap[4])
+
+    tgn.eval()
+    with torch.no_grad():
+        se, de, ne = tgn.compute_temporal_embeddings(sb, db, neg, tb, eb, K)
+        ne = ne.view(B, 3, -1)
+        assert torch.equal(ne[0], ne[1])                                   # duplicate roots -> identical rows
+        restore()
+        perm = rs.permutation(B)
+        se2, de2, ne2 = tgn.compute_temporal_embeddings(sb[perm], db[perm], neg.reshape(B, 3)[perm].reshape(-1), tb[perm],
+                                                        eb[perm], K)
+        pt = torch.from_numpy(perm).to(DEV)
+        assert torch.equal(se2, se[pt]) and torch.equal(de2, de[pt]) and torch.equal(ne2.view(B, 3, -1), ne[pt])
+    # linearity of the backward in the upstream gradient (power-of-two scale: exact up to the atomics' summation order)
+    grads = []
+    for scale in (1.0, 4.0):
+        restore()
+        tgn.train()                            # dropout = 0 in this model
+        for p in tgn.parameters():
+            p.grad = None
+        se, de, ne = tgn.compute_temporal_embeddings(sb, db, neg, tb, eb, K)
+        emb = torch.cat([se, de, ne])
+        w = torch.linspace(-1, 1, emb.numel(), device=DEV).view_as(emb)
+        (emb * w).sum().mul(scale).backward()
+        grads.append({n: p.grad.clone() for n, p in tgn.named_parameters() if p.grad is not None})
+    for n, g1 in grads[0].items():
+        g4 = grads[1][n]
+        den = g1.abs().max().item()
+        if den < 1e-12:
+            continue
+        assert ((g4 / 4.0 - g1).abs().max().item() / den) < 2e-5, n
