@@ -60,9 +60,6 @@ static bool aligned4(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 #ifndef GEMM_EXP
 #define GEMM_EXP 0       // timing-only ablations (wrong results): 1 = no global loads / LDS stores after the first tile, 2 = no MFMA,
 #endif                   //                                          3 = no barriers + no reloads
-#ifndef GEMM_DBUF
-#define GEMM_DBUF 0      // 1: two LDS buffers, one barrier per k-tile (1 workgroup per CU)
-#endif
 
 // four consecutive floats of which `nv` lie inside the matrix; `safe` is any valid 16-byte aligned address,
 // loaded instead of an out-of-range one so that the load itself needs no branch
@@ -90,14 +87,14 @@ __device__ __forceinline__ float4 ld4(const float* p, int nv, const float* safe)
 template <bool A_KM, bool B_KM, int TILE, bool VEC>
 __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const int by, int zb, const int split_in,
                                           float* __restrict__ lds_a, float* __restrict__ lds_b) {
-  constexpr bool SMALL = (TILE == 1), MED = (TILE == 2);
-  constexpr int TBM = SMALL ? 32 : (MED ? 64 : BM);
+  constexpr bool SMALL = (TILE == 1);
+  constexpr int TBM = SMALL ? 32 : BM;
   constexpr int NJ = SMALL ? 3 : 11;
-  constexpr int NI = MED ? 1 : 2;              // 16-row strips per wavefront
+  constexpr int NI = 2;                        // 16-row strips per wavefront
   constexpr int NA = TBM / 32;                 // float4 per thread for the A tile
-  constexpr int LDAK = MED ? 80 : LDA_KM;      // k-major A row stride, = 16 mod 32
-  float* const As[2] = {lds_a, lds_a + AS_FLOATS};   // second buffer only exists with GEMM_DBUF
-  float* const Bs[2] = {lds_b, lds_b + BS_FLOATS};
+  constexpr int LDAK = LDA_KM;                 // k-major A row stride, = 16 mod 32
+  float* const As[1] = {lds_a};
+  float* const Bs[1] = {lds_b};
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -118,7 +115,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
     kbeg = split * chunk;
     kend0 = min(Kext0, kbeg + chunk);
   }
-  const int wrow = SMALL ? 0 : (MED ? 16 * wave : 32 * wave);      // first tile row of this wavefront
+  const int wrow = SMALL ? 0 : 32 * wave;      // first tile row of this wavefront
   const int wcol = SMALL ? 16 * wave : 0;      // first tile column; SMALL strides columns by 64
 
   f32x4 acc[NI][NJ];
@@ -299,16 +296,10 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
     for (int t = 0; t < T; ++t) {
       const bool more = (GEMM_EXP == 1 || GEMM_EXP == 3) ? false : (t + 1 < T);
       if (more) load_tile(t + 1);                // global loads in flight during the MFMAs below
-      if (GEMM_DBUF) {
-        compute_tile(t & 1);
-        if (more) store_tile((t + 1) & 1);
-        __syncthreads();
-      } else {
-        if (GEMM_EXP != 2) compute_tile(0);
-        if (GEMM_EXP != 3) __syncthreads();      // every wavefront is done reading the tile
-        if (more) store_tile(0);
-        if (GEMM_EXP != 3) __syncthreads();
-      }
+      if (GEMM_EXP != 2) compute_tile(0);
+      if (GEMM_EXP != 3) __syncthreads();        // every wavefront is done reading the tile
+      if (more) store_tile(0);
+      if (GEMM_EXP != 3) __syncthreads();
     }
   }
 
@@ -352,8 +343,8 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
 }
 
 #define GEMM_LDS_DECL                                                                    \
-  __shared__ __attribute__((aligned(16))) float lds_a[(GEMM_DBUF ? 2 : 1) * AS_FLOATS]; \
-  __shared__ __attribute__((aligned(16))) float lds_b[(GEMM_DBUF ? 2 : 1) * BS_FLOATS]
+  __shared__ __attribute__((aligned(16))) float lds_a[AS_FLOATS]; \
+  __shared__ __attribute__((aligned(16))) float lds_b[BS_FLOATS]
 
 template <bool A_KM, bool B_KM, int TILE, bool VEC>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(const GemmDev p) {
@@ -1175,23 +1166,6 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
   return PFO_OK;
 }
 
-// sums the split-K slabs: out[m, n] (+)= sum_z slab[z][m][n]
-__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int nsplit, int split_chunk,
-                                     const int32_t* __restrict__ k_dev, int Kfull, int M, int N, float* __restrict__ out,
-                                     int64_t ldo, int accumulate) {
-  int K = Kfull;
-  if (k_dev) K = min(K, *k_dev);
-  int nz = (K + split_chunk - 1) / split_chunk;
-  nz = min(nz, nsplit);
-  const int64_t total = (int64_t)M * N;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < nz; ++z) s += slabs[(int64_t)z * total + e];
-    const int m = (int)(e / N), n = (int)(e - (int64_t)m * N);
-    float* o = out + (int64_t)m * ldo + n;
-    *o = accumulate ? (*o + s) : s;
-  }
-}
 
 static void to_dev(const PfoGemm& g, GemmDev& d) {
   for (int s = 0; s < 2; ++s) {
@@ -1271,13 +1245,13 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
     }
     if (g.b_kmajor) GEMM_GO(true, true, 0, dim3(tm, tn, g.batch)); else GEMM_GO(true, false, 0, dim3(tm, tn, g.batch));
   } else {
-    // tile rows per workgroup: 128 (BIG), 64 (MED: finer tail quantisation, 3 workgroups per CU) or 32 (SMALL: the
-    // layer-2 launches, where 128-row tiles would leave most of the 256 CUs without work)
-    static const int force = getenv("PFO_GEMM_TILE") ? atoi(getenv("PFO_GEMM_TILE")) : -1;   // A/B switch: 0 BIG, 1 SMALL, 2 MED
+    // tile rows per workgroup: 128 (BIG) or 32 (SMALL: launches where 128-row tiles would leave most of the 256 CUs
+    // without work)
+    static const int force = getenv("PFO_GEMM_TILE") ? (atoi(getenv("PFO_GEMM_TILE")) != 0 ? 1 : 0) : -1;   // A/B switch: 0 BIG, 1 SMALL
     const int64_t big_tiles = (int64_t)pfo_ceil_div(g.M, BM) * tn * g.batch;
     int tile = big_tiles < 400 ? 1 : PFO_DEFAULT_TILE;
     if (force >= 0) tile = force;
-    const int rows = tile == 1 ? 32 : (tile == 2 ? 64 : BM);
+    const int rows = tile == 1 ? 32 : BM;
     const dim3 grid((unsigned)pfo_ceil_div(g.M, rows), tn, g.batch);
     // bf16x3 split contraction: 1 = when the caller supplies the pre-split image of B, 2 = also for plain row-major
     // B (split in the kernel), 0 = never (fp32 MFMA everywhere).  A/B switch.
@@ -1298,9 +1272,9 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
       kind = PFO_PROF_GEMM_BX;
       hipLaunchKernelGGL(gemm_bf16x3_kernel<false>, grid, dim3(GEMM_THREADS), 0, stream, d);
     } else if (g.b_kmajor) {
-      if (tile == 1) GEMM_GO(false, true, 1, grid); else if (tile == 2) GEMM_GO(false, true, 2, grid); else GEMM_GO(false, true, 0, grid);
+      if (tile == 1) GEMM_GO(false, true, 1, grid); else GEMM_GO(false, true, 0, grid);
     } else {
-      if (tile == 1) GEMM_GO(false, false, 1, grid); else if (tile == 2) GEMM_GO(false, false, 2, grid); else GEMM_GO(false, false, 0, grid);
+      if (tile == 1) GEMM_GO(false, false, 1, grid); else GEMM_GO(false, false, 0, grid);
     }
   }
 #undef GEMM_GO
@@ -1349,59 +1323,6 @@ int pfo_gemm_multi_launch(const PfoGemm* list, int n, hipStream_t stream) {
   return PFO_OK;
 }
 
-// ---------------------------------------------------------------------------------------------
-// column sums (bias gradients): two deterministic stages.  Stage 1: workgroup = 64 columns x 4 row lanes
-// over one of CS_CHUNKS row chunks (coalesced 256-byte row pieces); stage 2 folds the chunk partials.
-#define CS_CHUNKS 256
-__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X, int64_t ldx, int M, int N,
-                                                     const float* __restrict__ scale, int64_t scale_ld,
-                                                     const int32_t* __restrict__ m_dev, float* __restrict__ part) {
-  __shared__ float s_red[4][64];
-  int Mlim = M;
-  if (m_dev) Mlim = min(Mlim, *m_dev);
-  const int chunk = blockIdx.y;
-  const int rows_per = (Mlim + CS_CHUNKS - 1) / CS_CHUNKS;
-  const int rbeg = chunk * rows_per, rend = min(Mlim, rbeg + rows_per);
-  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + c;
-  float s = 0.f;
-  if (col < N)
-    for (int m = rbeg + rl; m < rend; m += 4) {
-      const float v = X[(int64_t)m * ldx + col];
-      s += scale ? v * scale[(int64_t)m * scale_ld] : v;
-    }
-  s_red[rl][c] = s;
-  __syncthreads();
-  if (rl == 0 && col < N) part[(int64_t)chunk * N + col] = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
-}
-__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, int N, float* __restrict__ out,
-                                                     int accumulate) {
-  __shared__ float s_red[4][64];
-  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + c;
-  float s = 0.f;
-  if (col < N)
-    for (int k = rl; k < CS_CHUNKS; k += 4) s += part[(int64_t)k * N + col];
-  s_red[rl][c] = s;
-  __syncthreads();
-  if (rl == 0 && col < N) {
-    const float t = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
-    out[col] = accumulate ? out[col] + t : t;
-  }
-}
-int64_t pfo_colsum_scratch_floats(int N) { return (int64_t)CS_CHUNKS * N; }
-
-int pfo_colsum_launch(const float* X, int64_t ldx, int M, int N, const float* scale, int64_t scale_ld,
-                      const int32_t* m_dev, float* out, int accumulate, float* scratch, hipStream_t stream) {
-  PFO_REQUIRE(X && out && scratch && M > 0 && N > 0, "bad arguments");
-  hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)pfo_ceil_div(N, 64), CS_CHUNKS), dim3(256), 0, stream, X, ldx, M, N,
-                     scale, scale_ld, m_dev, scratch);
-  PFO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)pfo_ceil_div(N, 64)), dim3(256), 0, stream, scratch, N, out,
-                     accumulate);
-  PFO_LAUNCH_CHECK();
-  return PFO_OK;
-}
 
 // ---------------------------------------------------------------------------------------------
 extern "C" int pfo_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, int64_t ldb,

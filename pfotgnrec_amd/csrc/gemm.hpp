@@ -64,7 +64,3 @@ struct PfoTnProblem {
 // all problems share the K extent (and its optional device-side bound); one GEMM launch + one reduce launch
 int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int32_t* k_dev, float* slabs,
                              int64_t slab_floats, hipStream_t stream);
-// out[n] (+)= sum_m X[m,n] * (scale ? scale[m*scale_ld] : 1); rows limited by m_dev when given
-int pfo_colsum_launch(const float* X, int64_t ldx, int M, int N, const float* scale, int64_t scale_ld,
-                      const int32_t* m_dev, float* out, int accumulate, float* scratch, hipStream_t stream);
-int64_t pfo_colsum_scratch_floats(int N);

@@ -42,7 +42,7 @@ struct Ws {
   LayerWs layer[PFO_MAX_LAYERS + 1];
   float *dh1, *dctx, *dQK, *dx1;
   float* dH[PFO_MAX_LAYERS + 1];
-  float *slabs, *colsum;
+  float* slabs;
   double *dtime, *fold_scratch;
   int32_t* tickets;
   int64_t slab_floats;
@@ -151,7 +151,6 @@ Ws carve(const pfo_tgn_config* c, void* base) {
   w.dx1 = take<float>(p, N1 * d.D);
   w.slab_floats = SLAB_FLOATS;
   w.slabs = take<float>(p, w.slab_floats);
-  w.colsum = take<float>(p, pfo_colsum_scratch_floats(3 * d.D + 2 * d.E + d.M));
   w.dtime = take<double>(p, (int64_t)pfo_attn_bwd_max_parts() * 2 * d.D);
   w.fold_scratch = take<double>(p, pfo_fold_parts_scratch_doubles(2 * d.D));
   w.bytes = p - reinterpret_cast<char*>(base);
