@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=512, help="interactions per oracle step in the CPU baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=1, help="timed oracle steps (one more runs first, untimed)")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event bracketing of kernel launches")
-    ap.add_argument("--prof-every", type=int, default=4,
+    ap.add_argument("--prof-every", type=int, default=8,
                     help="bracket the kernel launches of every Nth timed step with HIP events (the brackets cost ~0.2 ms "
                          "per step at C2, so the roofline sample is taken on a subset of the timed steps)")
     return ap.parse_args()
