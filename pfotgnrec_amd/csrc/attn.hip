@@ -148,19 +148,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
       for (int h = 0; h < H; ++h) {
         const float sc = part[c][h] * a.scale;
         if (lane == js[c]) my_s[h] = sc;
-        const float mn = fmaxf(m[h], sc);
-        const float corr = expf(m[h] - mn);
-        const float pr = expf(sc - mn);
+        // the score is wave-uniform: the running sums are rescaled only when the maximum actually moves (a scalar
+        // branch, taken for the first few keys of a row), otherwise a key costs one FMA per accumulator
+        if (sc > m[h]) {
+          const float corr = expf(m[h] - sc);
+          l[h] *= corr; ld[h] *= corr; ae[h] *= corr;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) { an[h][r] *= corr; at[h][r] *= corr; }
+          m[h] = sc;
+        }
+        const float pr = expf(sc - m[h]);
         const float pd = ((kb >> h) & 1u) ? pr * keep_scale : 0.f;
-        l[h] = fmaf(l[h], corr, pr);
-        ld[h] = fmaf(ld[h], corr, pd);
+        l[h] += pr;
+        ld[h] += pd;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-          an[h][r] = fmaf(an[h][r], corr, pd * kn[c][r]);
-          at[h][r] = fmaf(at[h][r], corr, pd * kt[c][r]);
+          an[h][r] = fmaf(pd, kn[c][r], an[h][r]);
+          at[h][r] = fmaf(pd, kt[c][r], at[h][r]);
         }
-        ae[h] = fmaf(ae[h], corr, pd * ke[c]);
-        m[h] = mn;
+        ae[h] = fmaf(pd, ke[c], ae[h]);
       }
     }
   }
