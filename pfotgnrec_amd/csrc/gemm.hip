@@ -41,6 +41,7 @@ struct GemmDev {
   float* slab_base;                // split-K: this problem's slab region
   int dyn_chunk;                   // split-K chunk = f(device-side K) instead of split_chunk
   const void* b_img; int b_img_rows;   // pre-split bf16x3 image of B (source 0) and its padded row count
+  const void* b_img2;                  // ... of the second K-concatenated source (same padded row count)
 };
 
 static bool aligned4(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
   int Ks = 0, cur_src = -1;
   const float* safe = p.A[0];
   // pre-split B: tile t, piece q of the rows n0.. is one contiguous BX_B_PIECE-byte run of the image
-  const char* img = BSPLIT ? reinterpret_cast<const char*>(p.b_img) + (int64_t)n0 * 64 : nullptr;
+  const char* img = nullptr;                           // bound per source in bind_src
   const int64_t img_piece = (int64_t)p.b_img_rows * 64;
 
   auto bind_src = [&](int src) {
@@ -480,6 +481,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
     Ks = p.K[src];
     const float* Ab = p.A[src] + zb * p.a_bs[src];
     const float* Bb = p.B[src] + zb * p.b_bs[src];
+    if constexpr (BSPLIT) img = reinterpret_cast<const char*>(src == 0 ? p.b_img : p.b_img2) + (int64_t)n0 * 64;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int gm = m0 + ((tid + 256 * i) >> 3);
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
       a_reg[i] = ld4<true>(a_row[i] + k, a_ok[i] ? Ks - k : 0, safe);
     }
     if constexpr (BSPLIT) {
-      const char* tile = img + (int64_t)t * 3 * img_piece;
+      const char* tile = img + (int64_t)(src == 0 ? t : t - T0) * 3 * img_piece;
       // 3 pieces x 704 units of 16 bytes = 8.25 units per thread (tail clamped); piece boundaries fall at units 704, 1408
       bx_for<9>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
@@ -1179,7 +1181,7 @@ static void to_dev(const PfoGemm& g, GemmDev& d) {
   d.relu = g.relu; d.accumulate = g.accumulate; d.nsplit = 1; d.split_chunk = 0;
   d.c_bs = g.c_bs; d.bias_bs = g.bias_bs; d.rs_bs = g.rs_bs;
   d.n_real = g.N; d.ones_scale = nullptr; d.os_ld = 0; d.slab_base = g.slabs; d.dyn_chunk = 0;
-  d.b_img = nullptr; d.b_img_rows = 0;
+  d.b_img = nullptr; d.b_img_rows = 0; d.b_img2 = nullptr;
 }
 
 
@@ -1199,6 +1201,13 @@ int pfo_bimg_launch(const PfoBimg* list, int n, hipStream_t stream) {
   hipLaunchKernelGGL(bimg_kernel, dim3((unsigned)pfo_ceil_div(most, 256), n), dim3(256), 0, stream, d);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
+}
+
+bool pfo_gemm_takes_bx_big(int M, int N) {
+  static const int bx = getenv("PFO_GEMM_BF16X3") ? atoi(getenv("PFO_GEMM_BF16X3")) : PFO_DEFAULT_BF16X3;
+  static const int bx_min_tiles = getenv("PFO_BX_MIN_TILES") ? atoi(getenv("PFO_BX_MIN_TILES")) : PFO_BX_MIN_TILES;
+  static const bool forced = getenv("PFO_GEMM_TILE") != nullptr;
+  return bx >= 1 && !forced && (int64_t)pfo_ceil_div(M, BM) * pfo_ceil_div(N, BN) >= bx_min_tiles;
 }
 
 int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
@@ -1263,8 +1272,8 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
       d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN);
       if (!g.m_dev) kind = PFO_PROF_GEMM_BX_SKINNY;
       hipLaunchKernelGGL(gemm_bx_skinny_kernel, dim3((unsigned)pfo_ceil_div(g.M, SK_ROWS), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
-    } else if (g.b_img && g.K[1] == 0 && a_rowvec && (g.bx_force || (bx >= 1 && big_tiles >= bx_min_tiles && force < 0))) {
-      d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN);
+    } else if (g.b_img && (g.K[1] == 0 || g.b_img2) && a_rowvec && (g.bx_force || (bx >= 1 && big_tiles >= bx_min_tiles && force < 0))) {
+      d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN); d.b_img2 = g.b_img2;
       if (!g.m_dev) kind = PFO_PROF_GEMM_BX;       // device-side row counts stay "time only"
       hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0,
                          stream, d);

@@ -31,6 +31,7 @@ struct PfoGemm {
   float* slabs = nullptr; int64_t slab_floats = 0;
   // optional pre-split bf16x3 image of op(B) for source 0 (pfo_bimg_launch); used by the large row-major launches
   const void* b_img = nullptr;
+  const void* b_img2 = nullptr;     // image of the second source's B (two K-concatenated sources in one bf16x3 launch)
   int bx_force = 0;                 // tests: 1 = the 128-row bf16x3 kernel, 2 = the 32-row one, whatever the heuristic says
 };
 
@@ -44,6 +45,8 @@ int64_t pfo_bimg_bytes(int N, int K);
 int pfo_bimg_launch(const PfoBimg* list, int n, hipStream_t stream);
 
 int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream);
+// true when a row-major launch of this size (with images) takes the 128-row bf16x3 kernel, which accepts two sources
+bool pfo_gemm_takes_bx_big(int M, int N);
 // several small plain problems (any operand layouts, no device-side counts, no split-K) in one launch
 #define PFO_GEMM_MULTI_MAX 10
 int pfo_gemm_multi_launch(const PfoGemm* list, int n, hipStream_t stream);

@@ -469,13 +469,17 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     a.ctx = lw.ctx; a.attw = lw.attw; a.inv = lw.inv;
     RUN(pfo_attn_fwd_launch(a, s));
     // ---- h1 = relu(ctx' W1ovT + x W1[:, E:]^T + b1)   (MergeLayer fc1 with out_proj and the value projection folded in)
-    {
+    if (pfo_gemm_takes_bx_big(N, D)) {
+      // both K-concatenated sources ([ctx' | x] against [W1ov | W1[:, E:]]) in one launch: h1 is written once
+      PfoGemm g = g_nn(lw.ctx, HCp, lw.W1ovT, D, lw.h1, D, N, D, HCp);
+      g.A[1] = xA; g.lda[1] = D; g.a_idx[1] = x_idx; g.B[1] = p.w1 + E; g.ldb[1] = E + D; g.K[1] = D;
+      g.bias = p.b1; g.relu = 1; g.b_img = lw.iW1ov; g.b_img2 = lw.iW1b;
+      RUN(pfo_gemm_launch(g, s));
+    } else {
       PfoGemm g = g_nn(lw.ctx, HCp, lw.W1ovT, D, lw.h1, D, N, D, HCp);
       g.b_img = lw.iW1ov;
       RUN(pfo_gemm_launch(g, s));
-    }
-    {
-      PfoGemm g = g_nt(xA, D, x_idx, p.w1 + E, E + D, lw.h1, D, N, D, D, p.b1);
+      g = g_nt(xA, D, x_idx, p.w1 + E, E + D, lw.h1, D, N, D, D, p.b1);
       g.accumulate = 1; g.relu = 1; g.b_img = lw.iW1b;
       RUN(pfo_gemm_launch(g, s));
     }
@@ -543,13 +547,10 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       q.b_img = lw.iW2T;
       RUN(pfo_gemm_launch(q, s));
     }
-    // merged fc1: d ctx' = dh1 W1ovT^T, dx = dh1 W1[:, E:]
+    // merged fc1: d ctx' = dh1 W1ovT^T (dx = dh1 W1[:, E:] is taken together with the query/key part below)
     {
       PfoGemm q = g_nt(w.dh1, D, nullptr, lw.W1ovT, D, w.dctx, HCp, N, HCp, D, nullptr);
       q.b_img = lw.iW1ovT;
-      RUN(pfo_gemm_launch(q, s));
-      q = g_nn(w.dh1, D, p.w1 + E, E + D, dx, D, N, D, D);
-      q.b_img = lw.iW1bT;
       RUN(pfo_gemm_launch(q, s));
     }
     set_tn(tn[1], lw.ctx, HCp, w.dh1, D, nullptr, HCp, D, lw.dW1ovT, D, nullptr);       // dW1ovT = ctx'^T dh1
@@ -573,8 +574,17 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
     RUN(pfo_fold_parts_launch(w.dtime, n_parts, 2 * D, G.tw, 1, w.fold_scratch, w.tickets, s));      // time_w and time_b are adjacent in the layout
     // merged query/key projection: dx += dqk' Wqk, dWqk = dqk'^T x, gqk = colsum(dqk')
-    {
+    if (pfo_gemm_takes_bx_big(N, D)) {
+      // dx = [dqk' | dh1] [Wqk ; W1[:, E:]] : both sources in one launch, dx written once
       PfoGemm q = g_nn(w.dQK, HCp, lw.Wqk, D, dx, D, N, D, HCp);
+      q.A[1] = w.dh1; q.lda[1] = D; q.B[1] = p.w1 + E; q.ldb[1] = E + D; q.K[1] = D;
+      q.b_img = lw.iWqkT; q.b_img2 = lw.iW1bT;
+      RUN(pfo_gemm_launch(q, s));
+    } else {
+      PfoGemm q = g_nn(w.dh1, D, p.w1 + E, E + D, dx, D, N, D, D);
+      q.b_img = lw.iW1bT;
+      RUN(pfo_gemm_launch(q, s));
+      q = g_nn(w.dQK, HCp, lw.Wqk, D, dx, D, N, D, HCp);
       q.accumulate = 1; q.b_img = lw.iWqkT;
       RUN(pfo_gemm_launch(q, s));
     }
