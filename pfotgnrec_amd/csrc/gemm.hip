@@ -637,7 +637,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const G
   int Mlim = p.M;
   if (p.m_dev) Mlim = min(Mlim, *p.m_dev);
   if (m0 >= Mlim) return;
-  const int T = (p.K[0] + BK - 1) / BK;
+  const int T0 = (p.K[0] + BK - 1) / BK;
+  const int T1 = (p.K[1] > 0 && p.A[1]) ? (p.K[1] + BK - 1) / BK : 0;     // optional second K-concatenated source
+  const int T = T0 + T1;
   f32x4 acc[2][3];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -649,17 +651,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const G
   f32x4 i_st[2][9];
   const int a_r = tid >> 3, a_c4 = tid & 7;
   const bool a_ok = m0 + a_r < Mlim;
-  int64_t ridx = a_ok ? m0 + a_r : 0;
-  if (a_ok && p.a_idx[0]) ridx = p.a_idx[0][m0 + a_r];
-  const float* a_row = p.A[0] + ridx * p.lda[0];
+  int64_t ridx0 = a_ok ? m0 + a_r : 0, ridx1 = ridx0;
+  if (a_ok && p.a_idx[0]) ridx0 = p.a_idx[0][m0 + a_r];
+  if (a_ok && T1 > 0 && p.a_idx[1]) ridx1 = p.a_idx[1][m0 + a_r];
+  const float* a_row0 = p.A[0] + ridx0 * p.lda[0];
+  const float* a_row1 = T1 > 0 ? p.A[1] + ridx1 * p.lda[1] : a_row0;
   const float* safe = p.A[0];
-  const char* img = reinterpret_cast<const char*>(p.b_img) + (int64_t)n0 * 64;
+  const char* img0 = reinterpret_cast<const char*>(p.b_img) + (int64_t)n0 * 64;
+  const char* img1 = T1 > 0 ? reinterpret_cast<const char*>(p.b_img2) + (int64_t)n0 * 64 : img0;
   const int64_t img_piece = (int64_t)p.b_img_rows * 64;
   auto load_global = [&](int t, auto sc) {
     constexpr int st = decltype(sc)::value;
-    const int k = t * BK + 4 * a_c4;
-    a_st[st] = ld4<true>(a_row + k, a_ok ? p.K[0] - k : 0, safe);
-    const char* tile = img + (int64_t)t * 3 * img_piece;
+    const bool second = t >= T0;
+    const int ts = second ? t - T0 : t;
+    const int k = ts * BK + 4 * a_c4;
+    a_st[st] = ld4<true>((second ? a_row1 : a_row0) + k, a_ok ? (second ? p.K[1] : p.K[0]) - k : 0, safe);
+    const char* tile = (second ? img1 : img0) + (int64_t)ts * 3 * img_piece;
     bx_for<9>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       const int unit = min(tid + 256 * u, 3 * (BX_B_PIECE / 16) - 1);
@@ -1203,11 +1210,13 @@ int pfo_bimg_launch(const PfoBimg* list, int n, hipStream_t stream) {
   return PFO_OK;
 }
 
-bool pfo_gemm_takes_bx_big(int M, int N) {
+bool pfo_gemm_takes_bx(int M, int N) {
   static const int bx = getenv("PFO_GEMM_BF16X3") ? atoi(getenv("PFO_GEMM_BF16X3")) : PFO_DEFAULT_BF16X3;
   static const int bx_min_tiles = getenv("PFO_BX_MIN_TILES") ? atoi(getenv("PFO_BX_MIN_TILES")) : PFO_BX_MIN_TILES;
   static const bool forced = getenv("PFO_GEMM_TILE") != nullptr;
-  return bx >= 1 && !forced && (int64_t)pfo_ceil_div(M, BM) * pfo_ceil_div(N, BN) >= bx_min_tiles;
+  static const int sk = getenv("PFO_GEMM_SKINNY") ? atoi(getenv("PFO_GEMM_SKINNY")) : 1;
+  if (bx < 1 || forced) return false;
+  return sk != 0 || (int64_t)pfo_ceil_div(M, BM) * pfo_ceil_div(N, BN) >= bx_min_tiles;
 }
 
 int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
@@ -1268,8 +1277,8 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
     static const int bx_min_tiles = getenv("PFO_BX_MIN_TILES") ? atoi(getenv("PFO_BX_MIN_TILES")) : PFO_BX_MIN_TILES;
     const bool a_rowvec = a_vec && g.batch == 1;
     static const int sk = getenv("PFO_GEMM_SKINNY") ? atoi(getenv("PFO_GEMM_SKINNY")) : 1;                  // A/B switch
-    if (g.b_img && g.K[1] == 0 && a_rowvec && (g.bx_force == 2 || (bx >= 1 && sk && !g.bx_force && force < 0 && big_tiles < bx_min_tiles))) {
-      d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN);
+    if (g.b_img && (g.K[1] == 0 || g.b_img2) && a_rowvec && (g.bx_force == 2 || (bx >= 1 && sk && !g.bx_force && force < 0 && big_tiles < bx_min_tiles))) {
+      d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN); d.b_img2 = g.b_img2;
       if (!g.m_dev) kind = PFO_PROF_GEMM_BX_SKINNY;
       hipLaunchKernelGGL(gemm_bx_skinny_kernel, dim3((unsigned)pfo_ceil_div(g.M, SK_ROWS), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
     } else if (g.b_img && (g.K[1] == 0 || g.b_img2) && a_rowvec && (g.bx_force || (bx >= 1 && big_tiles >= bx_min_tiles && force < 0))) {
@@ -1277,6 +1286,10 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
       if (!g.m_dev) kind = PFO_PROF_GEMM_BX;       // device-side row counts stay "time only"
       hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0,
                          stream, d);
+    } else if (g.K[1] > 0 && g.b_img2) {
+      // the caller fused two sources whose float B operands may differ in layout: only the image kernels can take that
+      pfo_set_error("pfo_gemm_launch: a two-source launch with weight images needs 16-byte aligned row-major A operands");
+      return PFO_ERR_INVALID;
     } else if (bx >= 2 && !g.b_kmajor && tile == 0 && vec) {
       kind = PFO_PROF_GEMM_BX;
       hipLaunchKernelGGL(gemm_bf16x3_kernel<false>, grid, dim3(GEMM_THREADS), 0, stream, d);

@@ -45,8 +45,9 @@ int64_t pfo_bimg_bytes(int N, int K);
 int pfo_bimg_launch(const PfoBimg* list, int n, hipStream_t stream);
 
 int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream);
-// true when a row-major launch of this size (with images) takes the 128-row bf16x3 kernel, which accepts two sources
-bool pfo_gemm_takes_bx_big(int M, int N);
+// true when a row-major launch of this size (aligned operands, images supplied) takes a bf16x3 kernel: those accept two
+// K-concatenated sources whose B operands differ in layout
+bool pfo_gemm_takes_bx(int M, int N);
 // several small plain problems (any operand layouts, no device-side counts, no split-K) in one launch
 #define PFO_GEMM_MULTI_MAX 10
 int pfo_gemm_multi_launch(const PfoGemm* list, int n, hipStream_t stream);

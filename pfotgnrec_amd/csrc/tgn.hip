@@ -469,7 +469,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     a.ctx = lw.ctx; a.attw = lw.attw; a.inv = lw.inv;
     RUN(pfo_attn_fwd_launch(a, s));
     // ---- h1 = relu(ctx' W1ovT + x W1[:, E:]^T + b1)   (MergeLayer fc1 with out_proj and the value projection folded in)
-    if (pfo_gemm_takes_bx_big(N, D)) {
+    if (pfo_gemm_takes_bx(N, D)) {
       // both K-concatenated sources ([ctx' | x] against [W1ov | W1[:, E:]]) in one launch: h1 is written once
       PfoGemm g = g_nn(lw.ctx, HCp, lw.W1ovT, D, lw.h1, D, N, D, HCp);
       g.A[1] = xA; g.lda[1] = D; g.a_idx[1] = x_idx; g.B[1] = p.w1 + E; g.ldb[1] = E + D; g.K[1] = D;
@@ -574,7 +574,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
     RUN(pfo_fold_parts_launch(w.dtime, n_parts, 2 * D, G.tw, 1, w.fold_scratch, w.tickets, s));      // time_w and time_b are adjacent in the layout
     // merged query/key projection: dx += dqk' Wqk, dWqk = dqk'^T x, gqk = colsum(dqk')
-    if (pfo_gemm_takes_bx_big(N, D)) {
+    if (pfo_gemm_takes_bx(N, D)) {
       // dx = [dqk' | dh1] [Wqk ; W1[:, E:]] : both sources in one launch, dx written once
       PfoGemm q = g_nn(w.dQK, HCp, lw.Wqk, D, dx, D, N, D, HCp);
       q.A[1] = w.dh1; q.lda[1] = D; q.B[1] = p.w1 + E; q.ldb[1] = E + D; q.K[1] = D;
