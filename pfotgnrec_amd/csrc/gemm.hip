@@ -842,6 +842,10 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
     b_bias_e[i] = (p.n_real < p.N && e >= 0 && e < 4) ? e : -1;
   }
 
+  // Branch-free staging loads: every lane loads from a clamped, always-valid address and the out-of-range values are
+  // selected to zero afterwards (per-lane conditions around loads compile to exec-mask branch sequences: the first
+  // version of this loop spent as many scalar as vector instructions).
+  const int k_last = max(Ks - 1, 0);
   auto load_tile = [&](int t) {
     const int k0 = kbeg + t * BK;
 #pragma unroll
@@ -853,13 +857,15 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
     for (int i = 0; i < 6; ++i) {
       const int k = k0 + b_kr[i];
       const bool ok = b_live[i] && k < Ks && b_n[i] < p.N;
-      int64_t krow = ok ? k : 0;
-      if (ok && p.b_idx) krow = p.b_idx[k];
+      const int kc = min(k, k_last);
+      int64_t krow = kc;
+      if (p.b_idx) krow = p.b_idx[kc];                                  // wave-uniform test, unconditional load
       b_reg[i] = ld4<true>(p.B[0] + krow * ldb + b_n[i], ok ? p.n_real - b_n[i] : 0, safe);
-      if (b_bias_e[i] >= 0 && ok) {
-        const float one = p.ones_scale ? p.ones_scale[(int64_t)k * p.os_ld] : 1.f;     // bias column (see gemm_tile)
-        const int e = b_bias_e[i];
-        if (e == 0) b_reg[i].x = one; else if (e == 1) b_reg[i].y = one; else if (e == 2) b_reg[i].z = one; else b_reg[i].w = one;
+      if (p.n_real < p.N) {                                              // wave-uniform: this problem carries a bias column
+        const float one = p.ones_scale ? p.ones_scale[(int64_t)kc * p.os_ld] : 1.f;
+        const int e = ok ? b_bias_e[i] : -1;
+        b_reg[i].x = e == 0 ? one : b_reg[i].x; b_reg[i].y = e == 1 ? one : b_reg[i].y;
+        b_reg[i].z = e == 2 ? one : b_reg[i].z; b_reg[i].w = e == 3 ? one : b_reg[i].w;
       }
     }
   };
@@ -870,7 +876,7 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
     for (int i = 0; i < 6; ++i)
       if (b_live[i]) tx_split_store(Bs, TX_B_PIECE, b_off[i], b_reg[i]);
   };
-  const bool strip_on[2] = {m0 + wrow < p.M, m0 + wrow + 16 < p.M};
+  const int strips = __builtin_amdgcn_readfirstlane((m0 + wrow + 16 < p.M) ? 2 : ((m0 + wrow < p.M) ? 1 : 0));
   auto compute_tile = [&]() {
     bf16x8 a[2][3];
 #pragma unroll
@@ -881,19 +887,21 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
 #pragma unroll
       for (int q = 0; q < 3; ++q) b[q] = tx_read(Bs + q * TX_B_PIECE, TX_B_ROW, 15, j, g, r);
     };
+    auto mma1 = [&](const bf16x8 (&b)[3], int i, int j) {
+      f32x4 c = acc[i][j];
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[0], c, 0, 0, 0);
+      acc[i][j] = c;
+    };
+    // a wavefront whose strips lie beyond M skips their MFMAs (172-row gradients): `strips` is wave-uniform (an SGPR
+    // after readfirstlane), so these are scalar branches, not exec-mask sequences
     auto mma = [&](const bf16x8 (&b)[3], int j) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (!strip_on[i]) continue;
-        f32x4 c = acc[i][j];
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[0], c, 0, 0, 0);
-        acc[i][j] = c;
-      }
+      if (strips >= 1) mma1(b, 0, j);
+      if (strips >= 2) mma1(b, 1, j);
     };
     bf16x8 b0[3], b1[3];                      // double-buffered B fragments (see gemm_bf16x3_kernel)
     ldb(b0, 0);
