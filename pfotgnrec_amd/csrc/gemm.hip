@@ -37,7 +37,6 @@ struct GemmDev {
   int nsplit; int split_chunk;     // k-major split-K
   int64_t a_bs[2], b_bs[2], c_bs, bias_bs, rs_bs;
   int n_real;                      // columns of B that exist in memory; column n_real (if < N) is the bias column
-  const float* ones_scale; int64_t os_ld;   // value of the bias column per k row (null: 1.0)
   float* slab_base;                // split-K: this problem's slab region
   int dyn_chunk;                   // split-K chunk = f(device-side K) instead of split_chunk
   const void* b_img; int b_img_rows;   // pre-split bf16x3 image of B (source 0) and its padded row count
@@ -205,7 +204,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
           // bias column: dW's extra column accumulates sum_k dY[k][m] * (scale[k] or 1)
           const int e = p.n_real - n;
           if (e >= 0 && e < 4) {
-            const float one = p.ones_scale ? p.ones_scale[(int64_t)k * p.os_ld] : 1.f;
+            const float one = 1.f;
             if (e == 0) b_reg[i].x = one; else if (e == 1) b_reg[i].y = one; else if (e == 2) b_reg[i].z = one; else b_reg[i].w = one;
           }
         }
@@ -846,6 +845,18 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
   // selected to zero afterwards (per-lane conditions around loads compile to exec-mask branch sequences: the first
   // version of this loop spent as many scalar as vector instructions).
   const int k_last = max(Ks - 1, 0);
+  // gathered B rows: the row indices of tile t+1 are fetched while tile t is staged, so the row loads of a tile never
+  // wait for an index load issued just before them
+  int b_row_next[6];
+  auto fetch_rows = [&](int t) {
+    const int k0 = kbeg + t * BK;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int kc = min(k0 + b_kr[i], k_last);
+      b_row_next[i] = p.b_idx ? p.b_idx[kc] : kc;                       // wave-uniform test, unconditional load
+    }
+  };
+  fetch_rows(0);
   auto load_tile = [&](int t) {
     const int k0 = kbeg + t * BK;
 #pragma unroll
@@ -857,17 +868,13 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
     for (int i = 0; i < 6; ++i) {
       const int k = k0 + b_kr[i];
       const bool ok = b_live[i] && k < Ks && b_n[i] < p.N;
-      const int kc = min(k, k_last);
-      int64_t krow = kc;
-      if (p.b_idx) krow = p.b_idx[kc];                                  // wave-uniform test, unconditional load
-      b_reg[i] = ld4<true>(p.B[0] + krow * ldb + b_n[i], ok ? p.n_real - b_n[i] : 0, safe);
-      if (p.n_real < p.N) {                                              // wave-uniform: this problem carries a bias column
-        const float one = p.ones_scale ? p.ones_scale[(int64_t)kc * p.os_ld] : 1.f;
-        const int e = ok ? b_bias_e[i] : -1;
-        b_reg[i].x = e == 0 ? one : b_reg[i].x; b_reg[i].y = e == 1 ? one : b_reg[i].y;
-        b_reg[i].z = e == 2 ? one : b_reg[i].z; b_reg[i].w = e == 3 ? one : b_reg[i].w;
-      }
+      b_reg[i] = ld4<true>(p.B[0] + (int64_t)b_row_next[i] * ldb + b_n[i], ok ? p.n_real - b_n[i] : 0, safe);
+      // bias column: dW's extra column accumulates sum_k dY[k][m]
+      const int e = ok ? b_bias_e[i] : -1;
+      b_reg[i].x = e == 0 ? 1.f : b_reg[i].x; b_reg[i].y = e == 1 ? 1.f : b_reg[i].y;
+      b_reg[i].z = e == 2 ? 1.f : b_reg[i].z; b_reg[i].w = e == 3 ? 1.f : b_reg[i].w;
     }
+    if (t + 1 < T) fetch_rows(t + 1);
   };
   auto store_tile = [&]() {
 #pragma unroll
@@ -1042,7 +1049,6 @@ int pfo_rank1_launch(const float* u, int64_t ldu, const float* v, int64_t ldv, i
 #define TN_MAX_PROBLEMS 16
 struct TnProbDev {
   const float* A; int64_t lda; const float* B; int64_t ldb; const int32_t* b_idx;
-  const float* ones_scale; int64_t os_ld;
   float* C; int64_t ldc; float* bias_out; int bias_accumulate, c_accumulate;
   int M, N_real, N;          // N = N_real + (bias_out ? 1 : 0)
   int tile_begin, tn;        // first flattened tile, column tiles
@@ -1073,7 +1079,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_group_kernel(const TnGro
   d.nsplit = 2;                      // any value > 1: selects the slab epilogue; the real split index comes from blockIdx.y
   d.split_chunk = g.chunk;
   d.a_bs[0] = d.a_bs[1] = d.b_bs[0] = d.b_bs[1] = d.c_bs = d.bias_bs = d.rs_bs = 0;
-  d.n_real = pr.N_real; d.ones_scale = pr.ones_scale; d.os_ld = pr.os_ld;
+  d.n_real = pr.N_real;
   // slab region of this problem: [nsplit][M][N]; gemm_tile indexes it as (zb * nsplit + split) with zb = 0
   d.slab_base = g.slabs + pr.slab_off - (int64_t)0;
   d.nsplit = g.nsplit > 1 ? g.nsplit : 2;
@@ -1094,7 +1100,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_group_bx_kernel(const
   d.A[0] = pr.A; d.lda[0] = pr.lda; d.B[0] = pr.B; d.ldb[0] = pr.ldb; d.b_idx = pr.b_idx;
   d.K[0] = g.K; d.M = pr.M; d.N = pr.N; d.m_dev = g.k_dev;
   d.split_chunk = g.chunk;
-  d.n_real = pr.N_real; d.ones_scale = pr.ones_scale; d.os_ld = pr.os_ld;
+  d.n_real = pr.N_real;
   d.slab_base = g.slabs + pr.slab_off;
   d.nsplit = g.nsplit;
   d.dyn_chunk = (g.k_dev != nullptr && g.nsplit > 1) ? 1 : 0;
@@ -1149,7 +1155,7 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
     PFO_REQUIRE(s.A && s.B && s.C && s.M > 0 && s.N > 0, "bad problem");
     TnProbDev& d = g.p[i];
     d.A = s.A; d.lda = s.lda; d.B = s.B; d.ldb = s.ldb; d.b_idx = s.b_idx;
-    d.ones_scale = s.ones_scale; d.os_ld = s.os_ld; d.C = s.C; d.ldc = s.ldc;
+    d.C = s.C; d.ldc = s.ldc;
     d.bias_out = s.bias_out; d.bias_accumulate = s.bias_accumulate; d.c_accumulate = s.c_accumulate;
     d.M = s.M; d.N_real = s.N; d.N = s.N + (s.bias_out ? 1 : 0);
     d.tn = (int)pfo_ceil_div(d.N, BN);
@@ -1195,7 +1201,7 @@ static void to_dev(const PfoGemm& g, GemmDev& d) {
   d.relu_src = g.relu_src; d.relu_ld = g.relu_ld; d.M = g.M; d.N = g.N; d.m_dev = g.m_dev;
   d.relu = g.relu; d.accumulate = g.accumulate; d.nsplit = 1; d.split_chunk = 0;
   d.c_bs = g.c_bs; d.bias_bs = g.bias_bs; d.rs_bs = g.rs_bs;
-  d.n_real = g.N; d.ones_scale = nullptr; d.os_ld = 0; d.slab_base = g.slabs; d.dyn_chunk = 0;
+  d.n_real = g.N; d.slab_base = g.slabs; d.dyn_chunk = 0;
   d.b_img = nullptr; d.b_img_rows = 0; d.b_img2 = nullptr;
 }
 

@@ -56,14 +56,13 @@ int pfo_rank1_launch(const float* u, int64_t ldu, const float* v, int64_t ldv, i
                      hipStream_t stream);
 
 // One weight gradient dW[M,N] += A[K,M]^T B[K,N] (A = dY, B = X, both row-major over the K instance rows) with an
-// optional bias gradient bias_out[M] (+)= sum_k A[k][m] * (ones_scale ? ones_scale[k*os_ld] : 1) carried as column N.
+// optional bias gradient bias_out[M] (+)= sum_k A[k][m] carried as column N.
 struct PfoTnProblem {
   const float* A = nullptr; int64_t lda = 0;
   const float* B = nullptr; int64_t ldb = 0; const int32_t* b_idx = nullptr;
   int M = 0, N = 0;
   float* C = nullptr; int64_t ldc = 0; int c_accumulate = 1;
   float* bias_out = nullptr; int bias_accumulate = 1;
-  const float* ones_scale = nullptr; int64_t os_ld = 0;
 };
 // all problems share the K extent (and its optional device-side bound); one GEMM launch + one reduce launch
 int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int32_t* k_dev, float* slabs,
