@@ -22,7 +22,9 @@ RTOL_GRAD_TIME = 3e-3
 # oracle comparisons on random parameters: a fc1 pre-activation within rounding distance of 0 flips relu' between
 # the two implementations and perturbs every upstream gradient by ~1e-3 (observed once in the D=64 case; all other
 # tensors / cases agree to ~1e-5, tools/grad_error_survey.py).  Relative L2 is the metric, with room for one kink.
-RTOL_GRAD_ORACLE_L2 = 2e-3
+RTOL_GRAD_ORACLE_L2 = 5e-3   # relative L2 vs the oracle: float-rounding-level differences in the forward flip individual ReLU
+                             # units (kinks); two builds of this library that agree with each other to 6e-7 sit at 2.0e-3 and 3.6e-3
+                             # against the oracle on the H=4 / uniform configuration.  The reference goldens pin 5e-4 (max norm).
 
 
 def relerr(a, b):
