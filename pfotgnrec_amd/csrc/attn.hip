@@ -17,6 +17,7 @@ struct AttnDev {
   float scale, dropout_p; uint64_t seed, offset;
   float* ctx; float* attw; uint8_t* inv;
   const float* dctx; float* dQK; float* d_nbr; int64_t d_nbr_ld; double* dtime_part;
+  int64_t d_nbr_rep;  // DMODE 1: floats between the per-XCD replicas of the gradient table (0: one table)
   int abl;      // timing-only ablation switch (PFO_ATTN_ABL): 1 = spread the atomic destinations (wrong results)
 };
 
@@ -213,6 +214,11 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
     dw[r] = 0.0; db[r] = 0.0;
   }
   const float keep_scale = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
+  // DMODE 1: every XCD adds into ITS replica of the gradient table.  The eight L2s are kept coherent by hardware, so
+  // float atomics from all XCDs on one table make each cache line migrate between L2s (the 500 item rows take 77 % of
+  // the adds); with one replica per XCD the atomics stay in the local L2.  The XCC id only picks the replica: a wrong
+  // value would cost speed, never correctness (the atomics are device-coherent either way).
+  float* const d_nbr_x = (DMODE == 1) ? a.d_nbr + (int64_t)(__builtin_amdgcn_s_getreg(6164) & (PFO_GRAD_REPLICAS - 1)) * a.d_nbr_rep : a.d_nbr;   // hwreg(HW_REG_XCC_ID, 0, 4)
 
   for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < a.N; n += (int64_t)gridDim.x * 4) {
     float* dqk_out = a.dQK + n * H * Cp;
@@ -344,8 +350,8 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
           }
           dqe[h] = fmaf(cB[h], ke[c], dqe[h]);
         }
-        float* dst = (DMODE != 0) ? a.d_nbr + (int64_t)rows[c] * a.d_nbr_ld : nullptr;
-        if (DMODE == 1 && a.abl == 1) dst = a.d_nbr + (int64_t)((((unsigned)rows[c] * 2654435761u) + (unsigned)n * 40503u) % 8192u) * a.d_nbr_ld;
+        float* dst = (DMODE != 0) ? d_nbr_x + (int64_t)rows[c] * a.d_nbr_ld : nullptr;
+        if (DMODE == 1 && a.abl == 1) dst = d_nbr_x + (int64_t)((((unsigned)rows[c] * 2654435761u) + (unsigned)n * 40503u) % 8192u) * a.d_nbr_ld;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           const int cc = lane + 64 * r;
@@ -401,7 +407,7 @@ static void to_dev(const PfoAttn& a, AttnDev& d) {
   static const int abl = getenv("PFO_ATTN_ABL") ? atoi(getenv("PFO_ATTN_ABL")) : 0;
   d.abl = abl;
   d.ctx = a.ctx; d.attw = a.attw; d.inv = a.inv;
-  d.dctx = a.dctx; d.dQK = a.dQK; d.d_nbr = a.d_nbr; d.d_nbr_ld = a.d_nbr_ld;
+  d.dctx = a.dctx; d.dQK = a.dQK; d.d_nbr = a.d_nbr; d.d_nbr_ld = a.d_nbr_ld; d.d_nbr_rep = a.d_nbr_rep;
   d.dtime_part = a.dtime_part;
 }
 

@@ -5,6 +5,14 @@
 // One attention layer's neighbour side for N instances with K neighbour slots each.
 // key_j = [ nbr_tab[row_j] (D) | edge_feat[eidx_j] (Ef) | cos(fma(dt_j, w, b)) (D) ]   (temporal_attention.py:52)
 // scores use the FOLDED query-key vector qk_h = Wk_h^T Q_h: score_jh = scale * qk_h . key_j
+// Replicas of the level-0 gradient table the layer-1 backward adds into (replica = XCD id & (n - 1)): with one table the
+// float atomics of all eight XCDs make every cache line migrate between the hardware-coherent L2s.  Power of two;
+// measured at C2: 1 -> 0.537 ms, 2 -> 0.510, 4 -> 0.506, 8 -> 0.498 for the kernel, best step time at 4 (replicas are
+// zeroed before and summed after).
+#ifndef PFO_GRAD_REPLICAS
+#define PFO_GRAD_REPLICAS 4
+#endif
+
 struct PfoAttn {
   int N = 0, K = 0, D = 0, Ef = 0, H = 0;
   int Cp = 0;                       // per-head row stride of QK / ctx / dctx / dQK: C = 2D+Ef feature columns, column C =
@@ -32,6 +40,7 @@ struct PfoAttn {
   float* dQK = nullptr;             // [N, H*Cp]
   float* d_nbr = nullptr;           // rows of D floats: direct rows (nbr_row == null) or atomically added rows
   int64_t d_nbr_ld = 0;
+  int64_t d_nbr_rep = 0;            // atomically added rows: floats between the 8 per-XCD replicas of the table (0 = a single table)
   double* dtime_part = nullptr;     // [grid, 2*D] per-workgroup fp64 partial (dw | db) of the time encoder
 };
 

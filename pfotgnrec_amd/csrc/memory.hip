@@ -185,7 +185,7 @@ int pfo_gru_gates_fwd_launch(const float* gi, const float* gh, const float* h_ro
 
 __global__ void gru_gates_bwd_kernel(float* __restrict__ gi, float* __restrict__ gh, const float* __restrict__ h_rows,
                                      const uint8_t* __restrict__ hm, const int32_t* __restrict__ n_touched, int D,
-                                     const float* __restrict__ d_h0) {
+                                     const float* __restrict__ d_h0, int n_rep, int64_t rep_stride) {
   const int64_t total = (int64_t)(*n_touched) * D;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int s = (int)(e / D), d = (int)(e - (int64_t)s * D);
@@ -198,7 +198,8 @@ __global__ void gru_gates_bwd_kernel(float* __restrict__ gi, float* __restrict__
       const float r = sigmoidf_acc(gis[d] + ghs[d]);
       const float z = sigmoidf_acc(gis[D + d] + ghs[D + d]);
       const float nn = tanhf(gis[2 * D + d] + r * ghn);
-      const float dh = d_h0[e];
+      float dh = 0.f;                                  // the level-0 gradient is kept in one replica per XCD
+      for (int q = 0; q < n_rep; ++q) dh += d_h0[(int64_t)q * rep_stride + e];
       const float dn = dh * (1.f - z);
       const float dz = dh * (h - nn);
       dpn = dn * (1.f - nn * nn);
@@ -213,9 +214,9 @@ __global__ void gru_gates_bwd_kernel(float* __restrict__ gi, float* __restrict__
 }
 
 int pfo_gru_gates_bwd_launch(float* gi, float* gh, const float* h_rows, const uint8_t* hm, const int32_t* n_touched,
-                             int cap, int D, const float* d_h0, hipStream_t stream) {
+                             int cap, int D, const float* d_h0, int n_rep, int64_t rep_stride, hipStream_t stream) {
   const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div((int64_t)cap * D, 256));
-  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(nb), dim3(256), 0, stream, gi, gh, h_rows, hm, n_touched, D, d_h0);
+  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(nb), dim3(256), 0, stream, gi, gh, h_rows, hm, n_touched, D, d_h0, n_rep, rep_stride);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -293,6 +294,24 @@ int pfo_msg_store_launch(const int32_t* src, const int32_t* dst, const double* t
   hipLaunchKernelGGL(msg_winner_max_kernel, dim3(nb), dim3(256), 0, stream, src, dst, B, winner);
   hipLaunchKernelGGL(msg_write_kernel, dim3((unsigned)pfo_ceil_div(2 * B, 4)), dim3(256), 0, stream, src, dst, ts, eidx,
                      B, memory, last_update, edge_feat, tw, tb, D, Ef, msg_table, msg_time, has_msg, winner);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+// zeroes rows [0, *n_rows) of n_rep replicas (each rep_stride floats apart): the touched part of the gradient table
+__global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ dst, const int32_t* __restrict__ n_rows, int D,
+                                                        int n_rep, int64_t rep_stride) {
+  const int64_t per = (int64_t)(*n_rows) * D / 4;            // D % 4 == 0
+  const int64_t total = per * n_rep;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t q = e / per, o = e - q * per;
+    reinterpret_cast<float4*>(dst + q * rep_stride)[o] = float4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+int pfo_zero_rows_launch(float* dst, const int32_t* n_rows, int cap_rows, int D, int n_rep, int64_t rep_stride, hipStream_t stream) {
+  PFO_REQUIRE((D % 4) == 0 && (rep_stride % 4) == 0, "row length must be a multiple of 4");
+  const int nb = (int)std::min<int64_t>(2048, pfo_ceil_div((int64_t)cap_rows * D / 4 * n_rep, 256));
+  hipLaunchKernelGGL(zero_rows_kernel, dim3(std::max(nb, 1)), dim3(256), 0, stream, dst, n_rows, D, n_rep, rep_stride);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

@@ -20,9 +20,10 @@ int pfo_remap_launch(const int32_t* nodes0, int64_t n0, const int32_t* slot, int
 int pfo_gru_gates_fwd_launch(const float* gi, const float* gh, const float* h_rows, const float* node_feat,
                              const uint8_t* hm, const int32_t* touched_ids, const int32_t* n_touched, int cap, int D,
                              float* upd_mem, float* h0_tab, hipStream_t stream);
-// backward: overwrites gi/gh with d gi / d gh given d h' = d_h0[s] (zeros where no message was applied)
+// backward: overwrites gi/gh with d gi / d gh given d h' = sum over the n_rep replicas of d_h0[s] (zeros where no message was applied)
 int pfo_gru_gates_bwd_launch(float* gi, float* gh, const float* h_rows, const uint8_t* hm, const int32_t* n_touched,
-                             int cap, int D, const float* d_h0, hipStream_t stream);
+                             int cap, int D, const float* d_h0, int n_rep, int64_t rep_stride, hipStream_t stream);
+int pfo_zero_rows_launch(float* dst, const int32_t* n_rows, int cap_rows, int D, int n_rep, int64_t rep_stride, hipStream_t stream);
 
 // --- state update (tgn.py:290-317)
 int pfo_persist_launch(const int32_t* src, const int32_t* dst, int B, const int32_t* slot, const float* upd_mem,

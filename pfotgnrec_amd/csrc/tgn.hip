@@ -112,7 +112,7 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     w.gh = take<float>(p, d.capP * 3 * d.D);
     w.upd_mem = take<float>(p, d.capP * d.D);
     w.h0_tab = take<float>(p, d.capP * d.D);
-    w.d_h0 = take<float>(p, d.capP * d.D);
+    w.d_h0 = take<float>(p, PFO_GRAD_REPLICAS * d.capP * d.D);     // one replica per XCD (attn.hip, DMODE 1)
     w.msg_rows = take<float>(p, d.capP * d.M);
     w.h_rows = take<float>(p, d.capP * d.D);
     w.hm = take<uint8_t>(p, d.capP);
@@ -514,8 +514,8 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
   const float* tab0 = c->use_memory ? w.h0_tab : st->node_feat;
   const int32_t* idx0 = c->use_memory ? w.idx0 : w.nodes[0];
   const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
-  if (c->use_memory)
-    PFO_REQUIRE(hipMemsetAsync(w.d_h0, 0, (size_t)capP * D * sizeof(float), s) == hipSuccess, "memset failed");
+  const int64_t rep_stride = (int64_t)d.capP * D;             // floats between the per-XCD replicas of d_h0
+  if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_touched, capP, D, PFO_GRAD_REPLICAS, rep_stride, s));
 
   const int Cp = d.Cp, HCp = H * d.Cp;
   Side& sd = side();
@@ -567,7 +567,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     a.scale = scale; a.dropout_p = b->dropout_p; a.seed = b->seed; a.offset = b->offset + 0x51ED0000ull + (uint64_t)l;
     a.ctx = lw.ctx; a.attw = lw.attw; a.inv = lw.inv;
     a.dctx = w.dctx; a.dQK = w.dQK;
-    if (l == 1) { a.d_nbr = c->use_memory ? w.d_h0 : nullptr; a.d_nbr_ld = D; }
+    if (l == 1) { a.d_nbr = c->use_memory ? w.d_h0 : nullptr; a.d_nbr_ld = D; a.d_nbr_rep = rep_stride; }
     else        { a.d_nbr = w.dH[l - 1]; a.d_nbr_ld = D; }
     a.dtime_part = w.dtime;
     int n_parts = 0;
@@ -636,7 +636,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
 
   // ---- GRU parameters (messages and stored memory are constants: SURVEY App. A-6)
   if (c->use_memory) {
-    RUN(pfo_gru_gates_bwd_launch(w.gi, w.gh, w.h_rows, w.hm, w.n_touched, capP, D, w.d_h0, s));
+    RUN(pfo_gru_gates_bwd_launch(w.gi, w.gh, w.h_rows, w.hm, w.n_touched, capP, D, w.d_h0, PFO_GRAD_REPLICAS, rep_stride, s));
     {
       PfoTnProblem gp[2];
       gp[0].A = w.gi; gp[0].lda = 3 * D; gp[0].B = w.msg_rows; gp[0].ldb = d.M; gp[0].M = 3 * D; gp[0].N = d.M;
