@@ -34,7 +34,7 @@ __device__ __forceinline__ unsigned attn_keep_bits(uint64_t seed, uint64_t offse
 // stages per chunk instead of per key), then the online-softmax state is advanced key by key.  Per-slot metadata
 // (row, edge id, dt, validity) is loaded once, one slot per lane, and broadcast with v_readlane.
 #ifndef KC_FWD
-#define KC_FWD 4
+#define KC_FWD 2
 #endif
 #ifndef KC_BWD
 #define KC_BWD 2
@@ -97,28 +97,40 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
     for (int r = 0; r < NR; ++r) { an[h][r] = 0.f; at[h][r] = 0.f; }
   }
 
+  // Software pipeline over chunks of KC_FWD keys: the rows of chunk c+1 are gathered while chunk c is scored, so a
+  // wavefront pays the gather latency once per instance, not once per chunk.
   unsigned long long vm = valid;
-  while (vm) {
-    int js[KC_FWD];
+  int js[KC_FWD], js_n[KC_FWD];
+  float kn[KC_FWD][NR], ke[KC_FWD], kn_n[KC_FWD][NR], ke_n[KC_FWD];
+  auto pick = [&](int (&jj)[KC_FWD]) {
 #pragma unroll
     for (int c = 0; c < KC_FWD; ++c) {
-      js[c] = vm ? (__ffsll((long long)vm) - 1) : -1;
+      jj[c] = vm ? (__ffsll((long long)vm) - 1) : -1;
       vm &= vm - 1ull;
     }
-    float kn[KC_FWD][NR], kt[KC_FWD][NR], ke[KC_FWD], dtv[KC_FWD];
+  };
+  auto gather = [&](const int (&jj)[KC_FWD], float (&kk)[KC_FWD][NR], float (&ee)[KC_FWD]) {
 #pragma unroll
     for (int c = 0; c < KC_FWD; ++c) {
-      const int j = js[c] < 0 ? 0 : js[c];
+      const int j = jj[c] < 0 ? 0 : jj[c];
       const float* src = a.nbr_tab + (int64_t)rl_i(my_row, j) * a.nbr_ld;
       const int e = rl_i(my_e, j);
-      dtv[c] = rl_f(my_dt, j);
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const int cc = lane + 64 * r;
-        kn[c][r] = (js[c] >= 0 && (r < NR - 1 || cc < D)) ? src[cc] : 0.f;
+        kk[c][r] = (jj[c] >= 0 && (r < NR - 1 || cc < D)) ? src[cc] : 0.f;
       }
-      ke[c] = (js[c] >= 0 && lane < Ef) ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
+      ee[c] = (jj[c] >= 0 && lane < Ef) ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
     }
+  };
+  pick(js);
+  gather(js, kn, ke);
+  while (js[0] >= 0) {
+    pick(js_n);
+    if (js_n[0] >= 0) gather(js_n, kn_n, ke_n);
+    float kt[KC_FWD][NR], dtv[KC_FWD];
+#pragma unroll
+    for (int c = 0; c < KC_FWD; ++c) dtv[c] = rl_f(my_dt, js[c] < 0 ? 0 : js[c]);
     float part[KC_FWD][H];
 #pragma unroll
     for (int c = 0; c < KC_FWD; ++c) {
@@ -169,6 +181,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
         }
         ae[h] = fmaf(pd, ke[c], ae[h]);
       }
+    }
+#pragma unroll
+    for (int c = 0; c < KC_FWD; ++c) {
+      js[c] = js_n[c]; ke[c] = ke_n[c];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) kn[c][r] = kn_n[c][r];
     }
   }
 #pragma unroll
