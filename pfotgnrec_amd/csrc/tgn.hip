@@ -340,6 +340,19 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   // it are what the main stream is waiting for.  All layers share each launch.
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
+  // ---- frontier expansion: K1 per level (utils.py:163-219 called from embedding_module.py:125).  Enqueued before the
+  // side-stream work below: it depends on nothing else, and the GPU samples while the host is still enqueueing
+  for (int l = L; l >= 1; --l) {
+    const int64_t* dr = (b->uniform == 1) ? b->draws[L - l] : nullptr;
+    PFO_REQUIRE(b->uniform != 1 || dr, "missing draws for a level");
+    // level L reads the caller's roots directly; every level writes [its own nodes | their neighbours] as the next one
+    const int32_t* lvl_nodes = (l == L) ? b->roots : w.nodes[l];
+    const double* lvl_ts = (l == L) ? b->root_ts : w.ts[l];
+    RUN(pfo_tnbr_sample(st->indptr, st->adj_nbr, st->adj_eidx, st->adj_ts, c->n_nodes, lvl_nodes, lvl_ts, n[l], K,
+                        b->uniform, dr, b->seed, b->offset + (uint64_t)l * 0x100000000ull, nullptr, w.eidx[l], nullptr,
+                        w.dt[l], w.nodes[l - 1], l > 1 ? w.ts[l - 1] : nullptr, stream));
+  }
+
   if (c->use_memory) {
     // the GRU contractions come first on the main stream: their two weight images get their own launch and event
     PfoBimg im[2];
@@ -390,18 +403,6 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   }
   HIPOK(hipEventRecord(sd.layer[0], ss), "event record failed");        // composite weights and images of all layers are ready
   bool composites_awaited = false;
-
-  // ---- frontier expansion: K1 per level (utils.py:163-219 called from embedding_module.py:125)
-  for (int l = L; l >= 1; --l) {
-    const int64_t* dr = (b->uniform == 1) ? b->draws[L - l] : nullptr;
-    PFO_REQUIRE(b->uniform != 1 || dr, "missing draws for a level");
-    // level L reads the caller's roots directly; every level writes [its own nodes | their neighbours] as the next one
-    const int32_t* lvl_nodes = (l == L) ? b->roots : w.nodes[l];
-    const double* lvl_ts = (l == L) ? b->root_ts : w.ts[l];
-    RUN(pfo_tnbr_sample(st->indptr, st->adj_nbr, st->adj_eidx, st->adj_ts, c->n_nodes, lvl_nodes, lvl_ts, n[l], K,
-                        b->uniform, dr, b->seed, b->offset + (uint64_t)l * 0x100000000ull, nullptr, w.eidx[l], nullptr,
-                        w.dt[l], w.nodes[l - 1], l > 1 ? w.ts[l - 1] : nullptr, stream));
-  }
 
   // ---- lazy memory update for the touched nodes (tgn.py:251; memory_updater.py:35-53)
   const float* tab0;
