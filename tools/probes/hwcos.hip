@@ -1,4 +1,4 @@
-// Probe: accuracy of the hardware v_cos_f32 / v_sin_f32 (input in revolutions) on [-0.125, 0.125] and [-0.5, 0.5]
+// Probe (build: hipcc -O2 --offload-arch=gfx950 hwcos.hip -o hwcos): accuracy of the hardware v_cos_f32 / v_sin_f32 (input in revolutions) on [-0.125, 0.125] and [-0.5, 0.5]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>
