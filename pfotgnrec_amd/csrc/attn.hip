@@ -208,7 +208,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
   }
 }
 
+#ifndef ATTN_BWD_MAX_BLOCKS
 #define ATTN_BWD_MAX_BLOCKS 2048
+#endif
 int pfo_attn_bwd_max_parts() { return ATTN_BWD_MAX_BLOCKS; }
 
 // DMODE: what happens to the neighbour-row gradients - 0 none (layer 1 without memory: level-0 rows are constants),

@@ -37,7 +37,8 @@ int pfo_msg_store_launch(const int32_t* src, const int32_t* dst, const double* t
 // --- small ops (misc.hip)
 // dst[idx[r]] += src[r] (rows with idx < 0, or whose skip_if_zero entry is 0, are skipped)
 int pfo_scatter_add_rows_launch(const float* src, int64_t ld_src, const int32_t* idx, const int32_t* skip_if_zero,
-                                int64_t n_rows, int D, float* dst, int64_t ld_dst, hipStream_t stream);
+                                int64_t n_rows, int D, float* dst, int64_t ld_dst, int n_rep, int64_t rep_stride,
+                                hipStream_t stream);
 // cq = Wq[:, D:2D] cos(b) + bq folded query bias: backward of that term
 //   gq[E] = colsum(dQ);  d bq += gq;  d Wq[:, D:] += gq (x) cosb;  d tb += -sin(tb) * (Wq[:, D:]^T gq)
 int pfo_cq_backward_launch(const float* gq, const float* Wq, const float* tb, int D, float* d_bq, float* d_Wq,

@@ -217,7 +217,9 @@ extern "C" int pfo_adam_step(float* param, const float* grad, float* exp_avg, fl
 template <int MODE>
 __global__ void scatter_add_rows_kernel(const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ idx,
                                         const int32_t* __restrict__ skip_if_zero, int64_t n_rows, int D,
-                                        float* __restrict__ dst, int64_t ld_dst) {
+                                        float* __restrict__ dst_all, int64_t ld_dst, int n_rep, int64_t rep_stride) {
+  // with replicas of the destination table, every XCD adds into its own (attn.hpp PFO_GRAD_REPLICAS)
+  float* __restrict__ dst = dst_all + (n_rep > 1 ? (int64_t)(__builtin_amdgcn_s_getreg(6164) & (n_rep - 1)) * rep_stride : 0);
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -250,12 +252,14 @@ __global__ void scatter_add_rows_kernel(const float* __restrict__ src, int64_t l
   }
 }
 int pfo_scatter_add_rows_launch(const float* src, int64_t ld_src, const int32_t* idx, const int32_t* skip_if_zero,
-                                int64_t n_rows, int D, float* dst, int64_t ld_dst, hipStream_t stream) {
+                                int64_t n_rows, int D, float* dst, int64_t ld_dst, int n_rep, int64_t rep_stride,
+                                hipStream_t stream) {
+  PFO_REQUIRE(n_rep >= 1 && (n_rep & (n_rep - 1)) == 0, "replica count must be a power of two");
   PFO_REQUIRE(D <= 256, "row length must be <= 256");
   static const int mode = getenv("PFO_SCATTER_MODE") ? atoi(getenv("PFO_SCATTER_MODE")) : 0;
   const int nb = (int)std::min<int64_t>(2048, pfo_ceil_div(n_rows, 16));
-  if (mode == 0) hipLaunchKernelGGL(scatter_add_rows_kernel<0>, dim3(nb), dim3(256), 0, stream, src, ld_src, idx, skip_if_zero, n_rows, D, dst, ld_dst);
-  else hipLaunchKernelGGL(scatter_add_rows_kernel<1>, dim3(nb), dim3(256), 0, stream, src, ld_src, idx, skip_if_zero, n_rows, D, dst, ld_dst);
+  if (mode == 0) hipLaunchKernelGGL(scatter_add_rows_kernel<0>, dim3(nb), dim3(256), 0, stream, src, ld_src, idx, skip_if_zero, n_rows, D, dst, ld_dst, n_rep, rep_stride);
+  else hipLaunchKernelGGL(scatter_add_rows_kernel<1>, dim3(nb), dim3(256), 0, stream, src, ld_src, idx, skip_if_zero, n_rows, D, dst, ld_dst, n_rep, rep_stride);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

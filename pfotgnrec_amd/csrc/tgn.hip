@@ -600,7 +600,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     set_tn(tn[3], w.dQK, HCp, xA, D, x_idx, HCp, D, lw.dWqk, D, lw.gqk);
     tn[3].c_accumulate = 0; tn[3].bias_accumulate = 0;
     RUN(pfo_gemm_tn_group_launch(tn, 4, N, nullptr, w.slabs, w.slab_floats, s));
-    if (l == 1 && c->use_memory) RUN(pfo_scatter_add_rows_launch(w.dx1, D, idx0, w.nodes[0], N, D, w.d_h0, D, s));
+    if (l == 1 && c->use_memory) RUN(pfo_scatter_add_rows_launch(w.dx1, D, idx0, w.nodes[0], N, D, w.d_h0, D, PFO_GRAD_REPLICAS, rep_stride, s));
 
     // ---- chain the composite-weight gradients back to the parameters (tiny products, side stream)
     HIPOK(hipEventRecord(sd.layer[l], s), "event record failed");
