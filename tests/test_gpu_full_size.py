@@ -196,3 +196,43 @@ def test_full_size_embedding_properties(c2):
         if den < 1e-12:
             continue
         assert ((g4 / 4.0 - g1).abs().max().item() / den) < 2e-5, n
+
+
+def test_full_size_candidate_draw_and_mv_selection():
+    """C3 (`ours` path) at full size: 20 candidate negatives per interaction from the Philox sampler (semantics of
+    utils.py:86-114: items that exist as train destinations, never in the portfolio, distinct when enough are
+    available), then the MV rank fusion of main.py:209-304 checked against the oracle for every row of the batch."""
+    from oracle import mv_select as omv
+    from pfotgnrec_amd.rand_edge_sampler import item_availability, DeviceNegativeSampler
+    cfg = CONFIGS["C3"]
+    g = make_graph(cfg, with_prices=True)
+    d = g.data
+    B, NC = 512, 20
+    s = cfg.n_edges // 2
+    sl = slice(s, s + B)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(DEV)
+    avail = item_availability(d.destinations, g.upper_u, cfg.n_items)
+    sampler = DeviceNegativeSampler(avail, g.upper_u, DEV, seed=1)
+    port_idx, port_len = t(g.portfolio_idx[sl], np.int32), t(g.portfolio_len[sl], np.int32)
+    cand_neg = sampler.sample(port_idx, port_len, NC, offset=3)                # node ids [B, 20]
+    cn = cand_neg.cpu().numpy().astype(np.int64)
+    items = cn - g.upper_u - 1                                                  # 0-based item indices
+    assert items.min() >= 0 and items.max() < cfg.n_items
+    av = np.asarray(avail).astype(bool)
+    assert av[items].all()                                                      # only items seen as destinations
+    for b in range(B):
+        port = set(g.portfolio_idx[s + b, :g.portfolio_len[s + b]].tolist())
+        row = items[b].tolist()
+        assert not (set(row) & port)                                            # portfolio items are excluded (utils.py:96)
+        if av.sum() - len(port) >= NC:
+            assert len(set(row)) == NC                                          # without replacement (utils.py:111)
+    # MV selection on [dst | 20 negatives]
+    mvs = P.MVSampler(g.prices, g.upper_u, DEV, gamma=2.0, lambda_mv=0.5, p_pos_num=1, p_neg_num=3)
+    day = g.day_of(d.timestamps[sl]).astype(np.int32)
+    cand = torch.cat([t(d.destinations[sl], np.int32).unsqueeze(1), cand_neg.to(torch.int32)], 1).contiguous()
+    p_pos, p_neg = mvs.select_device(t(day, np.int32), cand, port_idx, port_len)
+    cand_items = cand.cpu().numpy().astype(np.int64) - g.upper_u - 1
+    rp, rn, Y, NR = omv.mv_select(g.prices, day, cand_items, g.portfolio_idx[sl], g.portfolio_len[sl], 2.0, 0.5, 1, 3)
+    got_p = p_pos.cpu().numpy().reshape(B, 1).astype(np.int64) - g.upper_u - 1
+    got_n = p_neg.cpu().numpy().reshape(B, 3).astype(np.int64) - g.upper_u - 1
+    assert np.array_equal(got_p, rp) and np.array_equal(got_n, rn)              # canonical tie policy on both sides
