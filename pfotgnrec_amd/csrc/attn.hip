@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
 #ifndef ATTN_BWD_MAX_BLOCKS
 #define ATTN_BWD_MAX_BLOCKS 2048
 #endif
-int pfo_attn_bwd_max_parts() { return ATTN_BWD_MAX_BLOCKS; }
+int pfo_attn_bwd_max_parts() { return ATTN_TIME_BINS; }
 
 // DMODE: what happens to the neighbour-row gradients - 0 none (layer 1 without memory: level-0 rows are constants),
 // 1 float atomics into the rows `nbr_row` names (layer 1 over the touched-node table), 2 plain stores (layers >= 2,
@@ -415,7 +415,8 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
   for (int c = threadIdx.x; c < 2 * D; c += 256) {
     const int which = c / D, cc = c - which * D;
     const double v = s_red[0][which][cc] + s_red[1][which][cc] + s_red[2][which][cc] + s_red[3][which][cc];
-    a.dtime_part[(int64_t)blockIdx.x * 2 * D + c] = v;
+    // fp64 atomics into one of ATTN_TIME_BINS accumulator rows (all layers of a step share them; folded once at the end)
+    atomicAdd(&a.dtime_part[(int64_t)(blockIdx.x & (ATTN_TIME_BINS - 1)) * 2 * D + c], v);
   }
 }
 
@@ -499,6 +500,6 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
   else { ATTN_DISPATCH(attn_bwd_kernel_direct, grid); }
   PFO_LAUNCH_CHECK();
   pfo_prof_end(PFO_PROF_ATTN_BWD, bytes, stream);
-  if (n_parts) *n_parts = grid;
+  if (n_parts) *n_parts = ATTN_TIME_BINS;
   return PFO_OK;
 }

@@ -13,6 +13,8 @@
 #define PFO_GRAD_REPLICAS 4
 #endif
 
+#define ATTN_TIME_BINS 64          // power of two
+
 struct PfoAttn {
   int N = 0, K = 0, D = 0, Ef = 0, H = 0;
   int Cp = 0;                       // per-head row stride of QK / ctx / dctx / dQK: C = 2D+Ef feature columns, column C =
@@ -41,10 +43,10 @@ struct PfoAttn {
   float* d_nbr = nullptr;           // rows of D floats: direct rows (nbr_row == null) or atomically added rows
   int64_t d_nbr_ld = 0;
   int64_t d_nbr_rep = 0;            // atomically added rows: floats between the 8 per-XCD replicas of the table (0 = a single table)
-  double* dtime_part = nullptr;     // [grid, 2*D] per-workgroup fp64 partial (dw | db) of the time encoder
+  double* dtime_part = nullptr;     // [ATTN_TIME_BINS, 2*D] fp64 accumulators (dw | db) of the time encoder: ADDED to (zero them per step)
 };
 
 int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream);
-// returns the number of workgroups (rows of dtime_part written) in *n_parts
+// *n_parts receives ATTN_TIME_BINS (rows of dtime_part that may hold contributions)
 int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream);
 int pfo_attn_bwd_max_parts();

@@ -303,8 +303,21 @@ __global__ __launch_bounds__(256) void fold_parts_kernel(const double* __restric
   const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + c;
   double s = 0.0;
-  if (col < n)
-    for (int p = blockIdx.y * 4 + pl; p < n_parts; p += 4 * FOLD_SLICES) s += parts[(int64_t)p * n + col];
+  if (col < n) {
+    // eight part rows in flight per thread (they lie 4 * FOLD_SLICES rows apart: one at a time, every load is a full
+    // memory round trip); fixed order -> reproducible
+    int p = blockIdx.y * 4 + pl;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (; p + 7 * 4 * FOLD_SLICES < n_parts; p += 8 * 4 * FOLD_SLICES) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = parts[(int64_t)(p + u * 4 * FOLD_SLICES) * n + col];
+      s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+      s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
+    }
+    for (; p < n_parts; p += 4 * FOLD_SLICES) s0 += parts[(int64_t)p * n + col];
+    s = (s0 + s1) + (s2 + s3);
+  }
   s_red[pl][c] = s;
   __syncthreads();
   if (pl == 0 && col < n) scratch[(int64_t)blockIdx.y * n + col] = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
@@ -315,8 +328,13 @@ __global__ __launch_bounds__(256) void fold_parts_kernel(const double* __restric
   if (!s_last) return;
   __threadfence();
   if (pl == 0 && col < n) {
-    double t = 0.0;
-    for (int y = 0; y < FOLD_SLICES; ++y) t += scratch[(int64_t)y * n + col];
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+    for (int y = 0; y < FOLD_SLICES; y += 4) {
+      t0 += scratch[(int64_t)y * n + col]; t1 += scratch[(int64_t)(y + 1) * n + col];
+      t2 += scratch[(int64_t)(y + 2) * n + col]; t3 += scratch[(int64_t)(y + 3) * n + col];
+    }
+    const double t = (t0 + t1) + (t2 + t3);
     out[col] = accumulate ? (float)((double)out[col] + t) : (float)t;
   }
   if (threadIdx.x == 0) tickets[blockIdx.x] = 0;

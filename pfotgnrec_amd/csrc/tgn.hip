@@ -99,6 +99,7 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     lw.W1ovT = take<float>(p, (int64_t)d.H * d.Cp * d.D);
     lw.cqk = take<float>(p, (int64_t)d.H * d.Cp);
   }
+  w.dtime = take<double>(p, (int64_t)pfo_attn_bwd_max_parts() * 2 * d.D);      // time-encoder gradient bins, also cleared per step
   w.zero_bytes = (size_t)(p - reinterpret_cast<char*>(w.zero));
   w.cosb = take<float>(p, d.D);
   if (c->use_memory) {
@@ -151,7 +152,6 @@ Ws carve(const pfo_tgn_config* c, void* base) {
   w.dx1 = take<float>(p, N1 * d.D);
   w.slab_floats = SLAB_FLOATS;
   w.slabs = take<float>(p, w.slab_floats);
-  w.dtime = take<double>(p, (int64_t)pfo_attn_bwd_max_parts() * 2 * d.D);
   w.fold_scratch = take<double>(p, pfo_fold_parts_scratch_doubles(2 * d.D));
   w.bytes = p - reinterpret_cast<char*>(base);
   return w;
@@ -581,7 +581,6 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     a.dtime_part = w.dtime;
     int n_parts = 0;
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
-    RUN(pfo_fold_parts_launch(w.dtime, n_parts, 2 * D, G.tw, 1, w.fold_scratch, w.tickets, s));      // time_w and time_b are adjacent in the layout
     // merged query/key projection: dx += dqk' Wqk, dWqk = dqk'^T x, gqk = colsum(dqk')
     if (pfo_gemm_takes_bx(N, D)) {
       // dx = [dqk' | dh1] [Wqk ; W1[:, E:]] : both sources in one launch, dx written once
@@ -659,6 +658,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
   // stream's folds also accumulate, so it runs here, after both are done
   HIPOK(hipEventRecord(sd.done, ss), "event record failed");
   HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
+  RUN(pfo_fold_parts_launch(w.dtime, pfo_attn_bwd_max_parts(), 2 * D, G.tw, 1, w.fold_scratch, w.tickets, s));   // time_w, time_b adjacent
   for (int l = 1; l <= L; ++l)
     RUN(pfo_cq_backward_launch(w.layer[l].gq, P.l[l].wq, P.tb, D, G.l[l].b_in, G.l[l].wq, G.tb, s));   // cq = Wq[:, D:] cos(b) + bq
   return PFO_OK;
