@@ -117,6 +117,9 @@ class TGN(nn.Module):
         self.seed = 0
         self.dp_rank, self.dp_world = 0, 1
         self.eval_chunk_roots = 16384     # roots per forward-only pass (evaluation.py scores B*(2+N_ITEMS) roots per batch)
+        # memory_updater.py:25,41 assert that no pending message is older than its node's last update; the check reads
+        # device state back (one sync per call), so it is off unless asked for
+        self.debug_checks = False
 
         E, C, M = 2 * D, 2 * D + Ef, 3 * D + Ef
         lay = self._layout
@@ -335,6 +338,10 @@ class TGN(nn.Module):
         _lib.require_gpu(self.device)
         B = int(src.shape[0])
         K = int(n_neighbors)
+        if self.debug_checks and self.use_memory:
+            m = self.memory
+            late = (m.has_msg > 0) & (m.last_update > m.msg_time)
+            assert not bool(late.any()), "Trying to update memory to time in the past"      # memory_updater.py:25,41
         lo, hi = 0, B
         if self.dp_world > 1:
             per = (B + self.dp_world - 1) // self.dp_world

@@ -309,3 +309,30 @@ def test_evaluation_fast_path_chunked_roots_and_rank_metrics():
         for i, k in enumerate((1, 3, 5)):
             assert hits[b, i].item() == float(r[b] < k)
             assert abs(ndcg[b, i].item() - (1 / np.log2(r[b] + 2) if r[b] < k else 0.0)) < 1e-6
+
+
+def test_debug_check_reports_updates_into_the_past():
+    """memory_updater.py:25,41: feeding an earlier batch after a later one must raise the reference's AssertionError
+    (opt-in here: the check synchronises the device)."""
+    cfg = SyntheticConfig("t", 200, 20, 3000, 32, 1, 5, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    tgn = P.TGN(P.get_neighbor_finder(d, uniform=False), g.node_features, g.edge_features, DEV, n_layers=1, n_heads=2,
+                dropout=0.0, use_memory=True, memory_dimension=32, message_function="identity", n_neighbors=5)
+    tgn.debug_checks = True
+    rs = np.random.RandomState(0)
+    B = 30
+
+    def run(s):
+        neg = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * 3)
+        with torch.no_grad():
+            tgn.compute_temporal_embeddings(d.sources[s:s + B], d.destinations[s:s + B], neg, d.timestamps[s:s + B],
+                                            d.edge_idxs[s:s + B], 5)
+    run(2000)                       # messages at t ~ late
+    run(2030)                       # persists them (last_update ~ late), stores new ones
+    # a batch from the distant past touching the same graph: its messages carry old times; once such a message is
+    # pending for a node whose last_update is later, the next call must refuse
+    run(100)
+    with pytest.raises(AssertionError, match="time in the past"):
+        run(130)
+        run(160)
