@@ -256,6 +256,9 @@ def main():
             achieved = v["work"] / v["count"] / per_launch_s / 1e12
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None}
+            if peak != MFMA_F32_PEAK_TF:
+                roof["arithmetic"] = ("fp32 contraction as a 3-way bf16 operand split: 6 v_mfma_f32_16x16x32_bf16 per fp32 "
+                                      "product block; peak = dense bf16 MFMA peak / 6")
         else:
             achieved = v["work"] / v["count"] / per_launch_s / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
