@@ -51,7 +51,7 @@ def parse():
     return ap.parse_args()
 
 
-PMC_KERNEL = {"gemm_bx": "void gemm_bf16x3_kernel<true>", "gemm_tn_bx": "gemm_tn_group_bx_kernel",
+PMC_KERNEL = {"gemm_bx": "gemm_bx_areg_kernel", "gemm_tn_bx": "gemm_tn_group_bx_kernel",
               "gemm_bx_skinny": "gemm_bx_skinny_kernel",
               "gemm_nt": "void gemm_f32_kernel<false, false, 0, true>",
               "gemm_nn": "void gemm_f32_kernel<false, true, 0, true>",

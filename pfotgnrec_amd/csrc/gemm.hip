@@ -54,6 +54,9 @@ static bool aligned4(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 #ifndef BX_EXP
 #define BX_EXP 0      // timing-only ablations of the bf16x3 kernel (wrong results): 1 = first tile only, 2 = no MFMA, 3 = no LDS refill
 #endif
+#ifndef PFO_DEFAULT_AREG
+#define PFO_DEFAULT_AREG 1
+#endif
 #ifndef PFO_BX_MIN_TILES
 #define PFO_BX_MIN_TILES 400
 #endif
@@ -604,6 +607,159 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
   const int64_t ldc = p.ldc;
   const float* bias = p.bias ? p.bias + zb * p.bias_bs : nullptr;
   const float* rs = p.row_scale ? p.row_scale + zb * p.rs_bs : nullptr;
+  const bool n4 = bx_n4(p, Cb, ldc, bias);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = m0 + wrow + 16 * i + r;
+    if (row >= Mlim) continue;
+    const float rscale = rs ? rs[(int64_t)row * p.rs_ld] : 1.f;
+    const bool zero = p.row_zero ? (p.row_zero[row] != 0) : false;
+#pragma unroll
+    for (int j = 0; j < 11; ++j) {
+      const int col = n0 + 16 * j + 4 * g;
+      if (col < p.N) bx_store4(p, Cb, ldc, bias, rscale, zero, n4, row, col, acc[i][j]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Second form of the pre-split-image kernel: the A tile never touches LDS.  Every wavefront loads the 32 rows it owns
+// straight in MFMA fragment order (lane (r, g): row r, k = 8g..8g+7 = two float4), splits them in registers into the
+// three bf16x8 fragments, and only the shared B image goes through LDS - double-buffered, so a k-tile costs ONE barrier
+// and the copy of tile t+1 into the other buffer runs beside the MFMAs of tile t.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_areg_kernel(const GemmDev p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 3 * BX_B_PIECE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int Mlim = p.M;
+  if (p.m_dev) Mlim = min(Mlim, *p.m_dev);
+  if (m0 >= Mlim) return;
+  const int wrow = 32 * wave;
+
+  f32x4 acc[2][11];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 11; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int T0 = (p.K[0] + BK - 1) / BK;
+  const int T1 = (p.K[1] > 0 && p.A[1]) ? (p.K[1] + BK - 1) / BK : 0;
+  const int T = T0 + T1;
+  const float* safe = p.A[0];
+  const int64_t img_piece = (int64_t)p.b_img_rows * 64;
+  // rows of this lane (one per strip) for both sources
+  const float* a_row[2][2];
+  bool a_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int gm = m0 + wrow + 16 * i + r;
+    a_ok[i] = gm < Mlim;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      int64_t ridx = a_ok[i] ? gm : 0;
+      if (a_ok[i] && (s2 == 0 || T1 > 0) && p.a_idx[s2]) ridx = p.a_idx[s2][gm];
+      a_row[s2][i] = (s2 == 0 || T1 > 0) ? p.A[s2] + ridx * p.lda[s2] + 8 * g : p.A[0];
+    }
+  }
+  const char* img[2] = {reinterpret_cast<const char*>(p.b_img) + (int64_t)n0 * 64,
+                        T1 > 0 ? reinterpret_cast<const char*>(p.b_img2) + (int64_t)n0 * 64 : nullptr};
+
+  float4 a_raw[2][2];                 // [strip][half]: k = k0 + 8g + 4*half ..
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // B image tile -> LDS by asynchronous global->LDS loads (the LDS image IS the global image: a lane-linear copy, no
+  // staging registers, no ds_write); `buf` is the buffer being filled for tile t
+  auto load_global = [&](int t, int buf) {
+    const int src = t < T0 ? 0 : 1;
+    const int ts = src == 0 ? t : t - T0;
+    const int k = ts * BK + 8 * g;
+    const int Ks = p.K[src];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        a_raw[i][h] = ld4<true>(a_row[src][i] + ts * BK + 4 * h, a_ok[i] ? Ks - (k + 4 * h) : 0, safe);
+    const char* tile = img[src] + (int64_t)ts * 3 * img_piece;
+    char* Bs = lds + buf * 3 * BX_B_PIECE;
+    bx_for<9>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      if (u < 8 || wave == 0) {                              // 2112 units of 16 bytes: the 9th round is wavefront 0 only
+        const int unit = tid + 256 * u;
+        const int q = (unit >= 2 * (BX_B_PIECE / 16)) ? 2 : (unit >= BX_B_PIECE / 16 ? 1 : 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(tile + q * img_piece + (unit - q * (BX_B_PIECE / 16)) * 16),
+                                         (lptr_t)(Bs + (64 * wave + 256 * u) * 16), 16, 0, 0);
+      }
+    });
+  };
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  bf16x8 a[2][3];
+  auto split_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      uint2 lo[3], hi[3];
+      bx_split4(a_raw[i][0], lo[0], lo[1], lo[2]);
+      bx_split4(a_raw[i][1], hi[0], hi[1], hi[2]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const u32x4 w = {lo[q].x, lo[q].y, hi[q].x, hi[q].y};
+        a[i][q] = __builtin_bit_cast(bf16x8, w);
+      }
+    }
+  };
+  const int frag_off = r * 64 + ((g ^ bx_swz(r)) << 4);
+  auto compute_tile = [&](int buf) {
+    const char* Bs = lds + buf * 3 * BX_B_PIECE;
+    auto ldb = [&](bf16x8 (&b)[3], int j) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) b[q] = *reinterpret_cast<const bf16x8*>(Bs + q * BX_B_PIECE + (16 * j) * 64 + frag_off);
+    };
+    auto mma = [&](const bf16x8 (&b)[3], int j) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f32x4 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][2], c, 0, 0, 0);   // operands swapped, smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[2], a[i][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[i][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[i][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+    };
+    bf16x8 b0[3], b1[3];
+    ldb(b0, 0);
+#pragma unroll
+    for (int j = 0; j < 11; j += 2) {
+      if (j + 1 < 11) ldb(b1, j + 1);
+      mma(b0, j);
+      if (j + 2 < 11) ldb(b0, j + 2);
+      if (j + 1 < 11) mma(b1, j + 1);
+    }
+  };
+
+  if (T > 0) {
+    load_global(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    split_a();
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      const bool more = t + 1 < T;
+      if (more) load_global(t + 1, (t + 1) & 1);   // A rows to registers, B image tile to the other LDS buffer: in flight
+      compute_tile(t & 1);                         // during the MFMAs of this tile
+      if (more) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA is ordered only by the issuing wave's vmcnt + the barrier
+        split_a();                                 // this wavefront's own fragments for tile t+1
+      }
+      __syncthreads();
+    }
+  }
+
+  float* Cb = p.C;
+  const int64_t ldc = p.ldc;
+  const float* bias = p.bias;
+  const float* rs = p.row_scale;
   const bool n4 = bx_n4(p, Cb, ldc, bias);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -1298,8 +1454,12 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
     } else if (g.b_img && (g.K[1] == 0 || g.b_img2) && a_rowvec && (g.bx_force || (bx >= 1 && big_tiles >= bx_min_tiles && force < 0))) {
       d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN); d.b_img2 = g.b_img2;
       if (!g.m_dev) kind = PFO_PROF_GEMM_BX;       // device-side row counts stay "time only"
-      hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0,
-                         stream, d);
+      static const int areg = getenv("PFO_GEMM_AREG") ? atoi(getenv("PFO_GEMM_AREG")) : PFO_DEFAULT_AREG;    // A/B switch
+      if (areg && g.batch == 1)
+        hipLaunchKernelGGL(gemm_bx_areg_kernel, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
+      else
+        hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0,
+                           stream, d);
     } else if (g.K[1] > 0 && g.b_img2) {
       // the caller fused two sources whose float B operands may differ in layout: only the image kernels can take that
       pfo_set_error("pfo_gemm_launch: a two-source launch with weight images needs 16-byte aligned row-major A operands");
