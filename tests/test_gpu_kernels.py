@@ -217,7 +217,8 @@ def _gemm_bf16x3(A, B, bias, b_km, relu=0):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 344, 172), (300, 348, 172), (257, 696, 172), (129, 172, 516), (64, 64, 32),
-                                   (1000, 516, 520), (130, 86, 348), (77, 348, 88), (4099, 177, 44), (5000, 172, 696)])
+                                   (1000, 516, 520), (130, 86, 348), (77, 348, 88), (4099, 177, 44), (5000, 172, 696),
+                                   (4500, 348, 172), (4300, 520, 88), (4097, 700, 36)])
 def test_gemm_bf16x3_split_contraction_matches_float64(M, N, K):
     """fp32 contraction on the bf16 matrix cores (3-way operand split, 6 piece products): fp32-level accuracy.
     Operands with a wide dynamic range (exponents differ along k) so that dropped low pieces would show."""
