@@ -251,6 +251,10 @@ def dense_messages(tgn, n_nodes, M):
 
 
 def g5():
+    # Note: every recorded step stores its own inputs (state_dict, memory, pending messages, batch, draws) next to its
+    # outputs, so a fixture is self-contained.  The 5-step trajectory itself is not bit-reproducible across runs of this
+    # script for the 2-layer memory case (multi-threaded CPU reductions in the reference's torch ops); regenerating
+    # replaces that fixture with an equally valid one.
     R = ref_modules()
     for tag, L, use_mem, uniform, H, path in (("L1_mem", 1, True, False, 2, "base"), ("L2_mem", 2, True, False, 2, "base"),
                                                ("L2_nomem_uniform", 2, False, True, 4, "base"), ("L1_mem_p", 1, True, False, 2, "p")):
