@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
 """Throughput of the TGN training step on MI355X (BASELINE.json metric: interactions/s, TGN fwd + BPR step).
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched under torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch of synthetic interactions, the loop body of
 main.py:160-394: candidate-negative draw -> temporal neighbour sampling -> lazy memory update (GRU)
 -> L-layer temporal graph attention -> BPR loss -> backward -> Adam -> memory persist + raw-message
-store.  Workload at N=1: BASELINE.json configs[1] (C2: 50k users x 500 items, 1M edges, 2-layer
-attention, 20 neighbours, dim 172, batch 512, 3 negatives).  Inputs are resident in HBM before the
-timed region.  N > 1: edge-batch data parallelism, weak scaling (512 interactions per GPU per step,
-global batch 512*N), one RCCL all-reduce of the flat gradient buffer per step.
+store.  Inputs are resident in HBM before the timed region.
+
+N = 1: BASELINE.json configs[1] (C2: 50k users x 500 items, 1M edges, 2-layer attention, 20 neighbours,
+dim 172, batch 512, 3 negatives).
+N > 1: one process per GPU over RCCL.  When the ranks are not already there (no WORLD_SIZE in the
+environment, i.e. plain ``python bench.py --gpus N``) this process starts N child ranks itself - before
+touching any GPU - and relays rank 0's line; under ``python -m torch.distributed.run`` it IS a rank.
+Default workload for N > 1 is BASELINE.json configs[3] (C4: 500k users, 10M edges) at a FIXED global batch
+of 4096 interactions cut into N shards (strong scaling, SURVEY 8d/8e: TGN semantics are identical for every
+N), one all-reduce of the flat gradient buffer per step; the line also carries the same workload on ONE
+of those GPUs (``strong_scaling_reference``) and the weak-scaling figure on C2 (512 interactions per GPU).
+``--config`` / ``--scaling`` override.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   "roofline":     live HIP-event timing of the dominant kernel family over the timed region
   "cpu_baseline": the oracle (numpy restatement of the reference) timed on this host, bounded sample
+The timed region is K steps; when K steps take less than --min-seconds (2 s) the K-step block is repeated
+(each block bracketed by barrier + synchronize) and the line reports the mean over all blocks.
 """
 import argparse
 import json
@@ -37,13 +47,21 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C3", "C4", "C5"])
+    ap.add_argument("--config", default=None, choices=["C1", "C2", "C3", "C4", "C5"],
+                    help="default: C2 on one GPU, C4 (global batch 4096 fixed) on several")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N > 1: weak = --batch interactions per GPU, strong = the config's batch cut into N shards "
+                         "(default: strong for C4, weak otherwise)")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step timed block until this much time is covered")
+    ap.add_argument("--no-secondary", action="store_true", help="N > 1: skip the single-GPU reference and the weak-scaling C2 figure")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="start the N ranks, rendezvous, all-reduce the rank ids and print a line; no GPU work (CPU test of the launcher)")
     ap.add_argument("--batch", type=int, default=0, help="interactions per GPU per step (default: the config's)")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=512, help="interactions per oracle step in the CPU baseline sample")
-    ap.add_argument("--cpu-steps", type=int, default=1, help="timed oracle steps (one more runs first, untimed)")
+    ap.add_argument("--cpu-steps", type=int, default=4, help="timed oracle steps (one more runs first, untimed)")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event bracketing of kernel launches")
     ap.add_argument("--prof-every", type=int, default=8,
                     help="bracket the kernel launches of every Nth timed step with HIP events (the brackets cost ~0.2 ms "
@@ -128,152 +146,278 @@ def cpu_baseline(cfg, graph, batch, steps):
     return batch / float(np.median(times)), float(np.sum(times))
 
 
+def launch_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: start N ranks as CHILD processes (one per GPU, RCCL rendezvous
+    on 127.0.0.1) before this process has touched a GPU, relay rank 0's stdout, exit with the worst child status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PFO_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for q in procs[1:]:
+        rc = rc or q.wait()
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
+def launcher_selftest(args):
+    import torch
+    import torch.distributed as dist
+    from pfotgnrec_amd.distributed import init_from_env
+    rank, world, _ = init_from_env(backend=os.environ.get("PFO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(rank)], device=dev)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "world_size": dist.get_world_size(),
+                          "backend": dist.get_backend(), "rank_sum": float(t.item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+class Workload:
+    """One configuration resident on this rank's GPU: graph, model, optimizer, device-side batch sources."""
+
+    def __init__(self, args, cfg_name, dev, rank, world, scaling):
+        import torch
+        import pfotgnrec_amd as P
+        from pfotgnrec_amd.distributed import broadcast_parameters
+        from pfotgnrec_amd.synthetic import CONFIGS, make_graph
+        from pfotgnrec_amd.rand_edge_sampler import item_availability, DeviceNegativeSampler
+        self.P, self.torch, self.args, self.dev, self.rank, self.world = P, torch, args, dev, rank, world
+        cfg = self.cfg = CONFIGS[cfg_name]
+        self.scaling = scaling
+        self.per_gpu = args.batch or cfg.batch
+        # weak: every GPU brings per_gpu interactions (global batch grows); strong: the config's batch is cut into shards
+        self.B = self.per_gpu * world if scaling == "weak" else self.per_gpu
+        self.ours = cfg.name == "C3"                          # C3 = C2 + MV-efficient sampler (main.py `ours` path)
+        graph = self.graph = make_graph(cfg, with_prices=self.ours)
+        d = graph.data
+        # the CSR is built on the device (two stable sorts) - the host build takes ~10 s per 10 M edges and every rank needs one
+        nf = P.NeighborFinder.from_arrays(d.sources, d.destinations, d.edge_idxs, d.timestamps, uniform=cfg.uniform, device=dev)
+        tgn = self.tgn = P.TGN(nf, graph.node_features, graph.edge_features, dev, n_layers=cfg.n_layers, n_heads=cfg.n_heads,
+                               dropout=args.dropout, use_memory=cfg.use_memory, memory_dimension=cfg.dim,
+                               message_function="identity", n_neighbors=cfg.n_neighbors)
+        tgn.set_data_parallel(rank, world)
+        broadcast_parameters(tgn.flat_parameters, world)
+        if cfg.use_memory:
+            steady_state_init(tgn, None)
+        self.opt = P.FusedAdam(tgn, lr=args.lr)
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+        self.src_all, self.dst_all = t(d.sources, np.int32), t(d.destinations, np.int32)
+        self.ts_all, self.eidx_all = t(d.timestamps, np.float64), t(d.edge_idxs, np.int32)
+        self.port_idx_all, self.port_len_all = t(graph.portfolio_idx, np.int32), t(graph.portfolio_len, np.int32)
+        self.sampler = DeviceNegativeSampler(item_availability(d.destinations, graph.upper_u, cfg.n_items), graph.upper_u, dev, seed=1)
+        self.n_neg = 3
+        self.mvs = None
+        if self.ours:
+            self.mvs = P.MVSampler(graph.prices, graph.upper_u, dev, gamma=2.0, lambda_mv=0.5, p_pos_num=1, p_neg_num=3)
+            self.day_all = t(graph.day_of(d.timestamps), np.int32)
+        self.start = cfg.n_edges // 2                         # neighbourhoods are populated (SURVEY 8d)
+        self.span = cfg.n_edges - self.start - self.B         # batches wrap inside the second half of the edge list
+        assert self.span > 0, "batch larger than the timed half of the graph"
+        tgn.train()
+
+    def set_world(self, rank, world):
+        """Re-targets the resident model at a different data-parallel layout (the single-GPU reference of an N-rank run)."""
+        self.rank, self.world = rank, world
+        self.tgn.set_data_parallel(rank, world)
+
+    def step(self, i):
+        from pfotgnrec_amd.distributed import allreduce_flat_grad
+        P, torch, tgn, cfg, B, n_neg = self.P, self.torch, self.tgn, self.cfg, self.B, self.n_neg
+        lo = self.start + (i * B) % self.span
+        sl = slice(lo, lo + B)
+        if self.mvs is None:
+            neg = self.sampler.sample(self.port_idx_all[sl], self.port_len_all[sl], n_neg, offset=i)            # utils.py:86-114
+            emb, b = tgn.embed_device(self.src_all[sl], self.dst_all[sl], [neg.reshape(-1)], [n_neg], self.ts_all[sl],
+                                      self.eidx_all[sl], cfg.n_neighbors)                                     # tgn.py:219-327
+            loss = P.bpr_loss(emb, b, n_neg, pos_block=1, grad_scale=tgn.dp_grad_scale)                         # main.py:364-381
+        else:
+            cand_neg = self.sampler.sample(self.port_idx_all[sl], self.port_len_all[sl], 20, offset=i)          # main.py:194-195
+            cand = torch.cat([self.dst_all[sl].unsqueeze(1), cand_neg], 1).contiguous()                        # main.py:207
+            p_pos, p_neg = self.mvs.select_device(self.day_all[sl], cand, self.port_idx_all[sl], self.port_len_all[sl])   # main.py:209-304
+            emb, b = tgn.embed_device(self.src_all[sl], self.dst_all[sl], [p_pos.reshape(-1), p_neg.reshape(-1)], [1, 3],
+                                      self.ts_all[sl], self.eidx_all[sl], cfg.n_neighbors)                    # tgn.py:102-217
+            loss = P.bpr_loss(emb, b, n_neg, pos_block=2, grad_scale=tgn.dp_grad_scale)                         # main.py:321-337
+        loss.backward()                                                                                        # main.py:388
+        allreduce_flat_grad(tgn.flat_grad, self.world)
+        self.opt.step()                                                                                        # main.py:389
+        self.opt.zero_grad(set_to_none=True)
+        return loss
+
+    def timed(self, steps, warmup, min_seconds, prof_every=0, first_step=0, collective=True):
+        """W warm-up steps, then blocks of exactly K steps, each bracketed by barrier + synchronize on both sides, until
+        min_seconds are covered; per block the MAX over ranks is taken.  Returns (seconds, timed steps, blocks, loss, sampled)."""
+        import torch.distributed as dist
+        from pfotgnrec_amd import _lib
+        torch = self.torch
+        multi = collective and self.world > 1
+        i = first_step
+        for _ in range(warmup):
+            self.step(i)
+            i += 1
+        total, n_steps, blocks, n_prof = 0.0, 0, 0, 0
+        loss = None
+        while True:
+            if multi:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                sampled = prof_every > 0 and (k % prof_every == 0) and blocks == 0
+                if sampled:
+                    _lib.prof_enable(True)
+                    n_prof += 1
+                loss = self.step(i)
+                i += 1
+                if sampled:
+                    _lib.prof_enable(False)
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if multi:
+                tmax = torch.tensor([el], device=self.dev, dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                el = float(tmax.item())
+            total += el
+            n_steps += steps
+            blocks += 1
+            if total >= min_seconds or blocks >= 10000:
+                break
+        return total, n_steps, blocks, float(loss.detach()), n_prof
+
+    def describe(self):
+        cfg = self.cfg
+        return ("%s: %d users x %d items, %d edges, TGN L%d K%d D%d H%d %s, %d negatives, batch %s"
+                % (cfg.name, cfg.n_users, cfg.n_items, cfg.n_edges, cfg.n_layers, cfg.n_neighbors, cfg.dim, cfg.n_heads,
+                   "memory+GRU" if cfg.use_memory else "no memory, uniform sampling", self.n_neg,
+                   "%d/GPU" % self.per_gpu if self.scaling == "weak" else "%d global (fixed), %d shards" % (self.B, self.world)))
+
+
+def roofline_of(prof, n_prof_steps):
+    """Dominant kernel family by device time over the sampled steps.  Contractions on the bf16x3 kernels are priced against
+    the dense bf16 MFMA peak divided by the six piece products one fp32 product costs; the fp32-MFMA kernels against the
+    fp32 MFMA peak; the attention / sampling kernels against HBM."""
+    fam = {k: v for k, v in prof.items() if v["count"] > 0 and v["work"] > 0}
+    if not fam:
+        return None
+    dom = max(fam, key=lambda k: fam[k]["ms"])
+    v = fam[dom]
+    per_launch_s = v["ms"] / v["count"] * 1e-3
+    if dom.startswith("gemm"):
+        peak = MFMA_BF16_PEAK_TF / 6.0 if dom in BX_FAMILIES else MFMA_F32_PEAK_TF
+        achieved = v["work"] / v["count"] / per_launch_s / 1e12
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None}
+        if peak != MFMA_F32_PEAK_TF:
+            roof["arithmetic"] = ("fp32 contraction as a 3-way bf16 operand split: 6 v_mfma_f32_16x16x32_bf16 per fp32 "
+                                  "product block; peak = dense bf16 MFMA peak / 6")
+    else:
+        achieved = v["work"] / v["count"] / per_launch_s / 1e9
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}
+    roof["traffic"] = pmc_traffic(dom)
+    roof["kernel"] = dom
+    roof["avg_launch_us"] = round(per_launch_s * 1e6, 2)
+    roof["launches"] = int(v["count"])
+    roof["sampled_steps"] = n_prof_steps
+    roof["families_ms_per_step"] = {k: round(x["ms"] / max(1, n_prof_steps), 4) for k, x in prof.items() if x["count"] > 0}
+    tot = lambda ks: sum(prof[k]["work"] for k in ks if k in prof) / max(1e-9, sum(prof[k]["ms"] for k in ks if k in prof) * 1e-3)
+    roof["gemm_all_tflops"] = round(tot([k for k in prof if k.startswith("gemm")]) / 1e12, 2)
+    roof["attn_all_gbs"] = round(tot([k for k in prof if k.startswith("attn")]) / 1e9, 1)
+    return roof
+
+
+BX_FAMILIES = ("gemm_bx", "gemm_tn_bx", "gemm_bx_skinny", "gemm_gru")
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))                   # parent: nothing below runs here, no GPU is ever touched
+    if args.launcher_selftest:
+        return launcher_selftest(args)
     import torch
-    import pfotgnrec_amd as P
-    from pfotgnrec_amd import _lib
-    from pfotgnrec_amd.distributed import init_from_env, allreduce_flat_grad, broadcast_parameters
-    from pfotgnrec_amd.synthetic import CONFIGS, make_graph
     import torch.distributed as dist
+    from pfotgnrec_amd import _lib
+    from pfotgnrec_amd.distributed import init_from_env
 
     rank, world, local = init_from_env()
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     if os.environ.get("PFO_FORCE_DEVICE") is not None:      # test hook: several ranks on one GPU
         local = int(os.environ["PFO_FORCE_DEVICE"])
+    assert local < torch.cuda.device_count(), "rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count())
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    cfg = CONFIGS[args.config]
-    per_gpu = args.batch or cfg.batch
-    B = per_gpu * world                                   # weak scaling: global batch grows with the GPU count
-    ours = cfg.name == "C3"                               # C3 = C2 + MV-efficient sampler (main.py `ours` path)
-    graph = make_graph(cfg, with_prices=ours)
-    d = graph.data
-    nf = P.get_neighbor_finder(d, uniform=cfg.uniform)
-    tgn = P.TGN(nf, graph.node_features, graph.edge_features, dev, n_layers=cfg.n_layers, n_heads=cfg.n_heads,
-                dropout=args.dropout, use_memory=cfg.use_memory, memory_dimension=cfg.dim, message_function="identity",
-                n_neighbors=cfg.n_neighbors)
-    tgn.set_data_parallel(rank, world)
-    broadcast_parameters(tgn.flat_parameters, world)
-    if cfg.use_memory:
-        steady_state_init(tgn, None)
-    opt = P.FusedAdam(tgn, lr=args.lr)
-
-    # batch inputs resident in HBM before the timed region
-    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
-    src_all, dst_all = t(d.sources, np.int32), t(d.destinations, np.int32)
-    ts_all, eidx_all = t(d.timestamps, np.float64), t(d.edge_idxs, np.int32)
-    port_idx_all, port_len_all = t(graph.portfolio_idx, np.int32), t(graph.portfolio_len, np.int32)
-    from pfotgnrec_amd.rand_edge_sampler import item_availability, DeviceNegativeSampler
-    sampler = DeviceNegativeSampler(item_availability(d.destinations, graph.upper_u, cfg.n_items), graph.upper_u, dev, seed=1)
-    n_neg = 3
-    mvs = None
-    if ours:
-        mvs = P.MVSampler(graph.prices, graph.upper_u, dev, gamma=2.0, lambda_mv=0.5, p_pos_num=1, p_neg_num=3)
-        day_all = t(graph.day_of(d.timestamps), np.int32)
-    start = cfg.n_edges // 2                              # neighbourhoods are populated
-    n_steps_total = args.warmup + args.steps
-    span = cfg.n_edges - start - B                          # batches wrap inside the second half of the edge list
-    assert span > 0, "batch larger than the timed half of the graph"
-
-    def step(i):
-        lo = start + (i * B) % span
-        sl = slice(lo, lo + B)
-        if mvs is None:
-            neg = sampler.sample(port_idx_all[sl], port_len_all[sl], n_neg, offset=i)       # utils.py:86-114
-            emb, b = tgn.embed_device(src_all[sl], dst_all[sl], [neg.reshape(-1)], [n_neg], ts_all[sl], eidx_all[sl],
-                                      cfg.n_neighbors)                                      # tgn.py:219-327
-            loss = P.bpr_loss(emb, b, n_neg, pos_block=1, grad_scale=1.0 / world)           # main.py:364-381
-        else:
-            cand_neg = sampler.sample(port_idx_all[sl], port_len_all[sl], 20, offset=i)     # main.py:194-195
-            cand = torch.cat([dst_all[sl].unsqueeze(1), cand_neg], 1).contiguous()          # main.py:207
-            p_pos, p_neg = mvs.select_device(day_all[sl], cand, port_idx_all[sl], port_len_all[sl])   # main.py:209-304
-            emb, b = tgn.embed_device(src_all[sl], dst_all[sl], [p_pos.reshape(-1), p_neg.reshape(-1)], [1, 3], ts_all[sl],
-                                      eidx_all[sl], cfg.n_neighbors)                        # tgn.py:102-217
-            loss = P.bpr_loss(emb, b, n_neg, pos_block=2, grad_scale=1.0 / world)           # main.py:321-337
-        loss.backward()                                                                     # main.py:388
-        allreduce_flat_grad(tgn.flat_grad, world)
-        opt.step()                                                                          # main.py:389
-        opt.zero_grad(set_to_none=True)
-        return loss
-
-    tgn.train()
-    for i in range(args.warmup):
-        step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    n_prof_steps = 0
-    t0 = time.perf_counter()
-    for i in range(args.warmup, n_steps_total):
-        sampled = (not args.no_prof) and ((i - args.warmup) % max(1, args.prof_every) == 0)
-        if sampled:
-            _lib.prof_enable(True)
-            n_prof_steps += 1
-        loss = step(i)
-        if sampled:
-            _lib.prof_enable(False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    cfg_name = args.config or ("C2" if world == 1 else "C4")
+    scaling = args.scaling or ("strong" if (cfg_name == "C4" and world > 1) else "weak")
+    wl = Workload(args, cfg_name, dev, rank, world, scaling)
+    prof_every = 0 if args.no_prof else max(1, args.prof_every)
+    elapsed, n_timed, blocks, final_loss, n_prof_steps = wl.timed(args.steps, args.warmup, args.min_seconds, prof_every)
     prof = _lib.prof_collect() if not args.no_prof else None
     _lib.prof_enable(False)
-    final_loss = float(loss.detach())
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    B = wl.B
+    value = n_timed * B / elapsed
+    out = {
+        "metric": "interactions/sec (TGN fwd+BPR step)", "value": round(value, 1), "unit": "interactions/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / n_timed, 4),
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl.describe(), "global_batch": B, "parallelism": "dp%d" % world, "dropout": args.dropout,
+                   "final_loss": round(final_loss, 5), "timed_blocks": blocks, "timed_steps": n_timed,
+                   "timed_seconds": round(elapsed, 3),
+                   "collective": ("rccl all-reduce of the flat fp32 gradient, world %d" % dist.get_world_size()) if world > 1 else None},
+    }
+    if prof is not None:
+        roof = roofline_of(prof, n_prof_steps)
+        if roof:
+            out["roofline"] = roof
+
+    if world > 1 and not args.no_secondary:
+        # (1) the same workload on ONE of these GPUs (rank 0 alone, the others wait): the denominator of the strong-scaling
+        #     figure.  (2) weak scaling on C2, 512 interactions per GPU, what round 1 reported.
+        sec = {}
+        if scaling == "strong":
+            dist.barrier()
+            if rank == 0:
+                wl.set_world(0, 1)
+                el, n1, _, _, _ = wl.timed(args.steps, 2, min(args.min_seconds, 1.0), 0, first_step=100000, collective=False)
+                sec["strong_scaling_reference"] = {"n_gpus": 1, "value": round(n1 * B / el, 1), "ms_per_step": round(1e3 * el / n1, 4),
+                                                   "workload": "the same global batch on one GPU"}
+                wl.set_world(0, world)
+            dist.barrier()
+        if not (cfg_name == "C2" and scaling == "weak"):
+            del wl
+            torch.cuda.empty_cache()
+            w2 = Workload(args, "C2", dev, rank, world, "weak")
+            el, n2, _, _, _ = w2.timed(args.steps, args.warmup, min(args.min_seconds, 1.0), 0)
+            sec["weak_scaling_C2"] = {"n_gpus": world, "value": round(n2 * w2.B / el, 1), "ms_per_step": round(1e3 * el / n2, 4),
+                                      "workload": w2.describe(), "global_batch": w2.B}
+            del w2
+        out["secondary"] = sec
 
     if rank != 0:
         if world > 1:
             dist.barrier()
+            dist.destroy_process_group()
         return
-    value = args.steps * B / elapsed
-    out = {
-        "metric": "interactions/sec (TGN fwd+BPR step)", "value": round(value, 1), "unit": "interactions/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d users x %d items, %d edges, TGN L%d K%d D%d H%d %s, %d negatives, batch %d/GPU"
-                               % (cfg.name, cfg.n_users, cfg.n_items, cfg.n_edges, cfg.n_layers, cfg.n_neighbors, cfg.dim,
-                                  cfg.n_heads, "memory+GRU" if cfg.use_memory else "no memory, uniform sampling", n_neg, per_gpu),
-                   "global_batch": B, "parallelism": "dp%d" % world, "dropout": args.dropout, "final_loss": round(final_loss, 5)},
-    }
-    if prof is not None:
-        # dominant kernel family by device time over the sampled steps.  Contractions on the bf16x3 kernels are priced
-        # against the dense bf16 MFMA peak divided by the six piece products one fp32 product costs; the fp32-MFMA
-        # kernels against the fp32 MFMA peak; the attention / sampling kernels against HBM.
-        fam = {k: v for k, v in prof.items() if v["count"] > 0 and v["work"] > 0}
-        dom = max(fam, key=lambda k: fam[k]["ms"])
-        v = fam[dom]
-        per_launch_s = v["ms"] / v["count"] * 1e-3
-        if dom.startswith("gemm"):
-            peak = MFMA_BF16_PEAK_TF / 6.0 if dom in ("gemm_bx", "gemm_tn_bx", "gemm_bx_skinny") else MFMA_F32_PEAK_TF
-            achieved = v["work"] / v["count"] / per_launch_s / 1e12
-            roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None}
-            if peak != MFMA_F32_PEAK_TF:
-                roof["arithmetic"] = ("fp32 contraction as a 3-way bf16 operand split: 6 v_mfma_f32_16x16x32_bf16 per fp32 "
-                                      "product block; peak = dense bf16 MFMA peak / 6")
-        else:
-            achieved = v["work"] / v["count"] / per_launch_s / 1e9
-            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}
-        roof["traffic"] = pmc_traffic(dom)
-        roof["kernel"] = dom
-        roof["avg_launch_us"] = round(per_launch_s * 1e6, 2)
-        roof["launches"] = int(v["count"])
-        roof["sampled_steps"] = n_prof_steps
-        roof["families_ms_per_step"] = {k: round(x["ms"] / max(1, n_prof_steps), 4) for k, x in prof.items() if x["count"] > 0}
-        tot = lambda ks: sum(prof[k]["work"] for k in ks) / max(1e-9, sum(prof[k]["ms"] for k in ks) * 1e-3)
-        roof["gemm_all_tflops"] = round(tot(["gemm_nt", "gemm_nn", "gemm_tn", "gemm_bx", "gemm_tn_bx", "gemm_bx_skinny"]) / 1e12, 2)
-        roof["attn_all_gbs"] = round(tot(["attn_fwd", "attn_bwd"]) / 1e9, 1)
-        out["roofline"] = roof
     if not args.no_cpu_baseline and world == 1:
+        from pfotgnrec_amd.synthetic import CONFIGS, make_graph
         try:
             threads = os.cpu_count() or 1
             try:                                            # threads the BLAS behind numpy actually uses
@@ -281,17 +425,19 @@ def main():
                 threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
             except Exception:
                 pass
-            v, spent = cpu_baseline(cfg, graph, args.cpu_batch, args.cpu_steps)
+            cfg = CONFIGS[cfg_name]
+            v, spent = cpu_baseline(cfg, make_graph(cfg, with_prices=False), args.cpu_batch, args.cpu_steps)
             out["cpu_baseline"] = {"value": round(v, 2), "unit": "interactions/s", "cores": threads, "kind": "port",
                                    "sample": "%d step(s) of %d interactions of the same workload after one untimed step "
                                              "(oracle/tgn_oracle.py: numpy fp32 + BLAS + C fmaf/cosf helper, steady-state "
-                                             "memory), %.1f s timed" % (args.cpu_steps, args.cpu_batch, spent)}
+                                             "memory), median step, %.1f s timed" % (args.cpu_steps, args.cpu_batch, spent)}
         except Exception as e:  # the baseline never blocks the measurement
             out["cpu_baseline"] = {"value": None, "unit": "interactions/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": "failed: %r" % (e,)}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

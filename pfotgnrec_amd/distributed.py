@@ -3,8 +3,8 @@
 One process per GPU.  Every rank holds the full replicated state (parameters, Adam moments, CSR,
 features, memory, pending-message table); a global batch of B interactions is cut into ``world``
 contiguous shards and each rank samples/embeds/back-propagates only its shard's roots.  Exactly one
-collective per step: an all-reduce (sum) of the flat fp32 gradient buffer, with the local loss
-gradient pre-scaled by 1/world so the sum is the global-batch mean gradient.  The memory persist and
+collective per step: an all-reduce (sum) of the flat fp32 gradient buffer, with the local mean-loss
+gradient pre-scaled by (local batch / global batch) so the sum is the global-batch mean gradient.  The memory persist and
 raw-message store run for ALL global positives on every rank (they depend only on replicated state),
 so replicas stay identical without a second exchange.
 """
@@ -32,9 +32,9 @@ def init_from_env(backend=None):
 
 
 def shard_bounds(batch, rank, world):
-    """Contiguous shard [lo, hi) of a batch of ``batch`` interactions owned by ``rank``."""
-    per = (batch + world - 1) // world
-    return min(batch, rank * per), min(batch, (rank + 1) * per)
+    """Contiguous shard [lo, hi) of a batch of ``batch`` interactions owned by ``rank``: balanced (sizes differ by at
+    most one); shards are empty only when the batch is shorter than the world size (TGN.embed_device handles that)."""
+    return rank * batch // world, (rank + 1) * batch // world
 
 
 def allreduce_flat_grad(flat_grad, world):

@@ -29,8 +29,13 @@ def bpr_loss(emb, batch, n_neg, pos_block=1, grad_scale=1.0):
 
     emb [R,D] = [src B | dst B | (p_pos B) | neg B*n_neg]; ``pos_block`` = 1 when the positive is the destination
     (baseline path), 2 when it is the p_pos block (``ours`` path).  ``grad_scale`` multiplies the gradient only
-    (1/world_size under data parallelism so that summed gradients equal the global-batch mean).
+    (``tgn.dp_grad_scale`` = local/global batch under data parallelism, so that the summed gradients equal the
+    global-batch mean gradient also when the shards are uneven).
     """
+    if batch == 0:
+        # an empty data-parallel shard (global batch shorter than the world size): zero loss, zero gradient, but still
+        # a differentiable scalar so that every rank runs the same backward / all-reduce sequence
+        return emb.sum() * 0.0
     pos_off = pos_block * batch
     neg_off = (pos_block + 1) * batch
     return _BprFn.apply(emb, batch, pos_off, neg_off, n_neg, grad_scale)

@@ -7,8 +7,19 @@ import numpy as np
 
 from . import _lib
 
-_AVAIL_CACHE = {}
+_AVAIL_CACHE = []          # [(dst_list object, checksum, upper_u, n_items, availability)] - at most one entry
 _GLOBAL_CALLS = [0]
+
+
+def _checksum(a):
+    """Cheap content fingerprint of an id array: length, ends and a strided sample (an in-place edit of the cached
+    array between batches is caught unless it avoids every sampled position)."""
+    a = np.asarray(a)
+    n = a.shape[0]
+    if n == 0:
+        return (0,)
+    step = max(1, n // 1024)
+    return (n, int(a[0]), int(a[-1]), int(np.asarray(a[::step], np.int64).sum()))
 
 
 def item_availability(dst_list, upper_u, n_items):
@@ -63,11 +74,13 @@ class RandEdgeSampler:
         self.src_list = src_list
         self.upper_u = int(upper_u)
         self.n_items = len(map_item_id)
-        key = (id(dst_list), len(dst_list), self.upper_u, self.n_items)
-        if key not in _AVAIL_CACHE:                    # the reference re-runs np.unique every batch; same result
-            _AVAIL_CACHE.clear()
-            _AVAIL_CACHE[key] = item_availability(dst_list, self.upper_u, self.n_items)
-        self.item_avail = _AVAIL_CACHE[key]
+        # the reference re-runs np.unique(dst_list) every batch (utils.py:73) on the same long-lived array; the bitmap is
+        # cached on the array OBJECT (held here, so its id cannot be recycled) plus a content fingerprint
+        ck = _checksum(dst_list)
+        hit = _AVAIL_CACHE and _AVAIL_CACHE[0][0] is dst_list and _AVAIL_CACHE[0][1:4] == (ck, self.upper_u, self.n_items)
+        if not hit:
+            _AVAIL_CACHE[:] = [(dst_list, ck, self.upper_u, self.n_items, item_availability(dst_list, self.upper_u, self.n_items))]
+        self.item_avail = _AVAIL_CACHE[0][4]
         self.port_idx, self.port_len = pack_portfolios(portfolio_list, map_item_id)
         self.seed = seed
         self.device = device

@@ -38,7 +38,20 @@ def _normalise_edge_features(edge_features):
 class _Call:
     """Everything one forward/backward pair of native calls needs to agree on."""
     __slots__ = ("roots", "root_ts", "R", "K", "mode", "draws", "draw_ptrs", "seed", "offset", "dropout_p", "training",
-                 "extra", "batch_struct")
+                 "extra", "batch_struct", "ws", "ws_caps", "cfg", "pool", "__weakref__")
+
+    def release(self):
+        """Hands the call's workspace back to its TGN's pool (after the backward, or when the graph is dropped)."""
+        ws, pool = getattr(self, "ws", None), getattr(self, "pool", None)
+        if ws is not None and pool is not None:
+            pool.append((self.ws_caps, ws))
+        self.ws = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 class _EmbedFn(torch.autograd.Function):
@@ -52,13 +65,17 @@ class _EmbedFn(torch.autograd.Function):
     def forward(ctx, tgn, call, post, *params):
         emb = tgn._native_forward(call)
         if post is not None:
-            post()
+            post(call)
         ctx.tgn, ctx.call, ctx.n_params = tgn, call, len(params)
         return emb
 
     @staticmethod
     def backward(ctx, d_emb):
+        if ctx.call.ws is None:
+            raise RuntimeError("backward through a TGN forward whose workspace was already consumed "
+                               "(a second backward over the same call is not supported)")
         ctx.tgn._native_backward(ctx.call, d_emb.contiguous())
+        ctx.call.release()
         return (None, None, None) + (None,) * ctx.n_params
 
 
@@ -111,8 +128,11 @@ class TGN(nn.Module):
         self._flat = torch.zeros(self._layout.total, dtype=torch.float32, device=self.device)
         self._flat_grad = None
         self._views = []          # (parameter, offset, numel, shape)
-        self._ws = None
+        self._adj_cache = None
+        self.dp_grad_scale = 1.0
+        self._ws_pool = []        # free workspaces: [(caps, tensor)]
         self._ws_caps = (0, 0, 0)
+        self._last_ws = None      # (config, workspace) of the newest forward (debug_touched)
         self._step = 0
         self.seed = 0
         self.dp_rank, self.dp_world = 0, 1
@@ -228,7 +248,7 @@ class TGN(nn.Module):
             mem.device = self._flat.device
             self.memory_updater.layer_norm._apply(fn)
         self.device = self._flat.device
-        self._ws = None
+        self._ws_pool, self._last_ws, self._adj_cache = [], None, None
         return self
 
     # ------------------------------------------------------------------ neighbour finder plumbing
@@ -249,21 +269,38 @@ class TGN(nn.Module):
         self.dp_rank, self.dp_world = int(rank), int(world_size)
 
     # ------------------------------------------------------------------ native plumbing
-    def _ensure_workspace(self, R, K, B):
-        cr, ck, cb = self._ws_caps
-        if self._ws is None or R > cr or K > ck or B > cb:
-            cr, ck, cb = max(cr, R), max(ck, K), max(cb, B)
-            self._cfg.max_roots, self._cfg.max_neighbors, self._cfg.max_batch = cr, ck, cb
-            nbytes = _lib.load().pfo_tgn_workspace_bytes(ctypes.byref(self._cfg))
+    def _acquire_workspace(self, R, K, B):
+        """A workspace (and the config it was carved for) for ONE forward[/backward] pair.
+
+        Every outstanding training forward owns its workspace until its backward has run, so several forwards may
+        precede one backward (main.py:171 accumulates ``BACKPROP_EVERY`` batches) and an evaluation forward between a
+        training forward and its backward cannot clobber saved activations.  Workspaces are pooled: in the usual
+        one-forward-one-backward loop the same buffer (same device pointers) is reused every step.
+        """
+        need = (max(1, int(R)), max(1, int(K)), max(1, int(B)))
+        best = None
+        for i, (caps, _) in enumerate(self._ws_pool):
+            if all(c >= n for c, n in zip(caps, need)) and (best is None or caps < self._ws_pool[best][0]):
+                best = i
+        if best is not None:
+            caps, ws = self._ws_pool.pop(best)
+        else:
+            caps = tuple(max(c, n) for c, n in zip(self._ws_caps, need))
+            self._ws_caps = caps
+            self._ws_pool = [e for e in self._ws_pool if e[0] == caps]      # smaller buffers are not worth keeping
+            cfg = self._cfg_for(caps)
+            nbytes = _lib.load().pfo_tgn_workspace_bytes(ctypes.byref(cfg))
             if nbytes < 0:
                 raise _lib.PfoError("pfo_tgn_workspace_bytes: %s" % _lib.load().pfo_last_error().decode())
-            self._ws = None
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            self._ws_caps = (cr, ck, cb)
-        return self._ws
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return caps, self._cfg_for(caps), ws
+
+    def _cfg_for(self, caps):
+        c = self._cfg
+        return _lib.TgnConfig(c.n_nodes, c.n_edges_p1, c.D, c.Ef, c.n_layers, c.n_heads, c.use_memory, caps[0], caps[1], caps[2])
 
     def _state_struct(self):
-        indptr, nbr, eidx, ts = self.neighbor_finder.device_arrays(self.device)
+        indptr, nbr, eidx, ts = self._adjacency()
         self._keepalive = (indptr, nbr, eidx, ts)
         mem = self.memory
         return _lib.TgnState(indptr.data_ptr(), nbr.data_ptr(), eidx.data_ptr(), ts.data_ptr(),
@@ -274,7 +311,35 @@ class TGN(nn.Module):
                              mem.msg_time.data_ptr() if mem is not None else None,
                              mem.has_msg.data_ptr() if mem is not None else None, self._flat.data_ptr())
 
-    def _make_call(self, roots, root_ts, K, draws, training, extra):
+    def _adjacency(self):
+        """Device CSR of the current neighbour finder, checked against this model's node table.
+
+        The native step indexes ``indptr`` with every node id below ``n_nodes`` (= rows of the node-feature table) and
+        the feature / memory tables with every neighbour id the CSR returns.  ``get_neighbor_finder(data, uniform)``
+        (main.py:95) sizes its adjacency by the largest id *in that split*, which can be smaller: such a finder gets
+        its ``indptr`` padded with empty rows (the reference would raise IndexError for those ids).  A finder that
+        names nodes this model has no features for is refused.
+        """
+        nf = self.neighbor_finder
+        key = (id(nf), str(self.device))
+        if self._adj_cache is not None and self._adj_cache[0] == key and self._adj_cache[1] is nf:
+            return self._adj_cache[2]
+        indptr, nbr, eidx, ts = nf.device_arrays(self.device)
+        max_nbr = nf.max_neighbor_id() if hasattr(nf, "max_neighbor_id") else int(np.max(nf.nbr, initial=0))
+        if max_nbr >= self.n_nodes or nf.n_nodes > self.n_nodes and int(nf.indptr[-1]) != int(nf.indptr[self.n_nodes]):
+            raise ValueError("neighbour finder references node ids >= n_nodes (%d): node features have %d rows"
+                             % (max(max_nbr, nf.n_nodes - 1), self.n_nodes))
+        max_eidx = int(np.max(nf.eidx, initial=0))
+        if max_eidx >= self.edge_raw_features.shape[0]:
+            raise ValueError("neighbour finder references edge index %d but edge features have %d rows"
+                             % (max_eidx, self.edge_raw_features.shape[0]))
+        if indptr.shape[0] < self.n_nodes + 1:
+            pad = indptr[-1:].expand(self.n_nodes + 1 - indptr.shape[0])
+            indptr = torch.cat([indptr, pad]).contiguous()
+        self._adj_cache = (key, nf, (indptr, nbr, eidx, ts))
+        return self._adj_cache[2]
+
+    def _make_call(self, roots, root_ts, K, draws, dropout_p, extra, B):
         c = _Call()
         c.roots, c.root_ts, c.R, c.K = roots, root_ts, int(roots.shape[0]), int(K)
         uniform = bool(getattr(self.neighbor_finder, "uniform", False))
@@ -288,23 +353,25 @@ class TGN(nn.Module):
         self._step += 1
         c.seed = self.seed + getattr(self.neighbor_finder, "seed", 0)
         c.offset = self._step << 36
-        c.training = int(training)
-        c.dropout_p = self.dropout if training else 0.0
+        c.dropout_p = float(dropout_p)
+        c.training = int(dropout_p > 0.0)
         c.extra = extra
         c.batch_struct = _lib.TgnBatch(roots.data_ptr(), root_ts.data_ptr(), c.R, c.K, c.mode,
                                        ctypes.cast(c.draw_ptrs, ctypes.POINTER(ctypes.c_void_p)) if c.draw_ptrs else None,
                                        c.seed, c.offset, c.dropout_p, c.training,
                                        extra.data_ptr() if extra is not None else None,
                                        int(extra.shape[0]) if extra is not None else 0)
+        c.pool = self._ws_pool
+        c.ws_caps, c.cfg, c.ws = self._acquire_workspace(c.R, c.K, B)
         return c
 
-    def _native_forward(self, call):
+    def _native_forward(self, call, out=None):
         _lib.require_gpu(self.device)
-        ws = self._ensure_workspace(call.R, call.K, self._cur_batch)
         st = self._state_struct()
-        emb = torch.empty((call.R, self.n_node_features), dtype=torch.float32, device=self.device)
-        _lib.call("pfo_tgn_forward", ctypes.byref(self._cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
-                  ws.data_ptr(), emb.data_ptr(), _lib.stream_ptr())
+        emb = out if out is not None else torch.empty((call.R, self.n_node_features), dtype=torch.float32, device=self.device)
+        _lib.call("pfo_tgn_forward", ctypes.byref(call.cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
+                  call.ws.data_ptr(), emb.data_ptr(), _lib.stream_ptr())
+        self._last_ws = (call.cfg, call.ws)
         return emb
 
     def _attach_grads(self):
@@ -318,22 +385,26 @@ class TGN(nn.Module):
     def _native_backward(self, call, d_emb):
         self._attach_grads()
         st = self._state_struct()
-        _lib.call("pfo_tgn_backward", ctypes.byref(self._cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
-                  self._ws.data_ptr(), d_emb.data_ptr(), self._flat_grad.data_ptr(), _lib.stream_ptr())
+        _lib.call("pfo_tgn_backward", ctypes.byref(call.cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
+                  call.ws.data_ptr(), d_emb.data_ptr(), self._flat_grad.data_ptr(), _lib.stream_ptr())
 
-    def _native_update_state(self, src, dst, ts, eidx):
+    def _native_update_state(self, call, src, dst, ts, eidx):
         st = self._state_struct()
-        _lib.call("pfo_tgn_update_state", ctypes.byref(self._cfg), ctypes.byref(st), src.data_ptr(), dst.data_ptr(),
-                  ts.data_ptr(), eidx.data_ptr(), int(src.shape[0]), self._ws.data_ptr(), _lib.stream_ptr())
+        _lib.call("pfo_tgn_update_state", ctypes.byref(call.cfg), ctypes.byref(st), src.data_ptr(), dst.data_ptr(),
+                  ts.data_ptr(), eidx.data_ptr(), int(src.shape[0]), call.ws.data_ptr(), _lib.stream_ptr())
 
     # ------------------------------------------------------------------ the step
     def embed_device(self, src, dst, extra_roots, extra_repeat, edge_times, edge_idxs, n_neighbors, draws=None):
         """Device-resident core of both reference entry points.
 
         src/dst i32[B], edge_times f64[B], edge_idxs i32[B], extra_roots: list of i32 tensors [B*r_k] (negatives /
-        p_pos / p_neg, row-major per interaction) with repeat counts ``extra_repeat``; all on ``self.device``.
-        Returns the embedding matrix [R, D] in the order [src | dst | extra...] for THIS rank's shard of the batch,
-        and performs the memory persist + raw-message store for the whole batch (tgn.py:290-317).
+        p_pos / p_neg, row-major per interaction) with repeat counts ``extra_repeat``; all on ``self.device``; node ids
+        must lie in [0, n_nodes) (the numpy entry points check this, this one does not: it would cost a device sync).
+        Returns the embedding matrix [R, D] in the order [src | dst | extra...] for THIS rank's shard of the batch
+        (``R = b * (2 + sum(extra_repeat))``, ``b`` = the second return value; b may be 0 for a trailing rank when the
+        batch is shorter than the world size), and performs the memory persist + raw-message store for the whole batch
+        (tgn.py:290-317).  ``self.dp_grad_scale`` then holds b / B, the factor that turns this shard's mean-loss
+        gradient into its share of the global-batch mean gradient.
         """
         _lib.require_gpu(self.device)
         B = int(src.shape[0])
@@ -344,51 +415,88 @@ class TGN(nn.Module):
             assert not bool(late.any()), "Trying to update memory to time in the past"      # memory_updater.py:25,41
         lo, hi = 0, B
         if self.dp_world > 1:
-            per = (B + self.dp_world - 1) // self.dp_world
-            lo, hi = min(B, self.dp_rank * per), min(B, (self.dp_rank + 1) * per)
-        # roots = [src | dst | extra groups], root_ts = the interaction's edge time per root (tgn.py:123-124 / 238-239)
-        R = (hi - lo) * (2 + sum(int(r) for r in extra_repeat))
-        roots = torch.empty(R, dtype=torch.int32, device=self.device)
-        root_ts = torch.empty(R, dtype=torch.float64, device=self.device)
-        extra_roots = [t.contiguous() for t in extra_roots]
-        ng = len(extra_roots)
-        gptr = (ctypes.c_void_p * max(1, ng))(*[t.data_ptr() for t in extra_roots])
-        greps = (ctypes.c_int32 * max(1, ng))(*[int(r) for r in extra_repeat])
-        if hi > lo:
+            lo, hi = self.dp_rank * B // self.dp_world, (self.dp_rank + 1) * B // self.dp_world
+        b = hi - lo
+        self.dp_grad_scale = (b / float(B)) if B > 0 else 0.0
+        # roots = [src | dst | extra groups], root_ts = the interaction's edge time per root (tgn.py:123-124 / 238-239);
+        # a group with zero nodes per interaction (e.g. no negatives) contributes nothing
+        groups = [(t.contiguous(), int(r)) for t, r in zip(extra_roots, extra_repeat) if int(r) > 0]
+        R = b * (2 + sum(r for _, r in groups))
+        D = self.n_node_features
+        grad_mode = torch.is_grad_enabled()
+        dropout_p = self.dropout if self.training else 0.0       # dropout follows train()/eval(), not the autograd mode
+        extra = torch.cat([src, dst]).contiguous() if (self.use_memory and self.dp_world > 1) else None
+        if b == 0:
+            # empty shard (B < world): nothing to embed, but the state update still runs on every rank; one padding
+            # root keeps the native call well-formed (node 0 never has neighbours; its row is dropped below)
+            roots = torch.zeros(1, dtype=torch.int32, device=self.device)
+            root_ts = torch.full((1,), -1.0, dtype=torch.float64, device=self.device)
+        else:
+            roots = torch.empty(R, dtype=torch.int32, device=self.device)
+            root_ts = torch.empty(R, dtype=torch.float64, device=self.device)
+            ng = len(groups)
+            gptr = (ctypes.c_void_p * max(1, ng))(*[t.data_ptr() for t, _ in groups])
+            greps = (ctypes.c_int32 * max(1, ng))(*[r for _, r in groups])
             _lib.call("pfo_roots_assemble", src.data_ptr(), dst.data_ptr(), edge_times.data_ptr(), lo, hi, gptr, greps, ng,
                       roots.data_ptr(), root_ts.data_ptr(), _lib.stream_ptr())
         if K <= 0:                       # utils.py:175: a single all-padding column
             K, root_ts = 1, torch.full_like(root_ts, -1.0)
-        training = self.training and torch.is_grad_enabled()
-        extra = torch.cat([src, dst]).contiguous() if (self.use_memory and self.dp_world > 1) else None
-        self._cur_batch = B
         post = None
         if self.use_memory:
-            post = lambda: self._native_update_state(src, dst, edge_times, edge_idxs)
-        if training:
-            call = self._make_call(roots, root_ts, K, draws, training, extra)
+            post = lambda call: self._native_update_state(call, src, dst, edge_times, edge_idxs)
+        if b == 0:
+            call = self._make_call(roots, root_ts, K, None, 0.0, extra, B)
+            self._native_forward(call)
+            if post is not None:
+                post(call)
+            call.release()
+            emb = torch.zeros((0, D), dtype=torch.float32, device=self.device)
+            if grad_mode:
+                emb = emb + self._flat[:1].sum() * 0.0             # keeps an (empty) graph so callers can .backward()
+            return emb, 0
+        if grad_mode:
+            call = self._make_call(roots, root_ts, K, draws, dropout_p, extra, B)
             emb = _EmbedFn.apply(self, call, post, *self.hot_parameters())
-            return emb, hi - lo
+            return emb, b
         # forward only (evaluation.py:94: R = B*(2+N_ITEMS) roots): walk the roots in chunks through the same
         # kernels; memory is persisted once, after the last chunk, from a pass that covers the positives
-        R, cap = int(roots.shape[0]), int(self.eval_chunk_roots)
+        cap = int(self.eval_chunk_roots)
         if R <= cap or draws is not None:
-            emb = self._native_forward(self._make_call(roots, root_ts, K, draws, False, extra))
+            call = self._make_call(roots, root_ts, K, draws, dropout_p, extra, B)
+            emb = self._native_forward(call)
         else:
-            emb = torch.empty((R, self.n_node_features), dtype=torch.float32, device=self.device)
+            emb = torch.empty((R, D), dtype=torch.float32, device=self.device)
             pos = torch.cat([src, dst]).contiguous() if self.use_memory else None
             order = list(range(cap, R, cap)) + [0]                # chunk 0 (holds src|dst) last: its touched set feeds the persist
+            call = None
             for c0 in order:
                 c1 = min(R, c0 + cap)
                 ex = extra if c0 != 0 or pos is None else (pos if extra is None else extra)
-                call = self._make_call(roots[c0:c1].contiguous(), root_ts[c0:c1].contiguous(), K, None, False, ex)
-                emb[c0:c1] = self._native_forward(call)
+                if call is not None:
+                    call.release()
+                call = self._make_call(roots[c0:c1], root_ts[c0:c1], K, None, dropout_p, ex, B)
+                self._native_forward(call, out=emb[c0:c1])
         if post is not None:
-            post()
-        return emb, hi - lo
+            post(call)
+        call.release()
+        return emb, b
 
     def _to_dev(self, a, dtype):
         return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=dtype)).to(self.device)
+
+    def _nodes_to_dev(self, a, what):
+        """Host node ids -> i32 device tensor; ids outside [0, n_nodes) raise IndexError like the reference's table
+        lookups would (the native kernels index feature / memory / adjacency tables with them unchecked)."""
+        a = np.asarray(a)
+        if a.size and (int(a.min()) < 0 or int(a.max()) >= self.n_nodes):
+            raise IndexError("%s holds node ids outside [0, %d)" % (what, self.n_nodes))
+        return self._to_dev(a, np.int32)
+
+    def _edges_to_dev(self, a):
+        a = np.asarray(a)
+        if a.size and (int(a.min()) < 0 or int(a.max()) >= self.edge_raw_features.shape[0]):
+            raise IndexError("edge_idxs outside [0, %d)" % self.edge_raw_features.shape[0])
+        return self._to_dev(a, np.int32)
 
     def compute_temporal_embeddings(self, source_nodes, destination_nodes, p_neg_nodes, edge_times, edge_idxs,
                                     n_neighbors=20, draws=None):
@@ -396,9 +504,9 @@ class TGN(nn.Module):
         (src_emb [B,D], dst_emb [B,D], neg_emb [B*size,D])."""
         B = len(source_nodes)
         size = int(len(p_neg_nodes) / B)                                        # tgn.py:237
-        src, dst = self._to_dev(source_nodes, np.int32), self._to_dev(destination_nodes, np.int32)
-        neg = self._to_dev(p_neg_nodes, np.int32)
-        ts, eidx = self._to_dev(edge_times, np.float64), self._to_dev(edge_idxs, np.int32)
+        src, dst = self._nodes_to_dev(source_nodes, "source_nodes"), self._nodes_to_dev(destination_nodes, "destination_nodes")
+        neg = self._nodes_to_dev(p_neg_nodes, "p_neg_nodes")
+        ts, eidx = self._to_dev(edge_times, np.float64), self._edges_to_dev(edge_idxs)
         emb, b = self.embed_device(src, dst, [neg], [size], ts, eidx, n_neighbors, self._dev_draws(draws))
         return emb[:b], emb[b:2 * b], emb[2 * b:]
 
@@ -406,10 +514,10 @@ class TGN(nn.Module):
                                       edge_idxs, n_neighbors=20, draws=None):
         """tgn.py:102-217: (src_emb, dst_emb, p_pos_emb [B*p,D], p_neg_emb [B*q,D])."""
         B = len(source_nodes)
-        n_pos, n_neg = int(p_pos_nodes.shape[0] / B), int(p_neg_nodes.shape[0] / B)   # tgn.py:118-119
-        src, dst = self._to_dev(source_nodes, np.int32), self._to_dev(destination_nodes, np.int32)
-        pp, pn = self._to_dev(p_pos_nodes, np.int32), self._to_dev(p_neg_nodes, np.int32)
-        ts, eidx = self._to_dev(edge_times, np.float64), self._to_dev(edge_idxs, np.int32)
+        n_pos, n_neg = int(len(p_pos_nodes) / B), int(len(p_neg_nodes) / B)           # tgn.py:118-119
+        src, dst = self._nodes_to_dev(source_nodes, "source_nodes"), self._nodes_to_dev(destination_nodes, "destination_nodes")
+        pp, pn = self._nodes_to_dev(p_pos_nodes, "p_pos_nodes"), self._nodes_to_dev(p_neg_nodes, "p_neg_nodes")
+        ts, eidx = self._to_dev(edge_times, np.float64), self._edges_to_dev(edge_idxs)
         emb, b = self.embed_device(src, dst, [pp, pn], [n_pos, n_neg], ts, eidx, n_neighbors, self._dev_draws(draws))
         return emb[:b], emb[b:2 * b], emb[2 * b:(2 + n_pos) * b], emb[(2 + n_pos) * b:]
 
@@ -421,13 +529,14 @@ class TGN(nn.Module):
     # ------------------------------------------------------------------ introspection for tests
     def debug_touched(self):
         """(touched node ids, layer-0 feature table rows) of the last forward (use_memory only)."""
+        cfg, ws = self._last_ws
         dbg = _lib.TgnDebug()
-        _lib.call("pfo_tgn_debug_views", ctypes.byref(self._cfg), self._ws.data_ptr(), ctypes.byref(dbg))
-        base = self._ws.data_ptr()
+        _lib.call("pfo_tgn_debug_views", ctypes.byref(cfg), ws.data_ptr(), ctypes.byref(dbg))
+        base = ws.data_ptr()
 
         def view(ptr, count, dtype):
             off = ptr - base
-            return self._ws[off:off + count * torch.empty((), dtype=dtype).element_size()].view(dtype)
+            return ws[off:off + count * torch.empty((), dtype=dtype).element_size()].view(dtype)
         n = int(view(dbg.n_touched, 1, torch.int32).item())
         ids = view(dbg.touched_ids, n, torch.int32).clone()
         h0 = view(dbg.h0_table, n * self.n_node_features, torch.float32).view(n, -1).clone()

@@ -75,3 +75,18 @@ def test_shard_bounds_cover_batch_exactly():
             assert segs[0][0] == 0 and segs[-1][1] == B
             for a, b in zip(segs, segs[1:]):
                 assert a[1] == b[0]
+
+
+def test_bench_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` without torchrun: the parent starts two child ranks (before touching any GPU), they
+    rendezvous on 127.0.0.1 (gloo here, RCCL on a GPU box), all-reduce their rank ids, and rank 0's line reports world 2."""
+    import json
+    import subprocess
+    env = dict(os.environ, PFO_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--launcher-selftest"], env=env,
+                         capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["rank_sum"] == 1.0

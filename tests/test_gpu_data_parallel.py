@@ -14,7 +14,7 @@ from conftest import REPO, has_gpu
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")]
 
 
-def _run(rank, world, port, out_dir, n_steps):
+def _run(rank, world, port, out_dir, n_steps, B=48):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import torch.distributed as dist
@@ -34,15 +34,15 @@ def _run(rank, world, port, out_dir, n_steps):
     opt = P.FusedAdam(tgn, lr=1e-3)
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
     rs = np.random.RandomState(0)
-    B = 48
     tgn.train()
     for step in range(n_steps):
         s = 2500 + step * B
         neg = t(rs.randint(301, 326, size=B * 3), np.int32)
         emb, b = tgn.embed_device(t(d.sources[s:s + B], np.int32), t(d.destinations[s:s + B], np.int32), [neg], [3],
                                   t(d.timestamps[s:s + B], np.float64), t(d.edge_idxs[s:s + B], np.int32), 6)
-        assert b == B // world
-        loss = P.bpr_loss(emb, b, 3, grad_scale=1.0 / world)
+        assert b == (rank + 1) * B // world - rank * B // world         # balanced shards; empty when B < world
+        assert emb.shape[0] == 5 * b
+        loss = P.bpr_loss(emb, b, 3, grad_scale=tgn.dp_grad_scale)      # local mean * (b / B): shard sums = global mean
         loss.backward()
         allreduce_flat_grad(tgn.flat_grad, world)
         if step == 0:
@@ -51,7 +51,7 @@ def _run(rank, world, port, out_dir, n_steps):
         opt.step()
         opt.zero_grad(set_to_none=True)
     torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, "w%d_r%d.npz" % (world, rank)), params=tgn.flat_parameters.cpu().numpy(), grad0=grad0, mem0=mem0,
+    np.savez(os.path.join(out_dir, "w%d_r%d_B%d.npz" % (world, rank, B)), params=tgn.flat_parameters.cpu().numpy(), grad0=grad0, mem0=mem0,
              memory=tgn.memory.memory.cpu().numpy(), last_update=tgn.memory.last_update.cpu().numpy(),
              msg=tgn.memory.msg_table.cpu().numpy(), msg_t=tgn.memory.msg_time.cpu().numpy(), has=tgn.memory.has_msg.cpu().numpy())
     if world > 1:
@@ -59,18 +59,43 @@ def _run(rank, world, port, out_dir, n_steps):
         dist.destroy_process_group()
 
 
+def _spawn(world, port, tmp_path, n_steps, B):
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_run, args=(r, world, port, str(tmp_path), n_steps, B)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+
+
+@pytest.mark.parametrize("world,B", [(3, 7), (4, 2)])
+def test_uneven_and_empty_shards(tmp_path, world, B):
+    """B % world != 0 and B < world: every rank completes the step (an empty shard still runs the state update
+    and joins the all-reduce with a zero gradient), replicas stay bit-identical, and the summed shard gradients equal the
+    single-rank gradient of the global-batch mean loss."""
+    port = 29650 + (os.getpid() % 100) + 7 * world
+    _spawn(1, port, tmp_path, 2, B)
+    _spawn(world, port + 1, tmp_path, 2, B)
+    one = np.load(tmp_path / ("w1_r0_B%d.npz" % B))
+    rk = [np.load(tmp_path / ("w%d_r%d_B%d.npz" % (world, r, B))) for r in range(world)]
+    for r in range(1, world):
+        for k in one.files:
+            assert np.array_equal(rk[0][k], rk[r][k]), "replicas diverged: " + k
+    rel = lambda a, b: np.abs(a.astype(np.float64) - b).max() / (np.abs(b).max() + 1e-12)
+    D = 32
+    assert rel(rk[0]["grad0"][2 * D:], one["grad0"][2 * D:]) < 1e-4
+    assert rel(rk[0]["grad0"][:2 * D], one["grad0"][:2 * D]) < 3e-3
+    assert rel(rk[0]["mem0"], one["mem0"]) < 1e-5
+    assert np.array_equal(rk[0]["last_update"], one["last_update"]) and np.array_equal(rk[0]["has"], one["has"])
+
+
 def test_two_ranks_equal_one_rank(tmp_path):
     port = 29800 + (os.getpid() % 150)
-    ctx = mp.get_context("spawn")
     for world in (1, 2):
-        procs = [ctx.Process(target=_run, args=(r, world, port + world, str(tmp_path), 3)) for r in range(world)]
-        for p in procs:
-            p.start()
-        for p in procs:
-            p.join(600)
-            assert p.exitcode == 0
-    one = np.load(tmp_path / "w1_r0.npz")
-    r0, r1 = np.load(tmp_path / "w2_r0.npz"), np.load(tmp_path / "w2_r1.npz")
+        _spawn(world, port + world, tmp_path, 3, 48)
+    one = np.load(tmp_path / "w1_r0_B48.npz")
+    r0, r1 = np.load(tmp_path / "w2_r0_B48.npz"), np.load(tmp_path / "w2_r1_B48.npz")
     for k in one.files:
         assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k          # bit-identical replicas
     rel = lambda a, b: np.abs(a.astype(np.float64) - b).max() / (np.abs(b).max() + 1e-12)

@@ -1,0 +1,217 @@
+"""GPU tests added in round 2 for the host-side contract of the TGN facade and the literal drop-in loop:
+
+* several training forwards before one backward (main.py:171 BACKPROP_EVERY), an evaluation forward between a forward and
+  its backward: every outstanding call owns its workspace;
+* a neighbour finder built from a split whose largest id is below the node table's (main.py:95 leaves max_node_idx=None);
+* dropout follows train()/eval(), autograd follows torch.is_grad_enabled();
+* zero negatives;
+* main.py:160-394 in shape: package imports swapped per INTEGRATION.md, the torch BPR expression, torch.optim.Adam,
+  detach_memory(), set_neighbor_finder / direct attribute assignment.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")]
+
+import pfotgnrec_amd as P
+from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+
+DEV = "cuda:0"
+
+
+def _setup(L=2, D=32, K=6, H=2, dropout=0.0, use_memory=True, seed=9, uniform=False):
+    torch.manual_seed(seed)
+    cfg = SyntheticConfig("r2", 300, 25, 5000, D, L, K, H)
+    g = make_graph(cfg, with_prices=False)
+    tgn = P.TGN(P.get_neighbor_finder(g.data, uniform), g.node_features, g.edge_features, DEV, n_layers=L, n_heads=H,
+                dropout=dropout, use_memory=use_memory, memory_dimension=D, message_function="identity", n_neighbors=K)
+    return cfg, g, tgn
+
+
+def _batch(cfg, g, s, B, rs):
+    d = g.data
+    neg = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * 3)
+    return d.sources[s:s + B], d.destinations[s:s + B], neg, d.timestamps[s:s + B], d.edge_idxs[s:s + B]
+
+
+def _snapshot(tgn):
+    m = tgn.memory
+    return [t.clone() for t in (m.memory.data, m.last_update.data, m.msg_table, m.msg_time, m.has_msg)]
+
+
+def _restore(tgn, snap):
+    m = tgn.memory
+    with torch.no_grad():
+        for dst, src in zip((m.memory.data, m.last_update.data, m.msg_table, m.msg_time, m.has_msg), snap):
+            dst.copy_(src)
+
+
+def test_two_forwards_before_one_backward_and_eval_in_between():
+    cfg, g, tgn = _setup()
+    rs = np.random.RandomState(0)
+    b1, b2, b3 = (_batch(cfg, g, s, 40, rs) for s in (2500, 2540, 2580))
+    with torch.no_grad():
+        tgn.compute_temporal_embeddings(*_batch(cfg, g, 2400, 40, rs), 6)          # populate memory / messages
+    snap = _snapshot(tgn)
+
+    def loss_of(batch):
+        se, de, ne = tgn.compute_temporal_embeddings(*batch, 6)
+        return P.bpr_loss(torch.cat([se, de, ne]), 40, 3)
+
+    # reference: one backward per forward, gradients summed
+    tgn.train()
+    for p in tgn.parameters():
+        p.grad = None
+    l1 = loss_of(b1); l1.backward()
+    l2 = loss_of(b2); l2.backward()
+    want = tgn.flat_grad.clone()
+    mem_after = _snapshot(tgn)
+    # accumulated: two forwards, then ONE backward of the summed loss, with an evaluation forward in between
+    _restore(tgn, snap)
+    for p in tgn.parameters():
+        p.grad = None
+    l1 = loss_of(b1)
+    l2 = loss_of(b2)
+    tgn.eval()
+    with torch.no_grad():
+        bk = tgn.memory.backup_memory()
+        tgn.compute_temporal_embeddings(*b3, 6)                                     # a validation pass (main.py:396-420)
+        tgn.memory.restore_memory(bk)
+    tgn.train()
+    (l1 + l2).backward()
+    got = tgn.flat_grad
+    den = want.abs().max().item()
+    assert (got - want).abs().max().item() / den < 2e-5            # float atomics: order-dependent in the last bits
+    for a, b in zip(mem_after, _snapshot(tgn)):
+        assert torch.equal(a, b)
+    # the workspace of a finished call is not reusable for a second backward
+    l = loss_of(b1)
+    l.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="already consumed"):
+        l.backward()
+
+
+def test_finder_smaller_than_node_table_is_padded_and_larger_is_refused():
+    cfg, g, tgn = _setup(L=2, use_memory=True)
+    d = g.data
+    keep = np.maximum(d.sources, d.destinations) <= 310             # a "train split" that never sees items 311..325
+    sub = P.Data(d.sources[keep], d.destinations[keep], d.timestamps[keep], d.edge_idxs[keep])
+    small = P.get_neighbor_finder(sub, uniform=False)               # main.py:95: max_node_idx=None
+    assert small.n_nodes < tgn.n_nodes
+    full = P.get_neighbor_finder(sub, uniform=False, max_node_idx=tgn.n_nodes - 1)
+    rs = np.random.RandomState(1)
+    s, B = 3000, 32
+    sb, db, tb, eb = d.sources[s:s + B], d.destinations[s:s + B], d.timestamps[s:s + B], d.edge_idxs[s:s + B]
+    neg = rs.randint(311, 326, size=B * 3)                          # roots the small finder has no row for
+    outs = []
+    tgn.eval()
+    for nf in (small, full):
+        tgn.memory.__init_memory__()
+        tgn.set_neighbor_finder(nf)
+        with torch.no_grad():
+            outs.append(torch.cat(tgn.compute_temporal_embeddings(sb, db, neg, tb, eb, 6)))
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+    # ids beyond the node table: the reference raises IndexError from its feature lookup
+    with pytest.raises(IndexError):
+        tgn.compute_temporal_embeddings(sb, db, np.full(B * 3, tgn.n_nodes), tb, eb, 6)
+    big = P.NeighborFinder.from_arrays(np.array([1, tgn.n_nodes + 3]), np.array([305, 306]), np.array([1, 2]), np.array([1.0, 2.0]))
+    tgn.embedding_module.neighbor_finder = big                      # main.py:427 assigns the attribute directly
+    with pytest.raises(ValueError, match="node ids"):
+        tgn.compute_temporal_embeddings(sb, db, neg, tb, eb, 6)
+
+
+def test_dropout_follows_train_flag_and_autograd_follows_grad_mode():
+    cfg, g, tgn = _setup(L=1, dropout=0.5, use_memory=False)
+    rs = np.random.RandomState(2)
+    batch = _batch(cfg, g, 2600, 24, rs)
+
+    def run():
+        tgn._step = 3
+        return torch.cat(tgn.compute_temporal_embeddings(*batch, 6))
+    tgn.eval()
+    e_eval = run()                                                   # grad mode on, eval(): no dropout, differentiable
+    assert e_eval.requires_grad and e_eval.grad_fn is not None
+    e_eval.sum().backward()
+    assert tgn.flat_grad is not None and tgn.flat_grad.abs().sum().item() > 0
+    with torch.no_grad():
+        e_eval_ng = run()
+    assert torch.equal(e_eval.detach(), e_eval_ng)
+    tgn.train()
+    with torch.no_grad():
+        e_train_ng = run()                                           # train() under no_grad: dropout IS applied (the reference's nn.Dropout)
+    assert not e_train_ng.requires_grad
+    assert not torch.equal(e_train_ng, e_eval_ng)
+    e_train = run()
+    assert torch.equal(e_train.detach(), e_train_ng)                 # same Philox stream with and without autograd
+
+
+def test_zero_negatives_and_zero_neighbors():
+    cfg, g, tgn = _setup(L=1)
+    rs = np.random.RandomState(3)
+    sb, db, neg, tb, eb = _batch(cfg, g, 2700, 16, rs)
+    tgn.eval()
+    with torch.no_grad():
+        se, de, ne = tgn.compute_temporal_embeddings(sb, db, np.zeros(0, np.int64), tb, eb, 6)
+        assert se.shape == (16, 32) and de.shape == (16, 32) and ne.shape == (0, 32)
+        tgn.memory.__init_memory__()
+        se2, de2, ne2 = tgn.compute_temporal_embeddings(sb, db, neg, tb, eb, 6)
+        assert ne2.shape == (48, 32)
+        tgn.memory.__init_memory__()
+        se0, _, _ = tgn.compute_temporal_embeddings(sb, db, neg, tb, eb, 0)     # utils.py:175: one all-padding column
+        assert torch.isfinite(se0).all()
+
+
+def test_literal_main_loop_with_torch_bpr_and_torch_adam():
+    """main.py:160-394 with the package swapped in: the reference's own torch expressions for the BPR
+    loss (main.py:364-381), torch.optim.Adam(tgn.parameters()) (main.py:123), loss.backward(), optimizer.step(),
+    tgn.memory.detach_memory() (main.py:394) - three steps equal to the fused path (pfo_bpr_loss + FusedAdam)."""
+    rs0 = np.random.RandomState(4)
+    runs = []
+    for literal in (True, False):
+        cfg, g, tgn = _setup(L=2, D=32, K=6, seed=21)
+        d = g.data
+        train_ngh_finder = P.get_neighbor_finder(d, uniform=False)
+        optimizer = torch.optim.Adam(tgn.parameters(), lr=1e-3) if literal else P.FusedAdam(tgn, lr=1e-3)
+        tgn.memory.__init_memory__()                                     # main.py:153
+        tgn.set_neighbor_finder(train_ngh_finder)                        # main.py:156
+        rs = np.random.RandomState(4)
+        BATCH_SIZE, NUM_NEG_TRAIN, NUM_NEIGHBORS = 40, 3, 6
+        losses = []
+        for k in range(3):                                               # main.py:160
+            optimizer.zero_grad()                                        # main.py:169
+            start_idx = 2500 + k * BATCH_SIZE
+            end_idx = start_idx + BATCH_SIZE
+            sources_batch, destinations_batch = d.sources[start_idx:end_idx], d.destinations[start_idx:end_idx]
+            edge_idxs_batch, timestamps_batch = d.edge_idxs[start_idx:end_idx], d.timestamps[start_idx:end_idx]
+            negatives_batch = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=(BATCH_SIZE, NUM_NEG_TRAIN))
+            tgn = tgn.train()                                            # main.py:309
+            source_embedding, destination_embedding, negative_embedding = tgn.compute_temporal_embeddings(
+                sources_batch, destinations_batch, negatives_batch.flatten(), timestamps_batch, edge_idxs_batch, NUM_NEIGHBORS)
+            if literal:
+                bs = source_embedding.shape[0]                           # main.py:364-381
+                source_embedding = source_embedding.view(bs, 1, -1)
+                destination_embedding = destination_embedding.view(bs, 1, -1)
+                negative_embedding = negative_embedding.view(bs, NUM_NEG_TRAIN, -1)
+                pos_scores = torch.sum(source_embedding * destination_embedding, dim=2)
+                neg_scores = torch.matmul(source_embedding, negative_embedding.transpose(1, 2)).squeeze()
+                score_diff = pos_scores - neg_scores
+                score_diff_mean = torch.mean(score_diff, dim=1)
+                log_and_sigmoid = torch.log(torch.sigmoid(score_diff_mean))
+                loss = -torch.mean(log_and_sigmoid)
+            else:
+                loss = P.bpr_loss(torch.cat([source_embedding, destination_embedding, negative_embedding]), BATCH_SIZE, NUM_NEG_TRAIN)
+            loss.backward()                                              # main.py:388
+            optimizer.step()                                             # main.py:389
+            tgn.memory.detach_memory()                                   # main.py:394
+            losses.append(float(loss))
+        tgn.embedding_module.neighbor_finder = train_ngh_finder          # main.py:427
+        runs.append((losses, tgn.flat_parameters.clone(), tgn.memory.memory.clone(), tgn.memory.last_update.clone()))
+    (la, pa, ma, ua), (lb, pb, mb, ub) = runs
+    assert np.allclose(la, lb, rtol=2e-5, atol=1e-6), (la, lb)
+    # Adam turns rounding-level gradient differences into O(lr * 1e-3) parameter differences after three steps
+    assert (pa - pb).abs().max().item() < 1e-4
+    assert (ma - mb).abs().max().item() < 1e-4 * max(1.0, mb.abs().max().item())
+    assert torch.equal(ua, ub)

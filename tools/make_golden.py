@@ -295,6 +295,14 @@ def g5():
                 if use_mem:
                     tab, mt, cnt = dense_messages(tgn, n, M)
                     out.update({pre + "msg_tab": tab, pre + "msg_t": mt, pre + "msg_cnt": cnt})
+                # Adam moments BEFORE this step (main.py:123 optimizer): with them injected, the post-step parameters
+                # ("after_*") are a function of this step's gradients alone
+                names = {id(v): k for k, v in tgn.named_parameters()}
+                for pp_, st_ in opt.state.items():
+                    k = names[id(pp_)]
+                    out[pre + "adam_m_" + k] = st_["exp_avg"].detach().numpy().copy()
+                    out[pre + "adam_v_" + k] = st_["exp_avg_sq"].detach().numpy().copy()
+                    out[pre + "adam_t"] = np.array(int(st_["step"]))
             # uniform mode: log the draws in call order
             draws, orig = [], np.random.randint
             if uniform:
