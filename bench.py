@@ -269,6 +269,7 @@ class Workload:
             self.step(i)
             i += 1
         total, n_steps, blocks, n_prof = 0.0, 0, 0, 0
+        self.block_ms = []
         loss = None
         while True:
             if multi:
@@ -294,6 +295,7 @@ class Workload:
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 el = float(tmax.item())
             total += el
+            self.block_ms.append(1e3 * el / steps)
             n_steps += steps
             blocks += 1
             if total >= min_seconds or blocks >= 10000:
@@ -381,6 +383,8 @@ def main():
         "config": {"workload": wl.describe(), "global_batch": B, "parallelism": "dp%d" % world, "dropout": args.dropout,
                    "final_loss": round(final_loss, 5), "timed_blocks": blocks, "timed_steps": n_timed,
                    "timed_seconds": round(elapsed, 3),
+                   "block_ms_per_step": {"first": round(wl.block_ms[0], 4), "min": round(min(wl.block_ms), 4),
+                                         "median": round(float(np.median(wl.block_ms)), 4), "last": round(wl.block_ms[-1], 4)},
                    "collective": ("rccl all-reduce of the flat fp32 gradient, world %d" % dist.get_world_size()) if world > 1 else None},
     }
     if prof is not None:

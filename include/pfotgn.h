@@ -154,6 +154,15 @@ int pfo_rank_metrics(const float* emb, int64_t B, int32_t D, int32_t n_items, in
  */
 int pfo_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int32_t step, void* stream);
+/* The same update on up to PFO_ADAM_MAX_RANGES element ranges [lo[r], hi[r]) of the flat buffers, each with its own step
+ * count, in ONE launch.  torch.optim.Adam keeps a step counter per parameter tensor and skips tensors whose .grad is
+ * None (main.py:123 hands it every parameter; the GRU's are None on the first batch of an epoch, when no message is
+ * pending: memory_updater.py:38-40), so tensors can be one step apart for a whole run; ranges that are left out are
+ * not touched at all.  lo / hi / step are HOST arrays. */
+#define PFO_ADAM_MAX_RANGES 16
+int pfo_adam_step_ranges(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
+                         const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1, float beta2,
+                         float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * The TGN step (model/tgn.py:102-378 + modules/).  One POD config, one flat parameter buffer,

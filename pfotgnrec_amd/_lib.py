@@ -70,6 +70,8 @@ PROTOTYPES = {
     "pfo_rank_metrics": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP]),
     "pfo_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                 _VP]),
+    "pfo_adam_step_ranges": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                       C.POINTER(C.c_int32), C.c_float, C.c_float, C.c_float, C.c_float, _VP]),
     "pfo_tgn_param_layout": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnLayout)]),
     "pfo_tgn_workspace_bytes": (C.c_int64, [C.POINTER(TgnConfig)]),
     "pfo_tgn_forward": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP]),

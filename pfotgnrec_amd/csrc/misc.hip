@@ -2,6 +2,7 @@
 // row scatter-add, the folded query-bias backward, partial-slab folds.
 #include "memory.hpp"
 #include <string.h>
+#include <algorithm>
 #include <stdlib.h>
 
 static thread_local char g_err[512] = "";
@@ -207,6 +208,47 @@ extern "C" int pfo_adam_step(float* param, const float* grad, float* exp_avg, fl
   const int nb = (int)std::min<int64_t>(2048, pfo_ceil_div(n, 256));
   hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
                      beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+struct AdamRanges { int64_t lo[PFO_ADAM_MAX_RANGES], hi[PFO_ADAM_MAX_RANGES]; float lr_bc1[PFO_ADAM_MAX_RANGES], bc2_sqrt[PFO_ADAM_MAX_RANGES]; int n; };
+__global__ void adam_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                   float* __restrict__ v, const AdamRanges r, float b1, float b2, float eps) {
+  for (int q = 0; q < r.n; ++q) {
+    const float step_size = r.lr_bc1[q], bc2s = r.bc2_sqrt[q];
+    for (int64_t i = r.lo[q] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < r.hi[q]; i += (int64_t)gridDim.x * blockDim.x) {
+      const float gi = g[i];
+      const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+      const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+      m[i] = mi;
+      v[i] = vi;
+      p[i] -= step_size * (mi / (sqrtf(vi) / bc2s + eps));
+    }
+  }
+}
+extern "C" int pfo_adam_step_ranges(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
+                                    const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1,
+                                    float beta2, float eps, void* stream) {
+  PFO_REQUIRE(param && grad && exp_avg && exp_avg_sq, "null buffer");
+  PFO_REQUIRE(n_ranges >= 0 && n_ranges <= PFO_ADAM_MAX_RANGES, "too many ranges");
+  if (n_ranges == 0) return PFO_OK;
+  PFO_REQUIRE(lo && hi && step, "null range arrays");
+  AdamRanges r;
+  r.n = n_ranges;
+  int64_t longest = 0;
+  for (int q = 0; q < n_ranges; ++q) {
+    PFO_REQUIRE(lo[q] >= 0 && hi[q] >= lo[q] && step[q] >= 1, "bad range");
+    r.lo[q] = lo[q]; r.hi[q] = hi[q];
+    const double bc1 = 1.0 - pow((double)beta1, (double)step[q]);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step[q]);
+    r.lr_bc1[q] = lr / (float)bc1;
+    r.bc2_sqrt[q] = (float)sqrt(bc2);
+    longest = std::max(longest, hi[q] - lo[q]);
+  }
+  const int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, pfo_ceil_div(longest, 256)));
+  hipLaunchKernelGGL(adam_ranges_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, r,
+                     beta1, beta2, eps);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

@@ -31,6 +31,9 @@ class Memory(nn.Module):
         self.msg_table = torch.zeros((n_nodes, input_dimension), device=self.device)
         self.msg_time = torch.zeros(n_nodes, device=self.device)
         self.has_msg = torch.zeros(n_nodes, dtype=torch.uint8, device=self.device)
+        # host-side knowledge "some node holds a pending message": False = unknown (the TGN reads has_msg back once);
+        # the native state update sets it.  Decides whether the GRU takes part in a step (TGN._attach_grads)
+        self._any_msg = False
 
     def __init_memory__(self):
         """Zero the memory and drop every pending message (modules/memory.py:23-33); called per epoch (main.py:153).
@@ -43,6 +46,7 @@ class Memory(nn.Module):
             self.msg_table.zero_()
             self.msg_time.zero_()
             self.has_msg.zero_()
+        self._any_msg = False
 
     def get_memory(self, node_idxs):
         return self.memory[torch.as_tensor(node_idxs, device=self.memory.device, dtype=torch.long), :]
@@ -67,6 +71,7 @@ class Memory(nn.Module):
             self.msg_table.copy_(tab)
             self.msg_time.copy_(t)
             self.has_msg.copy_(has)
+        self._any_msg = False
 
     def detach_memory(self):
         """modules/memory.py:62-71.  Stored messages and memory never carry an autograd graph here."""
@@ -75,6 +80,7 @@ class Memory(nn.Module):
     def clear_messages(self, nodes):
         with torch.no_grad():
             self.has_msg[torch.as_tensor(nodes, device=self.has_msg.device, dtype=torch.long)] = 0
+        self._any_msg = False
 
     @property
     def messages(self):

@@ -1,4 +1,13 @@
-"""Adam over the TGN's flat parameter buffer: one kernel per step (torch.optim.Adam semantics, main.py:123,389)."""
+"""Adam over the TGN's flat parameter buffer: one kernel per step (torch.optim.Adam semantics, main.py:123,389).
+
+torch.optim.Adam keeps one step counter per parameter tensor and skips tensors whose ``.grad`` is None.  The
+reference hits that on the first batch after every ``__init_memory__`` (main.py:153): no message is pending, the GRU
+is never called (memory_updater.py:38-40) and its four tensors stay one step behind for the rest of the run.  The same
+bookkeeping is done here on the host; the device work is still ONE launch (``pfo_adam_step_ranges``: contiguous runs of
+tensors with equal step counts).
+"""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -10,20 +19,48 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(list(tgn.parameters()), dict(lr=lr, betas=betas, eps=eps))
         self._m = None
         self._v = None
-        self._t = 0
+        self._steps = {}            # parameter -> steps taken (torch.optim.Adam's state[p]["step"])
+
+    # tests / checkpoint restore: one step count for every tensor
+    @property
+    def _t(self):
+        return max(self._steps.values(), default=0)
+
+    @_t.setter
+    def _t(self, value):
+        self._steps = {p: int(value) for p in self.tgn.hot_parameters()}
+
+    def set_steps(self, steps_by_name):
+        """Per-tensor step counts (``{parameter name: steps taken}``), e.g. from a torch.optim.Adam state dict."""
+        names = dict(self.tgn.named_parameters())
+        for k, t in steps_by_name.items():
+            self._steps[names[k]] = int(t)
 
     @torch.no_grad()
     def step(self, closure=None):
         tgn = self.tgn
-        if tgn.flat_grad is None or any(p.grad is None for p in tgn.hot_parameters()):
+        if tgn.flat_grad is None:
             return None
         _lib.require_gpu(tgn.flat_parameters.device)
         if self._m is None or self._m.device != tgn.flat_parameters.device:
             self._m = torch.zeros_like(tgn.flat_parameters)
             self._v = torch.zeros_like(tgn.flat_parameters)
         g = self.param_groups[0]
-        self._t += 1
-        _lib.call("pfo_adam_step", tgn.flat_parameters.data_ptr(), tgn.flat_grad.data_ptr(), self._m.data_ptr(),
-                  self._v.data_ptr(), tgn.flat_parameters.numel(), float(g["lr"]), float(g["betas"][0]),
-                  float(g["betas"][1]), float(g["eps"]), self._t, _lib.stream_ptr())
+        lo, hi, st = [], [], []
+        for p, off, n, _ in sorted(tgn._views, key=lambda v: v[1]):
+            if p.grad is None:                       # torch.optim.Adam: skipped entirely (no moment decay, no step)
+                continue
+            t = self._steps.get(p, 0) + 1
+            self._steps[p] = t
+            if lo and hi[-1] == off and st[-1] == t:
+                hi[-1] = off + n
+            else:
+                lo.append(off); hi.append(off + n); st.append(t)
+        MAXR = 16
+        for i in range(0, len(lo), MAXR):
+            k = min(MAXR, len(lo) - i)
+            _lib.call("pfo_adam_step_ranges", tgn.flat_parameters.data_ptr(), tgn.flat_grad.data_ptr(), self._m.data_ptr(),
+                      self._v.data_ptr(), k, (ctypes.c_int64 * k)(*lo[i:i + k]), (ctypes.c_int64 * k)(*hi[i:i + k]),
+                      (ctypes.c_int32 * k)(*st[i:i + k]), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                      float(g["eps"]), _lib.stream_ptr())
         return None

@@ -38,7 +38,7 @@ def _normalise_edge_features(edge_features):
 class _Call:
     """Everything one forward/backward pair of native calls needs to agree on."""
     __slots__ = ("roots", "root_ts", "R", "K", "mode", "draws", "draw_ptrs", "seed", "offset", "dropout_p", "training",
-                 "extra", "batch_struct", "ws", "ws_caps", "cfg", "pool", "__weakref__")
+                 "extra", "batch_struct", "ws", "ws_caps", "cfg", "pool", "gru_applied", "__weakref__")
 
     def release(self):
         """Hands the call's workspace back to its TGN's pool (after the backward, or when the graph is dropped)."""
@@ -150,6 +150,8 @@ class TGN(nn.Module):
         self._register(self.time_encoder.w, "bias", lay.time_b, (D,))
 
         self.memory = None
+        self._gru_params = set()
+        self._gru_applied_now = True
         if self.use_memory:
             self.memory = Memory(n_nodes=self.n_nodes, memory_dimension=D, input_dimension=M, message_dimension=M,
                                  device=self.device)
@@ -161,6 +163,7 @@ class TGN(nn.Module):
             self._register(gru, "weight_hh", lay.gru_w_hh, (3 * D, D))
             self._register(gru, "bias_ih", lay.gru_b_ih, (3 * D,))
             self._register(gru, "bias_hh", lay.gru_b_hh, (3 * D,))
+            self._gru_params = set(gru.parameters())
 
         self.embedding_module = _Holder()
         self.embedding_module.neighbor_finder = neighbor_finder       # main.py:427 assigns this attribute directly
@@ -363,6 +366,7 @@ class TGN(nn.Module):
                                        int(extra.shape[0]) if extra is not None else 0)
         c.pool = self._ws_pool
         c.ws_caps, c.cfg, c.ws = self._acquire_workspace(c.R, c.K, B)
+        c.gru_applied = self._gru_applied_now
         return c
 
     def _native_forward(self, call, out=None):
@@ -374,21 +378,32 @@ class TGN(nn.Module):
         self._last_ws = (call.cfg, call.ws)
         return emb
 
-    def _attach_grads(self):
+    def _attach_grads(self, gru_applied=True):
+        """Every ``p.grad`` becomes a view of the flat gradient buffer the native backward accumulates into.  When the
+        GRU was not applied in the forward (no node held a pending message: the first batch after ``__init_memory__``)
+        the reference's autograd leaves the four GRU tensors' ``.grad`` at None (memory_updater.py:38-40 returns before
+        the cell is called) and torch.optim.Adam skips them; the same is done here."""
         if self._flat_grad is None:
             self._flat_grad = torch.zeros_like(self._flat)
-        if any(p.grad is None for p, _, _, _ in self._views):
+        missing = [v for v in self._views if v[0].grad is None]
+        if len(missing) == len(self._views):
             self._flat_grad.zero_()
-            for p, off, n, shape in self._views:
-                p.grad = self._flat_grad[off:off + n].view(shape)
+        else:
+            for _, off, n, _ in missing:
+                self._flat_grad[off:off + n].zero_()
+        for p, off, n, shape in missing:
+            if not gru_applied and p in self._gru_params:
+                continue
+            p.grad = self._flat_grad[off:off + n].view(shape)
 
     def _native_backward(self, call, d_emb):
-        self._attach_grads()
+        self._attach_grads(call.gru_applied)
         st = self._state_struct()
         _lib.call("pfo_tgn_backward", ctypes.byref(call.cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
                   call.ws.data_ptr(), d_emb.data_ptr(), self._flat_grad.data_ptr(), _lib.stream_ptr())
 
     def _native_update_state(self, call, src, dst, ts, eidx):
+        self.memory._any_msg = True
         st = self._state_struct()
         _lib.call("pfo_tgn_update_state", ctypes.byref(call.cfg), ctypes.byref(st), src.data_ptr(), dst.data_ptr(),
                   ts.data_ptr(), eidx.data_ptr(), int(src.shape[0]), call.ws.data_ptr(), _lib.stream_ptr())
@@ -413,6 +428,11 @@ class TGN(nn.Module):
             m = self.memory
             late = (m.has_msg > 0) & (m.last_update > m.msg_time)
             assert not bool(late.any()), "Trying to update memory to time in the past"      # memory_updater.py:25,41
+        # is any message pending?  Known on the host except right after __init_memory__ / a restore (one read-back then)
+        self._gru_applied_now = True
+        if self.use_memory and not self.memory._any_msg:
+            self._gru_applied_now = bool(self.memory.has_msg.any())
+            self.memory._any_msg = self._gru_applied_now
         lo, hi = 0, B
         if self.dp_world > 1:
             lo, hi = self.dp_rank * B // self.dp_world, (self.dp_rank + 1) * B // self.dp_world
@@ -450,10 +470,10 @@ class TGN(nn.Module):
             if post is not None:
                 post(call)
             call.release()
-            emb = torch.zeros((0, D), dtype=torch.float32, device=self.device)
             if grad_mode:
-                emb = emb + self._flat[:1].sum() * 0.0             # keeps an (empty) graph so callers can .backward()
-            return emb, 0
+                self._attach_grads(self._gru_applied_now)         # this rank still joins the all-reduce: with a zero gradient
+            # a leaf that requires grad: the caller's loss.backward() is a no-op instead of an error
+            return torch.zeros((0, D), dtype=torch.float32, device=self.device, requires_grad=grad_mode), 0
         if grad_mode:
             call = self._make_call(roots, root_ts, K, draws, dropout_p, extra, B)
             emb = _EmbedFn.apply(self, call, post, *self.hot_parameters())

@@ -302,7 +302,7 @@ def g5():
                     k = names[id(pp_)]
                     out[pre + "adam_m_" + k] = st_["exp_avg"].detach().numpy().copy()
                     out[pre + "adam_v_" + k] = st_["exp_avg_sq"].detach().numpy().copy()
-                    out[pre + "adam_t"] = np.array(int(st_["step"]))
+                    out[pre + "adam_t_" + k] = np.array(int(st_["step"]))      # per tensor: the GRU's lag one step (None grad in step 0)
             # uniform mode: log the draws in call order
             draws, orig = [], np.random.randint
             if uniform:
