@@ -12,7 +12,7 @@
 
 struct AttnDev {
   int N, K, D, Ef, H, Cp;
-  const float* QK; const float* nbr_tab; int64_t nbr_ld; const int32_t* nbr_row; int64_t nbr_row_base;
+  const float* QK; const int32_t* qk_row; int64_t qk_ld; const float* nbr_tab; int64_t nbr_ld; const int32_t* nbr_row; int64_t nbr_row_base;
   const int32_t* nbr_ids; const float* edge_feat; const int32_t* eidx; const float* dt; const float* tw; const float* tb;
   float scale, dropout_p; uint64_t seed, offset;
   float* ctx; float* attw; uint8_t* inv;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
 
   float tw[NR], tb[NR];
   float qn[H][NR], qt[H][NR], qe[H];
-  const float* qk = a.QK + n * H * Cp;
+  const float* qk = a.QK + (a.qk_row ? (int64_t)a.qk_row[n] : n) * a.qk_ld;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int c = lane + 64 * r;
@@ -265,7 +265,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
     }
     float qn[H][NR], qt[H][NR], qe[H], gn[H][NR], gt[H][NR], ge[H], t[H], dsb[H];
     float dqn[H][NR], dqt[H][NR], dqe[H];
-    const float* qk = a.QK + n * H * Cp;
+    const float* qk = a.QK + (a.qk_row ? (int64_t)a.qk_row[n] : n) * a.qk_ld;
     const float* dc = a.dctx + n * H * Cp;
     const float* cx = a.ctx + n * H * Cp;
 #pragma unroll
@@ -422,7 +422,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
 
 static void to_dev(const PfoAttn& a, AttnDev& d) {
   d.N = a.N; d.K = a.K; d.D = a.D; d.Ef = a.Ef; d.H = a.H; d.Cp = a.Cp;
-  d.QK = a.QK; d.nbr_tab = a.nbr_tab; d.nbr_ld = a.nbr_ld; d.nbr_row = a.nbr_row; d.nbr_row_base = a.nbr_row_base;
+  d.QK = a.QK; d.qk_row = a.qk_row; d.qk_ld = a.qk_ld > 0 ? a.qk_ld : (int64_t)a.H * a.Cp; d.nbr_tab = a.nbr_tab; d.nbr_ld = a.nbr_ld; d.nbr_row = a.nbr_row; d.nbr_row_base = a.nbr_row_base;
   d.nbr_ids = a.nbr_ids; d.edge_feat = a.edge_feat; d.eidx = a.eidx; d.dt = a.dt; d.tw = a.tw; d.tb = a.tb;
   d.scale = a.scale; d.dropout_p = a.dropout_p; d.seed = a.seed; d.offset = a.offset;
   static const int abl = getenv("PFO_ATTN_ABL") ? atoi(getenv("PFO_ATTN_ABL")) : 0;

@@ -19,7 +19,9 @@ struct PfoAttn {
   int N = 0, K = 0, D = 0, Ef = 0, H = 0;
   int Cp = 0;                       // per-head row stride of QK / ctx / dctx / dQK: C = 2D+Ef feature columns, column C =
                                     // sum_j a'_jh, column C+1 = valid flag on head 0, zero padding up to a multiple of 4
-  const float* QK = nullptr;        // [N, H*Cp]
+  const float* QK = nullptr;        // [N, H*Cp], or rows of qk_ld floats picked by qk_row
+  const int32_t* qk_row = nullptr;  // [N] row of QK per instance (layer 1: the touched-node table, several instances share a row); null: n
+  int64_t qk_ld = 0;                // row stride of QK in floats (0: H*Cp)
   const float* nbr_tab = nullptr;   // rows of D floats
   int64_t nbr_ld = 0;
   const int32_t* nbr_row = nullptr; // [N*K] row of nbr_tab per slot, or null: row = nbr_row_base + n*K + j

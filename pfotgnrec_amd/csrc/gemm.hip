@@ -32,6 +32,7 @@ struct GemmDev {
   float* C; int64_t ldc;
   const float* bias; const float* row_scale; int64_t rs_ld; const uint8_t* row_zero;
   const float* relu_src; int64_t relu_ld;
+  const float* add_src; int64_t add_ld; const int32_t* add_idx;
   int M, N; const int32_t* m_dev;
   int relu, accumulate;
   int nsplit; int split_chunk;     // k-major split-K
@@ -407,7 +408,7 @@ __device__ __forceinline__ void bx_split_store(char* base, int piece_bytes, int 
 
 // epilogue of the operand-swapped bf16x3 kernels: four consecutive columns col..col+3 of one output row
 __device__ __forceinline__ void bx_store4(const GemmDev& p, float* Cb, int64_t ldc, const float* bias, float rscale, bool zero,
-                                          bool n4, int row, int col, const f32x4 a) {
+                                          bool n4, int row, int col, const f32x4 a, const float* addrow = nullptr) {
   float v[4] = {a[0], a[1], a[2], a[3]};
   float* cp = Cb + (int64_t)row * ldc + col;
   if (n4) {
@@ -416,6 +417,7 @@ __device__ __forceinline__ void bx_store4(const GemmDev& p, float* Cb, int64_t l
       const float4 bv = *reinterpret_cast<const float4*>(bias + col);
       v[0] = fmaf(bv.x, rscale, v[0]); v[1] = fmaf(bv.y, rscale, v[1]); v[2] = fmaf(bv.z, rscale, v[2]); v[3] = fmaf(bv.w, rscale, v[3]);
     }
+    if (addrow) { const float4 o = *reinterpret_cast<const float4*>(addrow + col); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
     if (zero) { v[0] = v[1] = v[2] = v[3] = 0.f; }
     if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
     if (p.relu_src) {
@@ -430,6 +432,7 @@ __device__ __forceinline__ void bx_store4(const GemmDev& p, float* Cb, int64_t l
       float x = v[e];
       if (p.accumulate) x += cp[e];
       if (bias) x = fmaf(bias[col + e], rscale, x);
+      if (addrow) x += addrow[col + e];
       if (zero) x = 0.f;
       if (p.relu) x = fmaxf(x, 0.f);
       if (p.relu_src) x = (p.relu_src[(int64_t)row * p.relu_ld + col + e] > 0.f) ? x : 0.f;
@@ -439,6 +442,7 @@ __device__ __forceinline__ void bx_store4(const GemmDev& p, float* Cb, int64_t l
 }
 __device__ __forceinline__ bool bx_n4(const GemmDev& p, const float* Cb, int64_t ldc, const float* bias) {
   return (p.N & 3) == 0 && (ldc & 3) == 0 && (((uintptr_t)Cb) & 15) == 0 &&
+         (!p.add_src || ((p.add_ld & 3) == 0 && (((uintptr_t)p.add_src) & 15) == 0)) &&
          (!p.relu_src || ((p.relu_ld & 3) == 0 && (((uintptr_t)p.relu_src) & 15) == 0)) && (!bias || (((uintptr_t)bias) & 15) == 0);
 }
 
@@ -614,10 +618,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
     if (row >= Mlim) continue;
     const float rscale = rs ? rs[(int64_t)row * p.rs_ld] : 1.f;
     const bool zero = p.row_zero ? (p.row_zero[row] != 0) : false;
+    const float* addrow = p.add_src ? p.add_src + (int64_t)(p.add_idx ? p.add_idx[row] : row) * p.add_ld : nullptr;
 #pragma unroll
     for (int j = 0; j < 11; ++j) {
       const int col = n0 + 16 * j + 4 * g;
-      if (col < p.N) bx_store4(p, Cb, ldc, bias, rscale, zero, n4, row, col, acc[i][j]);
+      if (col < p.N) bx_store4(p, Cb, ldc, bias, rscale, zero, n4, row, col, acc[i][j], addrow);
     }
   }
 }
@@ -767,10 +772,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_areg_kernel(const Gem
     if (row >= Mlim) continue;
     const float rscale = rs ? rs[(int64_t)row * p.rs_ld] : 1.f;
     const bool zero = p.row_zero ? (p.row_zero[row] != 0) : false;
+    const float* addrow = p.add_src ? p.add_src + (int64_t)(p.add_idx ? p.add_idx[row] : row) * p.add_ld : nullptr;
 #pragma unroll
     for (int j = 0; j < 11; ++j) {
       const int col = n0 + 16 * j + 4 * g;
-      if (col < p.N) bx_store4(p, Cb, ldc, bias, rscale, zero, n4, row, col, acc[i][j]);
+      if (col < p.N) bx_store4(p, Cb, ldc, bias, rscale, zero, n4, row, col, acc[i][j], addrow);
     }
   }
 }
@@ -896,11 +902,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const G
     if (row >= Mlim) continue;
     const float rscale = p.row_scale ? p.row_scale[(int64_t)row * p.rs_ld] : 1.f;
     const bool zero = p.row_zero ? (p.row_zero[row] != 0) : false;
+    const float* addrow = p.add_src ? p.add_src + (int64_t)(p.add_idx ? p.add_idx[row] : row) * p.add_ld : nullptr;
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) {
       const int j = wave + 4 * jj;
       const int col = n0 + 16 * j + 4 * g;
-      if (j < 11 && col < p.N) bx_store4(p, Cb, ldc, p.bias, rscale, zero, n4, row, col, acc[i][jj]);
+      if (j < 11 && col < p.N) bx_store4(p, Cb, ldc, p.bias, rscale, zero, n4, row, col, acc[i][jj], addrow);
     }
   }
 }
@@ -1109,7 +1116,8 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
 // `trans`, src[k*ld + n] - so a k-major ("NN") operand becomes a row-major one for free.
 struct BimgDev {
   const float* src[PFO_BIMG_MAX]; int64_t ld[PFO_BIMG_MAX]; int N[PFO_BIMG_MAX], K[PFO_BIMG_MAX], trans[PFO_BIMG_MAX];
-  void* dst[PFO_BIMG_MAX]; int rows[PFO_BIMG_MAX];
+  void* dst[PFO_BIMG_MAX]; int rows[PFO_BIMG_MAX];      // rows: image rows this problem fills (incl. zero padding)
+  int row0[PFO_BIMG_MAX], rows_total[PFO_BIMG_MAX];     // first image row of the problem, padded rows of the whole image
 };
 __global__ __launch_bounds__(256) void bimg_kernel(const BimgDev g) {
   const int z = blockIdx.y;
@@ -1141,10 +1149,11 @@ __global__ __launch_bounds__(256) void bimg_kernel(const BimgDev g) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) w[q][e2] = (pc[1][q] & 0xFFFF0000u) | (pc[0][q] >> 16);
     }
-    const int64_t off = (int64_t)n * 64 + ((c ^ bx_swz(n)) << 4);
+    const int ng = n + g.row0[z];                               // row of the (possibly stacked) image
+    const int64_t off = (int64_t)ng * 64 + ((c ^ bx_swz(ng)) << 4);
 #pragma unroll
     for (int q = 0; q < 3; ++q)
-      *reinterpret_cast<uint4*>(dst + ((int64_t)t * 3 + q) * rows * 64 + off) = uint4{w[q][0], w[q][1], w[q][2], w[q][3]};
+      *reinterpret_cast<uint4*>(dst + ((int64_t)t * 3 + q) * g.rows_total[z] * 64 + off) = uint4{w[q][0], w[q][1], w[q][2], w[q][3]};
   }
 }
 
@@ -1232,6 +1241,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_group_kernel(const TnGro
   d.K[0] = g.K; d.K[1] = 0;
   d.C = nullptr; d.ldc = 0; d.bias = nullptr; d.row_scale = nullptr; d.rs_ld = 0; d.row_zero = nullptr;
   d.relu_src = nullptr; d.relu_ld = 0; d.M = pr.M; d.N = pr.N; d.m_dev = g.k_dev; d.relu = 0; d.accumulate = 0;
+  d.add_src = nullptr; d.add_ld = 0; d.add_idx = nullptr;
   d.nsplit = 2;                      // any value > 1: selects the slab epilogue; the real split index comes from blockIdx.y
   d.split_chunk = g.chunk;
   d.a_bs[0] = d.a_bs[1] = d.b_bs[0] = d.b_bs[1] = d.c_bs = d.bias_bs = d.rs_bs = 0;
@@ -1337,7 +1347,8 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
   else if (vec) hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   else hipLaunchKernelGGL(gemm_tn_group_kernel<false>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   PFO_LAUNCH_CHECK();
-  if (use_bx) pfo_prof_end(PFO_PROF_GEMM_TN_BX, flops, stream);        // the GEMM kernel alone
+  // the GEMM kernel alone; with a device-side K bound the host does not know the work: time only
+  if (use_bx) pfo_prof_end(k_dev ? PFO_PROF_GEMM_DEVM : PFO_PROF_GEMM_TN_BX, flops, stream);
   hipLaunchKernelGGL(tn_group_reduce_kernel, dim3((unsigned)std::min<int64_t>(1024, pfo_ceil_div(per_split, 256))), dim3(256), 0,
                      stream, g);
   PFO_LAUNCH_CHECK();
@@ -1355,6 +1366,7 @@ static void to_dev(const PfoGemm& g, GemmDev& d) {
   d.b_idx = g.b_idx;
   d.C = g.C; d.ldc = g.ldc; d.bias = g.bias; d.row_scale = g.row_scale; d.rs_ld = g.rs_ld; d.row_zero = g.row_zero;
   d.relu_src = g.relu_src; d.relu_ld = g.relu_ld; d.M = g.M; d.N = g.N; d.m_dev = g.m_dev;
+  d.add_src = g.add_src; d.add_ld = g.add_ld; d.add_idx = g.add_idx;
   d.relu = g.relu; d.accumulate = g.accumulate; d.nsplit = 1; d.split_chunk = 0;
   d.c_bs = g.c_bs; d.bias_bs = g.bias_bs; d.rs_bs = g.rs_bs;
   d.n_real = g.N; d.slab_base = g.slabs; d.dyn_chunk = 0;
@@ -1372,7 +1384,12 @@ int pfo_bimg_launch(const PfoBimg* list, int n, hipStream_t stream) {
     PFO_REQUIRE(list[i].src && list[i].dst && list[i].N > 0 && list[i].K > 0, "bad image problem");
     PFO_REQUIRE((((uintptr_t)list[i].dst) & 15) == 0, "image must be 16-byte aligned");
     d.src[i] = list[i].src; d.ld[i] = list[i].ld; d.N[i] = list[i].N; d.K[i] = list[i].K; d.trans[i] = list[i].trans;
-    d.dst[i] = list[i].dst; d.rows[i] = (int)pfo_align_up(list[i].N, BN);
+    d.dst[i] = list[i].dst;
+    d.row0[i] = list[i].row0;
+    d.rows_total[i] = list[i].rows_total > 0 ? (int)pfo_align_up(list[i].rows_total, BN) : (int)pfo_align_up(list[i].N, BN);
+    // rows this problem writes: a plain image and the last operand of a stack include the zero padding up to the padded end
+    d.rows[i] = list[i].rows_total > 0 ? (list[i].last ? d.rows_total[i] - d.row0[i] : list[i].N) : d.rows_total[i];
+    PFO_REQUIRE(d.row0[i] >= 0 && d.rows[i] >= list[i].N && d.row0[i] + d.rows[i] <= d.rows_total[i], "bad stacked image rows");
     most = std::max<int64_t>(most, (int64_t)pfo_ceil_div(list[i].K, 32) * d.rows[i] * 4);
   }
   hipLaunchKernelGGL(bimg_kernel, dim3((unsigned)pfo_ceil_div(most, 256), n), dim3(256), 0, stream, d);

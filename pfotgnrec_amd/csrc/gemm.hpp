@@ -5,7 +5,7 @@
 // C[M,N] = epilogue( sum over up to two K-concatenated sources  A_s[M,K_s] * op(B_s) )
 //   A_s row-major [M,K_s] (a_kmajor=0, optional row gather a_idx) or [K_s,M] (a_kmajor=1)
 //   B_s [N,K_s] (b_kmajor=0, nn.Linear layout) or [K_s,N] (b_kmajor=1, optional k-row gather b_idx)
-// epilogue order: + bias[n]*row_scale[m]  ->  row_zero  ->  relu  ->  * (relu_src>0)  ->  (+= C)
+// epilogue order: (+= C)  ->  + bias[n]*row_scale[m]  ->  + add_src[add_idx[m]][n]  ->  row_zero  ->  relu  ->  * (relu_src>0)
 struct PfoGemm {
   const float* A[2] = {nullptr, nullptr};
   int64_t lda[2] = {0, 0};
@@ -20,6 +20,8 @@ struct PfoGemm {
   const float* row_scale = nullptr; int64_t rs_ld = 1;
   const uint8_t* row_zero = nullptr;
   const float* relu_src = nullptr; int64_t relu_ld = 0;
+  // row-gathered addend (bf16x3 image kernels only): C[m][n] += add_src[add_idx ? add_idx[m] : m][n]
+  const float* add_src = nullptr; int64_t add_ld = 0; const int32_t* add_idx = nullptr;
   int M = 0, N = 0;
   const int32_t* m_dev = nullptr;   // device-side row count (rows M for row-major A, extent K for k-major A)
   int relu = 0, accumulate = 0;
@@ -40,6 +42,10 @@ struct PfoGemm {
 #define PFO_BIMG_MAX 24
 struct PfoBimg {
   const float* src = nullptr; int64_t ld = 0; int N = 0, K = 0, trans = 0; void* dst = nullptr;
+  // an image whose rows come from several operands stacked along n (e.g. [Wqk ; W1[:, E:]]): this problem fills image rows
+  // [row0, row0 + N) of an image of rows_total rows (padded to the tile width); the LAST operand of a stack sets `last`
+  // and also writes the zero padding rows up to the padded end.  rows_total = 0: a plain single-operand image
+  int row0 = 0, rows_total = 0, last = 0;
 };
 int64_t pfo_bimg_bytes(int N, int K);
 int pfo_bimg_launch(const PfoBimg* list, int n, hipStream_t stream);

@@ -117,6 +117,156 @@ int pfo_remap_launch(const int32_t* nodes0, int64_t n0, const int32_t* slot, int
   return PFO_OK;
 }
 
+// rows of the touched nodes from a full table: dst[s] = src[touched_ids[s]]   (no-memory models: level 0 = node features)
+__global__ void gather_rows_kernel(const float* __restrict__ src, int D, const int32_t* __restrict__ touched_ids,
+                                   const int32_t* __restrict__ n_touched, float* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int nt = *n_touched;
+  for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < nt; s += (gridDim.x * blockDim.x) >> 6) {
+    const float4* a = reinterpret_cast<const float4*>(src + (int64_t)touched_ids[s] * D);
+    float4* d = reinterpret_cast<float4*>(dst + (int64_t)s * D);
+    for (int c = lane; c < D / 4; c += 64) d[c] = a[c];
+  }
+}
+int pfo_gather_rows_launch(const float* src, int D, const int32_t* touched_ids, const int32_t* n_touched, int cap, float* dst,
+                           hipStream_t stream) {
+  PFO_REQUIRE((D % 4) == 0, "row length must be a multiple of 4");
+  const int nb = (int)std::min<int64_t>(4096, std::max<int64_t>(1, pfo_ceil_div(cap, 4)));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, stream, src, D, touched_ids, n_touched, dst);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Instances grouped by the touched-table row they read (layer 1: instance n reads row idx[n]).  The backward sums
+// per-instance gradients over each group BEFORE the contractions that only depend on the row, so those contractions run
+// over the ~10 k touched rows instead of the ~54 k instances.  Counting sort; the order inside a group is fixed
+// (ascending instance index) by a rank sort, so every sum over a group is reproducible.
+__global__ void seg_count_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ nodes, int N,
+                                 int32_t* __restrict__ cnt) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N && nodes[n] != 0) atomicAdd(&cnt[idx[n]], 1);       // padding instances (node 0) carry no gradient
+}
+// exclusive scan, level 1: per block of SCAN_BLOCK entries; block totals to `block_sum`
+__global__ __launch_bounds__(SCAN_BLOCK) void iscan_local_kernel(const int32_t* __restrict__ in, int n, int32_t* __restrict__ out,
+                                                                 int32_t* __restrict__ block_sum) {
+  __shared__ int s_w[SCAN_BLOCK / 64];
+  const int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int v = i < n ? in[i] : 0;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += u;
+  }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wave; ++w) woff += s_w[w];
+  if (i < n) out[i] = woff + incl - v;
+  if (threadIdx.x == SCAN_BLOCK - 1) block_sum[blockIdx.x] = woff + incl;
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void iscan_add_kernel(int32_t* __restrict__ out, int n, const int32_t* __restrict__ block_off,
+                                                               int32_t* __restrict__ copy) {
+  const int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  if (i < n) {
+    const int v = out[i] + block_off[blockIdx.x];
+    out[i] = v;
+    copy[i] = v;
+  }
+}
+__global__ void seg_place_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ nodes, int N,
+                                 int32_t* __restrict__ cursor, int32_t* __restrict__ members) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N && nodes[n] != 0) members[atomicAdd(&cursor[idx[n]], 1)] = n;
+}
+// one wavefront per group: members of the group in ascending order (rank sort; instance indices are distinct)
+__global__ void seg_sort_kernel(const int32_t* __restrict__ seg_ptr, int n_seg, const int32_t* __restrict__ in,
+                                int32_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < n_seg; s += (gridDim.x * blockDim.x) >> 6) {
+    const int lo = seg_ptr[s], cnt = seg_ptr[s + 1] - lo;
+    if (cnt <= 0) continue;
+    for (int i = lane; i < cnt; i += 64) {
+      const int x = in[lo + i];
+      int rank = 0;
+      for (int j = 0; j < cnt; ++j) rank += in[lo + j] < x;
+      out[lo + rank] = x;
+    }
+  }
+}
+int64_t pfo_seg_scratch_ints(int cap_rows) { return pfo_ceil_div(cap_rows + 1, SCAN_BLOCK) + 8; }
+int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int cap_rows, int32_t* seg_ptr, int32_t* cursor,
+                         int32_t* tmp, int32_t* members, int32_t* scratch, hipStream_t stream) {
+  PFO_REQUIRE(idx && nodes && seg_ptr && cursor && tmp && members && scratch && N > 0 && cap_rows > 0, "bad arguments");
+  const int n = cap_rows + 1;
+  PFO_REQUIRE(hipMemsetAsync(cursor, 0, (size_t)n * sizeof(int32_t), stream) == hipSuccess, "memset failed");
+  hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)pfo_ceil_div(N, 256)), dim3(256), 0, stream, idx, nodes, N, cursor);
+  const int nb = (int)pfo_ceil_div(n, SCAN_BLOCK);
+  hipLaunchKernelGGL(iscan_local_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, cursor, n, seg_ptr, scratch);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, scratch, nb, scratch + nb);
+  hipLaunchKernelGGL(iscan_add_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, seg_ptr, n, scratch, cursor);
+  hipLaunchKernelGGL(seg_place_kernel, dim3((unsigned)pfo_ceil_div(N, 256)), dim3(256), 0, stream, idx, nodes, N, cursor, tmp);
+  hipLaunchKernelGGL(seg_sort_kernel, dim3((unsigned)std::min<int64_t>(4096, pfo_ceil_div(cap_rows, 4))), dim3(256), 0, stream,
+                     seg_ptr, cap_rows, tmp, members);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+// out[s][0:W0) = sum over the group's members n of src0[n][0:W0), out[s][W0:W0+W1) = ... of src1[n][0:W1), s < *n_rows;
+// groups without members get zeros.  One wavefront per group, fixed member order -> reproducible.
+#define SEGSUM_R 16
+__global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ src0, int W0, const float* __restrict__ src1, int W1,
+                                                     const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ members,
+                                                     const int32_t* __restrict__ n_rows, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int W = W0 + W1;
+  const int nr = *n_rows;
+  for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < nr; s += (gridDim.x * blockDim.x) >> 6) {
+    const int lo = seg_ptr[s], hi = seg_ptr[s + 1];
+    for (int c0 = 0; c0 < W; c0 += 64 * SEGSUM_R) {
+      float acc[SEGSUM_R];
+#pragma unroll
+      for (int r = 0; r < SEGSUM_R; ++r) acc[r] = 0.f;
+      int m = lo;
+      for (; m + 1 < hi; m += 2) {                       // two member rows in flight
+        const int64_t na = members[m], nb = members[m + 1];
+        float va[SEGSUM_R], vb[SEGSUM_R];
+#pragma unroll
+        for (int r = 0; r < SEGSUM_R; ++r) {
+          const int c = c0 + lane + 64 * r;
+          va[r] = c < W0 ? src0[na * W0 + c] : (c < W ? src1[na * W1 + (c - W0)] : 0.f);
+          vb[r] = c < W0 ? src0[nb * W0 + c] : (c < W ? src1[nb * W1 + (c - W0)] : 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < SEGSUM_R; ++r) acc[r] = (acc[r] + va[r]) + vb[r];
+      }
+      if (m < hi) {
+        const int64_t na = members[m];
+#pragma unroll
+        for (int r = 0; r < SEGSUM_R; ++r) {
+          const int c = c0 + lane + 64 * r;
+          acc[r] += c < W0 ? src0[na * W0 + c] : (c < W ? src1[na * W1 + (c - W0)] : 0.f);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < SEGSUM_R; ++r) {
+        const int c = c0 + lane + 64 * r;
+        if (c < W) out[(int64_t)s * W + c] = acc[r];
+      }
+    }
+  }
+}
+int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, const int32_t* seg_ptr, const int32_t* members,
+                      const int32_t* n_rows, int cap_rows, float* out, hipStream_t stream) {
+  PFO_REQUIRE(src0 && src1 && seg_ptr && members && n_rows && out && W0 > 0 && W1 > 0, "bad arguments");
+  const int nb = (int)std::min<int64_t>(8192, std::max<int64_t>(1, pfo_ceil_div(cap_rows, 4)));
+  hipLaunchKernelGGL(segsum_kernel, dim3(nb), dim3(256), 0, stream, src0, W0, src1, W1, seg_ptr, members, n_rows, out);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -185,7 +335,8 @@ int pfo_gru_gates_fwd_launch(const float* gi, const float* gh, const float* h_ro
 
 __global__ void gru_gates_bwd_kernel(float* __restrict__ gi, float* __restrict__ gh, const float* __restrict__ h_rows,
                                      const uint8_t* __restrict__ hm, const int32_t* __restrict__ n_touched, int D,
-                                     const float* __restrict__ d_h0, int n_rep, int64_t rep_stride) {
+                                     const float* __restrict__ d_h0, int n_rep, int64_t rep_stride,
+                                     const float* __restrict__ d_extra) {
   const int64_t total = (int64_t)(*n_touched) * D;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int s = (int)(e / D), d = (int)(e - (int64_t)s * D);
@@ -200,6 +351,7 @@ __global__ void gru_gates_bwd_kernel(float* __restrict__ gi, float* __restrict__
       const float nn = tanhf(gis[2 * D + d] + r * ghn);
       float dh = 0.f;                                  // the level-0 gradient is kept in one replica per XCD
       for (int q = 0; q < n_rep; ++q) dh += d_h0[(int64_t)q * rep_stride + e];
+      if (d_extra) dh += d_extra[e];                   // the rows' own (query-side) gradient, already summed per row
       const float dn = dh * (1.f - z);
       const float dz = dh * (h - nn);
       dpn = dn * (1.f - nn * nn);
@@ -214,9 +366,11 @@ __global__ void gru_gates_bwd_kernel(float* __restrict__ gi, float* __restrict__
 }
 
 int pfo_gru_gates_bwd_launch(float* gi, float* gh, const float* h_rows, const uint8_t* hm, const int32_t* n_touched,
-                             int cap, int D, const float* d_h0, int n_rep, int64_t rep_stride, hipStream_t stream) {
+                             int cap, int D, const float* d_h0, int n_rep, int64_t rep_stride, const float* d_extra,
+                             hipStream_t stream) {
   const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div((int64_t)cap * D, 256));
-  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(nb), dim3(256), 0, stream, gi, gh, h_rows, hm, n_touched, D, d_h0, n_rep, rep_stride);
+  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(nb), dim3(256), 0, stream, gi, gh, h_rows, hm, n_touched, D, d_h0, n_rep, rep_stride,
+                     d_extra);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

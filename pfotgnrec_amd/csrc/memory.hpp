@@ -21,8 +21,20 @@ int pfo_gru_gates_fwd_launch(const float* gi, const float* gh, const float* h_ro
                              const uint8_t* hm, const int32_t* touched_ids, const int32_t* n_touched, int cap, int D,
                              float* upd_mem, float* h0_tab, hipStream_t stream);
 // backward: overwrites gi/gh with d gi / d gh given d h' = sum over the n_rep replicas of d_h0[s] (zeros where no message was applied)
+// d_extra (optional): one more [rows, D] addend of d h' (the rows' query-side gradient, layer 1)
 int pfo_gru_gates_bwd_launch(float* gi, float* gh, const float* h_rows, const uint8_t* hm, const int32_t* n_touched,
-                             int cap, int D, const float* d_h0, int n_rep, int64_t rep_stride, hipStream_t stream);
+                             int cap, int D, const float* d_h0, int n_rep, int64_t rep_stride, const float* d_extra,
+                             hipStream_t stream);
+// dst[s] = src[touched_ids[s]], s < *n_touched
+int pfo_gather_rows_launch(const float* src, int D, const int32_t* touched_ids, const int32_t* n_touched, int cap, float* dst,
+                           hipStream_t stream);
+// --- instances grouped by the touched-table row they read: seg_ptr[cap_rows + 1], members[N] (ascending inside a group)
+int64_t pfo_seg_scratch_ints(int cap_rows);
+int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int cap_rows, int32_t* seg_ptr, int32_t* cursor,
+                         int32_t* tmp, int32_t* members, int32_t* scratch, hipStream_t stream);
+// out[s] = [ sum_{n in group s} src0[n] | sum_{n in group s} src1[n] ]  (row widths W0, W1; s < *n_rows)
+int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, const int32_t* seg_ptr, const int32_t* members,
+                      const int32_t* n_rows, int cap_rows, float* out, hipStream_t stream);
 int pfo_zero_rows_launch(float* dst, const int32_t* n_rows, int cap_rows, int D, int n_rep, int64_t rep_stride, hipStream_t stream);
 
 // --- state update (tgn.py:290-317)

@@ -39,8 +39,13 @@ struct Ws {
   uint8_t* hm;
   float *cosb, *zero;
   void *iWih, *iWhh;
+  // layer 1 works on the touched-node table: QX[s] = h0_tab[s] [Wqk ; W1[:, E:]]^T + [cqk | 0] for every touched row s
+  // (the query-side projections of all instances that sit on node s), Dq = per-row sums of the instances' gradients
+  float *QX, *Dq, *dx_tab, *l1_bias;
+  void* iQX;
+  int32_t *seg_ptr, *seg_cur, *seg_tmp, *seg_mem, *seg_scratch;
   LayerWs layer[PFO_MAX_LAYERS + 1];
-  float *dh1, *dctx, *dQK, *dx1;
+  float *dh1, *dctx, *dQK;
   float* dH[PFO_MAX_LAYERS + 1];
   float* slabs;
   double *dtime, *fold_scratch;
@@ -97,22 +102,36 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     LayerWs& lw = w.layer[l];
     lw.Wqk = take<float>(p, (int64_t)d.H * d.Cp * d.D);
     lw.W1ovT = take<float>(p, (int64_t)d.H * d.Cp * d.D);
-    lw.cqk = take<float>(p, (int64_t)d.H * d.Cp);
+    // layer 1: cqk is the head of the bias of the stacked [Wqk ; W1[:, E:]] projection; its tail (D floats) stays zero
+    lw.cqk = take<float>(p, (int64_t)d.H * d.Cp + (l == 1 ? d.D : 0));
   }
+  w.l1_bias = w.layer[1].cqk;
   w.dtime = take<double>(p, (int64_t)pfo_attn_bwd_max_parts() * 2 * d.D);      // time-encoder gradient bins, also cleared per step
   w.zero_bytes = (size_t)(p - reinterpret_cast<char*>(w.zero));
   w.cosb = take<float>(p, d.D);
-  if (c->use_memory) {
+  {
+    const int WQ = d.H * d.Cp + d.D;
     w.slot = take<int32_t>(p, c->n_nodes);
-    w.winner = take<int32_t>(p, c->n_nodes);
     w.touched = take<int32_t>(p, d.capP);
     w.n_touched = take<int32_t>(p, 64);
     w.scan = take<int32_t>(p, pfo_compact_scratch_ints(c->n_nodes));
     w.idx0 = take<int32_t>(p, d.ncap[0]);
+    w.h0_tab = take<float>(p, d.capP * d.D);
+    w.QX = take<float>(p, d.capP * WQ);
+    w.Dq = take<float>(p, d.capP * WQ);
+    w.dx_tab = take<float>(p, d.capP * d.D);
+    w.iQX = take<char>(p, pfo_bimg_bytes(WQ, d.D));
+    w.seg_ptr = take<int32_t>(p, d.capP + 1);
+    w.seg_cur = take<int32_t>(p, d.capP + 1);
+    w.seg_tmp = take<int32_t>(p, d.ncap[1]);
+    w.seg_mem = take<int32_t>(p, d.ncap[1]);
+    w.seg_scratch = take<int32_t>(p, pfo_seg_scratch_ints((int)d.capP));
+  }
+  if (c->use_memory) {
+    w.winner = take<int32_t>(p, c->n_nodes);
     w.gi = take<float>(p, d.capP * 3 * d.D);
     w.gh = take<float>(p, d.capP * 3 * d.D);
     w.upd_mem = take<float>(p, d.capP * d.D);
-    w.h0_tab = take<float>(p, d.capP * d.D);
     w.d_h0 = take<float>(p, PFO_GRAD_REPLICAS * d.capP * d.D);     // one replica per XCD (attn.hip, DMODE 1)
     w.msg_rows = take<float>(p, d.capP * d.M);
     w.h_rows = take<float>(p, d.capP * d.D);
@@ -137,7 +156,7 @@ Ws carve(const pfo_tgn_config* c, void* base) {
       lw.iW1b = take<char>(p, pfo_bimg_bytes(d.D, d.D));   lw.iW1bT = take<char>(p, pfo_bimg_bytes(d.D, d.D));
       lw.iW2 = take<char>(p, pfo_bimg_bytes(d.D, d.D));    lw.iW2T = take<char>(p, pfo_bimg_bytes(d.D, d.D));
     }
-    lw.QK = take<float>(p, N * d.H * d.Cp);
+    lw.QK = l > 1 ? take<float>(p, N * d.H * d.Cp) : nullptr;      // layer 1 reads its rows from the touched-node table QX
     lw.attw = take<float>(p, N * d.H * Km);
     lw.inv = take<uint8_t>(p, N);
     lw.ctx = take<float>(p, N * d.H * d.Cp);
@@ -149,7 +168,6 @@ Ws carve(const pfo_tgn_config* c, void* base) {
   w.dh1 = take<float>(p, N1 * d.D);
   w.dctx = take<float>(p, N1 * d.H * d.Cp);
   w.dQK = take<float>(p, N1 * d.H * d.Cp);
-  w.dx1 = take<float>(p, N1 * d.D);
   w.slab_floats = SLAB_FLOATS;
   w.slabs = take<float>(p, w.slab_floats);
   w.fold_scratch = take<double>(p, pfo_fold_parts_scratch_doubles(2 * d.D));
@@ -222,7 +240,7 @@ PfoGemm g_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const int
 // dependent launches; they run beside the main stream's work and are joined by events where their results are needed.
 struct Side {
   hipStream_t s = nullptr;
-  hipEvent_t fork = nullptr, done = nullptr, gru_fork = nullptr, gru_join = nullptr;
+  hipEvent_t fork = nullptr, done = nullptr, gru_fork = nullptr, gru_join = nullptr, seg_done = nullptr;
   hipEvent_t layer[PFO_MAX_LAYERS + 1] = {};
   bool ok = false;
 };
@@ -234,6 +252,7 @@ Side& side() {
     good = good && hipEventCreateWithFlags(&sd.done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.gru_fork, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.gru_join, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.seg_done, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; l <= PFO_MAX_LAYERS; ++l) good = good && hipEventCreateWithFlags(&sd.layer[l], hipEventDisableTiming) == hipSuccess;
     sd.ok = good;
   }
@@ -392,9 +411,16 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
       a2[3] = g_nt(p.bo, E, nullptr, p.w1, E + D, lw.W1ovT + (int64_t)(C + 1) * D, D, 1, D, E, nullptr);   // row C+1 of head 0: (W1 bo)^T
       n2 += 4;
       // bf16x3 images of this layer's weight operands, in both orientations (forward and data-gradient launches)
-      img(lw.Wqk, D, HCp, D, 0, lw.iWqk);        img(lw.Wqk, D, D, HCp, 1, lw.iWqkT);
+      if (l == 1) {
+        // layer 1 projects the touched-node table once: [Wqk ; W1[:, E:]] stacked along the output dimension
+        img(lw.Wqk, D, HCp, D, 0, w.iQX);        im[ni - 1].row0 = 0;   im[ni - 1].rows_total = HCp + D;
+        img(p.w1 + E, E + D, D, D, 0, w.iQX);    im[ni - 1].row0 = HCp; im[ni - 1].rows_total = HCp + D; im[ni - 1].last = 1;
+      } else {
+        img(lw.Wqk, D, HCp, D, 0, lw.iWqk);      img(p.w1 + E, E + D, D, D, 0, lw.iW1b);
+      }
+      img(lw.Wqk, D, D, HCp, 1, lw.iWqkT);
       img(lw.W1ovT, D, HCp, D, 0, lw.iW1ovT);    img(lw.W1ovT, D, D, HCp, 1, lw.iW1ov);
-      img(p.w1 + E, E + D, D, D, 0, lw.iW1b);    img(p.w1 + E, E + D, D, D, 1, lw.iW1bT);
+      img(p.w1 + E, E + D, D, D, 1, lw.iW1bT);
       img(p.w2, D, D, D, 0, lw.iW2);             img(p.w2, D, D, D, 1, lw.iW2T);
     }
     for (int i = 0; i < n1; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(st1 + i, std::min(PFO_GEMM_MULTI_MAX, n1 - i), ss));
@@ -404,16 +430,17 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   HIPOK(hipEventRecord(sd.layer[0], ss), "event record failed");        // composite weights and images of all layers are ready
   bool composites_awaited = false;
 
-  // ---- lazy memory update for the touched nodes (tgn.py:251; memory_updater.py:35-53)
-  const float* tab0;
-  const int32_t* idx0;
+  // ---- the nodes this step reads (roots and every sampled neighbour, all levels; + the caller's extra nodes), compacted:
+  // slot[v] = row of v in the per-step tables, idx0[i] = row of the i-th level-0 reference
+  PFO_REQUIRE(b->n_extra >= 0 && b->n_extra <= 2 * c->max_batch, "n_extra exceeds 2 * max_batch");
+  PFO_REQUIRE(b->n_extra == 0 || b->extra_nodes, "null extra_nodes");
+  RUN(pfo_touch_compact_launch(w.nodes[0], n[0], b->extra_nodes, b->n_extra, c->n_nodes, w.slot, w.touched, w.n_touched,
+                               w.scan, s));
+  RUN(pfo_remap_launch(w.nodes[0], n[0], w.slot, w.idx0, s));
+  const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
+  // ---- level-0 rows of the touched nodes: memory' + node features (embedding_module.py:93-98), memory' = the lazily
+  // updated memory (tgn.py:251; memory_updater.py:35-53)
   if (c->use_memory) {
-    PFO_REQUIRE(b->n_extra >= 0 && b->n_extra <= 2 * c->max_batch, "n_extra exceeds 2 * max_batch");
-    PFO_REQUIRE(b->n_extra == 0 || b->extra_nodes, "null extra_nodes");
-    RUN(pfo_touch_compact_launch(w.nodes[0], n[0], b->extra_nodes, b->n_extra, c->n_nodes, w.slot, w.touched, w.n_touched,
-                                 w.scan, s));
-    RUN(pfo_remap_launch(w.nodes[0], n[0], w.slot, w.idx0, s));
-    const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
     RUN(pfo_pack_rows_launch(st->msg_table, d.M, st->memory, D, st->has_msg, w.touched, w.n_touched, capP, w.msg_rows,
                              w.h_rows, w.hm, s));
     HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");         // images of W_ih / W_hh
@@ -431,12 +458,12 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     HIPOK(hipStreamWaitEvent(s, sd.gru_join, 0), "event wait failed");
     RUN(pfo_gru_gates_fwd_launch(w.gi, w.gh, w.h_rows, st->node_feat, w.hm, w.touched, w.n_touched, capP, D, w.upd_mem,
                                  w.h0_tab, s));
-    tab0 = w.h0_tab;
-    idx0 = w.idx0;
   } else {
-    tab0 = st->node_feat;
-    idx0 = w.nodes[0];
+    RUN(pfo_gather_rows_launch(st->node_feat, D, w.touched, w.n_touched, capP, w.h0_tab, s));
   }
+  const float* tab0 = w.h0_tab;
+  const int32_t* idx0 = w.idx0;
+  const int WQ = HCp + D;
 
   // One attention layer = THREE large contractions around the neighbour-tile attention kernel (taken
   // to its end).  With one query per instance every projection that touches only that instance folds into a
@@ -461,15 +488,21 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
       HIPOK(hipStreamWaitEvent(s, sd.layer[0], 0), "event wait failed");   // composite weights are ready
       composites_awaited = true;
     }
-    // ---- qk' = x Wqk^T + cqk
-    {
+    // ---- qk' = x Wqk^T + cqk.  Layer 1: x is a row of the touched-node table, shared by every instance that sits on
+    // that node (~54 k instances on ~11 k nodes at C2): ONE projection of the table, [qk' | x W1[:, E:]^T] per row
+    if (l == 1) {
+      PfoGemm g = g_nt(tab0, D, nullptr, lw.Wqk, D, w.QX, WQ, capP, WQ, D, w.l1_bias);
+      g.m_dev = w.n_touched; g.b_img = w.iQX;
+      RUN(pfo_gemm_launch(g, s));
+    } else {
       PfoGemm g = g_nt(xA, D, x_idx, lw.Wqk, D, lw.QK, HCp, N, HCp, D, lw.cqk);
       g.b_img = lw.iWqk;
       RUN(pfo_gemm_launch(g, s));
     }
     PfoAttn a;
     a.N = N; a.K = K; a.D = D; a.Ef = Ef; a.H = H; a.Cp = Cp;
-    a.QK = lw.QK; a.nbr_tab = xA; a.nbr_ld = D;
+    a.QK = (l == 1) ? w.QX : lw.QK; a.qk_row = (l == 1) ? idx0 : nullptr; a.qk_ld = (l == 1) ? WQ : HCp;
+    a.nbr_tab = xA; a.nbr_ld = D;
     a.nbr_row = (l == 1) ? idx0 + N : nullptr;
     a.nbr_row_base = N;
     a.nbr_ids = w.nodes[l - 1] + N;
@@ -478,7 +511,14 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     a.ctx = lw.ctx; a.attw = lw.attw; a.inv = lw.inv;
     RUN(pfo_attn_fwd_launch(a, s));
     // ---- h1 = relu(ctx' W1ovT + x W1[:, E:]^T + b1)   (MergeLayer fc1 with out_proj and the value projection folded in)
-    if (pfo_gemm_takes_bx(N, D)) {
+    if (l == 1) {
+      // the x term was projected with the table: it arrives as a row-gathered addend of the epilogue
+      PFO_REQUIRE(pfo_gemm_takes_bx(N, D), "the touched-table layer needs the bf16x3 image kernels");
+      PfoGemm g = g_nn(lw.ctx, HCp, lw.W1ovT, D, lw.h1, D, N, D, HCp);
+      g.bias = p.b1; g.relu = 1; g.b_img = lw.iW1ov;
+      g.add_src = w.QX + HCp; g.add_ld = WQ; g.add_idx = idx0;
+      RUN(pfo_gemm_launch(g, s));
+    } else if (pfo_gemm_takes_bx(N, D)) {
       // both K-concatenated sources ([ctx' | x] against [W1ov | W1[:, E:]]) in one launch: h1 is written once
       PfoGemm g = g_nn(lw.ctx, HCp, lw.W1ovT, D, lw.h1, D, N, D, HCp);
       g.A[1] = xA; g.lda[1] = D; g.a_idx[1] = x_idx; g.B[1] = p.w1 + E; g.ldb[1] = E + D; g.K[1] = D;
@@ -520,16 +560,22 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
   bind(lay, grad, G, d.L, c->use_memory != 0);
   const int L = d.L, D = d.D, Ef = d.Ef, H = d.H, E = d.E, C = d.C, dh = d.dh, K = b->K;
   const float scale = 1.0f / sqrtf((float)dh);
-  const float* tab0 = c->use_memory ? w.h0_tab : st->node_feat;
-  const int32_t* idx0 = c->use_memory ? w.idx0 : w.nodes[0];
+  const float* tab0 = w.h0_tab;
+  const int32_t* idx0 = w.idx0;
   const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
   const int64_t rep_stride = (int64_t)d.capP * D;             // floats between the per-XCD replicas of d_h0
   if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_touched, capP, D, PFO_GRAD_REPLICAS, rep_stride, s));
 
-  const int Cp = d.Cp, HCp = H * d.Cp;
+  const int Cp = d.Cp, HCp = H * d.Cp, WQ = HCp + D;
   Side& sd = side();
   PFO_REQUIRE(sd.ok, "could not create the side stream");
   hipStream_t ss = sd.s;
+  // layer-1 instances grouped by the touched-table row they sit on (needed only when the layer-1 gradients are summed
+  // per row, late in this call): built on the side stream, beside the layer-L .. 2 work
+  HIPOK(hipEventRecord(sd.fork, s), "event record failed");
+  HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
+  RUN(pfo_seg_build_launch(idx0, w.nodes[0], (int)n[1], capP, w.seg_ptr, w.seg_cur, w.seg_tmp, w.seg_mem, w.seg_scratch, ss));
+  HIPOK(hipEventRecord(sd.seg_done, ss), "event record failed");
   for (int l = L; l >= 1; --l) {
     const int N = (int)n[l];
     const LayerWs& lw = w.layer[l];
@@ -538,7 +584,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     const float* dOut = (l == L) ? d_emb : w.dH[l];
     const float* xA = (l == 1) ? tab0 : w.layer[l - 1].Hout;
     const int32_t* x_idx = (l == 1) ? idx0 : nullptr;
-    float* dx = (l == 1) ? w.dx1 : w.dH[l - 1];              // rows [0, N) of the previous level's gradient
+    float* dx = (l == 1) ? nullptr : w.dH[l - 1];            // rows [0, N) of the previous level's gradient
 
     // Data gradients first (a chain of GEMMs + the attention core); every weight / bias gradient of the layer is
     // then taken in ONE grouped split-K launch (bias gradients ride along as an extra column).
@@ -564,11 +610,12 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     }
     set_tn(tn[1], lw.ctx, HCp, w.dh1, D, nullptr, HCp, D, lw.dW1ovT, D, nullptr);       // dW1ovT = ctx'^T dh1
     tn[1].c_accumulate = 0;
-    set_tn(tn[2], w.dh1, D, xA, D, x_idx, D, D, g.w1 + E, E + D, g.b1);                // dW1[:, E:], db1
+    if (l > 1) set_tn(tn[2], w.dh1, D, xA, D, x_idx, D, D, g.w1 + E, E + D, g.b1);     // dW1[:, E:], db1
     // attention core
     PfoAttn a;
     a.N = N; a.K = K; a.D = D; a.Ef = Ef; a.H = H; a.Cp = Cp;
-    a.QK = lw.QK; a.nbr_tab = xA; a.nbr_ld = D;
+    a.QK = (l == 1) ? w.QX : lw.QK; a.qk_row = (l == 1) ? idx0 : nullptr; a.qk_ld = (l == 1) ? WQ : HCp;
+    a.nbr_tab = xA; a.nbr_ld = D;
     a.nbr_row = (l == 1) ? idx0 + N : nullptr;
     a.nbr_row_base = N;
     a.nbr_ids = w.nodes[l - 1] + N;
@@ -582,24 +629,45 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     int n_parts = 0;
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
     // merged query/key projection: dx += dqk' Wqk, dWqk = dqk'^T x, gqk = colsum(dqk')
-    if (pfo_gemm_takes_bx(N, D)) {
-      // dx = [dqk' | dh1] [Wqk ; W1[:, E:]] : both sources in one launch, dx written once
-      PfoGemm q = g_nn(w.dQK, HCp, lw.Wqk, D, dx, D, N, D, HCp);
-      q.A[1] = w.dh1; q.lda[1] = D; q.B[1] = p.w1 + E; q.ldb[1] = E + D; q.K[1] = D;
-      q.b_img = lw.iWqkT; q.b_img2 = lw.iW1bT;
-      RUN(pfo_gemm_launch(q, s));
+    if (l == 1) {
+      // Layer 1: x is a row of the touched-node table shared by all instances on that node, so everything that is linear
+      // in the per-instance gradients (dqk', dh1) and otherwise depends on x only - the data gradient of x and the two
+      // weight gradients against x - is taken AFTER summing those gradients per table row: contractions over the
+      // ~11 k touched rows instead of the ~54 k instances.
+      RUN(pfo_gemm_tn_group_launch(tn, 2, N, nullptr, w.slabs, w.slab_floats, s));          // dW2 / db2, dW1ovT: over instances
+      HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");
+      RUN(pfo_segsum_launch(w.dQK, HCp, w.dh1, D, w.seg_ptr, w.seg_mem, w.n_touched, capP, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
+      if (c->use_memory) {
+        // d h0_tab (query side) = Dq [Wqk ; W1[:, E:]]; the GRU backward adds it to the key-side rows the attention scattered
+        PfoGemm q = g_nn(w.Dq, WQ, lw.Wqk, D, w.dx_tab, D, capP, D, HCp);
+        q.A[1] = w.Dq + HCp; q.lda[1] = WQ; q.B[1] = p.w1 + E; q.ldb[1] = E + D; q.K[1] = D;
+        q.b_img = lw.iWqkT; q.b_img2 = lw.iW1bT; q.m_dev = w.n_touched;
+        RUN(pfo_gemm_launch(q, s));
+      }
+      PfoTnProblem tb[2];
+      set_tn(tb[0], w.Dq, WQ, tab0, D, nullptr, HCp, D, lw.dWqk, D, lw.gqk);               // dWqk = (sum dqk')^T h0, gqk
+      tb[0].c_accumulate = 0; tb[0].bias_accumulate = 0;
+      set_tn(tb[1], w.Dq + HCp, WQ, tab0, D, nullptr, D, D, g.w1 + E, E + D, g.b1);        // dW1[:, E:], db1
+      RUN(pfo_gemm_tn_group_launch(tb, 2, capP, w.n_touched, w.slabs, w.slab_floats, s));
     } else {
-      PfoGemm q = g_nn(w.dh1, D, p.w1 + E, E + D, dx, D, N, D, D);
-      q.b_img = lw.iW1bT;
-      RUN(pfo_gemm_launch(q, s));
-      q = g_nn(w.dQK, HCp, lw.Wqk, D, dx, D, N, D, HCp);
-      q.accumulate = 1; q.b_img = lw.iWqkT;
-      RUN(pfo_gemm_launch(q, s));
+      if (pfo_gemm_takes_bx(N, D)) {
+        // dx = [dqk' | dh1] [Wqk ; W1[:, E:]] : both sources in one launch, dx written once
+        PfoGemm q = g_nn(w.dQK, HCp, lw.Wqk, D, dx, D, N, D, HCp);
+        q.A[1] = w.dh1; q.lda[1] = D; q.B[1] = p.w1 + E; q.ldb[1] = E + D; q.K[1] = D;
+        q.b_img = lw.iWqkT; q.b_img2 = lw.iW1bT;
+        RUN(pfo_gemm_launch(q, s));
+      } else {
+        PfoGemm q = g_nn(w.dh1, D, p.w1 + E, E + D, dx, D, N, D, D);
+        q.b_img = lw.iW1bT;
+        RUN(pfo_gemm_launch(q, s));
+        q = g_nn(w.dQK, HCp, lw.Wqk, D, dx, D, N, D, HCp);
+        q.accumulate = 1; q.b_img = lw.iWqkT;
+        RUN(pfo_gemm_launch(q, s));
+      }
+      set_tn(tn[3], w.dQK, HCp, xA, D, x_idx, HCp, D, lw.dWqk, D, lw.gqk);
+      tn[3].c_accumulate = 0; tn[3].bias_accumulate = 0;
+      RUN(pfo_gemm_tn_group_launch(tn, 4, N, nullptr, w.slabs, w.slab_floats, s));
     }
-    set_tn(tn[3], w.dQK, HCp, xA, D, x_idx, HCp, D, lw.dWqk, D, lw.gqk);
-    tn[3].c_accumulate = 0; tn[3].bias_accumulate = 0;
-    RUN(pfo_gemm_tn_group_launch(tn, 4, N, nullptr, w.slabs, w.slab_floats, s));
-    if (l == 1 && c->use_memory) RUN(pfo_scatter_add_rows_launch(w.dx1, D, idx0, w.nodes[0], N, D, w.d_h0, D, PFO_GRAD_REPLICAS, rep_stride, s));
 
     // ---- chain the composite-weight gradients back to the parameters (tiny products, side stream)
     HIPOK(hipEventRecord(sd.layer[l], s), "event record failed");
@@ -644,7 +712,8 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
 
   // ---- GRU parameters (messages and stored memory are constants: SURVEY App. A-6)
   if (c->use_memory) {
-    RUN(pfo_gru_gates_bwd_launch(w.gi, w.gh, w.h_rows, w.hm, w.n_touched, capP, D, w.d_h0, PFO_GRAD_REPLICAS, rep_stride, s));
+    RUN(pfo_gru_gates_bwd_launch(w.gi, w.gh, w.h_rows, w.hm, w.n_touched, capP, D, w.d_h0, PFO_GRAD_REPLICAS, rep_stride,
+                                 w.dx_tab, s));
     {
       PfoTnProblem gp[2];
       gp[0].A = w.gi; gp[0].lda = 3 * D; gp[0].B = w.msg_rows; gp[0].ldb = d.M; gp[0].M = 3 * D; gp[0].N = d.M;
