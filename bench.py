@@ -269,7 +269,7 @@ class Workload:
             self.step(i)
             i += 1
         total, n_steps, blocks, n_prof = 0.0, 0, 0, 0
-        self.block_ms = []
+        self.block_ms, self.host_ms = [], []
         loss = None
         while True:
             if multi:
@@ -285,6 +285,7 @@ class Workload:
                 i += 1
                 if sampled:
                     _lib.prof_enable(False)
+            self.host_ms.append(1e3 * (time.perf_counter() - t0) / steps)      # host time to ENQUEUE a step (no wait)
             torch.cuda.synchronize()
             if multi:
                 dist.barrier()
@@ -385,6 +386,7 @@ def main():
                    "timed_seconds": round(elapsed, 3),
                    "block_ms_per_step": {"first": round(wl.block_ms[0], 4), "min": round(min(wl.block_ms), 4),
                                          "median": round(float(np.median(wl.block_ms)), 4), "last": round(wl.block_ms[-1], 4)},
+                   "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4),
                    "collective": ("rccl all-reduce of the flat fp32 gradient, world %d" % dist.get_world_size()) if world > 1 else None},
     }
     if prof is not None:

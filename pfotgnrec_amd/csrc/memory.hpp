@@ -30,8 +30,11 @@ int pfo_gather_rows_launch(const float* src, int D, const int32_t* touched_ids, 
                            hipStream_t stream);
 // --- instances grouped by the touched-table row they read: seg_ptr[cap_rows + 1], members[N] (ascending inside a group)
 int64_t pfo_seg_scratch_ints(int cap_rows);
-int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int cap_rows, int32_t* seg_ptr, int32_t* cursor,
-                         int32_t* tmp, int32_t* members, int32_t* scratch, hipStream_t stream);
+// inside a group the members are ordered by (run key, instance): key = key_src[n*K + K-1] (the newest neighbour's edge id:
+// equal keys <=> identical most-recent neighbour lists) or the instance index when key_src is null
+int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int cap_rows, const int32_t* key_src, int K,
+                         int32_t* seg_ptr, int32_t* cursor, int32_t* tmp, int32_t* members, int32_t* scratch,
+                         hipStream_t stream);
 // out[s] = [ sum_{n in group s} src0[n] | sum_{n in group s} src1[n] ]  (row widths W0, W1; s < *n_rows)
 int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, const int32_t* seg_ptr, const int32_t* members,
                       const int32_t* n_rows, int cap_rows, float* out, hipStream_t stream);
@@ -47,10 +50,6 @@ int pfo_msg_store_launch(const int32_t* src, const int32_t* dst, const double* t
                          int32_t* winner, hipStream_t stream);
 
 // --- small ops (misc.hip)
-// dst[idx[r]] += src[r] (rows with idx < 0, or whose skip_if_zero entry is 0, are skipped)
-int pfo_scatter_add_rows_launch(const float* src, int64_t ld_src, const int32_t* idx, const int32_t* skip_if_zero,
-                                int64_t n_rows, int D, float* dst, int64_t ld_dst, int n_rep, int64_t rep_stride,
-                                hipStream_t stream);
 // cq = Wq[:, D:2D] cos(b) + bq folded query bias: backward of that term
 //   gq[E] = colsum(dQ);  d bq += gq;  d Wq[:, D:] += gq (x) cosb;  d tb += -sin(tb) * (Wq[:, D:]^T gq)
 int pfo_cq_backward_launch(const float* gq, const float* Wq, const float* tb, int D, float* d_bq, float* d_Wq,

@@ -253,59 +253,6 @@ extern "C" int pfo_adam_step_ranges(float* param, const float* grad, float* exp_
   return PFO_OK;
 }
 
-// ---------------------------------------------------------------------------------------------
-// dst[idx[r]] += src[r] for whole rows.  Four rows per wavefront iteration: their index and data loads are issued
-// together, then the atomics (one 256-byte piece per instruction).
-template <int MODE>
-__global__ void scatter_add_rows_kernel(const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ idx,
-                                        const int32_t* __restrict__ skip_if_zero, int64_t n_rows, int D,
-                                        float* __restrict__ dst_all, int64_t ld_dst, int n_rep, int64_t rep_stride) {
-  // with replicas of the destination table, every XCD adds into its own (attn.hpp PFO_GRAD_REPLICAS)
-  float* __restrict__ dst = dst_all + (n_rep > 1 ? (int64_t)(__builtin_amdgcn_s_getreg(6164) & (n_rep - 1)) * rep_stride : 0);
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t r0 = wave * 4; r0 < n_rows; r0 += n_waves * 4) {
-    int t[4];
-    float v[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t r = r0 + u;
-      t[u] = r < n_rows ? idx[r] : -1;
-      if (r < n_rows && skip_if_zero && skip_if_zero[r] == 0) t[u] = -1;   // padding node: thousands of rows would hit ONE destination
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int d = lane + 64 * q;
-        v[u][q] = (r < n_rows && d < D) ? src[r * ld_src + d] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (t[u] < 0) continue;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int d = lane + 64 * q;
-        if (d < D) {
-          if (MODE == 0) atomicAdd(dst + (int64_t)t[u] * ld_dst + d, v[u][q]);
-          else dst[(int64_t)t[u] * ld_dst + d] = v[u][q];     // timing experiment only
-        }
-      }
-    }
-  }
-}
-int pfo_scatter_add_rows_launch(const float* src, int64_t ld_src, const int32_t* idx, const int32_t* skip_if_zero,
-                                int64_t n_rows, int D, float* dst, int64_t ld_dst, int n_rep, int64_t rep_stride,
-                                hipStream_t stream) {
-  PFO_REQUIRE(n_rep >= 1 && (n_rep & (n_rep - 1)) == 0, "replica count must be a power of two");
-  PFO_REQUIRE(D <= 256, "row length must be <= 256");
-  static const int mode = getenv("PFO_SCATTER_MODE") ? atoi(getenv("PFO_SCATTER_MODE")) : 0;
-  const int nb = (int)std::min<int64_t>(2048, pfo_ceil_div(n_rows, 16));
-  if (mode == 0) hipLaunchKernelGGL(scatter_add_rows_kernel<0>, dim3(nb), dim3(256), 0, stream, src, ld_src, idx, skip_if_zero, n_rows, D, dst, ld_dst, n_rep, rep_stride);
-  else hipLaunchKernelGGL(scatter_add_rows_kernel<1>, dim3(nb), dim3(256), 0, stream, src, ld_src, idx, skip_if_zero, n_rows, D, dst, ld_dst, n_rep, rep_stride);
-  PFO_LAUNCH_CHECK();
-  return PFO_OK;
-}
-
 // one workgroup per time dimension d: d Wq[:, D+d] += gq * cos(b_d);  d tb[d] += -sin(b_d) * sum_e Wq[e, D+d] gq[e]
 __global__ __launch_bounds__(256) void cq_backward_kernel(const float* __restrict__ gq, const float* __restrict__ Wq,
                                                           const float* __restrict__ tb, int D, float* __restrict__ d_bq,

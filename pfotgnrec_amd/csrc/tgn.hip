@@ -574,7 +574,8 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
   // per row, late in this call): built on the side stream, beside the layer-L .. 2 work
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
-  RUN(pfo_seg_build_launch(idx0, w.nodes[0], (int)n[1], capP, w.seg_ptr, w.seg_cur, w.seg_tmp, w.seg_mem, w.seg_scratch, ss));
+  RUN(pfo_seg_build_launch(idx0, w.nodes[0], (int)n[1], capP, b->uniform ? nullptr : w.eidx[1], K, w.seg_ptr, w.seg_cur,
+                           w.seg_tmp, w.seg_mem, w.seg_scratch, ss));
   HIPOK(hipEventRecord(sd.seg_done, ss), "event record failed");
   for (int l = L; l >= 1; --l) {
     const int N = (int)n[l];
