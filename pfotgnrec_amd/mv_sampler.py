@@ -16,17 +16,35 @@ def log_returns(prices):
     return np.ascontiguousarray(np.log(prices[:, :, 1:] / prices[:, :, :-1]))
 
 
-def prices_from_time_feature(time_feature, map_item_id):
-    """The reference's ``time_feature[day_key][stock_code] -> 30 prices`` dict -> (sorted day keys, f64[day,item,30])."""
+def prices_from_time_feature(time_feature, map_item_id, upper_u=None):
+    """The reference's ``time_feature[day_key][stock] -> 30 prices`` dict (``time_feature_future_{p}.pkl``, main.py:88) ->
+    (sorted day keys, f64[day, item, 30]).
+
+    main.py looks a stock up by its CODE for portfolio members (``time_feature[t][p]``, main.py:223) and by its item NODE ID
+    for candidates (``time_feature[t][c]``, main.py:217/224), so both kinds of keys are accepted: str keys go through
+    ``map_item_id`` (code -> 0-based item index), integer keys are node ids (item index = id - upper_u - 1).  Items a day does
+    not list keep a constant price of 1 (zero log-returns)."""
     days = sorted(time_feature.keys())
     n_items = len(map_item_id)
     first = next(iter(time_feature[days[0]].values()))
     arr = np.ones((len(days), n_items, len(first)), np.float64)
     for d, key in enumerate(days):
-        for code, p in time_feature[key].items():
-            if code in map_item_id:
-                arr[d, map_item_id[code]] = p
+        for stock, p in time_feature[key].items():
+            if isinstance(stock, str):
+                if stock in map_item_id:
+                    arr[d, map_item_id[stock]] = p
+            elif upper_u is not None:
+                i = int(stock) - int(upper_u) - 1
+                if 0 <= i < n_items:
+                    arr[d, i] = p
     return days, arr
+
+
+def day_indices(timestamps, days):
+    """main.py:212: ``t = str(ts)[:8]`` picks the trading day of an interaction; -> index into ``days`` (KeyError like the
+    reference's dict lookup when the day is missing)."""
+    pos = {str(k): i for i, k in enumerate(days)}
+    return np.array([pos[str(ts)[:8]] for ts in np.asarray(timestamps).tolist()], np.int32)
 
 
 class MVSampler:

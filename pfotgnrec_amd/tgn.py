@@ -137,6 +137,7 @@ class TGN(nn.Module):
         self.seed = 0
         self.dp_rank, self.dp_world = 0, 1
         self.eval_chunk_roots = 16384     # roots per forward-only pass (evaluation.py scores B*(2+N_ITEMS) roots per batch)
+        self.eval_dedup = True            # forward-only passes embed every distinct (node, time) root once
         # memory_updater.py:25,41 assert that no pending message is older than its node's last update; the check reads
         # device state back (one sync per call), so it is off unless asked for
         self.debug_checks = False
@@ -479,7 +480,17 @@ class TGN(nn.Module):
             emb = _EmbedFn.apply(self, call, post, *self.hot_parameters())
             return emb, b
         # forward only (evaluation.py:94: R = B*(2+N_ITEMS) roots): walk the roots in chunks through the same
-        # kernels; memory is persisted once, after the last chunk, from a pass that covers the positives
+        # kernels; memory is persisted once, after the last chunk, from a pass that covers the positives.
+        # An embedding is a function of (node, time) only, and every interaction of an evaluation batch scores the SAME
+        # items (evaluation.py:88-89): interactions that share a timestamp (day-granular data) repeat whole blocks of
+        # roots.  Those are embedded once and gathered back.
+        inverse = None
+        if self.eval_dedup and draws is None and R >= 4096:
+            uniq, inv = torch.unique(torch.stack([roots.to(torch.float64), root_ts], 1), dim=0, return_inverse=True)
+            if uniq.shape[0] < R:
+                inverse, R_full = inv, R
+                roots, root_ts = uniq[:, 0].to(torch.int32).contiguous(), uniq[:, 1].contiguous()
+                R = int(roots.shape[0])
         cap = int(self.eval_chunk_roots)
         if R <= cap or draws is not None:
             call = self._make_call(roots, root_ts, K, draws, dropout_p, extra, B)
@@ -499,6 +510,8 @@ class TGN(nn.Module):
         if post is not None:
             post(call)
         call.release()
+        if inverse is not None:
+            emb = emb.index_select(0, inverse)
         return emb, b
 
     def _to_dev(self, a, dtype):

@@ -329,6 +329,31 @@ def test_evaluation_fast_path_chunked_roots_and_rank_metrics():
     for a, b in zip(states[0], states[1]):
         assert torch.equal(a, b)
     emb = outs[0]
+    # the same evaluation batch through the oracle: eval-mode embeddings of all B * (2 + N_ITEMS) roots and the state after
+    onf = OracleNeighborFinder(*build_adjacency(d.sources, d.destinations, d.edge_idxs, d.timestamps))
+    torch.manual_seed(3)
+    tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=2, dropout=0.2,
+                use_memory=True, memory_dimension=32, message_function="identity")
+    names = [k for k in tgn.state_dict() if "layer_norm" not in k and not k.startswith("memory.")]
+    ref = T.OracleTGN(onf, g.node_features, g.edge_features, {k: tgn.state_dict()[k].cpu().numpy() for k in names}, 2, 2, True)
+    for warm in (2900, 2950):
+        w = slice(warm, warm + B)
+        ref.compute_temporal_embeddings(d.sources[w], d.destinations[w], d.destinations[w].repeat(3), d.timestamps[w], d.edge_idxs[w], 6)
+    rse, rde, rne = ref.compute_temporal_embeddings(d.sources[sl], d.destinations[sl], neg, d.timestamps[sl], d.edge_idxs[sl], 6)
+    assert relerr(emb.cpu().numpy(), np.concatenate([rse, rde, rne])) < RTOL_EMB
+    assert relerr(states[0][0].cpu().numpy(), ref.memory) < RTOL_EMB and np.array_equal(states[0][1].cpu().numpy(), ref.last_update)
+    # duplicate (node, time) roots are embedded once: two interactions at one timestamp share their 25 item roots
+    tgn.eval(); tgn.eval_dedup = True
+    ts_dup = d.timestamps[sl].copy(); ts_dup[1::2] = ts_dup[0::2]
+    big = np.tile(neg, 9)                                                # R = 20 * 9 * 25 + 40 >= 4096: the dedup path
+    bsrc, bdst, bts, bei = (np.tile(a, 9) for a in (d.sources[sl], d.destinations[sl], ts_dup, d.edge_idxs[sl]))
+    res = []
+    for flag in (True, False):
+        tgn.eval_dedup = flag
+        tgn.memory.__init_memory__()
+        with torch.no_grad():
+            res.append(torch.cat(tgn.compute_temporal_embeddings(bsrc, bdst, big, bts, bei, 6)))
+    assert res[0].shape[0] == 180 * 27 and torch.equal(res[0], res[1])
     rank, hits, ndcg = P.rank_metrics(emb, B, n_items)
     e = emb.cpu().numpy().astype(np.float64)
     src, dst, ngs = e[:B], e[B:2 * B], e[2 * B:].reshape(B, n_items, -1)
@@ -369,3 +394,24 @@ def test_debug_check_reports_updates_into_the_past():
     with pytest.raises(AssertionError, match="time in the past"):
         run(130)
         run(160)
+
+
+def test_rank_metrics_against_reference_fixture():
+    """pfo_rank_metrics vs the reference's recall_at_k / ndcg_at_k (fixture g6, generated by tools/make_golden.py from
+    evaluation.py:11-21,122-128): embeddings are built so that the dot products ARE the fixture's scores."""
+    g = load_golden("g6_eval_metrics")
+    s = g["scores"]
+    B, N = s.shape[0], s.shape[1] - 1
+    D = 8
+    emb = np.zeros((B * (2 + N), D), np.float32)
+    emb[:B, 0] = 1.0                                              # source = e0: score = first component of the other side
+    emb[B:2 * B, 0] = s[:, 0]
+    emb[2 * B:, 0] = s[:, 1:].reshape(-1)
+    rank, hits, ndcg = P.rank_metrics(torch.from_numpy(emb).to(DEV), B, N)
+    r = rank.cpu().numpy()
+    assert np.array_equal(r, g["n_greater"] + g["n_equal"])       # canonical tie policy: behind every negative that scores >= it
+    free = g["n_equal"] == 0
+    assert np.array_equal(r[free], g["pos_rank"][free])            # without ties: the reference's ranking position
+    assert np.all(g["pos_rank"] <= r) and np.all(g["pos_rank"] >= g["n_greater"])
+    assert np.array_equal(hits.cpu().numpy()[free].astype(np.float64), g["recall"][free])
+    assert np.allclose(ndcg.cpu().numpy()[free], g["ndcg"][free], rtol=0, atol=1e-6)

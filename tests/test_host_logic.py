@@ -118,3 +118,56 @@ def test_get_data_reads_the_reference_file_format(tmp_path):
     assert train.timestamps.max() <= v < val.timestamps.min() and val.timestamps.max() <= t < test.timestamps.min()
     assert np.array_equal(full.sources, d.sources) and list(full.portfolios[5]) == list(d.portfolios[5])
     assert np.array_equal(ef, g.edge_features)
+
+
+def test_price_ingest_matches_reference_expressions():
+    """the reference's price pickle (day -> stock -> 30 prices; main.py:88, 212-227) packed into the dense
+    [day, item, 30] tensor the MV kernel consumes; features = the reference's own np.log(p[1:] / p[:-1]) (fixture g7)."""
+    from conftest import load_golden
+    from pfotgnrec_amd.mv_sampler import prices_from_time_feature, log_returns, day_indices
+    g = load_golden("g7_price_ingest")
+    days, codes, prices = [str(x) for x in g["days"]], [str(x) for x in g["codes"]], g["prices"]
+    upper_u = 100
+    # the dict the way the pickle holds it: stock codes for portfolio lookups AND item node ids for candidate lookups
+    tf = {dk: {} for dk in days}
+    for i, dk in enumerate(days):
+        for j, c in enumerate(codes):
+            tf[dk][c] = prices[i, j]
+            tf[dk][upper_u + 1 + j] = prices[i, j]
+    map_item_id = {c: j for j, c in enumerate(codes)}
+    got_days, arr = prices_from_time_feature(tf, map_item_id, upper_u=upper_u)
+    assert got_days == sorted(days) and np.array_equal(arr, prices)
+    only_ids = {dk: {k: v for k, v in tf[dk].items() if not isinstance(k, str)} for dk in days}
+    assert np.array_equal(prices_from_time_feature(only_ids, map_item_id, upper_u=upper_u)[1], prices)
+    ret = log_returns(arr)                                           # what MVSampler uploads
+    day = day_indices(g["ts_batch"], got_days)                       # str(ts)[:8]
+    feats, mus, k = g["features"], g["mus"], 0
+    for b in range(len(day)):
+        for q in range(int(g["cand_len"][b])):
+            item = int(g["cand_idx"][b, q])
+            assert np.array_equal(ret[day[b], item], feats[k])        # bit-exact fp64
+            assert np.mean(ret[day[b], item]) == mus[k]
+            k += 1
+    assert k == len(feats)
+    with pytest.raises(KeyError):
+        day_indices([202402010000], got_days)
+
+
+def test_eval_ranking_policy_against_reference_metrics():
+    """evaluation.py:114-145 (fixture g6: rankings and recall / NDCG from the reference's own functions).  Canonical tie
+    policy here: the positive ranks behind every negative that scores >= it.  Without ties that IS the
+    reference's ranking; with ties the reference's position (np.argsort is not stable) lies in [n_greater, n_greater +
+    n_equal] and ours is that interval's upper end."""
+    from conftest import load_golden
+    g = load_golden("g6_eval_metrics")
+    s = g["scores"]
+    rank = (s[:, 1:] >= s[:, :1]).sum(1)
+    assert np.array_equal(rank, g["n_greater"] + g["n_equal"])
+    free = g["n_equal"] == 0
+    assert free.sum() >= 40 and np.array_equal(rank[free], g["pos_rank"][free])
+    assert np.all((g["pos_rank"] >= g["n_greater"]) & (g["pos_rank"] <= rank))
+    for i, k in enumerate(g["topk"]):
+        rec = (rank < k).astype(np.float64)
+        nd = np.where(rank < k, 1.0 / np.log2(rank + 2.0), 0.0)
+        assert np.array_equal(rec[free], g["recall"][free, i])
+        assert np.allclose(nd[free], g["ndcg"][free, i], rtol=0, atol=1e-12)

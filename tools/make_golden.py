@@ -7,7 +7,7 @@ reference's outputs.  The fixtures are data only - no reference source text is
 stored.  The inline MV block of main.py (not importable: wandb/CUDA/data files)
 is executed in place from the reference tree, as SURVEY.md App. E describes.
 
-Usage:  python tools/make_golden.py [g1 g2 g3 g4 g5]      (default: all)
+Usage:  python tools/make_golden.py [g1 g2 g3 g4 g5 g6 g7]      (default: all)
 Library versions used are recorded in each fixture (``versions``).
 """
 import os
@@ -370,9 +370,70 @@ def g5():
         save("g5_step_" + tag, **out)
 
 
+def g6():
+    """Ranking metrics of evaluation.py:114-145 through the reference's own recall_at_k / ndcg_at_k (evaluation.py:11-21):
+    score rows [positive | N negatives], ranking = np.argsort(scores)[::-1], positive = index 0.  Rows cover clear
+    winners / losers, exact ties between the positive and negatives (the destination itself can be among the negatives:
+    utils.py:96 only removes the portfolio), ties among negatives only, and all-equal rows."""
+    import evaluation as ev                                   # the reference module (imports cleanly: sklearn, tqdm present)
+    rs = np.random.RandomState(11)
+    B, N = 96, 25
+    scores = rs.randn(B, 1 + N).astype(np.float32)
+    kind = np.zeros(B, np.int64)
+    for b in range(B):
+        k = b % 6
+        kind[b] = k
+        if k == 1:                                            # the destination appears among the negatives: an exact tie
+            scores[b, 1 + rs.randint(N)] = scores[b, 0]
+        elif k == 2:                                          # several negatives tie with the positive
+            scores[b, 1 + rs.choice(N, 3, replace=False)] = scores[b, 0]
+        elif k == 3:                                          # ties among negatives only
+            scores[b, 1 + rs.choice(N, 4, replace=False)] = scores[b, 1]
+        elif k == 4:                                          # positive on top / at the bottom
+            scores[b, 0] = scores[b].max() + 1.0 if b % 12 == 4 else scores[b].min() - 1.0
+        elif k == 5 and b % 12 == 5:                          # everything equal
+            scores[b, :] = 0.25
+    topk = [1, 3, 5]
+    pos_rank = np.zeros(B, np.int64)                          # position of the positive in the reference's ranking
+    recall = np.zeros((B, 3)); ndcg = np.zeros((B, 3))
+    n_greater = (scores[:, 1:] > scores[:, :1]).sum(1)        # the positive's rank lies in [n_greater, n_greater + n_equal]
+    n_equal = (scores[:, 1:] == scores[:, :1]).sum(1)
+    for b in range(B):
+        ranking = np.argsort(scores[b])[::-1]                 # evaluation.py:122
+        pos_rank[b] = int(np.where(ranking == 0)[0][0])
+        recall[b] = [ev.recall_at_k(ranking, [0], k) for k in topk]   # evaluation.py:127
+        ndcg[b] = [ev.ndcg_at_k(ranking, [0], k) for k in topk]       # evaluation.py:128
+        assert n_greater[b] <= pos_rank[b] <= n_greater[b] + n_equal[b]
+    save("g6_eval_metrics", scores=scores, kind=kind, pos_rank=pos_rank, recall=recall, ndcg=ndcg, n_greater=n_greater,
+         n_equal=n_equal, topk=np.array(topk))
+
+
+def g7():
+    """Price ingest the way main.py consumes it: ``time_feature[str(ts)[:8]][code]`` -> 30 prices (main.py:88-89, 212-227),
+    log-returns np.log(p[1:] / p[:-1]); the fixture holds a small pickled-dict equivalent as arrays (day keys, codes,
+    prices) plus the per-interaction features the reference's expressions produce for them."""
+    rs = np.random.RandomState(13)
+    days = ["20240102", "20240103", "20240105"]
+    codes = ["005930", "000660", "035420", "051910"]
+    prices = 100.0 * np.exp(np.cumsum(rs.randn(len(days), len(codes), 30) * 0.02, axis=2))
+    time_feature = {dkey: {c: prices[i, j] for j, c in enumerate(codes)} for i, dkey in enumerate(days)}
+    map_item_id = {c: j for j, c in enumerate(codes)}
+    ts_batch = np.array([202401021530, 202401030915, 202401051200, 202401021000], np.int64)
+    cand = [["005930", "035420"], ["000660"], ["051910", "005930", "000660"], ["035420"]]
+    feats, mus, shapes = [], [], []
+    for ts, stocks in zip(ts_batch, cand):
+        ts_ = str(ts)[:8]                                                        # main.py:212
+        feature_ = np.array([time_feature[ts_][c] for c in stocks])              # main.py:217
+        feature = np.log(feature_[:, 1:] / feature_[:, :-1])                     # main.py:218
+        feats.append(feature); mus.append(np.mean(feature, axis=1)); shapes.append(len(stocks))
+    save("g7_price_ingest", days=np.array(days), codes=np.array(codes), prices=prices, ts_batch=ts_batch,
+         cand_idx=np.array([[map_item_id[c] for c in st] + [-1] * (3 - len(st)) for st in cand]),
+         cand_len=np.array(shapes), features=np.concatenate(feats), mus=np.concatenate(mus))
+
+
 if __name__ == "__main__":
     import warnings
     warnings.filterwarnings("ignore")
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     for w in which:
         globals()[w]()
