@@ -150,6 +150,26 @@ int pfo_rank_metrics(const float* emb, int64_t B, int32_t D, int32_t n_items, in
                      float* ndcg_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Time-sorted adjacency built on the device: replaces get_neighbor_finder / NeighborFinder.__init__ (utils/utils.py:117-148).
+ * Every edge e contributes (dst, eidx, ts) to row src[e] and (src, eidx, ts) to row dst[e]; rows are sorted by timestamp,
+ * ties in edge order (Python's stable sorted(key=ts), utils.py:139).  A stable LSD radix sort of the 2E entries; the eight
+ * timestamp passes are skipped when the log is already chronological.  All pointers are device pointers; `workspace` holds
+ * pfo_csr_build_workspace_bytes(E, n_nodes) bytes; indptr has n_nodes + 1 entries, the adjacency arrays 2E.
+ */
+int64_t pfo_csr_build_workspace_bytes(int64_t E, int64_t n_nodes);
+int pfo_csr_build(const int32_t* src, const int32_t* dst, const int32_t* eidx, const double* ts, int64_t E, int64_t n_nodes,
+                  int64_t* indptr, int32_t* adj_nbr, int32_t* adj_eidx, double* adj_ts, void* workspace,
+                  int64_t workspace_bytes, void* stream);
+/* Merge of a CSR of NEW edges (built by pfo_csr_build over n_nodes rows) into an existing one (n_old_nodes <= n_nodes rows):
+ * the result equals a rebuild over [old edges ; new edges] - inside a row a new entry goes behind every old entry whose
+ * timestamp is <= its own.  Output arrays hold old + new entries; new_indptr has n_nodes + 1 entries.
+ */
+int pfo_csr_append(const int64_t* old_indptr, const int32_t* old_nbr, const int32_t* old_eidx, const double* old_ts,
+                   int64_t n_old_nodes, const int64_t* add_indptr, const int32_t* add_nbr, const int32_t* add_eidx,
+                   const double* add_ts, int64_t n_nodes, int64_t* new_indptr, int32_t* new_nbr, int32_t* new_eidx,
+                   double* new_ts, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Adam step over a flat parameter buffer (torch.optim.Adam defaults, main.py:123,389).
  */
 int pfo_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

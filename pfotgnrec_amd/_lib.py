@@ -70,6 +70,9 @@ PROTOTYPES = {
     "pfo_rank_metrics": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP]),
     "pfo_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                 _VP]),
+    "pfo_csr_build_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
+    "pfo_csr_build": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int64, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
+    "pfo_csr_append": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, _VP, _VP]),
     "pfo_adam_step_ranges": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                        C.POINTER(C.c_int32), C.c_float, C.c_float, C.c_float, C.c_float, _VP]),
     "pfo_tgn_param_layout": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnLayout)]),

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpfotgn.so")
-SOURCES = ["sampler.hip", "gemm.hip", "attn.hip", "memory.hip", "misc.hip", "tgn.hip"]
+SOURCES = ["sampler.hip", "gemm.hip", "attn.hip", "memory.hip", "misc.hip", "csr.hip", "tgn.hip"]
 ARCH = "gfx950"
 
 
@@ -47,7 +47,7 @@ def build(force=False, verbose=False, defines=(), tag=""):
             subprocess.check_call(cmd)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(7, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     if force or _newer(lib, objs):
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs

@@ -204,6 +204,16 @@ __global__ void seg_sort_kernel(const int32_t* __restrict__ seg_ptr, int n_seg, 
     }
   }
 }
+int pfo_iscan_launch(const int32_t* in, int64_t n, int32_t* out, int32_t* scratch, hipStream_t stream) {
+  PFO_REQUIRE(in && out && scratch && n > 0 && n < ((int64_t)1 << 31), "bad arguments");
+  const int nb = (int)pfo_ceil_div(n, SCAN_BLOCK);
+  hipLaunchKernelGGL(iscan_local_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, in, (int)n, out, scratch);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, scratch, nb, scratch + nb);
+  hipLaunchKernelGGL(iscan_add_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, out, (int)n, scratch, out);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
 int64_t pfo_seg_scratch_ints(int cap_rows) { return pfo_ceil_div(cap_rows + 1, SCAN_BLOCK) + 8; }
 int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int cap_rows, const int32_t* key_src, int K,
                          int32_t* seg_ptr, int32_t* cursor, int32_t* tmp, int32_t* members, int32_t* scratch,

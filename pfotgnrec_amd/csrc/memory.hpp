@@ -28,6 +28,8 @@ int pfo_gru_gates_bwd_launch(float* gi, float* gh, const float* h_rows, const ui
 // dst[s] = src[touched_ids[s]], s < *n_touched
 int pfo_gather_rows_launch(const float* src, int D, const int32_t* touched_ids, const int32_t* n_touched, int cap, float* dst,
                            hipStream_t stream);
+// exclusive scan of n ints (n < 2^31; scratch: n / 1024 + 16 ints); in == out is allowed
+int pfo_iscan_launch(const int32_t* in, int64_t n, int32_t* out, int32_t* scratch, hipStream_t stream);
 // --- instances grouped by the touched-table row they read: seg_ptr[cap_rows + 1], members[N] (ascending inside a group)
 int64_t pfo_seg_scratch_ints(int cap_rows);
 // inside a group the members are ordered by (run key, instance): key = key_src[n*K + K-1] (the newest neighbour's edge id:

@@ -42,28 +42,34 @@ def build_csr(sources, destinations, edge_idxs, timestamps, max_node_idx=None):
 
 
 def build_csr_device(sources, destinations, edge_idxs, timestamps, device, max_node_idx=None):
-    """Same adjacency as ``build_csr`` built on the GPU: two STABLE device sorts (by timestamp, then by
-    owner) reproduce the per-node ``sorted(key=ts)`` with ties in edge order; the host build's Python-free lexsort
-    takes ~1 s per million edges, this takes milliseconds.  torch.sort is plumbing here (one-off setup, not the hot path)."""
+    """Same adjacency as ``build_csr`` built on the GPU by the native stable radix sort ``pfo_csr_build`` (SURVEY §8f-2;
+    csrc/csr.hip): the reference's Python build takes 3.8 s per million edges, the host lexsort ~1 s, this milliseconds.
+    Returns device tensors (indptr i64[n+1], nbr i32[2E], eidx i32[2E], ts f64[2E])."""
     import torch
     _lib.require_gpu(device)
     dev = torch.device(device)
-    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
-    src, dst = t(sources, torch.int64), t(destinations, torch.int64)
-    eid, ts = t(edge_idxs, torch.int64), t(timestamps, torch.float64)
-    E = src.shape[0]
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(np.asarray(a)), dtype=dt, device=dev).contiguous()
+    if len(sources) and (int(np.max(sources)) >= 2 ** 31 or int(np.max(destinations)) >= 2 ** 31 or int(np.max(edge_idxs)) >= 2 ** 31):
+        raise ValueError("node / edge ids must fit in int32")
+    src, dst, eid, ts = t(sources, torch.int32), t(destinations, torch.int32), t(edge_idxs, torch.int32), t(timestamps, torch.float64)
+    E = int(src.shape[0])
     if max_node_idx is None:
-        max_node_idx = int(torch.maximum(src.max(), dst.max()).item()) if E else 0
-    owner = torch.stack([src, dst], 1).reshape(-1)          # edge order, source entry before destination entry
-    other = torch.stack([dst, src], 1).reshape(-1)
-    eid2, ts2 = eid.repeat_interleave(2), ts.repeat_interleave(2)
-    o1 = torch.sort(ts2, stable=True).indices
-    o2 = torch.sort(owner[o1], stable=True).indices
-    order = o1[o2]
-    counts = torch.bincount(owner, minlength=max_node_idx + 1)
-    indptr = torch.zeros(max_node_idx + 2, dtype=torch.int64, device=dev)
-    indptr[1:] = torch.cumsum(counts, 0)
-    return indptr, other[order].to(torch.int32), eid2[order].to(torch.int32), ts2[order].contiguous()
+        max_node_idx = int(max(int(np.max(sources)), int(np.max(destinations)))) if E else 0
+    return _csr_build_native(src, dst, eid, ts, max_node_idx + 1, dev)
+
+
+def _csr_build_native(src, dst, eid, ts, n_nodes, dev):
+    import torch
+    E = int(src.shape[0])
+    nbytes = _lib.load().pfo_csr_build_workspace_bytes(E, n_nodes)
+    ws = torch.empty(max(1, nbytes), dtype=torch.uint8, device=dev)
+    indptr = torch.empty(n_nodes + 1, dtype=torch.int64, device=dev)
+    nbr = torch.empty(2 * E, dtype=torch.int32, device=dev)
+    eidx = torch.empty(2 * E, dtype=torch.int32, device=dev)
+    tss = torch.empty(2 * E, dtype=torch.float64, device=dev)
+    _lib.call("pfo_csr_build", _lib.ptr(src), _lib.ptr(dst), _lib.ptr(eid), _lib.ptr(ts), E, n_nodes, _lib.ptr(indptr),
+              _lib.ptr(nbr), _lib.ptr(eidx), _lib.ptr(tss), _lib.ptr(ws), nbytes, _lib.stream_ptr())
+    return indptr, nbr, eidx, tss
 
 
 class NeighborFinder:
@@ -111,6 +117,38 @@ class NeighborFinder:
             self._dev[key] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device)
                                    for a in (self.indptr, self.nbr, self.eidx, self.ts))
         return self._dev[key]
+
+    def append(self, sources, destinations, edge_idxs, timestamps, device=None):
+        """Adds new interactions to the adjacency in place (the reference can only rebuild, 3.8 s per million
+        edges).  Equal to a rebuild over [old edges ; new edges]: rows stay sorted by timestamp, a new entry goes behind
+        every older entry with the same timestamp.  The new edges are sorted on the device (``pfo_csr_build``) and merged
+        row by row (``pfo_csr_append``); node ids beyond the current table grow it."""
+        import torch
+        _lib.require_gpu(device)
+        if device is None:
+            device = next(iter(self._dev)) if self._dev else "cuda"
+        dev = torch.device(device)
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(np.asarray(a)), dtype=dt, device=dev).contiguous()
+        src, dst = t(sources, torch.int32), t(destinations, torch.int32)
+        eid, ts = t(edge_idxs, torch.int32), t(timestamps, torch.float64)
+        m = int(src.shape[0])
+        if m == 0:
+            return self
+        n_nodes = max(self.n_nodes, int(max(int(np.max(sources)), int(np.max(destinations)))) + 1)
+        o_ptr, o_nbr, o_eid, o_ts = self.device_arrays(dev)
+        a_ptr, a_nbr, a_eid, a_ts = _csr_build_native(src, dst, eid, ts, n_nodes, dev)
+        total = int(o_nbr.shape[0]) + 2 * m
+        n_ptr = torch.empty(n_nodes + 1, dtype=torch.int64, device=dev)
+        n_nbr = torch.empty(total, dtype=torch.int32, device=dev)
+        n_eid = torch.empty(total, dtype=torch.int32, device=dev)
+        n_ts = torch.empty(total, dtype=torch.float64, device=dev)
+        _lib.call("pfo_csr_append", _lib.ptr(o_ptr), _lib.ptr(o_nbr), _lib.ptr(o_eid), _lib.ptr(o_ts), self.n_nodes,
+                  _lib.ptr(a_ptr), _lib.ptr(a_nbr), _lib.ptr(a_eid), _lib.ptr(a_ts), n_nodes, _lib.ptr(n_ptr), _lib.ptr(n_nbr),
+                  _lib.ptr(n_eid), _lib.ptr(n_ts), _lib.stream_ptr())
+        self._dev = {str(dev): (n_ptr, n_nbr, n_eid, n_ts)}
+        self.indptr, self.nbr, self.eidx, self.ts = (a.cpu().numpy() for a in (n_ptr, n_nbr, n_eid, n_ts))
+        self.n_nodes = n_nodes
+        return self
 
     def next_stream_offset(self):
         self._calls += 1

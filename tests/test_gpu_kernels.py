@@ -296,3 +296,61 @@ def test_device_csr_build_equals_host_build():
             assert np.array_equal(a, b)
     nb, ei, et = nf.get_temporal_neighbor(g["b_q_nodes"], g["b_q_ts"], 4)
     assert np.array_equal(nb, g["b_K4_nbr"]) and np.array_equal(ei, g["b_K4_eidx"])
+
+
+# ------------------------------------------------------------------ f-2: device CSR build (native radix sort) + append
+def _csr_equal(a, b):
+    return all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("which", ["a", "b", "shuffled", "c2"])
+def test_native_csr_build_equals_host_build(which):
+    """pfo_csr_build (stable LSD radix sort on the device) against the host lexsort build, which g1 pins to the reference's
+    NeighborFinder: the g1 graphs (adversarial timestamp ties, zero-degree nodes), a log whose timestamps are NOT
+    chronological (the eight timestamp passes run), and the 1 M-edge C2 graph."""
+    from pfotgnrec_amd.neighbor_finder import build_csr, build_csr_device
+    if which in ("a", "b"):
+        g = load_golden("g1_sampler")
+        src, dst, eidx, ts = g[which + "_src"], g[which + "_dst"], g[which + "_eidx"], g[which + "_ts"]
+    elif which == "shuffled":
+        rs = np.random.RandomState(3)
+        E = 30000
+        src, dst = rs.randint(1, 400, E), rs.randint(400, 460, E)
+        ts = rs.randint(0, 500, E).astype(np.float64) - 100.0                     # unsorted, heavy ties, negative values
+        ts[::7] += 0.25
+        eidx = rs.permutation(E) + 1
+    else:
+        gr = make_graph(CONFIGS["C2"], with_prices=False, with_portfolios=False)
+        src, dst, eidx, ts = gr.data.sources, gr.data.destinations, gr.data.edge_idxs, gr.data.timestamps
+    host = build_csr(src, dst, eidx, ts, max_node_idx=int(max(src.max(), dst.max())) + 3)
+    devc = build_csr_device(src, dst, eidx, ts, DEV, max_node_idx=int(max(src.max(), dst.max())) + 3)
+    assert _csr_equal(host, [x.cpu().numpy() for x in devc])
+
+
+def test_neighbor_finder_append_equals_rebuild_and_reference():
+    """NeighborFinder.append: the adversarial g1 graph built from its first third and grown twice equals the one-shot build
+    (tie order included) and answers the fixture's queries exactly like the reference; node ids beyond the table grow it."""
+    g = load_golden("g1_sampler")
+    src, dst, eidx, ts = g["b_src"], g["b_dst"], g["b_eidx"], g["b_ts"]
+    E = len(src)
+    cuts = [0, E // 3, E // 2, E]
+    nf = P.NeighborFinder.from_arrays(src[:cuts[1]], dst[:cuts[1]], eidx[:cuts[1]], ts[:cuts[1]], device=DEV)
+    for a, b in zip(cuts[1:-1], cuts[2:]):
+        nf.append(src[a:b], dst[a:b], eidx[a:b], ts[a:b], device=DEV)
+    full = P.NeighborFinder.from_arrays(src, dst, eidx, ts)
+    assert nf.n_nodes == full.n_nodes
+    assert _csr_equal((nf.indptr, nf.nbr, nf.eidx, nf.ts), (full.indptr, full.nbr, full.eidx, full.ts))
+    for K in (4, 20):
+        nb, ei, et = nf.get_temporal_neighbor(g["b_q_nodes"], g["b_q_ts"], K)
+        assert np.array_equal(nb, g["b_K%d_nbr" % K]) and np.array_equal(ei, g["b_K%d_eidx" % K]) and np.array_equal(et, g["b_K%d_et" % K])
+    # out-of-order arrival: appending edges OLDER than what is there lands them in timestamp order, behind equal timestamps
+    rs = np.random.RandomState(9)
+    m = 50
+    s2, d2 = rs.randint(1, 10, m), rs.randint(13, 19 + 4, m)                   # ids 19..22 are new nodes
+    t2 = rs.randint(0, 25, m).astype(np.float64)
+    e2 = np.arange(E + 1, E + m + 1)
+    nf.append(s2, d2, e2, t2, device=DEV)
+    both = P.NeighborFinder.from_arrays(np.concatenate([src, s2]), np.concatenate([dst, d2]), np.concatenate([eidx, e2]),
+                                        np.concatenate([ts, t2]))
+    assert nf.n_nodes == both.n_nodes == 23
+    assert _csr_equal((nf.indptr, nf.nbr, nf.eidx, nf.ts), (both.indptr, both.nbr, both.eidx, both.ts))
