@@ -387,7 +387,8 @@ def main():
                    "block_ms_per_step": {"first": round(wl.block_ms[0], 4), "min": round(min(wl.block_ms), 4),
                                          "median": round(float(np.median(wl.block_ms)), 4), "last": round(wl.block_ms[-1], 4)},
                    "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4),
-                   "collective": ("rccl all-reduce of the flat fp32 gradient, world %d" % dist.get_world_size()) if world > 1 else None},
+                   "collective": ("%s all-reduce of the flat fp32 gradient, world %d"
+                                  % ("rccl" if dist.get_backend() == "nccl" else dist.get_backend(), dist.get_world_size())) if world > 1 else None},
     }
     if prof is not None:
         roof = roofline_of(prof, n_prof_steps)

@@ -47,7 +47,7 @@ struct Ws {
   LayerWs layer[PFO_MAX_LAYERS + 1];
   float *dh1, *dctx, *dQK;
   float* dH[PFO_MAX_LAYERS + 1];
-  float* slabs;
+  float *slabs, *slabs2;      // split-K slabs of the weight-gradient launches: main stream / side stream
   double *dtime, *fold_scratch;
   int32_t* tickets;
   int64_t slab_floats;
@@ -170,6 +170,7 @@ Ws carve(const pfo_tgn_config* c, void* base) {
   w.dQK = take<float>(p, N1 * d.H * d.Cp);
   w.slab_floats = SLAB_FLOATS;
   w.slabs = take<float>(p, w.slab_floats);
+  w.slabs2 = take<float>(p, w.slab_floats);
   w.fold_scratch = take<double>(p, pfo_fold_parts_scratch_doubles(2 * d.D));
   w.bytes = p - reinterpret_cast<char*>(base);
   return w;
@@ -240,7 +241,7 @@ PfoGemm g_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const int
 // dependent launches; they run beside the main stream's work and are joined by events where their results are needed.
 struct Side {
   hipStream_t s = nullptr;
-  hipEvent_t fork = nullptr, done = nullptr, gru_fork = nullptr, gru_join = nullptr, seg_done = nullptr;
+  hipEvent_t fork = nullptr, done = nullptr, gru_fork = nullptr, gru_join = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr;
   hipEvent_t layer[PFO_MAX_LAYERS + 1] = {};
   bool ok = false;
 };
@@ -253,6 +254,8 @@ Side& side() {
     good = good && hipEventCreateWithFlags(&sd.gru_fork, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.gru_join, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.seg_done, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.tn_a, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.tn_b, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; l <= PFO_MAX_LAYERS; ++l) good = good && hipEventCreateWithFlags(&sd.layer[l], hipEventDisableTiming) == hipSuccess;
     sd.ok = good;
   }
@@ -612,6 +615,13 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     set_tn(tn[1], lw.ctx, HCp, w.dh1, D, nullptr, HCp, D, lw.dW1ovT, D, nullptr);       // dW1ovT = ctx'^T dh1
     tn[1].c_accumulate = 0;
     if (l > 1) set_tn(tn[2], w.dh1, D, xA, D, x_idx, D, D, g.w1 + E, E + D, g.b1);     // dW1[:, E:], db1
+    if (l == 1) {
+      // The two weight gradients over the INSTANCES (dW2 / db2, dW1ovT) need only dOut, h1, ctx' and dh1: they run on the
+      // side stream beside the attention backward, which is latency-bound (matrix pipe idle, VALU ~45 % busy)
+      HIPOK(hipEventRecord(sd.tn_a, s), "event record failed");
+      HIPOK(hipStreamWaitEvent(ss, sd.tn_a, 0), "event wait failed");
+      RUN(pfo_gemm_tn_group_launch(tn, 2, N, nullptr, w.slabs2, w.slab_floats, ss));
+    }
     // attention core
     PfoAttn a;
     a.N = N; a.K = K; a.D = D; a.Ef = Ef; a.H = H; a.Cp = Cp;
@@ -635,9 +645,16 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       // in the per-instance gradients (dqk', dh1) and otherwise depends on x only - the data gradient of x and the two
       // weight gradients against x - is taken AFTER summing those gradients per table row: contractions over the
       // ~11 k touched rows instead of the ~54 k instances.
-      RUN(pfo_gemm_tn_group_launch(tn, 2, N, nullptr, w.slabs, w.slab_floats, s));          // dW2 / db2, dW1ovT: over instances
       HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");
       RUN(pfo_segsum_launch(w.dQK, HCp, w.dh1, D, w.seg_ptr, w.seg_mem, w.n_touched, capP, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
+      // the weight gradients over the table rows go to the side stream too (beside d h0 / the GRU backward on this one)
+      HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
+      HIPOK(hipStreamWaitEvent(ss, sd.tn_b, 0), "event wait failed");
+      PfoTnProblem tb[2];
+      set_tn(tb[0], w.Dq, WQ, tab0, D, nullptr, HCp, D, lw.dWqk, D, lw.gqk);               // dWqk = (sum dqk')^T h0, gqk
+      tb[0].c_accumulate = 0; tb[0].bias_accumulate = 0;
+      set_tn(tb[1], w.Dq + HCp, WQ, tab0, D, nullptr, D, D, g.w1 + E, E + D, g.b1);        // dW1[:, E:], db1
+      RUN(pfo_gemm_tn_group_launch(tb, 2, capP, w.n_touched, w.slabs2, w.slab_floats, ss));
       if (c->use_memory) {
         // d h0_tab (query side) = Dq [Wqk ; W1[:, E:]]; the GRU backward adds it to the key-side rows the attention scattered
         PfoGemm q = g_nn(w.Dq, WQ, lw.Wqk, D, w.dx_tab, D, capP, D, HCp);
@@ -645,11 +662,6 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
         q.b_img = lw.iWqkT; q.b_img2 = lw.iW1bT; q.m_dev = w.n_touched;
         RUN(pfo_gemm_launch(q, s));
       }
-      PfoTnProblem tb[2];
-      set_tn(tb[0], w.Dq, WQ, tab0, D, nullptr, HCp, D, lw.dWqk, D, lw.gqk);               // dWqk = (sum dqk')^T h0, gqk
-      tb[0].c_accumulate = 0; tb[0].bias_accumulate = 0;
-      set_tn(tb[1], w.Dq + HCp, WQ, tab0, D, nullptr, D, D, g.w1 + E, E + D, g.b1);        // dW1[:, E:], db1
-      RUN(pfo_gemm_tn_group_launch(tb, 2, capP, w.n_touched, w.slabs, w.slab_floats, s));
     } else {
       if (pfo_gemm_takes_bx(N, D)) {
         // dx = [dqk' | dh1] [Wqk ; W1[:, E:]] : both sources in one launch, dx written once
