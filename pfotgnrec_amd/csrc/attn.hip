@@ -46,8 +46,10 @@ __device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__
 template <int NR, int H>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 4 + wave;     // one instance per wavefront (a grid-stride form was measured: the
+  if (n >= a.N) return;                                 // loop-carried state cost 32 VGPRs = 2 waves/SIMD and 25 % of the time)
   const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef, Cp = a.Cp;   // Cp: per-head row stride (C + 2 extra columns, padded)
-  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < a.N; n += (int64_t)gridDim.x * 4) {
+
   float tw[NR], tb[NR];
   float qn[H][NR], qt[H][NR], qe[H];
   const float* qk = a.QK + (a.qk_row ? (int64_t)a.qk_row[n] : n) * a.qk_ld;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
     if (lane == 0) a.inv[n] = 1;
     for (int c = lane; c < H * Cp; c += 64) ctx[c] = 0.f;        // includes the Σa' and valid-flag columns
     for (int c = lane; c < H * K; c += 64) a.attw[n * H * K + c] = 0.f;
-    continue;
+    return;
   }
   if (lane == 0) a.inv[n] = 0;
 
@@ -204,7 +206,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
     // bias), C+1 = 1 on head 0 (multiplies the folded out_proj bias; absent on rows without a valid neighbour)
     if (lane < Cp - C) ctx[h * Cp + C + lane] = lane == 0 ? ld[h] * il : ((lane == 1 && h == 0) ? 1.f : 0.f);
   }
-  }   // instance loop
 }
 
 #ifndef ATTN_BWD_MAX_BLOCKS
@@ -476,11 +477,8 @@ int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream) {
   // algorithmic bytes per instance: K gathered rows + edge feature + (eidx, dt, id), qk in, ctx + weights out
   const double C = 2.0 * a.D + a.Ef;
   const double bytes = (double)a.N * (a.K * (4.0 * a.D + 4.0 * a.Ef + 12.0) + 2.0 * a.H * C * 4.0 + 4.0 * a.H * a.K);
-  // PFO_ATTN_FWD_BLOCKS > 0: that many workgroups walk the instances (grid-stride); default: one instance per wavefront
-  static const int fwd_blocks = getenv("PFO_ATTN_FWD_BLOCKS") ? atoi(getenv("PFO_ATTN_FWD_BLOCKS")) : 0;
-  const int64_t fgrid = fwd_blocks > 0 ? std::min<int64_t>(fwd_blocks, pfo_ceil_div(a.N, 4)) : pfo_ceil_div(a.N, 4);
   pfo_prof_begin(stream);
-  ATTN_DISPATCH(attn_fwd_kernel, fgrid);
+  ATTN_DISPATCH(attn_fwd_kernel, pfo_ceil_div(a.N, 4));
   PFO_LAUNCH_CHECK();
   pfo_prof_end(PFO_PROF_ATTN_FWD, bytes, stream);
   return PFO_OK;

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 kern=$1
 out=${2:-gpurun_out/pmc_kernel}
-CMD="python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-prof"
+CMD="python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-prof --min-seconds 0"
 for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA" "SQ_INSTS_LDS SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM" "GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_LDS_ADDR_CONFLICT"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/$tag -o p -- $CMD > /dev/null 2>&1

@@ -6,9 +6,9 @@ tag=${1:-r1}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag
 mkdir -p $out
-CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-prof"
+CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-prof --min-seconds 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- $CMD > $out/bench_under_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o p -- $CMD > $out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o p -- $CMD > $out/pmc_write.log 2>&1
-python3 bench.py --steps 60 --warmup 10 > $out/bench.json 2> $out/bench.err
+python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 tail -1 $out/bench.json | cut -c1-400
