@@ -18,6 +18,8 @@ struct AttnDev {
   float* ctx; float* attw; uint8_t* inv;
   const float* dctx; float* dQK; float* d_nbr; int64_t d_nbr_ld; double* dtime_part;
   int64_t d_nbr_rep;  // DMODE 1: floats between the per-XCD replicas of the gradient table (0: one table)
+  // run-merged layer-1 backward: instances in (table row, run key) order, seg_ptr[*n_rows] of them
+  const int32_t* members; const int32_t* seg_ptr; const int32_t* n_rows;
   int abl;      // timing-only ablation switch (PFO_ATTN_ABL): 1 = spread the atomic destinations (wrong results)
 };
 
@@ -420,6 +422,227 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Layer-1 backward with RUN MERGING.  The level-0 gradient scatter is bound by the float-atomic rate of the part (~1.3 TB/s of
+// added bytes: 454 MB per launch at C2; without the atomics the same kernel takes 0.35 instead of 0.49 ms).  Instances
+// arrive ordered by (touched-table row, run key) - memory.hpp pfo_seg_build_launch - so consecutive instances of a run sit
+// on the same node and have the SAME K neighbour rows.  One wavefront (a 64-thread workgroup) walks a chunk of RUN_CHUNK
+// consecutive members; the key-side gradient rows are summed in a wavefront-private LDS image [K][D] by plain
+// read-modify-writes (each lane owns its columns: no LDS atomics, which cost ~170 cycles per wave instruction here) and
+// leave as ONE set of float atomics when the run or the chunk ends - 2-3x fewer atomic bytes.  Everything else is
+// attn_bwd_body's arithmetic per instance, dqk' rows included.
+#ifndef RUN_CHUNK
+#define RUN_CHUNK 4     // measured at C2: 4 -> 1.86 ms/step, 8 -> 1.88, 16 -> 2.00 (a wavefront walks its chunk serially: long
+#endif                  // chunks merge more atomics but leave a tail), per-instance kernel 1.91
+
+template <int NR, int H>
+__global__ __launch_bounds__(64) void attn_bwd_runs_kernel(const AttnDev a) {
+  extern __shared__ __attribute__((aligned(16))) float s_acc[];       // [K][D]
+  const int lane = threadIdx.x;
+  const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef, Cp = a.Cp;
+  float tw[NR], tb[NR];
+  double dw[NR], db[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int c = lane + 64 * r;
+    tw[r] = c < D ? a.tw[c] : 0.f;
+    tb[r] = c < D ? a.tb[c] : 0.f;
+    dw[r] = 0.0; db[r] = 0.0;
+  }
+  for (int i = lane; i < K * D; i += 64) s_acc[i] = 0.f;
+  const float keep_scale = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
+  float* const d_nbr_x = a.d_nbr + (int64_t)(__builtin_amdgcn_s_getreg(6164) & (PFO_GRAD_REPLICAS - 1)) * a.d_nbr_rep;
+  const int M = a.seg_ptr[*a.n_rows];                            // members = instances that sit on a real node
+  const int n_chunks = (M + RUN_CHUNK - 1) / RUN_CHUNK;
+  auto flush = [&](int rows_l, unsigned long long vmask) {        // the run's rows: one float atomic per element
+    while (vmask) {
+      const int j = __ffsll((long long)vmask) - 1;
+      vmask &= vmask - 1ull;
+      float* dst = d_nbr_x + (int64_t)rl_i(rows_l, j) * a.d_nbr_ld;
+      float* ap = s_acc + j * D;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int cc = lane + 64 * r;
+        if (r < NR - 1 || cc < D) {
+          if (a.abl != 2) atomicAdd(dst + cc, ap[cc]);
+          ap[cc] = 0.f;
+        }
+      }
+    }
+  };
+
+  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    int run_slot = -1, run_key = 0, run_rows = 0;
+    unsigned long long run_valid = 0ull;
+    const int m_end = min(M, (chunk + 1) * RUN_CHUNK);
+    for (int m = chunk * RUN_CHUNK; m < m_end; ++m) {
+      const int64_t n = a.members[m];
+      float* dqk_out = a.dQK + n * H * Cp;
+      const int64_t slot0 = n * K;
+      const bool inK = lane < K;
+      const int my_id = inK ? a.nbr_ids[slot0 + lane] : 0;
+      const int my_row = inK ? a.nbr_row[slot0 + lane] : 0;
+      const int my_e = inK ? a.eidx[slot0 + lane] : 0;
+      const float my_dt = inK ? a.dt[slot0 + lane] : 0.f;
+      const unsigned long long valid = __ballot(inK && my_id != 0);
+      const int slot = a.qk_row[n];
+      const int key = rl_i(my_e, K - 1);                         // memory.hpp: equal keys <=> identical neighbour lists
+      if (slot != run_slot || key != run_key) {                  // a new run: the previous one's rows leave
+        flush(run_rows, run_valid);
+        run_slot = slot; run_key = key; run_rows = my_row; run_valid = valid;
+      }
+      if (valid == 0ull) {
+        for (int c = lane; c < H * Cp; c += 64) dqk_out[c] = 0.f;
+        continue;
+      }
+      float qn[H][NR], qt[H][NR], qe[H], gn[H][NR], gt[H][NR], ge[H], t[H], dsb[H];
+      float dqn[H][NR], dqt[H][NR], dqe[H];
+      const float* qk = a.QK + (int64_t)slot * a.qk_ld;
+      const float* dc = a.dctx + n * H * Cp;
+      const float* cx = a.ctx + n * H * Cp;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int c = lane + 64 * r;
+          const bool ok = c < D;
+          qn[h][r] = ok ? qk[h * Cp + c] : 0.f;
+          qt[h][r] = ok ? qk[h * Cp + D + Ef + c] : 0.f;
+          gn[h][r] = ok ? dc[h * Cp + c] : 0.f;
+          gt[h][r] = ok ? dc[h * Cp + D + Ef + c] : 0.f;
+          if (ok) part = fmaf(gn[h][r], cx[h * Cp + c], fmaf(gt[h][r], cx[h * Cp + D + Ef + c], part));
+          dqn[h][r] = 0.f; dqt[h][r] = 0.f;
+        }
+        qe[h] = lane < Ef ? qk[h * Cp + D + lane] : 0.f;
+        ge[h] = lane < Ef ? dc[h * Cp + D + lane] : 0.f;
+        if (lane < Ef) part = fmaf(ge[h], cx[h * Cp + D + lane], part);
+        dqe[h] = 0.f;
+        t[h] = part;
+        dsb[h] = dc[h * Cp + C];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int h = 0; h < H; ++h) t[h] += __shfl_xor(t[h], o, 64);
+#pragma unroll
+      for (int h = 0; h < H; ++h) t[h] = fmaf(dsb[h], cx[h * Cp + C], t[h]);
+      const unsigned keep = attn_keep_bits(a.seed, a.offset, n, lane, a.dropout_p);
+      float my_a[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) my_a[h] = inK ? a.attw[(n * H + h) * K + lane] : 0.f;
+
+      unsigned long long vm = valid;
+      while (vm) {
+        int js[KC_BWD];
+#pragma unroll
+        for (int c = 0; c < KC_BWD; ++c) {
+          js[c] = vm ? (__ffsll((long long)vm) - 1) : -1;
+          vm &= vm - 1ull;
+        }
+        float kn[KC_BWD][NR], kt[KC_BWD][NR], ks[KC_BWD][NR], ke[KC_BWD], dtv[KC_BWD];
+#pragma unroll
+        for (int c = 0; c < KC_BWD; ++c) {
+          const int j = js[c] < 0 ? 0 : js[c];
+          const float* src = a.nbr_tab + (int64_t)rl_i(my_row, j) * a.nbr_ld;
+          const int e = rl_i(my_e, j);
+          dtv[c] = rl_f(my_dt, j);
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const int cc = lane + 64 * r;
+            kn[c][r] = (js[c] >= 0 && (r < NR - 1 || cc < D)) ? src[cc] : 0.f;
+          }
+          ke[c] = (js[c] >= 0 && lane < Ef) ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
+        }
+        float part[KC_BWD][H];
+#pragma unroll
+        for (int c = 0; c < KC_BWD; ++c) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const int cc = lane + 64 * r;
+            float sv, cv;
+            pfo_sincosf(pfo_time_arg(dtv[c], tw[r], tb[r]), sv, cv);
+            const bool on = js[c] >= 0 && (r < NR - 1 || cc < D);
+            kt[c][r] = on ? cv : 0.f;
+            ks[c][r] = on ? sv : 0.f;
+          }
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            float pp = ke[c] * ge[h];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) pp = fmaf(kn[c][r], gn[h][r], fmaf(kt[c][r], gt[h][r], pp));
+            part[c][h] = pp;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < KC_BWD; ++c)
+#pragma unroll
+          for (int h = 0; h < H; ++h) part[c][h] = pfo_wave_sum_scalar(part[c][h]);
+#pragma unroll
+        for (int c = 0; c < KC_BWD; ++c) {
+          if (js[c] < 0) continue;
+          const unsigned kb = (unsigned)rl_i((int)keep, js[c]);
+          float cA[H], cB[H];
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            const float ks_h = ((kb >> h) & 1u) ? keep_scale : 0.f;
+            const float da = (part[c][h] + dsb[h]) * ks_h;
+            const float aj = rl_f(my_a[h], js[c]);
+            const float dscore = aj * (da - t[h]);
+            cA[h] = aj * ks_h;
+            cB[h] = dscore * a.scale;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+              dqn[h][r] = fmaf(cB[h], kn[c][r], dqn[h][r]);
+              dqt[h][r] = fmaf(cB[h], kt[c][r], dqt[h][r]);
+            }
+            dqe[h] = fmaf(cB[h], ke[c], dqe[h]);
+          }
+          float* ap = s_acc + js[c] * D;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const int cc = lane + 64 * r;
+            float dkn = 0.f, dkt = 0.f;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+              dkn = fmaf(cA[h], gn[h][r], fmaf(cB[h], qn[h][r], dkn));
+              dkt = fmaf(cA[h], gt[h][r], fmaf(cB[h], qt[h][r], dkt));
+            }
+            if (r < NR - 1 || cc < D) ap[cc] += dkn;             // this lane's own element of the run's image
+            const float gsin = -ks[c][r] * dkt;
+            dw[r] += (double)gsin * (double)dtv[c];
+            db[r] += (double)gsin;
+          }
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int c = lane + 64 * r;
+          if (c < D) {
+            dqk_out[h * Cp + c] = dqn[h][r];
+            dqk_out[h * Cp + D + Ef + c] = dqt[h][r];
+          }
+        }
+        if (lane < Ef) dqk_out[h * Cp + D + lane] = dqe[h];
+        if (lane < Cp - C) dqk_out[h * Cp + C + lane] = 0.f;
+      }
+    }
+    flush(run_rows, run_valid);                                  // the chunk's last run
+  }
+  // time-encoder partials: this wavefront's sums into the shared fp64 bins
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int c = lane + 64 * r;
+    if (c < D) {
+      double* bin = a.dtime_part + (int64_t)(blockIdx.x & (ATTN_TIME_BINS - 1)) * 2 * D;
+      atomicAdd(bin + c, dw[r]);
+      atomicAdd(bin + D + c, db[r]);
+    }
+  }
+}
+
 static void to_dev(const PfoAttn& a, AttnDev& d) {
   d.N = a.N; d.K = a.K; d.D = a.D; d.Ef = a.Ef; d.H = a.H; d.Cp = a.Cp;
   d.QK = a.QK; d.qk_row = a.qk_row; d.qk_ld = a.qk_ld > 0 ? a.qk_ld : (int64_t)a.H * a.Cp; d.nbr_tab = a.nbr_tab; d.nbr_ld = a.nbr_ld; d.nbr_row = a.nbr_row; d.nbr_row_base = a.nbr_row_base;
@@ -430,6 +653,7 @@ static void to_dev(const PfoAttn& a, AttnDev& d) {
   d.ctx = a.ctx; d.attw = a.attw; d.inv = a.inv;
   d.dctx = a.dctx; d.dQK = a.dQK; d.d_nbr = a.d_nbr; d.d_nbr_ld = a.d_nbr_ld; d.d_nbr_rep = a.d_nbr_rep;
   d.dtime_part = a.dtime_part;
+  d.members = a.members; d.seg_ptr = a.seg_ptr; d.n_rows = a.n_rows;
 }
 
 static int check_common(const PfoAttn& a) {
@@ -495,6 +719,39 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
   const double C = 2.0 * a.D + a.Ef;
   const double bytes = (double)a.N * (a.K * (8.0 * a.D + 4.0 * a.Ef + 12.0) + 4.0 * a.H * C * 4.0 + 4.0 * a.H * a.K);
   const int dmode = !a.d_nbr ? 0 : (a.nbr_row ? 1 : 2);
+  static const int runs_on = getenv("PFO_ATTN_RUNS") ? atoi(getenv("PFO_ATTN_RUNS")) : 1;                    // A/B switch
+  const size_t run_lds = (size_t)a.K * a.D * sizeof(float);
+  if (dmode == 1 && runs_on && a.members && a.seg_ptr && a.n_rows && a.qk_row && run_lds <= 64 * 1024) {
+    // run-merged form: single-wavefront workgroups, one chunk of members each (the grid-stride loop only matters when the
+    // grid is capped for an experiment)
+    static const int rblocks = getenv("PFO_ATTN_RUNS_BLOCKS") ? atoi(getenv("PFO_ATTN_RUNS_BLOCKS")) : 0;
+    const int64_t all_chunks = pfo_ceil_div(a.N, RUN_CHUNK);
+    const int rgrid = (int)(rblocks > 0 ? std::min<int64_t>(rblocks, all_chunks) : all_chunks);
+    pfo_prof_begin(stream);
+    const int NRv = (a.D + 63) / 64;
+    const dim3 g((unsigned)rgrid), b(64);
+    bool done = true;
+    switch (NRv * 8 + a.H) {
+      case 1 * 8 + 1: hipLaunchKernelGGL((attn_bwd_runs_kernel<1, 1>), g, b, run_lds, stream, d); break;
+      case 1 * 8 + 2: hipLaunchKernelGGL((attn_bwd_runs_kernel<1, 2>), g, b, run_lds, stream, d); break;
+      case 1 * 8 + 4: hipLaunchKernelGGL((attn_bwd_runs_kernel<1, 4>), g, b, run_lds, stream, d); break;
+      case 2 * 8 + 1: hipLaunchKernelGGL((attn_bwd_runs_kernel<2, 1>), g, b, run_lds, stream, d); break;
+      case 2 * 8 + 2: hipLaunchKernelGGL((attn_bwd_runs_kernel<2, 2>), g, b, run_lds, stream, d); break;
+      case 2 * 8 + 4: hipLaunchKernelGGL((attn_bwd_runs_kernel<2, 4>), g, b, run_lds, stream, d); break;
+      case 3 * 8 + 1: hipLaunchKernelGGL((attn_bwd_runs_kernel<3, 1>), g, b, run_lds, stream, d); break;
+      case 3 * 8 + 2: hipLaunchKernelGGL((attn_bwd_runs_kernel<3, 2>), g, b, run_lds, stream, d); break;
+      case 3 * 8 + 4: hipLaunchKernelGGL((attn_bwd_runs_kernel<3, 4>), g, b, run_lds, stream, d); break;
+      case 4 * 8 + 1: hipLaunchKernelGGL((attn_bwd_runs_kernel<4, 1>), g, b, run_lds, stream, d); break;
+      case 4 * 8 + 2: hipLaunchKernelGGL((attn_bwd_runs_kernel<4, 2>), g, b, run_lds, stream, d); break;
+      case 4 * 8 + 4: hipLaunchKernelGGL((attn_bwd_runs_kernel<4, 4>), g, b, run_lds, stream, d); break;
+      default: done = false;
+    }
+    PFO_REQUIRE(done, "unsupported (D, H) combination");
+    PFO_LAUNCH_CHECK();
+    pfo_prof_end(PFO_PROF_ATTN_BWD, bytes, stream);
+    if (n_parts) *n_parts = ATTN_TIME_BINS;
+    return PFO_OK;
+  }
   pfo_prof_begin(stream);
   if (dmode == 0) { ATTN_DISPATCH(attn_bwd_kernel_none, grid); }
   else if (dmode == 1) { ATTN_DISPATCH(attn_bwd_kernel, grid); }

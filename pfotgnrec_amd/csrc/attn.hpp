@@ -46,6 +46,12 @@ struct PfoAttn {
   int64_t d_nbr_ld = 0;
   int64_t d_nbr_rep = 0;            // atomically added rows: floats between the 8 per-XCD replicas of the table (0 = a single table)
   double* dtime_part = nullptr;     // [ATTN_TIME_BINS, 2*D] fp64 accumulators (dw | db) of the time encoder: ADDED to (zero them per step)
+  // optional (layer 1 over the touched-node table, atomically added rows, most-recent sampling): the instances ordered by
+  // (table row, run key) as built by pfo_seg_build_launch with key_src = eidx.  Consecutive members of a run share their K
+  // neighbour rows, so their key-side gradients are summed on chip and added once per run.
+  const int32_t* members = nullptr; // [seg_ptr[*n_rows]]
+  const int32_t* seg_ptr = nullptr; // [rows + 1]
+  const int32_t* n_rows = nullptr;  // device-side row count
 };
 
 int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream);

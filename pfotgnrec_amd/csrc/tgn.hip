@@ -638,6 +638,11 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     else        { a.d_nbr = w.dH[l - 1]; a.d_nbr_ld = D; }
     a.dtime_part = w.dtime;
     int n_parts = 0;
+    if (l == 1 && c->use_memory && !b->uniform) {
+      // key-side gradients of instances with identical neighbour lists leave as one set of atomics (attn.hip)
+      HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");
+      a.members = w.seg_mem; a.seg_ptr = w.seg_ptr; a.n_rows = w.n_touched;
+    }
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
     // merged query/key projection: dx += dqk' Wqk, dWqk = dqk'^T x, gqk = colsum(dqk')
     if (l == 1) {
