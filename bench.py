@@ -74,7 +74,8 @@ PMC_KERNEL = {"gemm_bx": "gemm_bx_areg_kernel", "gemm_tn_bx": "gemm_tn_group_bx_
               "gemm_nt": "void gemm_f32_kernel<false, false, 0, true>",
               "gemm_nn": "void gemm_f32_kernel<false, true, 0, true>",
               "gemm_tn": "void gemm_tn_group_kernel<true>",
-              "attn_fwd": "void attn_fwd_kernel<3, 2>", "attn_bwd": "void attn_bwd_kernel<3, 2>"}
+              "attn_fwd": "void attn_fwd_kernel<3, 2>", "attn_bwd": "void attn_bwd_kernel_direct<3, 2>",
+              "attn_bwd_runs": "void attn_bwd_runs_kernel<3, 2>"}
 
 
 def pmc_traffic(family):

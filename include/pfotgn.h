@@ -282,7 +282,8 @@ int pfo_tgn_debug_views(const pfo_tgn_config* cfg, void* workspace, pfo_tgn_debu
 #define PFO_PROF_GEMM_BX 7   /* row-major contractions taken by the bf16x3 kernel (flops = 2MNK)  */
 #define PFO_PROF_GEMM_TN_BX 8 /* grouped weight gradients on the bf16x3 kernel (GEMM kernel only)  */
 #define PFO_PROF_GEMM_BX_SKINNY 9 /* the 32-row bf16x3 kernel of the short (layer-2) launches           */
-#define PFO_PROF_KINDS 10
+#define PFO_PROF_ATTN_BWD_RUNS 10 /* layer-1 attention backward, run-merged kernel (attn_bwd_runs_kernel)  */
+#define PFO_PROF_KINDS 11
 int pfo_prof_enable(int32_t on);
 int pfo_prof_collect(double* ms, double* work, int64_t* count); /* HOST arrays of PFO_PROF_KINDS entries */
 

@@ -86,7 +86,8 @@ PROTOTYPES = {
     "pfo_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
-PROF_KINDS = ["gemm_nt", "gemm_nn", "gemm_tn", "gemm_devm", "attn_fwd", "attn_bwd", "sampler", "gemm_bx", "gemm_tn_bx", "gemm_bx_skinny"]
+PROF_KINDS = ["gemm_nt", "gemm_nn", "gemm_tn", "gemm_devm", "attn_fwd", "attn_bwd", "sampler", "gemm_bx", "gemm_tn_bx", "gemm_bx_skinny",
+              "attn_bwd_runs"]
 
 
 def prof_enable(on):

@@ -748,7 +748,7 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
     }
     PFO_REQUIRE(done, "unsupported (D, H) combination");
     PFO_LAUNCH_CHECK();
-    pfo_prof_end(PFO_PROF_ATTN_BWD, bytes, stream);
+    pfo_prof_end(PFO_PROF_ATTN_BWD_RUNS, bytes, stream);
     if (n_parts) *n_parts = ATTN_TIME_BINS;
     return PFO_OK;
   }

@@ -28,6 +28,7 @@ void pfo_set_error(const char* fmt, ...);
   } while (0)
 
 // live event timing (misc.hip); no-ops unless pfo_prof_enable(1)
+bool pfo_prof_on();   // while on, the step keeps its large launches on ONE stream so that every bracket times its kernel alone
 void pfo_prof_begin(hipStream_t s);
 void pfo_prof_end(int kind, double work, hipStream_t s);
 

@@ -31,6 +31,7 @@ hipEvent_t prof_event() {
   return e;
 }
 }  // namespace
+bool pfo_prof_on() { return g_prof_on; }
 void pfo_prof_begin(hipStream_t s) {
   if (!g_prof_on) return;
   g_pending = prof_event();

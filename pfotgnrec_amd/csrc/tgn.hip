@@ -618,9 +618,13 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     if (l == 1) {
       // The two weight gradients over the INSTANCES (dW2 / db2, dW1ovT) need only dOut, h1, ctx' and dh1: they run on the
       // side stream beside the attention backward, which is latency-bound (matrix pipe idle, VALU ~45 % busy)
-      HIPOK(hipEventRecord(sd.tn_a, s), "event record failed");
-      HIPOK(hipStreamWaitEvent(ss, sd.tn_a, 0), "event wait failed");
-      RUN(pfo_gemm_tn_group_launch(tn, 2, N, nullptr, w.slabs2, w.slab_floats, ss));
+      if (pfo_prof_on()) {        // event-bracketed step (bench.py's roofline sample): serial, so the bracket times the kernel alone
+        RUN(pfo_gemm_tn_group_launch(tn, 2, N, nullptr, w.slabs, w.slab_floats, s));
+      } else {
+        HIPOK(hipEventRecord(sd.tn_a, s), "event record failed");
+        HIPOK(hipStreamWaitEvent(ss, sd.tn_a, 0), "event wait failed");
+        RUN(pfo_gemm_tn_group_launch(tn, 2, N, nullptr, w.slabs2, w.slab_floats, ss));
+      }
     }
     // attention core
     PfoAttn a;
@@ -659,6 +663,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       set_tn(tb[0], w.Dq, WQ, tab0, D, nullptr, HCp, D, lw.dWqk, D, lw.gqk);               // dWqk = (sum dqk')^T h0, gqk
       tb[0].c_accumulate = 0; tb[0].bias_accumulate = 0;
       set_tn(tb[1], w.Dq + HCp, WQ, tab0, D, nullptr, D, D, g.w1 + E, E + D, g.b1);        // dW1[:, E:], db1
+      // (the layer's chain-back on the side stream needs dWqk / gqk: this launch stays there also while profiling)
       RUN(pfo_gemm_tn_group_launch(tb, 2, capP, w.n_touched, w.slabs2, w.slab_floats, ss));
       if (c->use_memory) {
         // d h0_tab (query side) = Dq [Wqk ; W1[:, E:]]; the GRU backward adds it to the key-side rows the attention scattered
