@@ -270,3 +270,32 @@ def test_literal_main_loop_with_torch_bpr_and_torch_adam():
     assert optB._steps[namesB["memory_updater.memory_updater.weight_ih"]] == 3 and optB._steps[namesB["time_encoder.w.weight"]] == 4
     A.embedding_module.neighbor_finder = train_ngh_finder            # main.py:427
     assert A.neighbor_finder is train_ngh_finder
+
+
+def test_torch_library_ops_match_the_ctypes_wrappers():
+    """north_star: "PyTorch-ROCm custom ops".  The stateless entry points are registered with torch.library
+    (pfotgnrec_amd/ops.py): same results as the direct wrappers, autograd through the BPR op, no CPU kernel."""
+    g = load_golden_r2("g1_sampler")
+    nf = P.NeighborFinder.from_arrays(g["a_src"], g["a_dst"], g["a_eidx"], g["a_ts"])
+    indptr, nbr, eidx, ts = nf.device_arrays(torch.device(DEV))
+    q = torch.from_numpy(g["a_q_nodes"].astype(np.int32)).to(DEV)
+    qt = torch.from_numpy(g["a_q_ts"].astype(np.float64)).to(DEV)
+    o_nbr, o_eidx, o_et = torch.ops.pfotgn.tnbr_sample(indptr, nbr, eidx, ts, q, qt, 10)
+    assert np.array_equal(o_nbr.cpu().numpy(), g["a_K10_nbr"]) and np.array_equal(o_et.cpu().numpy(), g["a_K10_et"])
+    t = torch.rand(7, 5, device=DEV) * 1e4
+    w, b = torch.rand(16, 1, device=DEV), torch.rand(16, device=DEV)
+    assert torch.equal(torch.ops.pfotgn.time_encode(t, w, b), P.time_encode(t, w.reshape(-1), b))
+    emb = torch.randn(5 * 12, 16, device=DEV, requires_grad=True)
+    l1 = P.ops.bpr_loss(emb, 12, 3)
+    l1.backward()
+    g1 = emb.grad.clone(); emb.grad = None
+    l2 = P.bpr_loss(emb, 12, 3)
+    l2.backward()
+    assert torch.equal(l1.detach(), l2.detach()) and torch.equal(g1, emb.grad)
+    with pytest.raises(Exception):
+        torch.ops.pfotgn.time_encode(torch.zeros(3), torch.ones(4, 1), torch.zeros(4))       # no CPU implementation
+
+
+def load_golden_r2(name):
+    from conftest import load_golden
+    return load_golden(name)

@@ -171,3 +171,28 @@ def test_eval_ranking_policy_against_reference_metrics():
         nd = np.where(rank < k, 1.0 / np.log2(rank + 2.0), 0.0)
         assert np.array_equal(rec[free], g["recall"][free, i])
         assert np.allclose(nd[free], g["ndcg"][free, i], rtol=0, atol=1e-12)
+
+
+def test_rand_edge_sampler_availability_cache_follows_content():
+    """the per-batch `np.unique(dst_list)` of utils.py:73 is cached on the array OBJECT (held, so its id cannot be
+    recycled) plus a content fingerprint - never on `id()` alone."""
+    import pfotgnrec_amd as P
+    from pfotgnrec_amd.rand_edge_sampler import item_availability
+    map_item_id = {"%06d" % (i + 1): i for i in range(10)}
+    upper_u = 100
+    src = np.array([1, 2, 3])
+    ports = [[""], ["000001"], ["000002", "000003"]]
+    a = np.array([101, 102, 103, 101], np.int64)
+    s1 = P.RandEdgeSampler(src, a, ports, upper_u, map_item_id)
+    assert s1.item_avail.tolist() == item_availability(a, upper_u, 10).tolist() == [1, 1, 1, 0, 0, 0, 0, 0, 0, 0]
+    s1b = P.RandEdgeSampler(src, a, ports, upper_u, map_item_id)
+    assert s1b.item_avail is s1.item_avail                               # same long-lived array: one bitmap
+    for _ in range(20):                                                   # temporaries of equal length (ids get recycled)
+        b = np.array([105, 106, 107, 108], np.int64) + (_ % 2)
+        s2 = P.RandEdgeSampler(src, b, ports, upper_u, map_item_id)
+        assert s2.item_avail.tolist() == item_availability(b, upper_u, 10).tolist()
+        del b
+    a[0] = 110                                                            # in-place edit of the cached array
+    s3 = P.RandEdgeSampler(src, a, ports, upper_u, map_item_id)
+    assert s3.item_avail.tolist() == item_availability(a, upper_u, 10).tolist()
+    assert s3.port_len.tolist() == [0, 1, 2]                              # '' dropped (utils.py:76)
