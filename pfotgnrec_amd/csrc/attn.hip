@@ -100,10 +100,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
   }
 
   // Software pipeline over chunks of KC_FWD keys: the rows of chunk c+1 are gathered while chunk c is scored, so a
-  // wavefront pays the gather latency once per instance, not once per chunk.
+  // wavefront pays the gather latency once per instance, not once per chunk.  Two register sets used alternately
+  // (A, B): copying the prefetched set over the current one cost 38 v_mov per iteration.
   unsigned long long vm = valid;
-  int js[KC_FWD], js_n[KC_FWD];
-  float kn[KC_FWD][NR], ke[KC_FWD], kn_n[KC_FWD][NR], ke_n[KC_FWD];
+  int jsA[KC_FWD], jsB[KC_FWD];
+  float knA[KC_FWD][NR], keA[KC_FWD], knB[KC_FWD][NR], keB[KC_FWD];
   auto pick = [&](int (&jj)[KC_FWD]) {
 #pragma unroll
     for (int c = 0; c < KC_FWD; ++c) {
@@ -125,22 +126,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
       ee[c] = (jj[c] >= 0 && lane < Ef) ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
     }
   };
-  pick(js);
-  gather(js, kn, ke);
-  while (js[0] >= 0) {
-    pick(js_n);
-    if (js_n[0] >= 0) gather(js_n, kn_n, ke_n);
-    float kt[KC_FWD][NR], dtv[KC_FWD];
+  auto process = [&](const int (&js)[KC_FWD], const float (&kn)[KC_FWD][NR], const float (&ke)[KC_FWD]) {
+    float kt[KC_FWD][NR], dtv[KC_FWD], arg[KC_FWD][NR];
 #pragma unroll
     for (int c = 0; c < KC_FWD; ++c) dtv[c] = rl_f(my_dt, js[c] < 0 ? 0 : js[c]);
-    float part[KC_FWD][H];
+    // time encoding of the chunk: ONE out-of-range test for all its arguments (wave-wide), then the fast reduction
+    bool big = false;
+#pragma unroll
+    for (int c = 0; c < KC_FWD; ++c)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        arg[c][r] = pfo_time_arg(dtv[c], tw[r], tb[r]);
+        big = big || !(fabsf(arg[c][r]) < 2.0e7f);
+      }
+    const bool any_big = __ballot(big) != 0ull;
+    float part[KC_FWD * H];
 #pragma unroll
     for (int c = 0; c < KC_FWD; ++c) {
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const int cc = lane + 64 * r;
         // lanes beyond D (last r only) evaluate a harmless cosine and are masked by a select, not a branch
-        const float cv = pfo_cosf(pfo_time_arg(dtv[c], tw[r], tb[r]));
+        const float cv = __builtin_expect(any_big, 0) ? pfo_cosf(arg[c][r]) : __builtin_amdgcn_cosf(pfo_revolutions_fast(arg[c][r]));
         kt[c][r] = (js[c] >= 0 && (r < NR - 1 || cc < D)) ? cv : 0.f;
       }
 #pragma unroll
@@ -148,31 +155,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
         float pp = ke[c] * qe[h];
 #pragma unroll
         for (int r = 0; r < NR; ++r) pp = fmaf(kn[c][r], qn[h][r], fmaf(kt[c][r], qt[h][r], pp));
-        part[c][h] = pp;
+        part[c * H + h] = pp;
       }
     }
-#pragma unroll
-    for (int c = 0; c < KC_FWD; ++c)
-#pragma unroll
-      for (int h = 0; h < H; ++h) part[c][h] = pfo_wave_sum_scalar(part[c][h]);
+    pfo_wave_sum_scalar_n<KC_FWD * H>(part);
 #pragma unroll
     for (int c = 0; c < KC_FWD; ++c) {
       if (js[c] < 0) continue;
       const unsigned kb = (unsigned)rl_i((int)keep, js[c]);
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        const float sc = part[c][h] * a.scale;
+        const float sc = part[c * H + h] * a.scale;
         if (lane == js[c]) my_s[h] = sc;
         // the score is wave-uniform: the running sums are rescaled only when the maximum actually moves (a scalar
         // branch, taken for the first few keys of a row), otherwise a key costs one FMA per accumulator
         if (sc > m[h]) {
-          const float corr = expf(m[h] - sc);
+          const float corr = pfo_exp_neg(m[h] - sc);
           l[h] *= corr; ld[h] *= corr; ae[h] *= corr;
 #pragma unroll
           for (int r = 0; r < NR; ++r) { an[h][r] *= corr; at[h][r] *= corr; }
           m[h] = sc;
         }
-        const float pr = expf(sc - m[h]);
+        const float pr = pfo_exp_neg(sc - m[h]);
         const float pd = ((kb >> h) & 1u) ? pr * keep_scale : 0.f;
         l[h] += pr;
         ld[h] += pd;
@@ -184,12 +188,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
         ae[h] = fmaf(pd, ke[c], ae[h]);
       }
     }
-#pragma unroll
-    for (int c = 0; c < KC_FWD; ++c) {
-      js[c] = js_n[c]; ke[c] = ke_n[c];
-#pragma unroll
-      for (int r = 0; r < NR; ++r) kn[c][r] = kn_n[c][r];
-    }
+  };
+  pick(jsA);
+  gather(jsA, knA, keA);
+  while (true) {
+    pick(jsB);
+    if (jsB[0] >= 0) gather(jsB, knB, keB);
+    process(jsA, knA, keA);
+    if (jsB[0] < 0) break;
+    pick(jsA);
+    if (jsA[0] >= 0) gather(jsA, knA, keA);
+    process(jsB, knB, keB);
+    if (jsA[0] < 0) break;
   }
 #pragma unroll
   for (int h = 0; h < H; ++h) {
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
       }
     }
     if (lane < Ef) ctx[h * Cp + D + lane] = ae[h] * il;
-    if (lane < K) a.attw[(n * H + h) * K + lane] = ((valid >> lane) & 1ull) ? expf(my_s[h] - m[h]) * il : 0.f;
+    if (lane < K) a.attw[(n * H + h) * K + lane] = ((valid >> lane) & 1ull) ? pfo_exp_neg(my_s[h] - m[h]) * il : 0.f;
     // extra columns consumed by the merged value/out/fc1 projection: C = Σ_j a'_jh (multiplies the folded value
     // bias), C+1 = 1 on head 0 (multiplies the folded out_proj bias; absent on rows without a valid neighbour)
     if (lane < Cp - C) ctx[h * Cp + C + lane] = lane == 0 ? ld[h] * il : ((lane == 1 && h == 0) ? 1.f : 0.f);

@@ -124,6 +124,29 @@ __device__ __forceinline__ float pfo_wave_sum_scalar(float v) {
   v = pfo_dpp_add<0x143, 0xC>(v);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// N independent wave-wide sums with their DPP stages interleaved: a dependent DPP chain needs wait states between its
+// steps (the compiler pads them with s_nop); stage by stage over N values there is always an independent instruction
+template <int N>
+__device__ __forceinline__ void pfo_wave_sum_scalar_n(float (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = pfo_dpp_add<0xB1, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = pfo_dpp_add<0x4E, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = pfo_dpp_add<0x124, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = pfo_dpp_add<0x128, 0xF>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = pfo_dpp_add<0x142, 0xA>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = pfo_dpp_add<0x143, 0xC>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[i]), 63));
+}
+// exp(x) for x <= 0 on the hardware exponential (v_exp_f32 = 2^x, ~1 ulp): softmax weights of wave-uniform scores.
+// expf()'s full range reduction costs ~10 instructions per call, and the attention kernels make 4-8 calls per key pair.
+__device__ __forceinline__ float pfo_exp_neg(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 __device__ __forceinline__ float pfo_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
