@@ -54,6 +54,10 @@ def parse():
                          "(default: strong for C4, weak otherwise)")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step timed block until this much time is covered")
     ap.add_argument("--no-secondary", action="store_true", help="N > 1: skip the single-GPU reference and the weak-scaling C2 figure")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step from a captured HIP graph (one launch per step instead of ~85).  auto (one GPU, per-GPU "
+                         "batch <= 256): capture, time ten steps either way during set-up and keep the faster form - the graph "
+                         "wins where the host's launch rate bounds the step (C1), the eager queue where the GPU does")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="start the N ranks, rendezvous, all-reduce the rank ids and print a line; no GPU work (CPU test of the launcher)")
     ap.add_argument("--batch", type=int, default=0, help="interactions per GPU per step (default: the config's)")
@@ -229,6 +233,39 @@ class Workload:
         self.span = cfg.n_edges - self.start - self.B         # batches wrap inside the second half of the edge list
         assert self.span > 0, "batch larger than the timed half of the graph"
         tgn.train()
+        # a HIP graph of the whole step for the launch-bound regime (pfotgnrec_amd/graph.py)
+        self.gstep, self.graph_note = None, "off"
+        want = args.graph == "on" or (args.graph == "auto" and world == 1 and self.B <= 256)
+        if want and world == 1:
+            try:
+                sl = slice(self.start, self.start + self.B)
+                self.gstep = P.GraphedTrainStep(tgn, self.opt, self.sampler, self.B, cfg.n_neighbors, n_neg=self.n_neg,
+                                                port_width=self.port_idx_all.shape[1], mv_sampler=self.mvs)
+                self.gstep.capture(*self._batch(sl))
+                self.graph_note = "on"
+                if args.graph == "auto":
+                    ms = {}
+                    for mode in ("graph", "eager"):
+                        fn = self.gstep if mode == "graph" else self.gstep.eager
+                        for k in range(13):                       # three untimed steps (allocator, caches), then ten timed
+                            if k == 3:
+                                torch.cuda.synchronize()
+                                t0 = time.perf_counter()
+                            lo = self.start + (k * self.B) % self.span
+                            fn(*self._batch(slice(lo, lo + self.B)))
+                        torch.cuda.synchronize()
+                        ms[mode] = 1e2 * (time.perf_counter() - t0)
+                    self.graph_note = "auto: graph %.3f ms/step, eager %.3f -> %s" % (ms["graph"], ms["eager"],
+                                                                                       "graph" if ms["graph"] < ms["eager"] else "eager")
+                    if ms["graph"] >= ms["eager"]:
+                        self.gstep.finish()
+                        self.gstep = None
+            except Exception as e:          # capture is an optimisation: the eager step is always available
+                self.gstep, self.graph_note = None, "failed (%s): eager" % (str(e)[:80],)
+
+    def _batch(self, sl):
+        return (self.src_all[sl], self.dst_all[sl], self.ts_all[sl], self.eidx_all[sl], self.port_idx_all[sl], self.port_len_all[sl],
+                self.day_all[sl] if self.mvs is not None else None)
 
     def set_world(self, rank, world):
         """Re-targets the resident model at a different data-parallel layout (the single-GPU reference of an N-rank run)."""
@@ -240,6 +277,9 @@ class Workload:
         P, torch, tgn, cfg, B, n_neg = self.P, self.torch, self.tgn, self.cfg, self.B, self.n_neg
         lo = self.start + (i * B) % self.span
         sl = slice(lo, lo + B)
+        if self.gstep is not None:
+            from pfotgnrec_amd import _lib as _l
+            return (self.gstep.eager if _l.prof_is_on() else self.gstep)(*self._batch(sl))   # bracketed steps run kernel by kernel
         if self.mvs is None:
             neg = self.sampler.sample(self.port_idx_all[sl], self.port_len_all[sl], n_neg, offset=i)            # utils.py:86-114
             emb, b = tgn.embed_device(self.src_all[sl], self.dst_all[sl], [neg.reshape(-1)], [n_neg], self.ts_all[sl],
@@ -387,7 +427,7 @@ def main():
                    "timed_seconds": round(elapsed, 3),
                    "block_ms_per_step": {"first": round(wl.block_ms[0], 4), "min": round(min(wl.block_ms), 4),
                                          "median": round(float(np.median(wl.block_ms)), 4), "last": round(wl.block_ms[-1], 4)},
-                   "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4),
+                   "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4), "hip_graph": wl.graph_note,
                    "collective": ("%s all-reduce of the flat fp32 gradient, world %d"
                                   % ("rccl" if dist.get_backend() == "nccl" else dist.get_backend(), dist.get_world_size())) if world > 1 else None},
     }

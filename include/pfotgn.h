@@ -67,6 +67,10 @@ int pfo_tnbr_sample(const int64_t* indptr, const int32_t* adj_nbr, const int32_t
 int pfo_neg_draw(const uint8_t* item_avail, int32_t n_items, const int32_t* port_idx, const int32_t* port_len,
                  int32_t port_stride, int64_t B, int32_t size, int32_t upper_u, uint64_t seed, uint64_t offset,
                  int32_t* out, void* stream);
+/* the same with a device word added to `offset` (graph-captured steps, see pfo_tgn_batch.offset_dev) */
+int pfo_neg_draw_dev(const uint8_t* item_avail, int32_t n_items, const int32_t* port_idx, const int32_t* port_len,
+                     int32_t port_stride, int64_t B, int32_t size, int32_t upper_u, uint64_t seed, uint64_t offset,
+                     const uint64_t* offset_dev, int32_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K2  mean-variance-efficient rank fusion.  Replaces the inline block main.py:209-304.
@@ -179,7 +183,12 @@ int pfo_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * None (main.py:123 hands it every parameter; the GRU's are None on the first batch of an epoch, when no message is
  * pending: memory_updater.py:38-40), so tensors can be one step apart for a whole run; ranges that are left out are
  * not touched at all.  lo / hi / step are HOST arrays. */
+/* ..._dev: the step count of range r is step[r] + *step_dev (a device word): a graph-captured step advances it on the device
+ * and the bias corrections are computed there */
 #define PFO_ADAM_MAX_RANGES 16
+int pfo_adam_step_ranges_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
+                             const int64_t* lo, const int64_t* hi, const int32_t* step, const int32_t* step_dev, float lr,
+                             float beta1, float beta2, float eps, void* stream);
 int pfo_adam_step_ranges(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
                          const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1, float beta2,
                          float eps, void* stream);
@@ -242,6 +251,9 @@ typedef struct pfo_tgn_batch {
                                  embedded here: data-parallel ranks pass the GLOBAL batch's positives so that
                                  pfo_tgn_update_state can persist all of them; may be NULL */
   int32_t n_extra;
+  const uint64_t* offset_dev; /* optional device word ADDED to `offset` by every kernel that draws random numbers (dropout
+                                 masks, Philox neighbour draws).  A step captured into a HIP graph keeps its kernel
+                                 arguments: the per-step stream position then lives here and is advanced on the device */
 } pfo_tgn_batch;
 
 /* Lazy memory update for touched nodes (tgn.py:251, memory_updater.py:35-53) + L-layer temporal graph

@@ -39,7 +39,7 @@ class TgnState(C.Structure):
 class TgnBatch(C.Structure):
     _fields_ = [("roots", _VP), ("root_ts", _VP), ("R", C.c_int32), ("K", C.c_int32), ("uniform", C.c_int32),
                 ("draws", C.POINTER(_VP)), ("seed", C.c_uint64), ("offset", C.c_uint64), ("dropout_p", C.c_float),
-                ("training", C.c_int32), ("extra_nodes", _VP), ("n_extra", C.c_int32)]
+                ("training", C.c_int32), ("extra_nodes", _VP), ("n_extra", C.c_int32), ("offset_dev", _VP)]
 
 
 class TgnDebug(C.Structure):
@@ -54,6 +54,8 @@ PROTOTYPES = {
                                   C.c_uint64, C.c_uint64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "pfo_neg_draw": (C.c_int, [_VP, C.c_int32, _VP, _VP, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_uint64,
                                C.c_uint64, _VP, _VP]),
+    "pfo_neg_draw_dev": (C.c_int, [_VP, C.c_int32, _VP, _VP, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_uint64,
+                                   C.c_uint64, _VP, _VP, _VP]),
     "pfo_mv_select": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, C.c_int32, _VP, _VP, C.c_int32,
                                 C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, _VP, _VP, _VP,
                                 _VP, _VP]),
@@ -75,6 +77,8 @@ PROTOTYPES = {
     "pfo_csr_append": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, _VP, _VP]),
     "pfo_adam_step_ranges": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                        C.POINTER(C.c_int32), C.c_float, C.c_float, C.c_float, C.c_float, _VP]),
+    "pfo_adam_step_ranges_dev": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                           C.POINTER(C.c_int32), _VP, C.c_float, C.c_float, C.c_float, C.c_float, _VP]),
     "pfo_tgn_param_layout": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnLayout)]),
     "pfo_tgn_workspace_bytes": (C.c_int64, [C.POINTER(TgnConfig)]),
     "pfo_tgn_forward": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP]),
@@ -90,8 +94,16 @@ PROF_KINDS = ["gemm_nt", "gemm_nn", "gemm_tn", "gemm_devm", "attn_fwd", "attn_bw
               "attn_bwd_runs"]
 
 
+_PROF_ON = [False]
+
+
 def prof_enable(on):
+    _PROF_ON[0] = bool(on)
     call("pfo_prof_enable", 1 if on else 0)
+
+
+def prof_is_on():
+    return _PROF_ON[0]
 
 
 def prof_collect():

@@ -14,7 +14,7 @@ struct AttnDev {
   int N, K, D, Ef, H, Cp;
   const float* QK; const int32_t* qk_row; int64_t qk_ld; const float* nbr_tab; int64_t nbr_ld; const int32_t* nbr_row; int64_t nbr_row_base;
   const int32_t* nbr_ids; const float* edge_feat; const int32_t* eidx; const float* dt; const float* tw; const float* tb;
-  float scale, dropout_p; uint64_t seed, offset;
+  float scale, dropout_p; uint64_t seed, offset; const uint64_t* offset_dev;
   float* ctx; float* attw; uint8_t* inv;
   const float* dctx; float* dQK; float* d_nbr; int64_t d_nbr_ld; double* dtime_part;
   int64_t d_nbr_rep;  // DMODE 1: floats between the per-XCD replicas of the gradient table (0: one table)
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
   }
   if (lane == 0) a.inv[n] = 0;
 
-  const unsigned keep = attn_keep_bits(a.seed, a.offset, n, lane, a.dropout_p);
+  const unsigned keep = attn_keep_bits(a.seed, a.offset + (a.offset_dev ? *a.offset_dev : 0ull), n, lane, a.dropout_p);
   const float keep_scale = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
 
   float m[H], l[H], ld[H], my_s[H];
@@ -309,7 +309,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
 #pragma unroll
     for (int h = 0; h < H; ++h) t[h] = fmaf(dsb[h], cx[h * Cp + C], t[h]);
 
-    const unsigned keep = attn_keep_bits(a.seed, a.offset, n, lane, a.dropout_p);
+    const unsigned keep = attn_keep_bits(a.seed, a.offset + (a.offset_dev ? *a.offset_dev : 0ull), n, lane, a.dropout_p);
     float my_a[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) my_a[h] = inK ? a.attw[(n * H + h) * K + lane] : 0.f;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64) void attn_bwd_runs_kernel(const AttnDev a) {
         for (int h = 0; h < H; ++h) t[h] += __shfl_xor(t[h], o, 64);
 #pragma unroll
       for (int h = 0; h < H; ++h) t[h] = fmaf(dsb[h], cx[h * Cp + C], t[h]);
-      const unsigned keep = attn_keep_bits(a.seed, a.offset, n, lane, a.dropout_p);
+      const unsigned keep = attn_keep_bits(a.seed, a.offset + (a.offset_dev ? *a.offset_dev : 0ull), n, lane, a.dropout_p);
       float my_a[H];
 #pragma unroll
       for (int h = 0; h < H; ++h) my_a[h] = inK ? a.attw[(n * H + h) * K + lane] : 0.f;
@@ -657,7 +657,7 @@ static void to_dev(const PfoAttn& a, AttnDev& d) {
   d.N = a.N; d.K = a.K; d.D = a.D; d.Ef = a.Ef; d.H = a.H; d.Cp = a.Cp;
   d.QK = a.QK; d.qk_row = a.qk_row; d.qk_ld = a.qk_ld > 0 ? a.qk_ld : (int64_t)a.H * a.Cp; d.nbr_tab = a.nbr_tab; d.nbr_ld = a.nbr_ld; d.nbr_row = a.nbr_row; d.nbr_row_base = a.nbr_row_base;
   d.nbr_ids = a.nbr_ids; d.edge_feat = a.edge_feat; d.eidx = a.eidx; d.dt = a.dt; d.tw = a.tw; d.tb = a.tb;
-  d.scale = a.scale; d.dropout_p = a.dropout_p; d.seed = a.seed; d.offset = a.offset;
+  d.scale = a.scale; d.dropout_p = a.dropout_p; d.seed = a.seed; d.offset = a.offset; d.offset_dev = a.offset_dev;
   static const int abl = getenv("PFO_ATTN_ABL") ? atoi(getenv("PFO_ATTN_ABL")) : 0;
   d.abl = abl;
   d.ctx = a.ctx; d.attw = a.attw; d.inv = a.inv;

@@ -62,7 +62,7 @@ extern "C" int pfo_prof_collect(double* ms, double* work, int64_t* count) {
   g_recs.clear();
   return PFO_OK;
 }
-extern "C" int pfo_abi_version(void) { return 1; }
+extern "C" int pfo_abi_version(void) { return 2; }
 
 // ---------------------------------------------------------------------------------------------
 __global__ void time_encode_kernel(const float* __restrict__ t, int64_t n, const float* __restrict__ w,
@@ -250,6 +250,48 @@ extern "C" int pfo_adam_step_ranges(float* param, const float* grad, float* exp_
   const int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, pfo_ceil_div(longest, 256)));
   hipLaunchKernelGGL(adam_ranges_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, r,
                      beta1, beta2, eps);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+// the same with the step counts on the device: t_r = base_r + *step_dev (graph-captured steps)
+struct AdamRangesDev { int64_t lo[PFO_ADAM_MAX_RANGES], hi[PFO_ADAM_MAX_RANGES]; int base[PFO_ADAM_MAX_RANGES]; int n; };
+__global__ void adam_ranges_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                       float* __restrict__ v, const AdamRangesDev r, const int32_t* __restrict__ step_dev,
+                                       float lr, float b1, float b2, float eps) {
+  const int sd = *step_dev;
+  for (int q = 0; q < r.n; ++q) {
+    const double t = (double)(r.base[q] + sd);
+    const float step_size = lr / (float)(1.0 - pow((double)b1, t));
+    const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
+    for (int64_t i = r.lo[q] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < r.hi[q]; i += (int64_t)gridDim.x * blockDim.x) {
+      const float gi = g[i];
+      const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+      const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+      m[i] = mi;
+      v[i] = vi;
+      p[i] -= step_size * (mi / (sqrtf(vi) / bc2s + eps));
+    }
+  }
+}
+extern "C" int pfo_adam_step_ranges_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
+                                        const int64_t* lo, const int64_t* hi, const int32_t* step, const int32_t* step_dev,
+                                        float lr, float beta1, float beta2, float eps, void* stream) {
+  PFO_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_dev, "null buffer");
+  PFO_REQUIRE(n_ranges >= 0 && n_ranges <= PFO_ADAM_MAX_RANGES, "too many ranges");
+  if (n_ranges == 0) return PFO_OK;
+  PFO_REQUIRE(lo && hi && step, "null range arrays");
+  AdamRangesDev r;
+  r.n = n_ranges;
+  int64_t longest = 0;
+  for (int q = 0; q < n_ranges; ++q) {
+    PFO_REQUIRE(lo[q] >= 0 && hi[q] >= lo[q] && step[q] >= 0, "bad range");
+    r.lo[q] = lo[q]; r.hi[q] = hi[q]; r.base[q] = step[q];
+    longest = std::max(longest, hi[q] - lo[q]);
+  }
+  const int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, pfo_ceil_div(longest, 256)));
+  hipLaunchKernelGGL(adam_ranges_dev_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, r,
+                     step_dev, lr, beta1, beta2, eps);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

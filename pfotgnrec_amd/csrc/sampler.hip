@@ -15,8 +15,9 @@ __global__ __launch_bounds__(256) void tnbr_sample_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ adj_nbr, const int32_t* __restrict__ adj_eidx,
     const double* __restrict__ adj_ts, int64_t n_nodes, const int32_t* __restrict__ q_nodes,
     const double* __restrict__ q_ts, int64_t n_q, int K, const int64_t* __restrict__ draws, uint64_t seed,
-    uint64_t offset, int32_t* __restrict__ out_nbr, int32_t* __restrict__ out_eidx, float* __restrict__ out_et,
-    float* __restrict__ out_dt, int32_t* __restrict__ next_nodes, double* __restrict__ next_ts) {
+    uint64_t offset, const uint64_t* __restrict__ offset_dev, int32_t* __restrict__ out_nbr, int32_t* __restrict__ out_eidx,
+    float* __restrict__ out_et, float* __restrict__ out_dt, int32_t* __restrict__ next_nodes, double* __restrict__ next_ts) {
+  if (MODE == 2 && offset_dev) offset += *offset_dev;
   __shared__ float s_time[16][PFO_MAX_NEIGHBORS];   // uniform modes: per-group sort scratch
   const int lane = threadIdx.x & 63;
   const int sub = lane & 15;
@@ -139,11 +140,10 @@ __global__ __launch_bounds__(256) void tnbr_sample_kernel(
   }
 }
 
-extern "C" int pfo_tnbr_sample(const int64_t* indptr, const int32_t* adj_nbr, const int32_t* adj_eidx,
-                               const double* adj_ts, int64_t n_nodes, const int32_t* q_nodes, const double* q_ts,
-                               int64_t n_q, int32_t K, int32_t mode, const int64_t* draws, uint64_t seed,
-                               uint64_t offset, int32_t* out_nbr, int32_t* out_eidx, float* out_et, float* out_dt,
-                               int32_t* next_nodes, double* next_ts, void* stream) {
+int pfo_tnbr_sample_dev(const int64_t* indptr, const int32_t* adj_nbr, const int32_t* adj_eidx, const double* adj_ts,
+                        int64_t n_nodes, const int32_t* q_nodes, const double* q_ts, int64_t n_q, int32_t K, int32_t mode,
+                        const int64_t* draws, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int32_t* out_nbr,
+                        int32_t* out_eidx, float* out_et, float* out_dt, int32_t* next_nodes, double* next_ts, void* stream) {
   PFO_REQUIRE(K >= 1 && K <= PFO_MAX_NEIGHBORS, "K must be in [1, 64]");
   PFO_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0, 1 or 2");
   PFO_REQUIRE(mode != 1 || draws != nullptr, "mode 1 needs injected draws");
@@ -156,8 +156,8 @@ extern "C" int pfo_tnbr_sample(const int64_t* indptr, const int32_t* adj_nbr, co
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(M)                                                                                                   \
   hipLaunchKernelGGL(tnbr_sample_kernel<M>, dim3((unsigned)blocks), dim3(threads), 0, s, indptr, adj_nbr, adj_eidx, \
-                     adj_ts, n_nodes, q_nodes, q_ts, n_q, (int)K, draws, seed, offset, out_nbr, out_eidx, out_et,   \
-                     out_dt, next_nodes, next_ts)
+                     adj_ts, n_nodes, q_nodes, q_ts, n_q, (int)K, draws, seed, offset, offset_dev, out_nbr, out_eidx,  \
+                     out_et, out_dt, next_nodes, next_ts)
   pfo_prof_begin(s);
   if (mode == 0) LAUNCH(0);
   else if (mode == 1) LAUNCH(1);
@@ -169,14 +169,24 @@ extern "C" int pfo_tnbr_sample(const int64_t* indptr, const int32_t* adj_nbr, co
   return PFO_OK;
 }
 
+extern "C" int pfo_tnbr_sample(const int64_t* indptr, const int32_t* adj_nbr, const int32_t* adj_eidx,
+                               const double* adj_ts, int64_t n_nodes, const int32_t* q_nodes, const double* q_ts,
+                               int64_t n_q, int32_t K, int32_t mode, const int64_t* draws, uint64_t seed,
+                               uint64_t offset, int32_t* out_nbr, int32_t* out_eidx, float* out_et, float* out_dt,
+                               int32_t* next_nodes, double* next_ts, void* stream) {
+  return pfo_tnbr_sample_dev(indptr, adj_nbr, adj_eidx, adj_ts, n_nodes, q_nodes, q_ts, n_q, K, mode, draws, seed, offset,
+                             nullptr, out_nbr, out_eidx, out_et, out_dt, next_nodes, next_ts, stream);
+}
+
 // ---------------------------------------------------------------------------------------------
 // candidate draw: utils/utils.py:86-114.  One wavefront per interaction, available items in LDS.
 __global__ __launch_bounds__(64) void neg_draw_kernel(const uint8_t* __restrict__ item_avail, int n_items,
                                                       const int32_t* __restrict__ port_idx,
                                                       const int32_t* __restrict__ port_len, int port_stride,
                                                       int size, int upper_u, uint64_t seed, uint64_t offset,
-                                                      int32_t* __restrict__ out) {
+                                                      const uint64_t* __restrict__ offset_dev, int32_t* __restrict__ out) {
   extern __shared__ int32_t s_list[];
+  if (offset_dev) offset += *offset_dev;
   const int lane = threadIdx.x;
   const int64_t b = blockIdx.x;
   const int plen = min(port_len[b], port_stride);
@@ -225,13 +235,18 @@ __global__ __launch_bounds__(64) void neg_draw_kernel(const uint8_t* __restrict_
 extern "C" int pfo_neg_draw(const uint8_t* item_avail, int32_t n_items, const int32_t* port_idx,
                             const int32_t* port_len, int32_t port_stride, int64_t B, int32_t size, int32_t upper_u,
                             uint64_t seed, uint64_t offset, int32_t* out, void* stream) {
+  return pfo_neg_draw_dev(item_avail, n_items, port_idx, port_len, port_stride, B, size, upper_u, seed, offset, nullptr, out, stream);
+}
+extern "C" int pfo_neg_draw_dev(const uint8_t* item_avail, int32_t n_items, const int32_t* port_idx,
+                                const int32_t* port_len, int32_t port_stride, int64_t B, int32_t size, int32_t upper_u,
+                                uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int32_t* out, void* stream) {
   PFO_REQUIRE(n_items > 0 && n_items <= 16384, "n_items must be in [1, 16384]");
   PFO_REQUIRE(size >= 1 && port_stride >= 0 && B >= 0, "bad sizes");
   if (B == 0) return PFO_OK;
   PFO_REQUIRE(item_avail && port_len && out && (port_idx || port_stride == 0), "null input");
   hipLaunchKernelGGL(neg_draw_kernel, dim3((unsigned)B), dim3(64), (size_t)n_items * sizeof(int32_t),
                      (hipStream_t)stream, item_avail, (int)n_items, port_idx, port_len, (int)port_stride, (int)size,
-                     (int)upper_u, seed, offset, out);
+                     (int)upper_u, seed, offset, offset_dev, out);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

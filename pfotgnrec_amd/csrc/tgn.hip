@@ -15,9 +15,9 @@
 #include <math.h>
 #include <string.h>
 
-extern "C" int pfo_tnbr_sample(const int64_t*, const int32_t*, const int32_t*, const double*, int64_t, const int32_t*,
-                               const double*, int64_t, int32_t, int32_t, const int64_t*, uint64_t, uint64_t, int32_t*,
-                               int32_t*, float*, float*, int32_t*, double*, void*);
+int pfo_tnbr_sample_dev(const int64_t*, const int32_t*, const int32_t*, const double*, int64_t, const int32_t*, const double*,
+                        int64_t, int32_t, int32_t, const int64_t*, uint64_t, uint64_t, const uint64_t*, int32_t*, int32_t*,
+                        float*, float*, int32_t*, double*, void*);
 
 namespace {
 
@@ -370,9 +370,9 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     // level L reads the caller's roots directly; every level writes [its own nodes | their neighbours] as the next one
     const int32_t* lvl_nodes = (l == L) ? b->roots : w.nodes[l];
     const double* lvl_ts = (l == L) ? b->root_ts : w.ts[l];
-    RUN(pfo_tnbr_sample(st->indptr, st->adj_nbr, st->adj_eidx, st->adj_ts, c->n_nodes, lvl_nodes, lvl_ts, n[l], K,
-                        b->uniform, dr, b->seed, b->offset + (uint64_t)l * 0x100000000ull, nullptr, w.eidx[l], nullptr,
-                        w.dt[l], w.nodes[l - 1], l > 1 ? w.ts[l - 1] : nullptr, stream));
+    RUN(pfo_tnbr_sample_dev(st->indptr, st->adj_nbr, st->adj_eidx, st->adj_ts, c->n_nodes, lvl_nodes, lvl_ts, n[l], K,
+                            b->uniform, dr, b->seed, b->offset + (uint64_t)l * 0x100000000ull, b->offset_dev, nullptr,
+                            w.eidx[l], nullptr, w.dt[l], w.nodes[l - 1], l > 1 ? w.ts[l - 1] : nullptr, stream));
   }
 
   if (c->use_memory) {
@@ -510,7 +510,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     a.nbr_row_base = N;
     a.nbr_ids = w.nodes[l - 1] + N;
     a.edge_feat = st->edge_feat; a.eidx = w.eidx[l]; a.dt = w.dt[l]; a.tw = P.tw; a.tb = P.tb;
-    a.scale = scale; a.dropout_p = b->dropout_p; a.seed = b->seed; a.offset = b->offset + 0x51ED0000ull + (uint64_t)l;
+    a.scale = scale; a.dropout_p = b->dropout_p; a.seed = b->seed; a.offset = b->offset + 0x51ED0000ull + (uint64_t)l; a.offset_dev = b->offset_dev;
     a.ctx = lw.ctx; a.attw = lw.attw; a.inv = lw.inv;
     RUN(pfo_attn_fwd_launch(a, s));
     // ---- h1 = relu(ctx' W1ovT + x W1[:, E:]^T + b1)   (MergeLayer fc1 with out_proj and the value projection folded in)
@@ -635,7 +635,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     a.nbr_row_base = N;
     a.nbr_ids = w.nodes[l - 1] + N;
     a.edge_feat = st->edge_feat; a.eidx = w.eidx[l]; a.dt = w.dt[l]; a.tw = P.tw; a.tb = P.tb;
-    a.scale = scale; a.dropout_p = b->dropout_p; a.seed = b->seed; a.offset = b->offset + 0x51ED0000ull + (uint64_t)l;
+    a.scale = scale; a.dropout_p = b->dropout_p; a.seed = b->seed; a.offset = b->offset + 0x51ED0000ull + (uint64_t)l; a.offset_dev = b->offset_dev;
     a.ctx = lw.ctx; a.attw = lw.attw; a.inv = lw.inv;
     a.dctx = w.dctx; a.dQK = w.dQK;
     if (l == 1) { a.d_nbr = c->use_memory ? w.d_h0 : nullptr; a.d_nbr_ld = D; a.d_nbr_rep = rep_stride; }

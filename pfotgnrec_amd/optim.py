@@ -30,6 +30,12 @@ class FusedAdam(torch.optim.Optimizer):
     def _t(self, value):
         self._steps = {p: int(value) for p in self.tgn.hot_parameters()}
 
+    def sync_steps(self, taken):
+        """Adds ``taken`` steps to every tensor that has a gradient (after replaying a captured step ``taken`` times)."""
+        for p in self.tgn.hot_parameters():
+            if p.grad is not None:
+                self._steps[p] = self._steps.get(p, 0) + int(taken)
+
     def set_steps(self, steps_by_name):
         """Per-tensor step counts (``{parameter name: steps taken}``), e.g. from a torch.optim.Adam state dict."""
         names = dict(self.tgn.named_parameters())
@@ -37,7 +43,10 @@ class FusedAdam(torch.optim.Optimizer):
             self._steps[names[k]] = int(t)
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, step_dev=None):
+        """``step_dev`` (1-element int32 device tensor): the step counts used are the host's plus that device word and the
+        host counters are NOT advanced - for steps captured into a HIP graph, which advances the word itself
+        (``sync_steps`` folds it back into the host counters afterwards)."""
         tgn = self.tgn
         if tgn.flat_grad is None:
             return None
@@ -50,8 +59,9 @@ class FusedAdam(torch.optim.Optimizer):
         for p, off, n, _ in sorted(tgn._views, key=lambda v: v[1]):
             if p.grad is None:                       # torch.optim.Adam: skipped entirely (no moment decay, no step)
                 continue
-            t = self._steps.get(p, 0) + 1
-            self._steps[p] = t
+            t = self._steps.get(p, 0) + (1 if step_dev is None else 0)
+            if step_dev is None:
+                self._steps[p] = t
             if lo and hi[-1] == off and st[-1] == t:
                 hi[-1] = off + n
             else:
@@ -59,6 +69,12 @@ class FusedAdam(torch.optim.Optimizer):
         MAXR = 16
         for i in range(0, len(lo), MAXR):
             k = min(MAXR, len(lo) - i)
+            if step_dev is not None:
+                _lib.call("pfo_adam_step_ranges_dev", tgn.flat_parameters.data_ptr(), tgn.flat_grad.data_ptr(), self._m.data_ptr(),
+                          self._v.data_ptr(), k, (ctypes.c_int64 * k)(*lo[i:i + k]), (ctypes.c_int64 * k)(*hi[i:i + k]),
+                          (ctypes.c_int32 * k)(*st[i:i + k]), step_dev.data_ptr(), float(g["lr"]), float(g["betas"][0]),
+                          float(g["betas"][1]), float(g["eps"]), _lib.stream_ptr())
+                continue
             _lib.call("pfo_adam_step_ranges", tgn.flat_parameters.data_ptr(), tgn.flat_grad.data_ptr(), self._m.data_ptr(),
                       self._v.data_ptr(), k, (ctypes.c_int64 * k)(*lo[i:i + k]), (ctypes.c_int64 * k)(*hi[i:i + k]),
                       (ctypes.c_int32 * k)(*st[i:i + k]), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),

@@ -56,14 +56,15 @@ class DeviceNegativeSampler:
         self.avail = torch.from_numpy(np.ascontiguousarray(item_avail, np.uint8)).to(self.device)
         self.seed = int(seed)
 
-    def sample(self, port_idx, port_len, size, offset):
-        """port_idx i32[B,W], port_len i32[B] device tensors -> i32[B,size] item node ids (device)."""
+    def sample(self, port_idx, port_len, size, offset, offset_dev=None):
+        """port_idx i32[B,W], port_len i32[B] device tensors -> i32[B,size] item node ids (device).  ``offset_dev``: optional
+        1-element int64 device tensor added to ``offset`` on the device (steps captured into a HIP graph)."""
         import torch
         B = port_len.shape[0]
         W = port_idx.shape[1] if port_idx.dim() == 2 else 0
         out = torch.empty((B, size), dtype=torch.int32, device=self.device)
-        _lib.call("pfo_neg_draw", _lib.ptr(self.avail), self.n_items, _lib.ptr(port_idx), _lib.ptr(port_len), W, B,
-                  size, self.upper_u, self.seed, int(offset), _lib.ptr(out), _lib.stream_ptr())
+        _lib.call("pfo_neg_draw_dev", _lib.ptr(self.avail), self.n_items, _lib.ptr(port_idx), _lib.ptr(port_len), W, B,
+                  size, self.upper_u, self.seed, int(offset), _lib.ptr(offset_dev), _lib.ptr(out), _lib.stream_ptr())
         return out
 
 

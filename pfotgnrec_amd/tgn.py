@@ -343,7 +343,7 @@ class TGN(nn.Module):
         self._adj_cache = (key, nf, (indptr, nbr, eidx, ts))
         return self._adj_cache[2]
 
-    def _make_call(self, roots, root_ts, K, draws, dropout_p, extra, B):
+    def _make_call(self, roots, root_ts, K, draws, dropout_p, extra, B, offset_dev=None):
         c = _Call()
         c.roots, c.root_ts, c.R, c.K = roots, root_ts, int(roots.shape[0]), int(K)
         uniform = bool(getattr(self.neighbor_finder, "uniform", False))
@@ -356,7 +356,9 @@ class TGN(nn.Module):
             c.draw_ptrs = (ctypes.c_void_p * self.n_layers)(*[d.data_ptr() for d in draws])
         self._step += 1
         c.seed = self.seed + getattr(self.neighbor_finder, "seed", 0)
-        c.offset = self._step << 36
+        # position in the Philox streams (dropout masks, uniform draws): the call counter - or, for a step captured into a HIP
+        # graph (whose kernel arguments are frozen), a device word the graph itself advances
+        c.offset = (self._step << 36) if offset_dev is None else 0
         c.dropout_p = float(dropout_p)
         c.training = int(dropout_p > 0.0)
         c.extra = extra
@@ -364,7 +366,8 @@ class TGN(nn.Module):
                                        ctypes.cast(c.draw_ptrs, ctypes.POINTER(ctypes.c_void_p)) if c.draw_ptrs else None,
                                        c.seed, c.offset, c.dropout_p, c.training,
                                        extra.data_ptr() if extra is not None else None,
-                                       int(extra.shape[0]) if extra is not None else 0)
+                                       int(extra.shape[0]) if extra is not None else 0,
+                                       offset_dev.data_ptr() if offset_dev is not None else None)
         c.pool = self._ws_pool
         c.ws_caps, c.cfg, c.ws = self._acquire_workspace(c.R, c.K, B)
         c.gru_applied = self._gru_applied_now
@@ -410,7 +413,7 @@ class TGN(nn.Module):
                   ts.data_ptr(), eidx.data_ptr(), int(src.shape[0]), call.ws.data_ptr(), _lib.stream_ptr())
 
     # ------------------------------------------------------------------ the step
-    def embed_device(self, src, dst, extra_roots, extra_repeat, edge_times, edge_idxs, n_neighbors, draws=None):
+    def embed_device(self, src, dst, extra_roots, extra_repeat, edge_times, edge_idxs, n_neighbors, draws=None, offset_dev=None):
         """Device-resident core of both reference entry points.
 
         src/dst i32[B], edge_times f64[B], edge_idxs i32[B], extra_roots: list of i32 tensors [B*r_k] (negatives /
@@ -419,7 +422,8 @@ class TGN(nn.Module):
         Returns the embedding matrix [R, D] in the order [src | dst | extra...] for THIS rank's shard of the batch
         (``R = b * (2 + sum(extra_repeat))``, ``b`` = the second return value; b may be 0 for a trailing rank when the
         batch is shorter than the world size), and performs the memory persist + raw-message store for the whole batch
-        (tgn.py:290-317).  ``self.dp_grad_scale`` then holds b / B, the factor that turns this shard's mean-loss
+        (tgn.py:290-317).  ``offset_dev`` (a 1-element int64 device tensor): position of the random streams for steps
+        captured into a HIP graph (pfotgnrec_amd/graph.py).  ``self.dp_grad_scale`` then holds b / B, the factor that turns this shard's mean-loss
         gradient into its share of the global-batch mean gradient.
         """
         _lib.require_gpu(self.device)
@@ -476,7 +480,7 @@ class TGN(nn.Module):
             # a leaf that requires grad: the caller's loss.backward() is a no-op instead of an error
             return torch.zeros((0, D), dtype=torch.float32, device=self.device, requires_grad=grad_mode), 0
         if grad_mode:
-            call = self._make_call(roots, root_ts, K, draws, dropout_p, extra, B)
+            call = self._make_call(roots, root_ts, K, draws, dropout_p, extra, B, offset_dev)
             emb = _EmbedFn.apply(self, call, post, *self.hot_parameters())
             return emb, b
         # forward only (evaluation.py:94: R = B*(2+N_ITEMS) roots): walk the roots in chunks through the same

@@ -299,3 +299,56 @@ def test_torch_library_ops_match_the_ctypes_wrappers():
 def load_golden_r2(name):
     from conftest import load_golden
     return load_golden(name)
+
+
+@pytest.mark.parametrize("ours", [False, True])
+def test_graphed_step_equals_eager_step(ours):
+    """pfotgnrec_amd/graph.py: the whole training step (candidate draw, [MV selection,] sampling, memory, attention, BPR,
+    backward, Adam, state update) replayed from ONE captured HIP graph equals the same step queued kernel by kernel - same
+    device-side stream positions, so the same dropout masks and negatives.  Lockstep (the replaying model takes over the
+    eager model's state before every step): free-running trajectories separate through Adam (SURVEY 7 hard part 5)."""
+    from pfotgnrec_amd.rand_edge_sampler import item_availability, DeviceNegativeSampler
+    lr = 1e-3
+    sides = []
+    for _ in range(2):
+        torch.manual_seed(31)
+        cfg = SyntheticConfig("gs", 300, 25, 5000, 32, 2, 6, 2)
+        g = make_graph(cfg, with_prices=ours)
+        d = g.data
+        tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=2, dropout=0.1,
+                    use_memory=True, memory_dimension=32, message_function="identity", n_neighbors=6)
+        opt = P.FusedAdam(tgn, lr=lr)
+        sampler = DeviceNegativeSampler(item_availability(d.destinations, g.upper_u, cfg.n_items), g.upper_u, DEV, seed=1)
+        mvs = P.MVSampler(g.prices, g.upper_u, DEV, gamma=2.0, lambda_mv=0.5, p_pos_num=1, p_neg_num=3) if ours else None
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(DEV)
+        B = 32
+        arrs = (t(d.sources, np.int32), t(d.destinations, np.int32), t(d.timestamps, np.float64), t(d.edge_idxs, np.int32),
+                t(g.portfolio_idx, np.int32), t(g.portfolio_len, np.int32), t(g.day_of(d.timestamps), np.int32))
+        gs = P.GraphedTrainStep(tgn, opt, sampler, B, 6, n_neg=3, port_width=arrs[4].shape[1], mv_sampler=mvs)
+        sides.append((tgn, opt, gs, arrs))
+    batch = lambda arrs, s: tuple(a[s:s + B] for a in arrs[:6]) + ((arrs[6][s:s + B],) if ours else (None,))
+    (tA, oA, gA, aA), (tB, oB, gB, aB) = sides
+    gA.capture(*batch(aA, 2400), warmup=2)                     # two eager steps + the capture (which executes nothing)
+    gB.capture(*batch(aB, 2400), warmup=2)
+    assert gA.graph is not None
+    for k in range(4):
+        with torch.no_grad():                                  # lockstep: A <- B (parameters, moments, memory, counters)
+            tA.flat_parameters.copy_(tB.flat_parameters)
+            oA._m.copy_(oB._m); oA._v.copy_(oB._v)
+            tA.memory.restore_memory(tB.memory.backup_memory()); tA.memory._any_msg = True
+            gA.rng_pos.copy_(gB.rng_pos); gA.adam_t.copy_(gB.adam_t)
+        before = tB.flat_parameters.clone()
+        la = float(gA(*batch(aA, 2432 + k * B)))               # ONE graph launch
+        lb = float(gB.eager(*batch(aB, 2432 + k * B)))         # ~85 launches
+        assert abs(la - lb) <= 2e-6 * max(1.0, abs(lb)), (k, la, lb)
+        ga, gb = tA.flat_grad, tB.flat_grad
+        assert (ga[64:] - gb[64:]).abs().max().item() <= 2e-5 * gb[64:].abs().max().item()
+        assert (ga[:64] - gb[:64]).abs().max().item() <= 3e-3 * gb[:64].abs().max().item()      # time encoder (D = 32: w, b)
+        dp = (tA.flat_parameters - tB.flat_parameters).abs()
+        assert dp.max().item() <= 2.1 * lr                     # Adam: a last-bit gradient difference moves a weight by at most ~lr
+        assert (dp > 1e-5).float().mean().item() < 2e-3        # ... and only where the gradient is at noise level
+        assert not torch.equal(before, tB.flat_parameters)
+        assert torch.equal(tA.memory.last_update, tB.memory.last_update) and torch.equal(tA.memory.msg_time, tB.memory.msg_time)
+        assert (tA.memory.memory - tB.memory.memory).abs().max().item() < 1e-5
+    assert gA.finish() == 4 and gB.finish() == 4
+    assert oA._steps[dict(tA.named_parameters())["time_encoder.w.weight"]] == 6
