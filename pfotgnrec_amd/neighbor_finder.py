@@ -95,6 +95,7 @@ class NeighborFinder:
         self.seed = 0 if seed is None else int(seed)
         self._calls = 0
         self._dev = {}
+        self._version = 0          # bumped whenever the adjacency changes (append): consumers re-fetch the device arrays
 
     @classmethod
     def from_arrays(cls, sources, destinations, edge_idxs, timestamps, uniform=False, max_node_idx=None, seed=None,
@@ -148,6 +149,7 @@ class NeighborFinder:
         self._dev = {str(dev): (n_ptr, n_nbr, n_eid, n_ts)}
         self.indptr, self.nbr, self.eidx, self.ts = (a.cpu().numpy() for a in (n_ptr, n_nbr, n_eid, n_ts))
         self.n_nodes = n_nodes
+        self._version += 1
         return self
 
     def next_stream_offset(self):

@@ -291,7 +291,8 @@ class TGN(nn.Module):
         else:
             caps = tuple(max(c, n) for c, n in zip(self._ws_caps, need))
             self._ws_caps = caps
-            self._ws_pool = [e for e in self._ws_pool if e[0] == caps]      # smaller buffers are not worth keeping
+            self._ws_pool[:] = [e for e in self._ws_pool if e[0] == caps]   # smaller buffers are not worth keeping (in place:
+                                                                            # outstanding calls hand theirs back to this list)
             cfg = self._cfg_for(caps)
             nbytes = _lib.load().pfo_tgn_workspace_bytes(ctypes.byref(cfg))
             if nbytes < 0:
@@ -325,7 +326,7 @@ class TGN(nn.Module):
         names nodes this model has no features for is refused.
         """
         nf = self.neighbor_finder
-        key = (id(nf), str(self.device))
+        key = (id(nf), str(self.device), getattr(nf, "_version", 0))        # append() bumps the version: new arrays
         if self._adj_cache is not None and self._adj_cache[0] == key and self._adj_cache[1] is nf:
             return self._adj_cache[2]
         indptr, nbr, eidx, ts = nf.device_arrays(self.device)

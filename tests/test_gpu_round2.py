@@ -123,6 +123,28 @@ def test_finder_smaller_than_node_table_is_padded_and_larger_is_refused():
         tgn.compute_temporal_embeddings(sb, db, neg, tb, eb, 6)
 
 
+def test_tgn_sees_edges_appended_to_its_finder():
+    """NeighborFinder.append replaces the device arrays: a TGN holding the finder must pick the new adjacency up."""
+    cfg, g, tgn = _setup(L=1, use_memory=False)
+    d = g.data
+    half = 2500
+    nf = P.NeighborFinder.from_arrays(d.sources[:half], d.destinations[:half], d.edge_idxs[:half], d.timestamps[:half],
+                                      max_node_idx=tgn.n_nodes - 1)
+    full = P.NeighborFinder.from_arrays(d.sources[:4000], d.destinations[:4000], d.edge_idxs[:4000], d.timestamps[:4000],
+                                        max_node_idx=tgn.n_nodes - 1)
+    rs = np.random.RandomState(5)
+    batch = _batch(cfg, g, 4000, 24, rs)
+    tgn.eval()
+    tgn.set_neighbor_finder(nf)
+    with torch.no_grad():
+        before = torch.cat(tgn.compute_temporal_embeddings(*batch, 6))
+        nf.append(d.sources[half:4000], d.destinations[half:4000], d.edge_idxs[half:4000], d.timestamps[half:4000], device=DEV)
+        after = torch.cat(tgn.compute_temporal_embeddings(*batch, 6))
+        tgn.set_neighbor_finder(full)
+        want = torch.cat(tgn.compute_temporal_embeddings(*batch, 6))
+    assert torch.equal(after, want) and not torch.equal(before, after)
+
+
 def test_dropout_follows_train_flag_and_autograd_follows_grad_mode():
     cfg, g, tgn = _setup(L=1, dropout=0.5, use_memory=False)
     rs = np.random.RandomState(2)
