@@ -496,7 +496,8 @@ __global__ __launch_bounds__(64) void attn_bwd_runs_kernel(const AttnDev a) {
       const float my_dt = inK ? a.dt[slot0 + lane] : 0.f;
       const unsigned long long valid = __ballot(inK && my_id != 0);
       const int slot = a.qk_row[n];
-      const int key = rl_i(my_e, K - 1);                         // memory.hpp: equal keys <=> identical neighbour lists
+      const int e_new = rl_i(my_e, K - 1);                       // common.hpp pfo_run_key: equal keys <=> identical neighbour lists
+      const int key = e_new * 2 + ((K >= 2 && e_new != 0 && rl_i(my_e, K >= 2 ? K - 2 : 0) == e_new) ? 1 : 0);
       if (slot != run_slot || key != run_key) {                  // a new run: the previous one's rows leave
         flush(run_rows, run_valid);
         run_slot = slot; run_key = key; run_rows = my_row; run_valid = valid;

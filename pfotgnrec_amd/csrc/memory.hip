@@ -181,10 +181,9 @@ __global__ void seg_place_kernel(const int32_t* __restrict__ idx, const int32_t*
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n < N && nodes[n] != 0) members[atomicAdd(&cursor[idx[n]], 1)] = n;
 }
-// one wavefront per group: members ordered by (run key, instance index).  The run key of an instance is the edge id in its
-// LAST neighbour slot (most-recent sampling: the K entries before the root time are determined by the newest of them, so
-// equal keys <=> identical neighbour lists; 0 = no neighbour) or, when `key_src` is null (uniform sampling: lists are
-// random), the instance index itself.  Instance indices are distinct, so ranks are too; the order is reproducible.
+// one wavefront per group: members ordered by (run key, instance index).  The run key of an instance (common.hpp
+// pfo_run_key) names the newest entry of its neighbour list: equal keys <=> identical neighbour lists under most-recent
+// sampling.  When `key_src` is null (uniform sampling: lists are random) the key is the instance index itself.  Instance indices are distinct, so ranks are too; the order is reproducible.
 __global__ void seg_sort_kernel(const int32_t* __restrict__ seg_ptr, int n_seg, const int32_t* __restrict__ in,
                                 const int32_t* __restrict__ key_src, int K, int32_t* __restrict__ out) {
   const int lane = threadIdx.x & 63;
@@ -193,11 +192,11 @@ __global__ void seg_sort_kernel(const int32_t* __restrict__ seg_ptr, int n_seg, 
     if (cnt <= 0) continue;
     for (int i = lane; i < cnt; i += 64) {
       const int x = in[lo + i];
-      const int kx = key_src ? key_src[(int64_t)x * K + K - 1] : x;
+      const int kx = key_src ? pfo_run_key(key_src + (int64_t)x * K, K) : x;
       int rank = 0;
       for (int j = 0; j < cnt; ++j) {
         const int y = in[lo + j];
-        const int ky = key_src ? key_src[(int64_t)y * K + K - 1] : y;
+        const int ky = key_src ? pfo_run_key(key_src + (int64_t)y * K, K) : y;
         rank += (ky < kx) || (ky == kx && y < x);
       }
       out[lo + rank] = x;

@@ -415,3 +415,57 @@ def test_rank_metrics_against_reference_fixture():
     assert np.all(g["pos_rank"] <= r) and np.all(g["pos_rank"] >= g["n_greater"])
     assert np.array_equal(hits.cpu().numpy()[free].astype(np.float64), g["recall"][free])
     assert np.allclose(ndcg.cpu().numpy()[free], g["ndcg"][free], rtol=0, atol=1e-6)
+
+
+def test_step_against_oracle_on_a_general_graph_with_self_loops_and_ties():
+    """Not bipartite: arbitrary node pairs, self-loops (both row entries of a self-loop carry one edge id) and few distinct
+    timestamps.  The run-merged layer-1 backward groups instances by (node, newest neighbour entry): this graph is where two
+    instances of a node can share the newest edge id and still differ in their neighbour lists."""
+    torch.manual_seed(77)
+    rs = np.random.RandomState(8)
+    n_nodes, E, D, K, L, H = 61, 1500, 16, 5, 2, 2
+    src = rs.randint(1, n_nodes, E)
+    dst = rs.randint(1, n_nodes, E)
+    dst[::9] = src[::9]                                            # self-loops
+    ts = np.sort(rs.randint(0, 60, E)).astype(np.float64)          # ~25 edges per timestamp
+    eidx = np.arange(1, E + 1)
+    node_feat, edge_feat = rs.rand(n_nodes, D), rs.randn(E + 1, 4)
+    edge_feat[0] = 0
+    nf = P.NeighborFinder.from_arrays(src, dst, eidx, ts, max_node_idx=n_nodes - 1)
+    tgn = P.TGN(nf, node_feat, edge_feat, DEV, n_layers=L, n_heads=H, dropout=0.0, use_memory=True, memory_dimension=D,
+                message_function="identity", n_neighbors=K)
+    with torch.no_grad():
+        tgn.time_encoder.w.bias.normal_(0, 0.3)
+    onf = OracleNeighborFinder(*build_adjacency(src, dst, eidx, ts, max_node_idx=n_nodes - 1))
+    names = [k for k in tgn.state_dict() if "layer_norm" not in k and not k.startswith("memory.")]
+    ref = T.OracleTGN(onf, node_feat, edge_feat, {k: tgn.state_dict()[k].cpu().numpy() for k in names}, L, H, True)
+    opt = P.FusedAdam(tgn, lr=1e-3)
+    B = 48
+    for step in range(3):
+        s = 900 + step * B
+        sb, db, tb, eb = src[s:s + B], dst[s:s + B], ts[s:s + B], eidx[s:s + B]
+        neg = rs.randint(1, n_nodes, size=B * 3)
+        ref.P = {k: tgn.state_dict()[k].detach().cpu().numpy().copy() for k in names}
+        tgn.train(); opt.zero_grad()
+        se, de, ne = tgn.compute_temporal_embeddings(sb, db, neg, tb, eb, K)
+        rse, rde, rne = ref.compute_temporal_embeddings(sb, db, neg, tb, eb, K)
+        emb = torch.cat([se, de, ne])
+        assert relerr(emb.detach().cpu().numpy(), np.concatenate([rse, rde, rne])) < RTOL_EMB
+        loss = P.bpr_loss(emb, B, 3)
+        loss.backward()
+        rl, cache = T.bpr_loss(rse, rde.reshape(B, 1, -1), rne.reshape(B, 3, -1))
+        ds, dp, dn = T.bpr_loss_backward(cache)
+        rgrads = ref.backward(np.concatenate([ds, dp.reshape(B, -1), dn.reshape(3 * B, -1)]))
+        for name, p in tgn.named_parameters():
+            if name not in rgrads or np.abs(rgrads[name]).max() < 1e-7:
+                continue
+            r = rgrads[name].reshape(p.shape)
+            if p.grad is None:                                      # step 0: no pending message, the GRU is not called
+                assert name.startswith("memory_updater") and np.abs(r).max() == 0
+                continue
+            got = p.grad.cpu().numpy().astype(np.float64)
+            e = np.linalg.norm(got - r) / (np.linalg.norm(r) + 1e-30)
+            assert e < (RTOL_GRAD_TIME if name.startswith("time_encoder") else RTOL_GRAD_ORACLE_L2), (step, name, e)
+        assert relerr(tgn.memory.memory.cpu().numpy(), ref.memory) < RTOL_EMB
+        assert np.array_equal(tgn.memory.last_update.cpu().numpy(), ref.last_update)
+        opt.step()
