@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64) void attn_bwd_runs_kernel(const AttnDev a) {
     const int m_end = min(M, (chunk + 1) * RUN_CHUNK);
     for (int m = chunk * RUN_CHUNK; m < m_end; ++m) {
       const int64_t n = a.members[m];
-      float* dqk_out = a.dQK + n * H * Cp;
+      float* dqk_out = a.dQK + (int64_t)m * H * Cp;             // row m, not n: the per-row sums then stream contiguous rows
       const int64_t slot0 = n * K;
       const bool inK = lane < K;
       const int my_id = inK ? a.nbr_ids[slot0 + lane] : 0;
@@ -719,6 +719,12 @@ int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream) {
   return PFO_OK;
 }
 
+bool pfo_attn_bwd_uses_runs(const PfoAttn& a) {
+  static const int runs_on = getenv("PFO_ATTN_RUNS") ? atoi(getenv("PFO_ATTN_RUNS")) : 1;                    // A/B switch
+  return a.d_nbr && a.nbr_row && runs_on && a.members && a.seg_ptr && a.n_rows && a.qk_row &&
+         (size_t)a.K * a.D * sizeof(float) <= 64 * 1024;
+}
+
 int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
   if (int rc = check_common(a)) return rc;
   PFO_REQUIRE(a.dctx && a.dQK && a.dtime_part, "null backward buffers");
@@ -730,9 +736,8 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
   const double C = 2.0 * a.D + a.Ef;
   const double bytes = (double)a.N * (a.K * (8.0 * a.D + 4.0 * a.Ef + 12.0) + 4.0 * a.H * C * 4.0 + 4.0 * a.H * a.K);
   const int dmode = !a.d_nbr ? 0 : (a.nbr_row ? 1 : 2);
-  static const int runs_on = getenv("PFO_ATTN_RUNS") ? atoi(getenv("PFO_ATTN_RUNS")) : 1;                    // A/B switch
   const size_t run_lds = (size_t)a.K * a.D * sizeof(float);
-  if (dmode == 1 && runs_on && a.members && a.seg_ptr && a.n_rows && a.qk_row && run_lds <= 64 * 1024) {
+  if (pfo_attn_bwd_uses_runs(a)) {
     // run-merged form: single-wavefront workgroups, one chunk of members each (the grid-stride loop only matters when the
     // grid is capped for an experiment)
     static const int rblocks = getenv("PFO_ATTN_RUNS_BLOCKS") ? atoi(getenv("PFO_ATTN_RUNS_BLOCKS")) : 0;

@@ -59,3 +59,6 @@ int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream);
 // *n_parts receives ATTN_TIME_BINS (rows of dtime_part that may hold contributions)
 int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream);
 int pfo_attn_bwd_max_parts();
+// true when pfo_attn_bwd_launch will take the run-merged kernel for `a`: dQK row m then belongs to the m-th MEMBER
+// (a.members[m]), not to instance m
+bool pfo_attn_bwd_uses_runs(const PfoAttn& a);

@@ -237,7 +237,8 @@ int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int ca
 #define SEGSUM_R 16
 __global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ src0, int W0, const float* __restrict__ src1, int W1,
                                                      const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ members,
-                                                     const int32_t* __restrict__ n_rows, float* __restrict__ out) {
+                                                     const int32_t* __restrict__ n_rows, int src0_by_position,
+                                                     float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int W = W0 + W1;
   const int nr = *n_rows;
@@ -250,22 +251,24 @@ __global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ s
       int m = lo;
       for (; m + 1 < hi; m += 2) {                       // two member rows in flight
         const int64_t na = members[m], nb = members[m + 1];
+        const int64_t pa = src0_by_position ? m : na, pb = src0_by_position ? m + 1 : nb;
         float va[SEGSUM_R], vb[SEGSUM_R];
 #pragma unroll
         for (int r = 0; r < SEGSUM_R; ++r) {
           const int c = c0 + lane + 64 * r;
-          va[r] = c < W0 ? src0[na * W0 + c] : (c < W ? src1[na * W1 + (c - W0)] : 0.f);
-          vb[r] = c < W0 ? src0[nb * W0 + c] : (c < W ? src1[nb * W1 + (c - W0)] : 0.f);
+          va[r] = c < W0 ? src0[pa * W0 + c] : (c < W ? src1[na * W1 + (c - W0)] : 0.f);
+          vb[r] = c < W0 ? src0[pb * W0 + c] : (c < W ? src1[nb * W1 + (c - W0)] : 0.f);
         }
 #pragma unroll
         for (int r = 0; r < SEGSUM_R; ++r) acc[r] = (acc[r] + va[r]) + vb[r];
       }
       if (m < hi) {
         const int64_t na = members[m];
+        const int64_t pa = src0_by_position ? m : na;
 #pragma unroll
         for (int r = 0; r < SEGSUM_R; ++r) {
           const int c = c0 + lane + 64 * r;
-          acc[r] += c < W0 ? src0[na * W0 + c] : (c < W ? src1[na * W1 + (c - W0)] : 0.f);
+          acc[r] += c < W0 ? src0[pa * W0 + c] : (c < W ? src1[na * W1 + (c - W0)] : 0.f);
         }
       }
 #pragma unroll
@@ -277,10 +280,11 @@ __global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ s
   }
 }
 int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, const int32_t* seg_ptr, const int32_t* members,
-                      const int32_t* n_rows, int cap_rows, float* out, hipStream_t stream) {
+                      const int32_t* n_rows, int cap_rows, int src0_by_position, float* out, hipStream_t stream) {
   PFO_REQUIRE(src0 && src1 && seg_ptr && members && n_rows && out && W0 > 0 && W1 > 0, "bad arguments");
   const int nb = (int)std::min<int64_t>(8192, std::max<int64_t>(1, pfo_ceil_div(cap_rows, 4)));
-  hipLaunchKernelGGL(segsum_kernel, dim3(nb), dim3(256), 0, stream, src0, W0, src1, W1, seg_ptr, members, n_rows, out);
+  hipLaunchKernelGGL(segsum_kernel, dim3(nb), dim3(256), 0, stream, src0, W0, src1, W1, seg_ptr, members, n_rows,
+                     src0_by_position, out);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

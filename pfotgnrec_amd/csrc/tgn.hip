@@ -647,6 +647,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");
       a.members = w.seg_mem; a.seg_ptr = w.seg_ptr; a.n_rows = w.n_touched;
     }
+    const int dqk_by_member = pfo_attn_bwd_uses_runs(a) ? 1 : 0;
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
     // merged query/key projection: dx += dqk' Wqk, dWqk = dqk'^T x, gqk = colsum(dqk')
     if (l == 1) {
@@ -655,7 +656,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       // weight gradients against x - is taken AFTER summing those gradients per table row: contractions over the
       // ~11 k touched rows instead of the ~54 k instances.
       HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");
-      RUN(pfo_segsum_launch(w.dQK, HCp, w.dh1, D, w.seg_ptr, w.seg_mem, w.n_touched, capP, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
+      RUN(pfo_segsum_launch(w.dQK, HCp, w.dh1, D, w.seg_ptr, w.seg_mem, w.n_touched, capP, dqk_by_member, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
       // the weight gradients over the table rows go to the side stream too (beside d h0 / the GRU backward on this one)
       HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
       HIPOK(hipStreamWaitEvent(ss, sd.tn_b, 0), "event wait failed");
