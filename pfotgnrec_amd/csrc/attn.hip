@@ -736,7 +736,8 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
   const double C = 2.0 * a.D + a.Ef;
   const double bytes = (double)a.N * (a.K * (8.0 * a.D + 4.0 * a.Ef + 12.0) + 4.0 * a.H * C * 4.0 + 4.0 * a.H * a.K);
   const int dmode = !a.d_nbr ? 0 : (a.nbr_row ? 1 : 2);
-  const size_t run_lds = (size_t)a.K * a.D * sizeof(float);
+  static const int lds_pad = getenv("PFO_ATTN_RUNS_LDSPAD") ? atoi(getenv("PFO_ATTN_RUNS_LDSPAD")) : 0;   // occupancy probe
+  const size_t run_lds = (size_t)a.K * a.D * sizeof(float) + lds_pad;
   if (pfo_attn_bwd_uses_runs(a)) {
     // run-merged form: single-wavefront workgroups, one chunk of members each (the grid-stride loop only matters when the
     // grid is capped for an experiment)

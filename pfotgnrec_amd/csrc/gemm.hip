@@ -1190,21 +1190,44 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_multi_kernel(const MultiDev
   }
 }
 
-// out[m, n] (+)= u[m] * v[n]
-__global__ void rank1_kernel(const float* __restrict__ u, int64_t ldu, const float* __restrict__ v, int64_t ldv, int M, int N,
-                             float* __restrict__ out, int64_t ldo) {
-  const int64_t total = (int64_t)M * N;
+// out[m, n] += u[m] * v[n], several independent updates in one launch (blockIdx.y = the update)
+struct Rank1Dev {
+  const float* u[PFO_RANK1_MAX]; const float* v[PFO_RANK1_MAX]; float* out[PFO_RANK1_MAX];
+  int64_t ldu[PFO_RANK1_MAX], ldv[PFO_RANK1_MAX], ldo[PFO_RANK1_MAX];
+  int M[PFO_RANK1_MAX], N[PFO_RANK1_MAX];
+};
+__global__ void rank1_kernel(const Rank1Dev g) {
+  const int q = blockIdx.y;
+  const int N = g.N[q];
+  const int64_t total = (int64_t)g.M[q] * N;
+  const float* __restrict__ u = g.u[q];
+  const float* __restrict__ v = g.v[q];
+  float* __restrict__ out = g.out[q];
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int m = (int)(e / N), n = (int)(e - (int64_t)m * N);
-    out[(int64_t)m * ldo + n] += u[(int64_t)m * ldu] * v[(int64_t)n * ldv];
+    out[(int64_t)m * g.ldo[q] + n] += u[(int64_t)m * g.ldu[q]] * v[(int64_t)n * g.ldv[q]];
   }
+}
+int pfo_rank1_multi_launch(const PfoRank1* list, int n, hipStream_t stream) {
+  PFO_REQUIRE(list && n >= 1 && n <= PFO_RANK1_MAX, "bad rank-1 list");
+  Rank1Dev g;
+  int64_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    const PfoRank1& r = list[i];
+    PFO_REQUIRE(r.u && r.v && r.out && r.M > 0 && r.N > 0, "bad rank-1 update");
+    g.u[i] = r.u; g.v[i] = r.v; g.out[i] = r.out; g.ldu[i] = r.ldu; g.ldv[i] = r.ldv; g.ldo[i] = r.ldo; g.M[i] = r.M; g.N[i] = r.N;
+    most = std::max(most, (int64_t)r.M * r.N);
+  }
+  const int nb = (int)std::min<int64_t>(512, pfo_ceil_div(most, 256));
+  hipLaunchKernelGGL(rank1_kernel, dim3(nb, n), dim3(256), 0, stream, g);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
 }
 int pfo_rank1_launch(const float* u, int64_t ldu, const float* v, int64_t ldv, int M, int N, float* out, int64_t ldo,
                      hipStream_t stream) {
-  const int nb = (int)std::min<int64_t>(512, pfo_ceil_div((int64_t)M * N, 256));
-  hipLaunchKernelGGL(rank1_kernel, dim3(nb), dim3(256), 0, stream, u, ldu, v, ldv, M, N, out, ldo);
-  PFO_LAUNCH_CHECK();
-  return PFO_OK;
+  PfoRank1 r;
+  r.u = u; r.ldu = ldu; r.v = v; r.ldv = ldv; r.M = M; r.N = N; r.out = out; r.ldo = ldo;
+  return pfo_rank1_multi_launch(&r, 1, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -58,6 +58,12 @@ bool pfo_gemm_takes_bx(int M, int N);
 #define PFO_GEMM_MULTI_MAX 10
 int pfo_gemm_multi_launch(const PfoGemm* list, int n, hipStream_t stream);
 // out[m, n] += u[m * ldu] * v[n * ldv]
+// several rank-1 updates out += u (x) v in one launch; the outputs must not overlap
+#define PFO_RANK1_MAX 12
+struct PfoRank1 {
+  const float* u = nullptr; int64_t ldu = 1; const float* v = nullptr; int64_t ldv = 1; int M = 0, N = 0; float* out = nullptr; int64_t ldo = 0;
+};
+int pfo_rank1_multi_launch(const PfoRank1* list, int n, hipStream_t stream);
 int pfo_rank1_launch(const float* u, int64_t ldu, const float* v, int64_t ldv, int M, int N, float* out, int64_t ldo,
                      hipStream_t stream);
 

@@ -86,10 +86,12 @@ int64_t pfo_compact_scratch_ints(int n_nodes) { return pfo_ceil_div(n_nodes, SCA
 
 int pfo_touch_compact_launch(const int32_t* nodes0, int64_t n0, const int32_t* extra, int64_t n_extra, int n_nodes,
                              int32_t* slot, int32_t* touched_ids, int32_t* n_touched, int32_t* scratch,
-                             hipStream_t stream) {
+                             bool slot_is_zero, hipStream_t stream) {
   PFO_REQUIRE(nodes0 && slot && touched_ids && n_touched && scratch && n0 > 0 && n_nodes > 0, "bad arguments");
-  hipError_t e = hipMemsetAsync(slot, 0, (size_t)n_nodes * sizeof(int32_t), stream);
-  PFO_REQUIRE(e == hipSuccess, "memset failed");
+  if (!slot_is_zero) {
+    hipError_t e = hipMemsetAsync(slot, 0, (size_t)n_nodes * sizeof(int32_t), stream);
+    PFO_REQUIRE(e == hipSuccess, "memset failed");
+  }
   const int nb = (int)pfo_ceil_div(n_nodes, SCAN_BLOCK);
   const int mb = (int)std::min<int64_t>(2048, pfo_ceil_div(n0, 256));
   hipLaunchKernelGGL(touch_mark_kernel, dim3(mb), dim3(256), 0, stream, nodes0, n0, n_nodes, slot);

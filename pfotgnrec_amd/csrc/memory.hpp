@@ -3,10 +3,11 @@
 #include "common.hpp"
 
 // --- touched-node compaction: slot[v] = rank of v among the nodes referenced this step, -1 otherwise
+// (slot_is_zero: the caller has already cleared slot[0, n_nodes) in stream order)
 int64_t pfo_compact_scratch_ints(int n_nodes);
 int pfo_touch_compact_launch(const int32_t* nodes0, int64_t n0, const int32_t* extra, int64_t n_extra, int n_nodes,
                              int32_t* slot, int32_t* touched_ids, int32_t* n_touched, int32_t* scratch,
-                             hipStream_t stream);
+                             bool slot_is_zero, hipStream_t stream);
 // packs the rows backward still needs after the state update overwrites them:
 //   msg_rows[s] = msg_table[id], h_rows[s] = memory[id], hm[s] = has_msg[id]   (id = touched_ids[s])
 int pfo_pack_rows_launch(const float* msg_table, int M, const float* memory, int D, const uint8_t* has_msg,

@@ -88,7 +88,7 @@ extern "C" int pfo_time_encode(const float* t, int64_t n, const float* w, const 
 // ---------------------------------------------------------------------------------------------
 // BPR (main.py:321-337): one wavefront per interaction
 __global__ void bpr_kernel(const float* __restrict__ emb, int64_t B, int D, int64_t pos_off, int64_t neg_off, int n_neg,
-                           float scale, float* __restrict__ loss_part, float* __restrict__ d_emb) {
+                           int64_t R, float scale, float* __restrict__ loss_part, float* __restrict__ d_emb) {
   const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (b >= B) return;
@@ -121,6 +121,13 @@ __global__ void bpr_kernel(const float* __restrict__ emb, int64_t B, int D, int6
       d_emb[b * D + d] = acc;
       d_emb[(pos_off + b) * D + d] = ddm * sd;
     }
+    // rows no pair touches (the destination block of the `ours` layout [src | dst | p_pos | neg], anything after the
+    // negatives) get their zero here: gap row g is written by interaction g mod B
+    const int64_t gap1 = pos_off - B, gap2 = neg_off - (pos_off + B), gap3 = R - (neg_off + B * n_neg);
+    for (int64_t gidx = b; gidx < gap1 + gap2 + gap3; gidx += B) {
+      const int64_t row = gidx < gap1 ? B + gidx : (gidx < gap1 + gap2 ? pos_off + B + (gidx - gap1) : neg_off + B * n_neg + (gidx - gap1 - gap2));
+      for (int d = lane; d < D; d += 64) d_emb[row * D + d] = 0.f;
+    }
   }
 }
 __global__ void bpr_mean_kernel(const float* __restrict__ loss_part, int64_t B, float* __restrict__ loss_out) {
@@ -136,12 +143,8 @@ extern "C" int pfo_bpr_loss(const float* emb, int64_t B, int32_t D, int64_t pos_
   PFO_REQUIRE(B > 0 && D > 0 && n_neg > 0, "bad sizes");
   PFO_REQUIRE(pos_off >= B && pos_off + B <= R && neg_off + B * n_neg <= R && neg_off >= pos_off + B, "bad offsets");
   hipStream_t s = (hipStream_t)stream;
-  if (d_emb) {
-    hipError_t e = hipMemsetAsync(d_emb, 0, (size_t)R * D * sizeof(float), s);
-    PFO_REQUIRE(e == hipSuccess, "memset failed");
-  }
   hipLaunchKernelGGL(bpr_kernel, dim3((unsigned)pfo_ceil_div(B, 4)), dim3(256), 0, s, emb, B, (int)D, pos_off, neg_off,
-                     (int)n_neg, scale, workspace, d_emb);
+                     (int)n_neg, R, scale, workspace, d_emb);
   hipLaunchKernelGGL(bpr_mean_kernel, dim3(1), dim3(64), 0, s, workspace, B, loss_out);
   PFO_LAUNCH_CHECK();
   return PFO_OK;

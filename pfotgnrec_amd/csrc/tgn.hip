@@ -241,7 +241,7 @@ PfoGemm g_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const int
 // dependent launches; they run beside the main stream's work and are joined by events where their results are needed.
 struct Side {
   hipStream_t s = nullptr;
-  hipEvent_t fork = nullptr, done = nullptr, gru_fork = nullptr, gru_join = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr;
+  hipEvent_t fork = nullptr, done = nullptr, gru_fork = nullptr, gru_join = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr, slot0 = nullptr;
   hipEvent_t layer[PFO_MAX_LAYERS + 1] = {};
   bool ok = false;
 };
@@ -256,6 +256,7 @@ Side& side() {
     good = good && hipEventCreateWithFlags(&sd.seg_done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.tn_a, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.tn_b, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.slot0, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; l <= PFO_MAX_LAYERS; ++l) good = good && hipEventCreateWithFlags(&sd.layer[l], hipEventDisableTiming) == hipSuccess;
     sd.ok = good;
   }
@@ -362,6 +363,9 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   // it are what the main stream is waiting for.  All layers share each launch.
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
+  // the compaction's flags are cleared beside the sampling launches rather than between them and the marking pass
+  HIPOK(hipMemsetAsync(w.slot, 0, (size_t)c->n_nodes * sizeof(int32_t), ss), "memset failed");
+  HIPOK(hipEventRecord(sd.slot0, ss), "event record failed");
   // ---- frontier expansion: K1 per level (utils.py:163-219 called from embedding_module.py:125).  Enqueued before the
   // side-stream work below: it depends on nothing else, and the GPU samples while the host is still enqueueing
   for (int l = L; l >= 1; --l) {
@@ -437,8 +441,9 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   // slot[v] = row of v in the per-step tables, idx0[i] = row of the i-th level-0 reference
   PFO_REQUIRE(b->n_extra >= 0 && b->n_extra <= 2 * c->max_batch, "n_extra exceeds 2 * max_batch");
   PFO_REQUIRE(b->n_extra == 0 || b->extra_nodes, "null extra_nodes");
+  HIPOK(hipStreamWaitEvent(s, sd.slot0, 0), "event wait failed");
   RUN(pfo_touch_compact_launch(w.nodes[0], n[0], b->extra_nodes, b->n_extra, c->n_nodes, w.slot, w.touched, w.n_touched,
-                               w.scan, s));
+                               w.scan, true, s));
   RUN(pfo_remap_launch(w.nodes[0], n[0], w.slot, w.idx0, s));
   const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
   // ---- level-0 rows of the touched nodes: memory' + node features (embedding_module.py:93-98), memory' = the lazily
@@ -606,24 +611,31 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       q.b_img = lw.iW2T;
       RUN(pfo_gemm_launch(q, s));
     }
+    set_tn(tn[1], lw.ctx, HCp, w.dh1, D, nullptr, HCp, D, lw.dW1ovT, D, nullptr);       // dW1ovT = ctx'^T dh1
+    tn[1].c_accumulate = 0;
+    // The two weight gradients over the INSTANCES (dW2 / db2, dW1ovT) need only dOut, h1, ctx' and dh1: they go to the side
+    // stream as soon as dh1 exists, beside the d ctx' contraction and the attention backward (measured: 15 us/step better than
+    // forking them next to the attention backward alone, whose single-wavefront workgroups starve a 74 KB-LDS kernel of slots)
+    static const int tna_mode = getenv("PFO_TNA_MODE") ? atoi(getenv("PFO_TNA_MODE")) : 2;   // A/B: 0 fork before the attention backward, 1 main stream
+    auto tn_a_side = [&]() -> int {
+      HIPOK(hipEventRecord(sd.tn_a, s), "event record failed");
+      HIPOK(hipStreamWaitEvent(ss, sd.tn_a, 0), "event wait failed");
+      RUN(pfo_gemm_tn_group_launch(tn, 2, N, nullptr, w.slabs2, w.slab_floats, ss));
+      return PFO_OK;
+    };
+    if (l == 1 && tna_mode == 2 && !pfo_prof_on()) RUN(tn_a_side());
     // merged fc1: d ctx' = dh1 W1ovT^T (dx = dh1 W1[:, E:] is taken together with the query/key part below)
     {
       PfoGemm q = g_nt(w.dh1, D, nullptr, lw.W1ovT, D, w.dctx, HCp, N, HCp, D, nullptr);
       q.b_img = lw.iW1ovT;
       RUN(pfo_gemm_launch(q, s));
     }
-    set_tn(tn[1], lw.ctx, HCp, w.dh1, D, nullptr, HCp, D, lw.dW1ovT, D, nullptr);       // dW1ovT = ctx'^T dh1
-    tn[1].c_accumulate = 0;
     if (l > 1) set_tn(tn[2], w.dh1, D, xA, D, x_idx, D, D, g.w1 + E, E + D, g.b1);     // dW1[:, E:], db1
     if (l == 1) {
-      // The two weight gradients over the INSTANCES (dW2 / db2, dW1ovT) need only dOut, h1, ctx' and dh1: they run on the
-      // side stream beside the attention backward, which is latency-bound (matrix pipe idle, VALU ~45 % busy)
-      if (pfo_prof_on()) {        // event-bracketed step (bench.py's roofline sample): serial, so the bracket times the kernel alone
+      if (pfo_prof_on() || tna_mode == 1) {        // event-bracketed step (bench.py's roofline sample): serial, so the bracket times the kernel alone
         RUN(pfo_gemm_tn_group_launch(tn, 2, N, nullptr, w.slabs, w.slab_floats, s));
-      } else {
-        HIPOK(hipEventRecord(sd.tn_a, s), "event record failed");
-        HIPOK(hipStreamWaitEvent(ss, sd.tn_a, 0), "event wait failed");
-        RUN(pfo_gemm_tn_group_launch(tn, 2, N, nullptr, w.slabs2, w.slab_floats, ss));
+      } else if (tna_mode == 0) {
+        RUN(tn_a_side());
       }
     }
     // attention core
@@ -715,13 +727,25 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       c1[5] = g_nt(p.wk, C, nullptr, lw.gqk, C, lw.gq, 1, dh, 1, C, nullptr);                // d cq_h = Wk_h gqk_h
       c1[5].batch = H; c1[5].a_bs[0] = (int64_t)dh * C; c1[5].b_bs[0] = Cp; c1[5].c_bs = dh;
       RUN(pfo_gemm_multi_launch(c1, 6, ss));
-      for (int h = 0; h < H; ++h) {
-        // W1ovT row C = bv_h^T W1oT_h  and  cqk_h = Wk_h^T cq_h : the outer-product halves of their gradients
-        RUN(pfo_rank1_launch(p.b_in + 2 * E + h * dh, 1, lw.dW1ovT + ((int64_t)h * Cp + C) * D, 1, dh, D,
-                             lw.dW1oT + (int64_t)h * dh * D, D, ss));
-        RUN(pfo_rank1_launch(lw.cq + h * dh, 1, lw.gqk + (int64_t)h * Cp, 1, dh, C, g.wk + (int64_t)h * dh * C, C, ss));
-      }
       const float* dc = lw.dW1ovT + (int64_t)(C + 1) * D;                                   // gradient of (W1 bo)^T
+      {
+        // the outer-product halves, one launch (disjoint outputs; all after c1, all before c2 - which reads dW1oT and
+        // accumulates into dW1 like the last of these):
+        //   W1ovT row C = bv_h^T W1oT_h,   cqk_h = Wk_h^T cq_h,   dW1[:, :E] += dc (x) bo
+        PFO_REQUIRE(2 * H + 1 <= PFO_RANK1_MAX, "too many heads");
+        PfoRank1 r1[PFO_RANK1_MAX];
+        for (int h = 0; h < H; ++h) {
+          PfoRank1& a1 = r1[2 * h];
+          a1.u = p.b_in + 2 * E + h * dh; a1.ldu = 1; a1.v = lw.dW1ovT + ((int64_t)h * Cp + C) * D; a1.ldv = 1;
+          a1.M = dh; a1.N = D; a1.out = lw.dW1oT + (int64_t)h * dh * D; a1.ldo = D;
+          PfoRank1& a2 = r1[2 * h + 1];
+          a2.u = lw.cq + h * dh; a2.ldu = 1; a2.v = lw.gqk + (int64_t)h * Cp; a2.ldv = 1;
+          a2.M = dh; a2.N = C; a2.out = g.wk + (int64_t)h * dh * C; a2.ldo = C;
+        }
+        PfoRank1& a3 = r1[2 * H];
+        a3.u = dc; a3.ldu = 1; a3.v = p.bo; a3.ldv = 1; a3.M = D; a3.N = E; a3.out = g.w1; a3.ldo = E + D;
+        RUN(pfo_rank1_multi_launch(r1, 2 * H + 1, ss));
+      }
       PfoGemm c2[3];
       c2[0] = g_nt(lw.dW1oT, D, nullptr, p.wo, E, g.w1, E + D, D, E, E, nullptr);           // dW1[:, :E] += dW1o Wo^T
       c2[0].a_kmajor = 1; c2[0].accumulate = 1;
@@ -730,7 +754,6 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       c2[2] = g_nt(p.w1, E + D, nullptr, dc, D, g.bo, 1, E, 1, D, nullptr);                // dbo += W1[:, :E]^T dc
       c2[2].a_kmajor = 1; c2[2].accumulate = 1;
       RUN(pfo_gemm_multi_launch(c2, 3, ss));
-      RUN(pfo_rank1_launch(dc, 1, p.bo, 1, D, E, g.w1, E + D, ss));                          // dW1[:, :E] += dc (x) bo
     }
   }
 
@@ -747,11 +770,11 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       RUN(pfo_gemm_tn_group_launch(gp, 2, capP, w.n_touched, w.slabs, w.slab_floats, s));
     }
   }
-  // join the side stream; the folded query-bias backward touches the time-encoder bias gradient, which the main
-  // stream's folds also accumulate, so it runs here, after both are done
+  // the time-encoder partial sums of the attention backwards fold while the side stream is still chaining (time_w, time_b
+  // adjacent); then join: the folded query-bias backward accumulates into the same time_b gradient, so it comes after both
+  RUN(pfo_fold_parts_launch(w.dtime, pfo_attn_bwd_max_parts(), 2 * D, G.tw, 1, w.fold_scratch, w.tickets, s));
   HIPOK(hipEventRecord(sd.done, ss), "event record failed");
   HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
-  RUN(pfo_fold_parts_launch(w.dtime, pfo_attn_bwd_max_parts(), 2 * D, G.tw, 1, w.fold_scratch, w.tickets, s));   // time_w, time_b adjacent
   for (int l = 1; l <= L; ++l)
     RUN(pfo_cq_backward_launch(w.layer[l].gq, P.l[l].wq, P.tb, D, G.l[l].b_in, G.l[l].wq, G.tb, s));   // cq = Wq[:, D:] cos(b) + bq
   return PFO_OK;
