@@ -240,7 +240,8 @@ PfoGemm g_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const int
 // Internal side stream: the composite-weight products (forward) and their gradient chain (backward) are tiny
 // dependent launches; they run beside the main stream's work and are joined by events where their results are needed.
 struct Side {
-  hipStream_t s = nullptr;
+  hipStream_t s = nullptr, s2 = nullptr;
+  hipEvent_t tn_a_done = nullptr, done2 = nullptr;
   hipEvent_t fork = nullptr, done = nullptr, gru_fork = nullptr, gru_join = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr, slot0 = nullptr;
   hipEvent_t layer[PFO_MAX_LAYERS + 1] = {};
   bool ok = false;
@@ -249,6 +250,9 @@ Side& side() {
   static Side sd;
   if (!sd.ok) {
     bool good = hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) == hipSuccess;
+    good = good && hipStreamCreateWithFlags(&sd.s2, hipStreamNonBlocking) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.tn_a_done, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.done2, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.gru_fork, hipEventDisableTiming) == hipSuccess;
@@ -621,6 +625,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       HIPOK(hipEventRecord(sd.tn_a, s), "event record failed");
       HIPOK(hipStreamWaitEvent(ss, sd.tn_a, 0), "event wait failed");
       RUN(pfo_gemm_tn_group_launch(tn, 2, N, nullptr, w.slabs2, w.slab_floats, ss));
+      HIPOK(hipEventRecord(sd.tn_a_done, ss), "event record failed");
       return PFO_OK;
     };
     if (l == 1 && tna_mode == 2 && !pfo_prof_on()) RUN(tn_a_side());
@@ -634,6 +639,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     if (l == 1) {
       if (pfo_prof_on() || tna_mode == 1) {        // event-bracketed step (bench.py's roofline sample): serial, so the bracket times the kernel alone
         RUN(pfo_gemm_tn_group_launch(tn, 2, N, nullptr, w.slabs, w.slab_floats, s));
+        HIPOK(hipEventRecord(sd.tn_a_done, s), "event record failed");
       } else if (tna_mode == 0) {
         RUN(tn_a_side());
       }
@@ -705,55 +711,60 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       RUN(pfo_gemm_tn_group_launch(tn, 4, N, nullptr, w.slabs, w.slab_floats, s));
     }
 
-    // ---- chain the composite-weight gradients back to the parameters (tiny products, side stream)
-    HIPOK(hipEventRecord(sd.layer[l], s), "event record failed");
-    HIPOK(hipStreamWaitEvent(ss, sd.layer[l], 0), "event wait failed");
+    // ---- chain the composite-weight gradients back to the parameters (tiny products, side streams).  Half A hangs off
+    // dW1ovT (the weight gradients over the instances), half B off dWqk / gqk (those over the table rows).  At layer 1 the
+    // two sources finish ~100 us apart on the side stream, so half A gets a stream of its own and is done before half B starts.
     {
-      PfoGemm c1[6];
-      c1[0] = g_nn(p.wv, C, lw.dW1ovT, D, lw.dW1oT, D, dh, D, C);                          // dW1oT_h = Wv_h dW1ovT_h
-      c1[0].batch = H; c1[0].a_bs[0] = (int64_t)dh * C; c1[0].b_bs[0] = (int64_t)Cp * D; c1[0].c_bs = (int64_t)dh * D;
-      c1[1] = g_nt(lw.W1oT, D, nullptr, lw.dW1ovT, D, g.wv, C, dh, C, D, nullptr);          // dWv_h += W1oT_h dW1ovT_h^T
-      c1[1].batch = H; c1[1].a_bs[0] = (int64_t)dh * D; c1[1].b_bs[0] = (int64_t)Cp * D; c1[1].c_bs = (int64_t)dh * C;
-      c1[1].accumulate = 1;
-      c1[2] = g_nt(lw.W1oT, D, nullptr, lw.dW1ovT + (int64_t)C * D, D, g.b_in + 2 * E, 1, dh, 1, D, nullptr);   // dbv_h += W1oT_h du_h
-      c1[2].batch = H; c1[2].a_bs[0] = (int64_t)dh * D; c1[2].b_bs[0] = (int64_t)Cp * D; c1[2].c_bs = dh;
-      c1[2].accumulate = 1;
-      c1[3] = g_nt(p.wq, E, nullptr, lw.dWqk, D, g.wk, C, dh, C, D, nullptr);               // dWk_h += Wq_h[:, :D] dWqk_h^T
-      c1[3].batch = H; c1[3].a_bs[0] = (int64_t)dh * E; c1[3].b_bs[0] = (int64_t)Cp * D; c1[3].c_bs = (int64_t)dh * C;
-      c1[3].accumulate = 1;
-      c1[4] = g_nn(p.wk, C, lw.dWqk, D, g.wq, E, dh, D, C);                                 // dWq_h[:, :D] += Wk_h dWqk_h
-      c1[4].batch = H; c1[4].a_bs[0] = (int64_t)dh * C; c1[4].b_bs[0] = (int64_t)Cp * D; c1[4].c_bs = (int64_t)dh * E;
-      c1[4].accumulate = 1;
-      c1[5] = g_nt(p.wk, C, nullptr, lw.gqk, C, lw.gq, 1, dh, 1, C, nullptr);                // d cq_h = Wk_h gqk_h
-      c1[5].batch = H; c1[5].a_bs[0] = (int64_t)dh * C; c1[5].b_bs[0] = Cp; c1[5].c_bs = dh;
-      RUN(pfo_gemm_multi_launch(c1, 6, ss));
+      PfoGemm ca[3], cb[3], c2[3];
+      ca[0] = g_nn(p.wv, C, lw.dW1ovT, D, lw.dW1oT, D, dh, D, C);                          // dW1oT_h = Wv_h dW1ovT_h
+      ca[0].batch = H; ca[0].a_bs[0] = (int64_t)dh * C; ca[0].b_bs[0] = (int64_t)Cp * D; ca[0].c_bs = (int64_t)dh * D;
+      ca[1] = g_nt(lw.W1oT, D, nullptr, lw.dW1ovT, D, g.wv, C, dh, C, D, nullptr);          // dWv_h += W1oT_h dW1ovT_h^T
+      ca[1].batch = H; ca[1].a_bs[0] = (int64_t)dh * D; ca[1].b_bs[0] = (int64_t)Cp * D; ca[1].c_bs = (int64_t)dh * C;
+      ca[1].accumulate = 1;
+      ca[2] = g_nt(lw.W1oT, D, nullptr, lw.dW1ovT + (int64_t)C * D, D, g.b_in + 2 * E, 1, dh, 1, D, nullptr);   // dbv_h += W1oT_h du_h
+      ca[2].batch = H; ca[2].a_bs[0] = (int64_t)dh * D; ca[2].b_bs[0] = (int64_t)Cp * D; ca[2].c_bs = dh;
+      ca[2].accumulate = 1;
+      cb[0] = g_nt(p.wq, E, nullptr, lw.dWqk, D, g.wk, C, dh, C, D, nullptr);               // dWk_h += Wq_h[:, :D] dWqk_h^T
+      cb[0].batch = H; cb[0].a_bs[0] = (int64_t)dh * E; cb[0].b_bs[0] = (int64_t)Cp * D; cb[0].c_bs = (int64_t)dh * C;
+      cb[0].accumulate = 1;
+      cb[1] = g_nn(p.wk, C, lw.dWqk, D, g.wq, E, dh, D, C);                                 // dWq_h[:, :D] += Wk_h dWqk_h
+      cb[1].batch = H; cb[1].a_bs[0] = (int64_t)dh * C; cb[1].b_bs[0] = (int64_t)Cp * D; cb[1].c_bs = (int64_t)dh * E;
+      cb[1].accumulate = 1;
+      cb[2] = g_nt(p.wk, C, nullptr, lw.gqk, C, lw.gq, 1, dh, 1, C, nullptr);                // d cq_h = Wk_h gqk_h
+      cb[2].batch = H; cb[2].a_bs[0] = (int64_t)dh * C; cb[2].b_bs[0] = Cp; cb[2].c_bs = dh;
       const float* dc = lw.dW1ovT + (int64_t)(C + 1) * D;                                   // gradient of (W1 bo)^T
-      {
-        // the outer-product halves, one launch (disjoint outputs; all after c1, all before c2 - which reads dW1oT and
-        // accumulates into dW1 like the last of these):
-        //   W1ovT row C = bv_h^T W1oT_h,   cqk_h = Wk_h^T cq_h,   dW1[:, :E] += dc (x) bo
-        PFO_REQUIRE(2 * H + 1 <= PFO_RANK1_MAX, "too many heads");
-        PfoRank1 r1[PFO_RANK1_MAX];
-        for (int h = 0; h < H; ++h) {
-          PfoRank1& a1 = r1[2 * h];
-          a1.u = p.b_in + 2 * E + h * dh; a1.ldu = 1; a1.v = lw.dW1ovT + ((int64_t)h * Cp + C) * D; a1.ldv = 1;
-          a1.M = dh; a1.N = D; a1.out = lw.dW1oT + (int64_t)h * dh * D; a1.ldo = D;
-          PfoRank1& a2 = r1[2 * h + 1];
-          a2.u = lw.cq + h * dh; a2.ldu = 1; a2.v = lw.gqk + (int64_t)h * Cp; a2.ldv = 1;
-          a2.M = dh; a2.N = C; a2.out = g.wk + (int64_t)h * dh * C; a2.ldo = C;
-        }
-        PfoRank1& a3 = r1[2 * H];
-        a3.u = dc; a3.ldu = 1; a3.v = p.bo; a3.ldv = 1; a3.M = D; a3.N = E; a3.out = g.w1; a3.ldo = E + D;
-        RUN(pfo_rank1_multi_launch(r1, 2 * H + 1, ss));
-      }
-      PfoGemm c2[3];
       c2[0] = g_nt(lw.dW1oT, D, nullptr, p.wo, E, g.w1, E + D, D, E, E, nullptr);           // dW1[:, :E] += dW1o Wo^T
       c2[0].a_kmajor = 1; c2[0].accumulate = 1;
       c2[1] = g_nt(p.w1, E + D, nullptr, lw.dW1oT, D, g.wo, E, E, E, D, nullptr);           // dWo += W1[:, :E]^T dW1o
       c2[1].a_kmajor = 1; c2[1].accumulate = 1;
       c2[2] = g_nt(p.w1, E + D, nullptr, dc, D, g.bo, 1, E, 1, D, nullptr);                // dbo += W1[:, :E]^T dc
       c2[2].a_kmajor = 1; c2[2].accumulate = 1;
-      RUN(pfo_gemm_multi_launch(c2, 3, ss));
+      // the outer-product halves of the composite gradients, one launch per half (disjoint outputs):
+      //   A: W1ovT row C = bv_h^T W1oT_h (into dW1oT, which c2 reads),  dW1[:, :E] += dc (x) bo     B: cqk_h = Wk_h^T cq_h
+      PFO_REQUIRE(H + 1 <= PFO_RANK1_MAX, "too many heads");
+      PfoRank1 ra[PFO_RANK1_MAX], rb[PFO_RANK1_MAX];
+      for (int h = 0; h < H; ++h) {
+        ra[h].u = p.b_in + 2 * E + h * dh; ra[h].ldu = 1; ra[h].v = lw.dW1ovT + ((int64_t)h * Cp + C) * D; ra[h].ldv = 1;
+        ra[h].M = dh; ra[h].N = D; ra[h].out = lw.dW1oT + (int64_t)h * dh * D; ra[h].ldo = D;
+        rb[h].u = lw.cq + h * dh; rb[h].ldu = 1; rb[h].v = lw.gqk + (int64_t)h * Cp; rb[h].ldv = 1;
+        rb[h].M = dh; rb[h].N = C; rb[h].out = g.wk + (int64_t)h * dh * C; rb[h].ldo = C;
+      }
+      ra[H].u = dc; ra[H].ldu = 1; ra[H].v = p.bo; ra[H].ldv = 1; ra[H].M = D; ra[H].N = E; ra[H].out = g.w1; ra[H].ldo = E + D;
+      hipStream_t sa = ss;
+      if (l == 1) {
+        // both sources were launched on side streams (or, bracketed for profiling, the first on the main stream): no need to
+        // hold the chain behind the main stream's d h0 contraction
+        sa = sd.s2;
+        HIPOK(hipStreamWaitEvent(sa, sd.tn_a_done, 0), "event wait failed");
+      } else {
+        HIPOK(hipEventRecord(sd.layer[l], s), "event record failed");
+        HIPOK(hipStreamWaitEvent(ss, sd.layer[l], 0), "event wait failed");
+      }
+      RUN(pfo_gemm_multi_launch(ca, 3, sa));
+      RUN(pfo_rank1_multi_launch(ra, H + 1, sa));
+      RUN(pfo_gemm_multi_launch(c2, 3, sa));
+      RUN(pfo_gemm_multi_launch(cb, 3, ss));
+      RUN(pfo_rank1_multi_launch(rb, H, ss));
     }
   }
 
@@ -775,6 +786,8 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
   RUN(pfo_fold_parts_launch(w.dtime, pfo_attn_bwd_max_parts(), 2 * D, G.tw, 1, w.fold_scratch, w.tickets, s));
   HIPOK(hipEventRecord(sd.done, ss), "event record failed");
   HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
+  HIPOK(hipEventRecord(sd.done2, sd.s2), "event record failed");
+  HIPOK(hipStreamWaitEvent(s, sd.done2, 0), "event wait failed");
   for (int l = 1; l <= L; ++l)
     RUN(pfo_cq_backward_launch(w.layer[l].gq, P.l[l].wq, P.tb, D, G.l[l].b_in, G.l[l].wq, G.tb, s));   // cq = Wq[:, D:] cos(b) + bq
   return PFO_OK;
