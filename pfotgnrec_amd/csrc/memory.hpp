@@ -56,8 +56,8 @@ int pfo_msg_store_launch(const int32_t* src, const int32_t* dst, const double* t
 // --- small ops (misc.hip)
 // cq = Wq[:, D:2D] cos(b) + bq folded query bias: backward of that term
 //   gq[E] = colsum(dQ);  d bq += gq;  d Wq[:, D:] += gq (x) cosb;  d tb += -sin(tb) * (Wq[:, D:]^T gq)
-int pfo_cq_backward_launch(const float* gq, const float* Wq, const float* tb, int D, float* d_bq, float* d_Wq,
-                           float* d_tb, hipStream_t stream);
+int pfo_cq_backward_launch(const float* const* gq, const float* const* Wq, int n_layers, const float* tb, int D, float* const* d_bq,
+                           float* const* d_Wq, float* d_tb, hipStream_t stream);
 // scratch: pfo_fold_parts_scratch_doubles(n) doubles; tickets: 64 ints, zero before the first use (self-resetting)
 int64_t pfo_fold_parts_scratch_doubles(int n);
 int pfo_fold_parts_launch(const double* parts, int n_parts, int n, float* out, int accumulate, double* scratch, int* tickets,

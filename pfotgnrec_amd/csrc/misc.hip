@@ -299,29 +299,44 @@ extern "C" int pfo_adam_step_ranges_dev(float* param, const float* grad, float* 
   return PFO_OK;
 }
 
-// one workgroup per time dimension d: d Wq[:, D+d] += gq * cos(b_d);  d tb[d] += -sin(b_d) * sum_e Wq[e, D+d] gq[e]
-__global__ __launch_bounds__(256) void cq_backward_kernel(const float* __restrict__ gq, const float* __restrict__ Wq,
-                                                          const float* __restrict__ tb, int D, float* __restrict__ d_bq,
-                                                          float* __restrict__ d_Wq, float* __restrict__ d_tb) {
+// one workgroup per time dimension d, every layer in turn: d Wq[:, D+d] += gq * cos(b_d);  d tb[d] += -sin(b_d) * sum_e Wq[e, D+d] gq[e]
+struct CqBwdDev {
+  const float* gq[PFO_MAX_LAYERS]; const float* Wq[PFO_MAX_LAYERS]; float* d_bq[PFO_MAX_LAYERS]; float* d_Wq[PFO_MAX_LAYERS];
+  int n;
+};
+__global__ __launch_bounds__(256) void cq_backward_kernel(const CqBwdDev q, const float* __restrict__ tb, int D, float* __restrict__ d_tb) {
   __shared__ float s_part[4];
   const int d = blockIdx.x, E = 2 * D;
   float sb, cb;
   pfo_sincosf(tb[d], sb, cb);                                     // query time feature is cos(fma(0, w, b)) = cos(b)
-  float part = 0.f;
-  for (int e = threadIdx.x; e < E; e += 256) {
-    const float g = gq[e];
-    d_Wq[(int64_t)e * E + D + d] += g * cb;
-    part = fmaf(Wq[(int64_t)e * E + D + d], g, part);
-    if (d == 0) d_bq[e] += g;
+  float total = 0.f;
+  for (int l = 0; l < q.n; ++l) {
+    const float* __restrict__ gq = q.gq[l];
+    const float* __restrict__ Wq = q.Wq[l];
+    float* __restrict__ d_Wq = q.d_Wq[l];
+    float* __restrict__ d_bq = q.d_bq[l];
+    float part = 0.f;
+    for (int e = threadIdx.x; e < E; e += 256) {
+      const float g = gq[e];
+      d_Wq[(int64_t)e * E + D + d] += g * cb;
+      part = fmaf(Wq[(int64_t)e * E + D + d], g, part);
+      if (d == 0) d_bq[e] += g;
+    }
+    part = pfo_wave_sum(part);
+    __syncthreads();                                              // the previous layer's partials have been read
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) total += (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
   }
-  part = pfo_wave_sum(part);
-  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
-  __syncthreads();
-  if (threadIdx.x == 0) d_tb[d] += -sb * (s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+  if (threadIdx.x == 0) d_tb[d] += -sb * total;
 }
-int pfo_cq_backward_launch(const float* gq, const float* Wq, const float* tb, int D, float* d_bq, float* d_Wq,
-                           float* d_tb, hipStream_t stream) {
-  hipLaunchKernelGGL(cq_backward_kernel, dim3(D), dim3(256), 0, stream, gq, Wq, tb, D, d_bq, d_Wq, d_tb);
+int pfo_cq_backward_launch(const float* const* gq, const float* const* Wq, int n_layers, const float* tb, int D, float* const* d_bq,
+                           float* const* d_Wq, float* d_tb, hipStream_t stream) {
+  PFO_REQUIRE(n_layers >= 1 && n_layers <= PFO_MAX_LAYERS, "bad layer count");
+  CqBwdDev q;
+  q.n = n_layers;
+  for (int l = 0; l < n_layers; ++l) { q.gq[l] = gq[l]; q.Wq[l] = Wq[l]; q.d_bq[l] = d_bq[l]; q.d_Wq[l] = d_Wq[l]; }
+  hipLaunchKernelGGL(cq_backward_kernel, dim3(D), dim3(256), 0, stream, q, tb, D, d_tb);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

@@ -781,15 +781,20 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       RUN(pfo_gemm_tn_group_launch(gp, 2, capP, w.n_touched, w.slabs, w.slab_floats, s));
     }
   }
-  // the time-encoder partial sums of the attention backwards fold while the side stream is still chaining (time_w, time_b
-  // adjacent); then join: the folded query-bias backward accumulates into the same time_b gradient, so it comes after both
+  // the time-encoder partial sums of the attention backwards fold while the side streams are still chaining (time_w, time_b
+  // adjacent; measured: on a side stream of its own, right after the attention backward, this fold costs 30 us/step);
+  // then join: the folded query-bias backward accumulates into the same time_b gradient, so it comes after both
   RUN(pfo_fold_parts_launch(w.dtime, pfo_attn_bwd_max_parts(), 2 * D, G.tw, 1, w.fold_scratch, w.tickets, s));
   HIPOK(hipEventRecord(sd.done, ss), "event record failed");
   HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
   HIPOK(hipEventRecord(sd.done2, sd.s2), "event record failed");
   HIPOK(hipStreamWaitEvent(s, sd.done2, 0), "event wait failed");
-  for (int l = 1; l <= L; ++l)
-    RUN(pfo_cq_backward_launch(w.layer[l].gq, P.l[l].wq, P.tb, D, G.l[l].b_in, G.l[l].wq, G.tb, s));   // cq = Wq[:, D:] cos(b) + bq
+  {
+    const float *gq[PFO_MAX_LAYERS], *wq[PFO_MAX_LAYERS];
+    float *dbq[PFO_MAX_LAYERS], *dwq[PFO_MAX_LAYERS];
+    for (int l = 1; l <= L; ++l) { gq[l - 1] = w.layer[l].gq; wq[l - 1] = P.l[l].wq; dbq[l - 1] = G.l[l].b_in; dwq[l - 1] = G.l[l].wq; }
+    RUN(pfo_cq_backward_launch(gq, wq, L, P.tb, D, dbq, dwq, G.tb, s));                  // cq = Wq[:, D:] cos(b) + bq
+  }
   return PFO_OK;
 }
 
