@@ -339,13 +339,24 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
         ke[c] = (js[c] >= 0 && lane < Ef) ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
       }
       float part[KC_BWD][H];
+      // time encoding of the chunk: ONE out-of-range test for all its arguments (wave-wide), as in the forward kernel
+      float targ[KC_BWD][NR];
+      bool big = false;
+#pragma unroll
+      for (int c = 0; c < KC_BWD; ++c)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          targ[c][r] = pfo_time_arg(dtv[c], tw[r], tb[r]);
+          big = big || !(fabsf(targ[c][r]) < 2.0e7f);
+        }
+      const bool any_big = __ballot(big) != 0ull;
 #pragma unroll
       for (int c = 0; c < KC_BWD; ++c) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           const int cc = lane + 64 * r;
-          float sv, cv;
-          pfo_sincosf(pfo_time_arg(dtv[c], tw[r], tb[r]), sv, cv);
+          const float u = __builtin_expect(any_big, 0) ? pfo_revolutions(targ[c][r]) : pfo_revolutions_fast(targ[c][r]);
+          const float sv = __builtin_amdgcn_sinf(u), cv = __builtin_amdgcn_cosf(u);
           const bool on = js[c] >= 0 && (r < NR - 1 || cc < D);     // select, not a branch (only the last r can be off)
           kt[c][r] = on ? cv : 0.f;
           ks[c][r] = on ? sv : 0.f;
@@ -437,53 +448,118 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
 // added bytes: 454 MB per launch at C2; without the atomics the same kernel takes 0.35 instead of 0.49 ms).  Instances
 // arrive ordered by (touched-table row, run key) - memory.hpp pfo_seg_build_launch - so consecutive instances of a run sit
 // on the same node and have the SAME K neighbour rows.  One wavefront (a 64-thread workgroup) walks a chunk of RUN_CHUNK
-// consecutive members; the key-side gradient rows are summed in a wavefront-private LDS image [K][D] by plain
-// read-modify-writes (each lane owns its columns: no LDS atomics, which cost ~170 cycles per wave instruction here) and
-// leave as ONE set of float atomics when the run or the chunk ends - 2-3x fewer atomic bytes.  Everything else is
-// attn_bwd_body's arithmetic per instance, dqk' rows included.
+// consecutive members and the key-side gradient rows of a run leave as ONE set of float atomics when the run or the chunk
+// ends - 2-3x fewer atomic bytes.
+//
+// The rows are not accumulated while the instances are walked.  The gradient of neighbour row j summed over a run is
+//     sum_i sum_h ( cA_ihj * g_ih  +  cB_ihj * q_h )        g_ih = d ctx'_h (node part) of instance i,  q_h = the node's query
+// with wave-uniform scalars cA (post-dropout weight) and cB (d score * scale), and q_h is the same for every instance of
+// the run.  So the walk only keeps the SCALARS - lane j holds cA of key j for each of the run's <= RUN_CHUNK instances and
+// the running sum of cB - and the rows are formed once per run from the re-read g rows (just used: cache hits): per key
+// (RUN_CHUNK + 1) * H FMAs per column instead of 2H FMAs plus an LDS read-modify-write per column PER INSTANCE.  The first
+// version of this kernel summed the rows in a wavefront-private LDS image [K][D] (13.8 KB): that image, not the work,
+// set the speed - 11 wavefronts per CU, and the kernel's time is inversely proportional to its occupancy (measured by
+// padding the allocation: 8 per CU 459 us, 5 per CU 765 us against 383 us).
 #ifndef RUN_CHUNK
 #define RUN_CHUNK 4     // measured at C2: 4 -> 1.86 ms/step, 8 -> 1.88, 16 -> 2.00 (a wavefront walks its chunk serially: long
 #endif                  // chunks merge more atomics but leave a tail), per-instance kernel 1.91
 
+#ifndef KC_RUNS
+#define KC_RUNS 2      // keys in flight per wavefront: 2 costs 14 registers, and occupancy is worth more here than ILP
+#endif
+#ifndef RUNS_WAVES
+#define RUNS_WAVES(NR, H) ((NR) * (H) <= 6 ? 3 : 2)
+#endif
 template <int NR, int H>
-__global__ __launch_bounds__(64) void attn_bwd_runs_kernel(const AttnDev a) {
-  extern __shared__ __attribute__((aligned(16))) float s_acc[];       // [K][D]
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(NR, H)))) void attn_bwd_runs_kernel(const AttnDev a) {
+  // Registers decide this kernel's speed (see above), so everything that is not touched every few instructions lives in
+  // the wavefront's 4 KB of LDS: the time-encoder parameters and the run's per-key scalars.
+  __shared__ float s_tw[NR * 64], s_tb[NR * 64];
+  __shared__ float s_cA[RUN_CHUNK][H][64], s_sB[H][64];
   const int lane = threadIdx.x;
   const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef, Cp = a.Cp;
-  float tw[NR], tb[NR];
-  double dw[NR], db[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int c = lane + 64 * r;
-    tw[r] = c < D ? a.tw[c] : 0.f;
-    tb[r] = c < D ? a.tb[c] : 0.f;
-    dw[r] = 0.0; db[r] = 0.0;
+    s_tw[c] = c < D ? a.tw[c] : 0.f;
+    s_tb[c] = c < D ? a.tb[c] : 0.f;
   }
-  for (int i = lane; i < K * D; i += 64) s_acc[i] = 0.f;
   const float keep_scale = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
   float* const d_nbr_x = a.d_nbr + (int64_t)(__builtin_amdgcn_s_getreg(6164) & (PFO_GRAD_REPLICAS - 1)) * a.d_nbr_rep;
   const int M = a.seg_ptr[*a.n_rows];                            // members = instances that sit on a real node
   const int n_chunks = (M + RUN_CHUNK - 1) / RUN_CHUNK;
-  auto flush = [&](int rows_l, unsigned long long vmask) {        // the run's rows: one float atomic per element
-    while (vmask) {
-      const int j = __ffsll((long long)vmask) - 1;
-      vmask &= vmask - 1ull;
-      float* dst = d_nbr_x + (int64_t)rl_i(rows_l, j) * a.d_nbr_ld;
-      float* ap = s_acc + j * D;
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const int cc = lane + 64 * r;
-        if (r < NR - 1 || cc < D) {
-          if (a.abl != 2) atomicAdd(dst + cc, ap[cc]);
-          ap[cc] = 0.f;
-        }
-      }
-    }
-  };
 
   for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    int run_slot = -1, run_key = 0, run_rows = 0;
+    // the time-encoder gradient of a chunk (<= RUN_CHUNK * K terms per column) is summed in fp32 and added to the fp64 bins
+    // once (the reference's autograd sums everything in fp32)
+    float dwc[NR], dbc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { dwc[r] = 0.f; dbc[r] = 0.f; }
+    // the current run: s_cA[i][h][j] = cA of key j for the run's i-th instance, s_sB[h][j] = sum of cB over its instances
+    int run_slot = -1, run_key = 0, run_rows = 0, run_len = 0, run_first = 0;
     unsigned long long run_valid = 0ull;
+#pragma unroll
+    for (int h = 0; h < H; ++h) s_sB[h][lane] = 0.f;
+    auto flush = [&]() {                                           // the run's rows: one float atomic per element
+      if (run_valid != 0ull && run_len > 0) {
+        const float* qk = a.QK + (int64_t)run_slot * a.qk_ld;
+        float qn[H][NR], g[RUN_CHUNK][H][NR];
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const int c = lane + 64 * r;
+            qn[h][r] = c < D ? qk[h * Cp + c] : 0.f;
+          }
+        float cAr[RUN_CHUNK][H], sB[H];                              // lane j: key j's scalars
+#pragma unroll
+        for (int i = 0; i < RUN_CHUNK; ++i) {
+          const bool on = i < run_len;                             // wave-uniform
+          const float* dc = a.dctx + (int64_t)a.members[on ? run_first + i : run_first] * H * Cp;
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            cAr[i][h] = on ? s_cA[i][h][lane] : 0.f;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+              const int c = lane + 64 * r;
+              g[i][h][r] = (on && c < D) ? dc[h * Cp + c] : 0.f;
+            }
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) sB[h] = s_sB[h][lane];
+        unsigned long long vmask = run_valid;
+        while (vmask) {
+          const int j = __ffsll((long long)vmask) - 1;
+          vmask &= vmask - 1ull;
+          float* dst = d_nbr_x + (int64_t)rl_i(run_rows, j) * a.d_nbr_ld;
+          float row[NR];
+#pragma unroll
+          for (int r = 0; r < NR; ++r) row[r] = 0.f;
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            const float sb = rl_f(sB[h], j);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) row[r] = fmaf(sb, qn[h][r], row[r]);
+#pragma unroll
+            for (int i = 0; i < RUN_CHUNK; ++i) {
+              const float ca = rl_f(cAr[i][h], j);                 // 0 beyond the run's length
+#pragma unroll
+              for (int r = 0; r < NR; ++r) row[r] = fmaf(ca, g[i][h][r], row[r]);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const int cc = lane + 64 * r;
+            if ((r < NR - 1 || cc < D) && a.abl != 2) atomicAdd(dst + cc, row[r]);
+          }
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < H; ++h) s_sB[h][lane] = 0.f;
+      run_len = 0;
+    };
+
     const int m_end = min(M, (chunk + 1) * RUN_CHUNK);
     for (int m = chunk * RUN_CHUNK; m < m_end; ++m) {
       const int64_t n = a.members[m];
@@ -499,13 +575,16 @@ __global__ __launch_bounds__(64) void attn_bwd_runs_kernel(const AttnDev a) {
       const int e_new = rl_i(my_e, K - 1);                       // common.hpp pfo_run_key: equal keys <=> identical neighbour lists
       const int key = e_new * 2 + ((K >= 2 && e_new != 0 && rl_i(my_e, K >= 2 ? K - 2 : 0) == e_new) ? 1 : 0);
       if (slot != run_slot || key != run_key) {                  // a new run: the previous one's rows leave
-        flush(run_rows, run_valid);
+        flush();
         run_slot = slot; run_key = key; run_rows = my_row; run_valid = valid;
       }
       if (valid == 0ull) {
         for (int c = lane; c < H * Cp; c += 64) dqk_out[c] = 0.f;
         continue;
       }
+      if (run_len == 0) run_first = m;                           // the run's instances are consecutive members
+      const int run_i = run_len;
+      run_len += 1;
       float qn[H][NR], qt[H][NR], qe[H], gn[H][NR], gt[H][NR], ge[H], t[H], dsb[H];
       float dqn[H][NR], dqt[H][NR], dqe[H];
       const float* qk = a.QK + (int64_t)slot * a.qk_ld;
@@ -537,7 +616,11 @@ __global__ __launch_bounds__(64) void attn_bwd_runs_kernel(const AttnDev a) {
 #pragma unroll
         for (int h = 0; h < H; ++h) t[h] += __shfl_xor(t[h], o, 64);
 #pragma unroll
-      for (int h = 0; h < H; ++h) t[h] = fmaf(dsb[h], cx[h * Cp + C], t[h]);
+      for (int h = 0; h < H; ++h) {
+        t[h] = fmaf(dsb[h], cx[h * Cp + C], t[h]);
+        t[h] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(t[h])));          // wave-uniform: scalar registers
+        dsb[h] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(dsb[h])));
+      }
       const unsigned keep = attn_keep_bits(a.seed, a.offset + (a.offset_dev ? *a.offset_dev : 0ull), n, lane, a.dropout_p);
       float my_a[H];
 #pragma unroll
@@ -545,15 +628,15 @@ __global__ __launch_bounds__(64) void attn_bwd_runs_kernel(const AttnDev a) {
 
       unsigned long long vm = valid;
       while (vm) {
-        int js[KC_BWD];
+        int js[KC_RUNS];
 #pragma unroll
-        for (int c = 0; c < KC_BWD; ++c) {
+        for (int c = 0; c < KC_RUNS; ++c) {
           js[c] = vm ? (__ffsll((long long)vm) - 1) : -1;
           vm &= vm - 1ull;
         }
-        float kn[KC_BWD][NR], kt[KC_BWD][NR], ks[KC_BWD][NR], ke[KC_BWD], dtv[KC_BWD];
+        float kn[KC_RUNS][NR], kt[KC_RUNS][NR], ks[KC_RUNS][NR], ke[KC_RUNS], dtv[KC_RUNS];
 #pragma unroll
-        for (int c = 0; c < KC_BWD; ++c) {
+        for (int c = 0; c < KC_RUNS; ++c) {
           const int j = js[c] < 0 ? 0 : js[c];
           const float* src = a.nbr_tab + (int64_t)rl_i(my_row, j) * a.nbr_ld;
           const int e = rl_i(my_e, j);
@@ -565,14 +648,25 @@ __global__ __launch_bounds__(64) void attn_bwd_runs_kernel(const AttnDev a) {
           }
           ke[c] = (js[c] >= 0 && lane < Ef) ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
         }
-        float part[KC_BWD][H];
+        float part[KC_RUNS][H];
+        // time encoding of the chunk: ONE out-of-range test for all its arguments (wave-wide), as in the forward kernel
+        float targ[KC_RUNS][NR];
+        bool big = false;
 #pragma unroll
-        for (int c = 0; c < KC_BWD; ++c) {
+        for (int c = 0; c < KC_RUNS; ++c)
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            targ[c][r] = pfo_time_arg(dtv[c], s_tw[lane + 64 * r], s_tb[lane + 64 * r]);
+            big = big || !(fabsf(targ[c][r]) < 2.0e7f);
+          }
+        const bool any_big = __ballot(big) != 0ull;
+#pragma unroll
+        for (int c = 0; c < KC_RUNS; ++c) {
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
             const int cc = lane + 64 * r;
-            float sv, cv;
-            pfo_sincosf(pfo_time_arg(dtv[c], tw[r], tb[r]), sv, cv);
+            const float u = __builtin_expect(any_big, 0) ? pfo_revolutions(targ[c][r]) : pfo_revolutions_fast(targ[c][r]);
+            const float sv = __builtin_amdgcn_sinf(u), cv = __builtin_amdgcn_cosf(u);
             const bool on = js[c] >= 0 && (r < NR - 1 || cc < D);
             kt[c][r] = on ? cv : 0.f;
             ks[c][r] = on ? sv : 0.f;
@@ -586,11 +680,11 @@ __global__ __launch_bounds__(64) void attn_bwd_runs_kernel(const AttnDev a) {
           }
         }
 #pragma unroll
-        for (int c = 0; c < KC_BWD; ++c)
+        for (int c = 0; c < KC_RUNS; ++c)
 #pragma unroll
           for (int h = 0; h < H; ++h) part[c][h] = pfo_wave_sum_scalar(part[c][h]);
 #pragma unroll
-        for (int c = 0; c < KC_BWD; ++c) {
+        for (int c = 0; c < KC_RUNS; ++c) {
           if (js[c] < 0) continue;
           const unsigned kb = (unsigned)rl_i((int)keep, js[c]);
           float cA[H], cB[H];
@@ -602,6 +696,7 @@ __global__ __launch_bounds__(64) void attn_bwd_runs_kernel(const AttnDev a) {
             const float dscore = aj * (da - t[h]);
             cA[h] = aj * ks_h;
             cB[h] = dscore * a.scale;
+            if (lane == js[c]) { s_cA[run_i][h][lane] = cA[h]; s_sB[h][lane] += cB[h]; }   // key js[c]'s share of the run's rows (flush)
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
               dqn[h][r] = fmaf(cB[h], kn[c][r], dqn[h][r]);
@@ -609,20 +704,14 @@ __global__ __launch_bounds__(64) void attn_bwd_runs_kernel(const AttnDev a) {
             }
             dqe[h] = fmaf(cB[h], ke[c], dqe[h]);
           }
-          float* ap = s_acc + js[c] * D;
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
-            const int cc = lane + 64 * r;
-            float dkn = 0.f, dkt = 0.f;
+            float dkt = 0.f;
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
-              dkn = fmaf(cA[h], gn[h][r], fmaf(cB[h], qn[h][r], dkn));
-              dkt = fmaf(cA[h], gt[h][r], fmaf(cB[h], qt[h][r], dkt));
-            }
-            if (r < NR - 1 || cc < D) ap[cc] += dkn;             // this lane's own element of the run's image
-            const float gsin = -ks[c][r] * dkt;
-            dw[r] += (double)gsin * (double)dtv[c];
-            db[r] += (double)gsin;
+            for (int h = 0; h < H; ++h) dkt = fmaf(cA[h], gt[h][r], fmaf(cB[h], qt[h][r], dkt));
+            const float gsin = -ks[c][r] * dkt;                 // d/d(arg) cos(arg) = -sin(arg); ks = 0 on lanes beyond D
+            dwc[r] = fmaf(gsin, dtv[c], dwc[r]);
+            dbc[r] += gsin;
           }
         }
       }
@@ -640,16 +729,16 @@ __global__ __launch_bounds__(64) void attn_bwd_runs_kernel(const AttnDev a) {
         if (lane < Cp - C) dqk_out[h * Cp + C + lane] = 0.f;
       }
     }
-    flush(run_rows, run_valid);                                  // the chunk's last run
-  }
-  // time-encoder partials: this wavefront's sums into the shared fp64 bins
+    flush();                                                     // the chunk's last run
+    // time-encoder partials: this chunk's sums into the shared fp64 bins
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const int c = lane + 64 * r;
-    if (c < D) {
-      double* bin = a.dtime_part + (int64_t)(blockIdx.x & (ATTN_TIME_BINS - 1)) * 2 * D;
-      atomicAdd(bin + c, dw[r]);
-      atomicAdd(bin + D + c, db[r]);
+    for (int r = 0; r < NR; ++r) {
+      const int c = lane + 64 * r;
+      if (c < D) {
+        double* bin = a.dtime_part + (int64_t)(chunk & (ATTN_TIME_BINS - 1)) * 2 * D;
+        atomicAdd(bin + c, (double)dwc[r]);
+        atomicAdd(bin + D + c, (double)dbc[r]);
+      }
     }
   }
 }
@@ -721,8 +810,7 @@ int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream) {
 
 bool pfo_attn_bwd_uses_runs(const PfoAttn& a) {
   static const int runs_on = getenv("PFO_ATTN_RUNS") ? atoi(getenv("PFO_ATTN_RUNS")) : 1;                    // A/B switch
-  return a.d_nbr && a.nbr_row && runs_on && a.members && a.seg_ptr && a.n_rows && a.qk_row &&
-         (size_t)a.K * a.D * sizeof(float) <= 64 * 1024;
+  return a.d_nbr && a.nbr_row && runs_on && a.members && a.seg_ptr && a.n_rows && a.qk_row && a.K <= 64;
 }
 
 int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
@@ -737,7 +825,7 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
   const double bytes = (double)a.N * (a.K * (8.0 * a.D + 4.0 * a.Ef + 12.0) + 4.0 * a.H * C * 4.0 + 4.0 * a.H * a.K);
   const int dmode = !a.d_nbr ? 0 : (a.nbr_row ? 1 : 2);
   static const int lds_pad = getenv("PFO_ATTN_RUNS_LDSPAD") ? atoi(getenv("PFO_ATTN_RUNS_LDSPAD")) : 0;   // occupancy probe
-  const size_t run_lds = (size_t)a.K * a.D * sizeof(float) + lds_pad;
+  const size_t run_lds = (size_t)lds_pad;
   if (pfo_attn_bwd_uses_runs(a)) {
     // run-merged form: single-wavefront workgroups, one chunk of members each (the grid-stride loop only matters when the
     // grid is capped for an experiment)
