@@ -12,7 +12,7 @@
 
 struct AttnDev {
   int N, K, D, Ef, H, Cp;
-  const float* QK; const int32_t* qk_row; int64_t qk_ld; const float* nbr_tab; int64_t nbr_ld; const int32_t* nbr_row; int64_t nbr_row_base;
+  const float* QK; const int32_t* qk_row; int64_t qk_ld; const float* nbr_tab; int64_t nbr_ld; const int32_t* nbr_row; int64_t nbr_row_base; int nbr_relu;
   const int32_t* nbr_ids; const float* edge_feat; const int32_t* eidx; const float* dt; const float* tw; const float* tb;
   float scale, dropout_p; uint64_t seed, offset; const uint64_t* offset_dev;
   float* ctx; float* attw; uint8_t* inv;
@@ -405,7 +405,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
             dkt = fmaf(cA[h], gt[h][r], fmaf(cB[h], qt[h][r], dkt));
           }
           if (r < NR - 1 || cc < D) {                    // 64 * (NR - 1) < D: only the last r needs the lane test
-            if (DMODE == 2) dst[cc] = dkn;
+            if (DMODE == 2) dst[cc] = (a.nbr_relu && !(kn[c][r] > 0.f)) ? 0.f : dkn;   // the row is a ReLU output of the layer below
             else if (DMODE == 1 && a.abl != 2) atomicAdd(dst + cc, dkn);
           }
           const float gsin = -ks[c][r] * dkt;            // d/d(arg) cos(arg) = -sin(arg); ks = 0 on lanes beyond D
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
 
 static void to_dev(const PfoAttn& a, AttnDev& d) {
   d.N = a.N; d.K = a.K; d.D = a.D; d.Ef = a.Ef; d.H = a.H; d.Cp = a.Cp;
-  d.QK = a.QK; d.qk_row = a.qk_row; d.qk_ld = a.qk_ld > 0 ? a.qk_ld : (int64_t)a.H * a.Cp; d.nbr_tab = a.nbr_tab; d.nbr_ld = a.nbr_ld; d.nbr_row = a.nbr_row; d.nbr_row_base = a.nbr_row_base;
+  d.QK = a.QK; d.qk_row = a.qk_row; d.qk_ld = a.qk_ld > 0 ? a.qk_ld : (int64_t)a.H * a.Cp; d.nbr_tab = a.nbr_tab; d.nbr_ld = a.nbr_ld; d.nbr_row = a.nbr_row; d.nbr_row_base = a.nbr_row_base; d.nbr_relu = a.nbr_relu;
   d.nbr_ids = a.nbr_ids; d.edge_feat = a.edge_feat; d.eidx = a.eidx; d.dt = a.dt; d.tw = a.tw; d.tb = a.tb;
   d.scale = a.scale; d.dropout_p = a.dropout_p; d.seed = a.seed; d.offset = a.offset; d.offset_dev = a.offset_dev;
   static const int abl = getenv("PFO_ATTN_ABL") ? atoi(getenv("PFO_ATTN_ABL")) : 0;

@@ -1190,22 +1190,24 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_multi_kernel(const MultiDev
   }
 }
 
-// out[m, n] += u[m] * v[n], several independent updates in one launch (blockIdx.y = the update)
+// out[m, n] += sum_r u_r[m] * v_r[n], several independent updates in one launch (blockIdx.y = the update)
 struct Rank1Dev {
   const float* u[PFO_RANK1_MAX]; const float* v[PFO_RANK1_MAX]; float* out[PFO_RANK1_MAX];
-  int64_t ldu[PFO_RANK1_MAX], ldv[PFO_RANK1_MAX], ldo[PFO_RANK1_MAX];
-  int M[PFO_RANK1_MAX], N[PFO_RANK1_MAX];
+  int64_t ldu[PFO_RANK1_MAX], ldv[PFO_RANK1_MAX], ldo[PFO_RANK1_MAX], u_rs[PFO_RANK1_MAX], v_rs[PFO_RANK1_MAX];
+  int M[PFO_RANK1_MAX], N[PFO_RANK1_MAX], reps[PFO_RANK1_MAX];
 };
 __global__ void rank1_kernel(const Rank1Dev g) {
   const int q = blockIdx.y;
-  const int N = g.N[q];
+  const int N = g.N[q], reps = g.reps[q];
   const int64_t total = (int64_t)g.M[q] * N;
   const float* __restrict__ u = g.u[q];
   const float* __restrict__ v = g.v[q];
   float* __restrict__ out = g.out[q];
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int m = (int)(e / N), n = (int)(e - (int64_t)m * N);
-    out[(int64_t)m * g.ldo[q] + n] += u[(int64_t)m * g.ldu[q]] * v[(int64_t)n * g.ldv[q]];
+    float acc = 0.f;
+    for (int r = 0; r < reps; ++r) acc = fmaf(u[r * g.u_rs[q] + (int64_t)m * g.ldu[q]], v[r * g.v_rs[q] + (int64_t)n * g.ldv[q]], acc);
+    out[(int64_t)m * g.ldo[q] + n] += acc;
   }
 }
 int pfo_rank1_multi_launch(const PfoRank1* list, int n, hipStream_t stream) {
@@ -1214,12 +1216,44 @@ int pfo_rank1_multi_launch(const PfoRank1* list, int n, hipStream_t stream) {
   int64_t most = 0;
   for (int i = 0; i < n; ++i) {
     const PfoRank1& r = list[i];
-    PFO_REQUIRE(r.u && r.v && r.out && r.M > 0 && r.N > 0, "bad rank-1 update");
+    PFO_REQUIRE(r.u && r.v && r.out && r.M > 0 && r.N > 0 && r.reps >= 1, "bad rank-1 update");
     g.u[i] = r.u; g.v[i] = r.v; g.out[i] = r.out; g.ldu[i] = r.ldu; g.ldv[i] = r.ldv; g.ldo[i] = r.ldo; g.M[i] = r.M; g.N[i] = r.N;
+    g.reps[i] = r.reps; g.u_rs[i] = r.u_rs; g.v_rs[i] = r.v_rs;
     most = std::max(most, (int64_t)r.M * r.N);
   }
   const int nb = (int)std::min<int64_t>(512, pfo_ceil_div(most, 256));
   hipLaunchKernelGGL(rank1_kernel, dim3(nb, n), dim3(256), 0, stream, g);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+// dst[i] (+)= sum_s src[s * stride + i]  (fixed order: reproducible), several destinations in one launch
+struct SumSlabsDev {
+  float* dst[PFO_SUM_SLABS_MAX]; const float* src[PFO_SUM_SLABS_MAX];
+  int64_t stride[PFO_SUM_SLABS_MAX], count[PFO_SUM_SLABS_MAX];
+  int n_slabs[PFO_SUM_SLABS_MAX], accumulate[PFO_SUM_SLABS_MAX];
+};
+__global__ void sum_slabs_kernel(const SumSlabsDev g) {
+  const int q = blockIdx.y;
+  const float* __restrict__ src = g.src[q];
+  float* __restrict__ dst = g.dst[q];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < g.count[q]; i += (int64_t)gridDim.x * blockDim.x) {
+    float acc = g.accumulate[q] ? dst[i] : 0.f;
+    for (int sl = 0; sl < g.n_slabs[q]; ++sl) acc += src[sl * g.stride[q] + i];
+    dst[i] = acc;
+  }
+}
+int pfo_sum_slabs_launch(const PfoSumSlabs* list, int n, hipStream_t stream) {
+  PFO_REQUIRE(list && n >= 1 && n <= PFO_SUM_SLABS_MAX, "bad slab list");
+  SumSlabsDev g;
+  int64_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    PFO_REQUIRE(list[i].dst && list[i].src && list[i].count > 0 && list[i].n_slabs >= 1, "bad slab sum");
+    g.dst[i] = list[i].dst; g.src[i] = list[i].src; g.stride[i] = list[i].stride; g.count[i] = list[i].count;
+    g.n_slabs[i] = list[i].n_slabs; g.accumulate[i] = list[i].accumulate;
+    most = std::max(most, list[i].count);
+  }
+  const int nb = (int)std::min<int64_t>(256, pfo_ceil_div(most, 256));
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3(nb, n), dim3(256), 0, stream, g);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

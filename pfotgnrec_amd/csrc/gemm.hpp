@@ -58,12 +58,19 @@ bool pfo_gemm_takes_bx(int M, int N);
 #define PFO_GEMM_MULTI_MAX 10
 int pfo_gemm_multi_launch(const PfoGemm* list, int n, hipStream_t stream);
 // out[m, n] += u[m * ldu] * v[n * ldv]
-// several rank-1 updates out += u (x) v in one launch; the outputs must not overlap
+// several updates out += sum_{r < reps} u_r (x) v_r in one launch (u_r = u + r * u_rs, v_r = v + r * v_rs); the outputs must not overlap
 #define PFO_RANK1_MAX 12
 struct PfoRank1 {
   const float* u = nullptr; int64_t ldu = 1; const float* v = nullptr; int64_t ldv = 1; int M = 0, N = 0; float* out = nullptr; int64_t ldo = 0;
+  int reps = 1; int64_t u_rs = 0, v_rs = 0;
 };
 int pfo_rank1_multi_launch(const PfoRank1* list, int n, hipStream_t stream);
+// dst[i] (+)= sum_{s < n_slabs} src[s * stride + i], i < count; several in one launch
+#define PFO_SUM_SLABS_MAX 4
+struct PfoSumSlabs {
+  float* dst = nullptr; const float* src = nullptr; int64_t stride = 0, count = 0; int n_slabs = 1, accumulate = 1;
+};
+int pfo_sum_slabs_launch(const PfoSumSlabs* list, int n, hipStream_t stream);
 int pfo_rank1_launch(const float* u, int64_t ldu, const float* v, int64_t ldv, int M, int N, float* out, int64_t ldo,
                      hipStream_t stream);
 

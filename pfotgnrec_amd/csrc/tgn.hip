@@ -22,9 +22,13 @@ int pfo_tnbr_sample_dev(const int64_t*, const int32_t*, const int32_t*, const do
 namespace {
 
 struct LayerWs {
-  float *QK, *attw, *ctx, *h1, *Hout;      // activations kept for backward
+  float *QK, *attw, *ctx, *h1;             // activations kept for backward
   float *cq, *Wqk, *cqk, *W1oT, *W1ovT;   // per-step composite weights (see the layer comment in pfo_tgn_forward)
   float *dWqk, *gqk, *dW1ovT, *dW1oT, *gq; // their gradients (per layer: the chain-back runs on the side stream)
+  // layers >= 2 take the PREVIOUS layer's h1 rows as input, with that layer's fc2 (out = W2 h1 + b2) folded into their own
+  // composites (see "fc2 fold" in pfo_tgn_forward): the folded weights, the two intermediates, and the gradients of all
+  float *T1, *tq, *Wqk_f, *cqk_f, *W1ovT_f, *W1b_f, *b1_f;
+  float *dT1, *dWqk_f, *gqk_f, *dW1ovT_f, *dW1b_f, *db1_f, *fold_slabs, *fold_vslabs;
   uint8_t* inv;
   // pre-split bf16x3 images of the weight operands of the large contractions (gemm.hpp PfoBimg): per step, side stream
   void *iWqk, *iWqkT, *iW1ov, *iW1ovT, *iW1b, *iW1bT, *iW2, *iW2T;
@@ -161,8 +165,18 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     lw.inv = take<uint8_t>(p, N);
     lw.ctx = take<float>(p, N * d.H * d.Cp);
     lw.h1 = take<float>(p, N * d.D);
-    lw.Hout = take<float>(p, N * d.D);
     if (l < d.L) w.dH[l] = take<float>(p, N * d.D);
+    if (l >= 2) {
+      const int64_t HCpD = (int64_t)d.H * d.Cp * d.D, HCp = (int64_t)d.H * d.Cp, DD = (int64_t)d.D * d.D;
+      lw.T1 = take<float>(p, HCpD);      lw.tq = take<float>(p, HCp);
+      lw.Wqk_f = take<float>(p, HCpD);   lw.cqk_f = take<float>(p, HCp);
+      lw.W1ovT_f = take<float>(p, HCpD); lw.W1b_f = take<float>(p, DD);   lw.b1_f = take<float>(p, d.D);
+      lw.dT1 = take<float>(p, HCpD);
+      lw.dWqk_f = take<float>(p, HCpD);  lw.gqk_f = take<float>(p, HCp);
+      lw.dW1ovT_f = take<float>(p, HCpD); lw.dW1b_f = take<float>(p, DD); lw.db1_f = take<float>(p, d.D);
+      lw.fold_slabs = take<float>(p, (2 * d.H + 2) * DD);
+      lw.fold_vslabs = take<float>(p, (int64_t)(d.H + 2) * d.D);
+    }
   }
   const int64_t N1 = d.ncap[1];
   w.dh1 = take<float>(p, N1 * d.D);
@@ -242,7 +256,7 @@ PfoGemm g_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const int
 struct Side {
   hipStream_t s = nullptr, s2 = nullptr;
   hipEvent_t tn_a_done = nullptr, done2 = nullptr;
-  hipEvent_t fork = nullptr, done = nullptr, gru_fork = nullptr, gru_join = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr, slot0 = nullptr;
+  hipEvent_t fork = nullptr, done = nullptr, gru_fork = nullptr, gru_join = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr, slot0 = nullptr, fold_done = nullptr;
   hipEvent_t layer[PFO_MAX_LAYERS + 1] = {};
   bool ok = false;
 };
@@ -261,6 +275,7 @@ Side& side() {
     good = good && hipEventCreateWithFlags(&sd.tn_a, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.tn_b, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.slot0, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.fold_done, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; l <= PFO_MAX_LAYERS; ++l) good = good && hipEventCreateWithFlags(&sd.layer[l], hipEventDisableTiming) == hipSuccess;
     sd.ok = good;
   }
@@ -421,24 +436,79 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
       a2[2].batch = H; a2[2].a_bs[0] = dh; a2[2].b_bs[0] = (int64_t)dh * D; a2[2].c_bs = (int64_t)Cp * D;
       a2[3] = g_nt(p.bo, E, nullptr, p.w1, E + D, lw.W1ovT + (int64_t)(C + 1) * D, D, 1, D, E, nullptr);   // row C+1 of head 0: (W1 bo)^T
       n2 += 4;
-      // bf16x3 images of this layer's weight operands, in both orientations (forward and data-gradient launches)
+      // bf16x3 images of this layer's weight operands, in both orientations (forward and data-gradient launches).
+      // Layers >= 2 take theirs from the fc2-folded composites below.
       if (l == 1) {
         // layer 1 projects the touched-node table once: [Wqk ; W1[:, E:]] stacked along the output dimension
         img(lw.Wqk, D, HCp, D, 0, w.iQX);        im[ni - 1].row0 = 0;   im[ni - 1].rows_total = HCp + D;
         img(p.w1 + E, E + D, D, D, 0, w.iQX);    im[ni - 1].row0 = HCp; im[ni - 1].rows_total = HCp + D; im[ni - 1].last = 1;
-      } else {
-        img(lw.Wqk, D, HCp, D, 0, lw.iWqk);      img(p.w1 + E, E + D, D, D, 0, lw.iW1b);
+        img(lw.Wqk, D, D, HCp, 1, lw.iWqkT);
+        img(lw.W1ovT, D, HCp, D, 0, lw.iW1ovT);  img(lw.W1ovT, D, D, HCp, 1, lw.iW1ov);
+        img(p.w1 + E, E + D, D, D, 1, lw.iW1bT);
       }
-      img(lw.Wqk, D, D, HCp, 1, lw.iWqkT);
-      img(lw.W1ovT, D, HCp, D, 0, lw.iW1ovT);    img(lw.W1ovT, D, D, HCp, 1, lw.iW1ov);
-      img(p.w1 + E, E + D, D, D, 1, lw.iW1bT);
-      img(p.w2, D, D, D, 0, lw.iW2);             img(p.w2, D, D, D, 1, lw.iW2T);
+      if (l == L) { img(p.w2, D, D, D, 0, lw.iW2); img(p.w2, D, D, D, 1, lw.iW2T); }   // only the top layer applies its fc2
     }
     for (int i = 0; i < n1; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(st1 + i, std::min(PFO_GEMM_MULTI_MAX, n1 - i), ss));
     for (int i = 0; i < n2; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(st2 + i, std::min(PFO_GEMM_MULTI_MAX, n2 - i), ss));
     for (int i = 0; i < ni; i += PFO_BIMG_MAX) RUN(pfo_bimg_launch(im + i, std::min(PFO_BIMG_MAX, ni - i), ss));
+    HIPOK(hipEventRecord(sd.layer[0], ss), "event record failed");      // layer 1 (and the top layer's fc2) can go
+
+    // ---- fc2 fold.  A layer l >= 2 reads rows of the previous layer, out = A h + b (A = W2, b = b2 of layer l-1, h = that
+    // layer's h1 row).  Every use of such a row is linear, so A and b move into THIS layer's composites and the previous
+    // layer's fc2 contraction over all its instances (and, backward, d h1 = d out W2 and dW2 = d out^T h1) disappears:
+    //   query side   qk'_h = Q_h x + cqk_h,  x = A s + b        ->  T1_h = Q_h A,  t_h = Q_h b + cqk_h
+    //   scores       qk'_h,node . (A k + b) = (A^T qk'_h,node) . k + const(j)   (the constant drops out of the softmax)
+    //                                                         ->  Q_f,h = [A^T T1_h,node ; T1_h,edge|time],  c_f,h likewise from t_h
+    //   context      sum_j a'_j (A k_j + b) = A c + b sum_j a'_j  ->  V_f,h,node = A^T V_h,node,  V_f,h[C] = V_h[C] + b^T V_h,node
+    //   x term       W1b (A s + b)                              ->  W1b_f = W1b A,  b1_f = b1 + W1b b
+    // (Q_h = Wqk_h, V_h = W1ovT_h; tiny products, two more dependent stages on this stream.)
+    if (L >= 2) {
+      PfoGemm f1[4 * PFO_MAX_LAYERS], f2[4 * PFO_MAX_LAYERS];
+      PfoBimg fim[6 * PFO_MAX_LAYERS];
+      int m1 = 0, m2 = 0, mi = 0;
+      const int64_t HCpD = (int64_t)HCp * D;
+      for (int l = 2; l <= L; ++l) {
+        const LayerWs& lw = w.layer[l];
+        const auto& p = P.l[l];
+        const float* A = P.l[l - 1].w2;
+        const float* bv = P.l[l - 1].b2;
+        HIPOK(hipMemcpyAsync(lw.W1ovT_f, lw.W1ovT, HCpD * sizeof(float), hipMemcpyDeviceToDevice, ss), "copy failed");
+        PfoGemm* a = f1 + m1;
+        a[0] = g_nn(lw.Wqk, D, A, D, lw.T1, D, HCp, D, D);                                    // T1 = Q A (all heads' rows)
+        a[1] = g_nt(bv, D, nullptr, lw.Wqk, D, lw.tq, HCp, 1, HCp, D, lw.cqk);               // t = Q b + cqk
+        a[2] = g_nn(p.w1 + E, E + D, A, D, lw.W1b_f, D, D, D, D);                            // W1b_f = W1b A
+        a[3] = g_nt(bv, D, nullptr, p.w1 + E, E + D, lw.b1_f, D, 1, D, D, p.b1);             // b1_f = b1 + W1b b
+        m1 += 4;
+      }
+      for (int i = 0; i < m1; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(f1 + i, std::min(PFO_GEMM_MULTI_MAX, m1 - i), ss));
+      for (int l = 2; l <= L; ++l) {
+        const LayerWs& lw = w.layer[l];
+        const float* A = P.l[l - 1].w2;
+        const float* bv = P.l[l - 1].b2;
+        HIPOK(hipMemcpyAsync(lw.Wqk_f, lw.T1, HCpD * sizeof(float), hipMemcpyDeviceToDevice, ss), "copy failed");   // edge | time rows stay
+        HIPOK(hipMemcpyAsync(lw.cqk_f, lw.tq, (size_t)HCp * sizeof(float), hipMemcpyDeviceToDevice, ss), "copy failed");
+        PfoGemm* a = f2 + m2;
+        a[0] = g_nn(A, D, lw.T1, D, lw.Wqk_f, D, D, D, D);        a[0].a_kmajor = 1;          // Q_f,node = A^T T1_node
+        a[0].batch = H; a[0].b_bs[0] = (int64_t)Cp * D; a[0].c_bs = (int64_t)Cp * D;
+        a[1] = g_nn(lw.tq, D, A, D, lw.cqk_f, D, 1, D, D);                                    // c_f,node = A^T t_node
+        a[1].batch = H; a[1].a_bs[0] = Cp; a[1].c_bs = Cp;
+        a[2] = g_nn(A, D, lw.W1ovT, D, lw.W1ovT_f, D, D, D, D);   a[2].a_kmajor = 1;          // V_f,node = A^T V_node
+        a[2].batch = H; a[2].b_bs[0] = (int64_t)Cp * D; a[2].c_bs = (int64_t)Cp * D;
+        a[3] = g_nn(bv, D, lw.W1ovT, D, lw.W1ovT_f + (int64_t)C * D, D, 1, D, D);             // V_f[C] = V[C] + b^T V_node
+        a[3].batch = H; a[3].b_bs[0] = (int64_t)Cp * D; a[3].c_bs = (int64_t)Cp * D; a[3].accumulate = 1;
+        m2 += 4;
+        auto fimg = [&](const float* src, int64_t ld, int N_, int K_, int trans, void* dst) {
+          fim[mi].src = src; fim[mi].ld = ld; fim[mi].N = N_; fim[mi].K = K_; fim[mi].trans = trans; fim[mi].dst = dst; ++mi;
+        };
+        fimg(lw.Wqk_f, D, HCp, D, 0, lw.iWqk);      fimg(lw.W1b_f, D, D, D, 0, lw.iW1b);
+        fimg(lw.Wqk_f, D, D, HCp, 1, lw.iWqkT);     fimg(lw.W1b_f, D, D, D, 1, lw.iW1bT);
+        fimg(lw.W1ovT_f, D, HCp, D, 0, lw.iW1ovT);  fimg(lw.W1ovT_f, D, D, HCp, 1, lw.iW1ov);
+      }
+      for (int i = 0; i < m2; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(f2 + i, std::min(PFO_GEMM_MULTI_MAX, m2 - i), ss));
+      for (int i = 0; i < mi; i += PFO_BIMG_MAX) RUN(pfo_bimg_launch(fim + i, std::min(PFO_BIMG_MAX, mi - i), ss));
+      HIPOK(hipEventRecord(sd.fold_done, ss), "event record failed");
+    }
   }
-  HIPOK(hipEventRecord(sd.layer[0], ss), "event record failed");        // composite weights and images of all layers are ready
   bool composites_awaited = false;
 
   // ---- the nodes this step reads (roots and every sampled neighbour, all levels; + the caller's extra nodes), compacted:
@@ -493,13 +563,21 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     const int N = (int)n[l];
     const LayerWs& lw = w.layer[l];
     const auto& p = P.l[l];
-    const float* xA = (l == 1) ? tab0 : w.layer[l - 1].Hout;
+    // layers >= 2 read the previous layer's h1 rows: its fc2 lives in this layer's folded composites (fc2 fold above)
+    const float* xA = (l == 1) ? tab0 : w.layer[l - 1].h1;
     const int32_t* x_idx = (l == 1) ? idx0 : nullptr;
+    const float* Wqk_l = (l == 1) ? lw.Wqk : lw.Wqk_f;
+    const float* cqk_l = (l == 1) ? lw.cqk : lw.cqk_f;
+    const float* W1ovT_l = (l == 1) ? lw.W1ovT : lw.W1ovT_f;
+    const float* W1b_l = (l == 1) ? p.w1 + E : lw.W1b_f;
+    const int64_t W1b_ld = (l == 1) ? E + D : D;
+    const float* b1_l = (l == 1) ? p.b1 : lw.b1_f;
 
     if (!composites_awaited) {
       HIPOK(hipStreamWaitEvent(s, sd.layer[0], 0), "event wait failed");   // composite weights are ready
       composites_awaited = true;
     }
+    if (l == 2) HIPOK(hipStreamWaitEvent(s, sd.fold_done, 0), "event wait failed");   // ... and the folded ones of the layers >= 2
     // ---- qk' = x Wqk^T + cqk.  Layer 1: x is a row of the touched-node table, shared by every instance that sits on
     // that node (~54 k instances on ~11 k nodes at C2): ONE projection of the table, [qk' | x W1[:, E:]^T] per row
     if (l == 1) {
@@ -507,7 +585,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
       g.m_dev = w.n_touched; g.b_img = w.iQX;
       RUN(pfo_gemm_launch(g, s));
     } else {
-      PfoGemm g = g_nt(xA, D, x_idx, lw.Wqk, D, lw.QK, HCp, N, HCp, D, lw.cqk);
+      PfoGemm g = g_nt(xA, D, x_idx, Wqk_l, D, lw.QK, HCp, N, HCp, D, cqk_l);
       g.b_img = lw.iWqk;
       RUN(pfo_gemm_launch(g, s));
     }
@@ -532,21 +610,22 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
       RUN(pfo_gemm_launch(g, s));
     } else if (pfo_gemm_takes_bx(N, D)) {
       // both K-concatenated sources ([ctx' | x] against [W1ov | W1[:, E:]]) in one launch: h1 is written once
-      PfoGemm g = g_nn(lw.ctx, HCp, lw.W1ovT, D, lw.h1, D, N, D, HCp);
-      g.A[1] = xA; g.lda[1] = D; g.a_idx[1] = x_idx; g.B[1] = p.w1 + E; g.ldb[1] = E + D; g.K[1] = D;
-      g.bias = p.b1; g.relu = 1; g.b_img = lw.iW1ov; g.b_img2 = lw.iW1b;
+      PfoGemm g = g_nn(lw.ctx, HCp, W1ovT_l, D, lw.h1, D, N, D, HCp);
+      g.A[1] = xA; g.lda[1] = D; g.a_idx[1] = x_idx; g.B[1] = W1b_l; g.ldb[1] = W1b_ld; g.K[1] = D;
+      g.bias = b1_l; g.relu = 1; g.b_img = lw.iW1ov; g.b_img2 = lw.iW1b;
       RUN(pfo_gemm_launch(g, s));
     } else {
-      PfoGemm g = g_nn(lw.ctx, HCp, lw.W1ovT, D, lw.h1, D, N, D, HCp);
+      PfoGemm g = g_nn(lw.ctx, HCp, W1ovT_l, D, lw.h1, D, N, D, HCp);
       g.b_img = lw.iW1ov;
       RUN(pfo_gemm_launch(g, s));
-      g = g_nt(xA, D, x_idx, p.w1 + E, E + D, lw.h1, D, N, D, D, p.b1);
+      g = g_nt(xA, D, x_idx, W1b_l, W1b_ld, lw.h1, D, N, D, D, b1_l);
       g.accumulate = 1; g.relu = 1; g.b_img = lw.iW1b;
       RUN(pfo_gemm_launch(g, s));
     }
-    {
-      // the last layer's rows ARE the requested embeddings (N == R): written in place, no copy
-      PfoGemm g = g_nt(lw.h1, D, nullptr, p.w2, D, l == L ? emb_out : lw.Hout, D, N, D, D, p.b2);
+    if (l == L) {
+      // out = W2 h1 + b2: only the top layer's rows ARE embeddings (N == R; written in place, no copy) - below it the
+      // contraction is folded into the next layer's composites
+      PfoGemm g = g_nt(lw.h1, D, nullptr, p.w2, D, emb_out, D, N, D, D, p.b2);
       g.b_img = lw.iW2;
       RUN(pfo_gemm_launch(g, s));
     }
@@ -594,51 +673,73 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     const LayerWs& lw = w.layer[l];
     const auto& p = P.l[l];
     const auto& g = G.l[l];
-    const float* dOut = (l == L) ? d_emb : w.dH[l];
-    const float* xA = (l == 1) ? tab0 : w.layer[l - 1].Hout;
+    // layers >= 2 work on the previous layer's h1 rows through their fc2-folded composites (pfo_tgn_forward, "fc2 fold"):
+    // their weight gradients land in the folded composites' gradient buffers and are unfolded on the side stream below
+    const bool folded = l >= 2;
+    const float* xA = (l == 1) ? tab0 : w.layer[l - 1].h1;
     const int32_t* x_idx = (l == 1) ? idx0 : nullptr;
     float* dx = (l == 1) ? nullptr : w.dH[l - 1];            // rows [0, N) of the previous level's gradient
+    const float* Wqk_l = folded ? lw.Wqk_f : lw.Wqk;
+    const float* W1ovT_l = folded ? lw.W1ovT_f : lw.W1ovT;
+    const float* W1b_l = folded ? lw.W1b_f : p.w1 + E;
+    const int64_t W1b_ld = folded ? D : E + D;
+    float* dWqk_l = folded ? lw.dWqk_f : lw.dWqk;
+    float* gqk_l = folded ? lw.gqk_f : lw.gqk;
+    float* dW1ovT_l = folded ? lw.dW1ovT_f : lw.dW1ovT;
 
     // Data gradients first (a chain of GEMMs + the attention core); every weight / bias gradient of the layer is
     // then taken in ONE grouped split-K launch (bias gradients ride along as an extra column).
     PfoTnProblem tn[4];
+    int ntn = 0;
     auto set_tn = [&](PfoTnProblem& q, const float* A, int64_t lda, const float* B, int64_t ldb, const int32_t* b_idx, int M_,
                       int N_, float* C_, int64_t ldc, float* bias_out) {
       q = PfoTnProblem();
       q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.b_idx = b_idx; q.M = M_; q.N = N_; q.C = C_; q.ldc = ldc; q.bias_out = bias_out;
     };
-    // fc2 (utils.py:17)
-    set_tn(tn[0], dOut, D, lw.h1, D, nullptr, D, D, g.w2, D, g.b2);
-    {
-      PfoGemm q = g_nn(dOut, D, p.w2, D, w.dh1, D, N, D, D);
+    const float* dh1;                                          // d loss / d (fc1 pre-activation)
+    if (l == L) {
+      // the top layer applies its fc2 (utils.py:17): dW2 / db2 and d h1 = relu'(.) (d out W2)
+      set_tn(tn[ntn++], d_emb, D, lw.h1, D, nullptr, D, D, g.w2, D, g.b2);
+      PfoGemm q = g_nn(d_emb, D, p.w2, D, w.dh1, D, N, D, D);
       q.relu_src = lw.h1; q.relu_ld = D;                     // ReLU backward
       q.b_img = lw.iW2T;
       RUN(pfo_gemm_launch(q, s));
+      dh1 = w.dh1;
+    } else {
+      // below the top the layer above wrote d h1 directly, ReLU mask applied by its producers (attention backward's key
+      // rows, the x-side contraction's epilogue): fc2 is part of that layer's composites
+      dh1 = w.dH[l];
     }
-    set_tn(tn[1], lw.ctx, HCp, w.dh1, D, nullptr, HCp, D, lw.dW1ovT, D, nullptr);       // dW1ovT = ctx'^T dh1
-    tn[1].c_accumulate = 0;
-    // The two weight gradients over the INSTANCES (dW2 / db2, dW1ovT) need only dOut, h1, ctx' and dh1: they go to the side
+    set_tn(tn[ntn], lw.ctx, HCp, dh1, D, nullptr, HCp, D, dW1ovT_l, D, nullptr);       // dW1ovT = ctx'^T dh1
+    tn[ntn].c_accumulate = 0;
+    ++ntn;
+    const int n_tn_a = ntn;
+    // The weight gradients over the INSTANCES (dW2 / db2 at the top, dW1ovT) need only d out, h1, ctx' and dh1: they go to the side
     // stream as soon as dh1 exists, beside the d ctx' contraction and the attention backward (measured: 15 us/step better than
     // forking them next to the attention backward alone, whose single-wavefront workgroups starve a 74 KB-LDS kernel of slots)
     static const int tna_mode = getenv("PFO_TNA_MODE") ? atoi(getenv("PFO_TNA_MODE")) : 2;   // A/B: 0 fork before the attention backward, 1 main stream
     auto tn_a_side = [&]() -> int {
       HIPOK(hipEventRecord(sd.tn_a, s), "event record failed");
       HIPOK(hipStreamWaitEvent(ss, sd.tn_a, 0), "event wait failed");
-      RUN(pfo_gemm_tn_group_launch(tn, 2, N, nullptr, w.slabs2, w.slab_floats, ss));
+      RUN(pfo_gemm_tn_group_launch(tn, n_tn_a, N, nullptr, w.slabs2, w.slab_floats, ss));
       HIPOK(hipEventRecord(sd.tn_a_done, ss), "event record failed");
       return PFO_OK;
     };
     if (l == 1 && tna_mode == 2 && !pfo_prof_on()) RUN(tn_a_side());
     // merged fc1: d ctx' = dh1 W1ovT^T (dx = dh1 W1[:, E:] is taken together with the query/key part below)
     {
-      PfoGemm q = g_nt(w.dh1, D, nullptr, lw.W1ovT, D, w.dctx, HCp, N, HCp, D, nullptr);
+      PfoGemm q = g_nt(dh1, D, nullptr, W1ovT_l, D, w.dctx, HCp, N, HCp, D, nullptr);
       q.b_img = lw.iW1ovT;
       RUN(pfo_gemm_launch(q, s));
     }
-    if (l > 1) set_tn(tn[2], w.dh1, D, xA, D, x_idx, D, D, g.w1 + E, E + D, g.b1);     // dW1[:, E:], db1
+    if (l > 1) {
+      set_tn(tn[ntn], dh1, D, xA, D, x_idx, D, D, lw.dW1b_f, D, lw.db1_f);              // d (W1[:, E:] A), d (b1 + W1[:, E:] b)
+      tn[ntn].c_accumulate = 0; tn[ntn].bias_accumulate = 0;
+      ++ntn;
+    }
     if (l == 1) {
       if (pfo_prof_on() || tna_mode == 1) {        // event-bracketed step (bench.py's roofline sample): serial, so the bracket times the kernel alone
-        RUN(pfo_gemm_tn_group_launch(tn, 2, N, nullptr, w.slabs, w.slab_floats, s));
+        RUN(pfo_gemm_tn_group_launch(tn, n_tn_a, N, nullptr, w.slabs, w.slab_floats, s));
         HIPOK(hipEventRecord(sd.tn_a_done, s), "event record failed");
       } else if (tna_mode == 0) {
         RUN(tn_a_side());
@@ -651,6 +752,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     a.nbr_tab = xA; a.nbr_ld = D;
     a.nbr_row = (l == 1) ? idx0 + N : nullptr;
     a.nbr_row_base = N;
+    a.nbr_relu = folded ? 1 : 0;                               // the keys are h1 rows of the layer below: d row *= (row > 0)
     a.nbr_ids = w.nodes[l - 1] + N;
     a.edge_feat = st->edge_feat; a.eidx = w.eidx[l]; a.dt = w.dt[l]; a.tw = P.tw; a.tb = P.tb;
     a.scale = scale; a.dropout_p = b->dropout_p; a.seed = b->seed; a.offset = b->offset + 0x51ED0000ull + (uint64_t)l; a.offset_dev = b->offset_dev;
@@ -674,7 +776,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       // weight gradients against x - is taken AFTER summing those gradients per table row: contractions over the
       // ~11 k touched rows instead of the ~54 k instances.
       HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");
-      RUN(pfo_segsum_launch(w.dQK, HCp, w.dh1, D, w.seg_ptr, w.seg_mem, w.n_touched, capP, dqk_by_member, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
+      RUN(pfo_segsum_launch(w.dQK, HCp, dh1, D, w.seg_ptr, w.seg_mem, w.n_touched, capP, dqk_by_member, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
       // the weight gradients over the table rows go to the side stream too (beside d h0 / the GRU backward on this one)
       HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
       HIPOK(hipStreamWaitEvent(ss, sd.tn_b, 0), "event wait failed");
@@ -692,28 +794,105 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
         RUN(pfo_gemm_launch(q, s));
       }
     } else {
+      // d h1 of the layer below, self rows [0, N): [dqk' | dh1] [Q_f ; W1b_f], masked by that layer's ReLU
       if (pfo_gemm_takes_bx(N, D)) {
-        // dx = [dqk' | dh1] [Wqk ; W1[:, E:]] : both sources in one launch, dx written once
-        PfoGemm q = g_nn(w.dQK, HCp, lw.Wqk, D, dx, D, N, D, HCp);
-        q.A[1] = w.dh1; q.lda[1] = D; q.B[1] = p.w1 + E; q.ldb[1] = E + D; q.K[1] = D;
+        // both sources in one launch, dx written once
+        PfoGemm q = g_nn(w.dQK, HCp, Wqk_l, D, dx, D, N, D, HCp);
+        q.A[1] = dh1; q.lda[1] = D; q.B[1] = W1b_l; q.ldb[1] = W1b_ld; q.K[1] = D;
         q.b_img = lw.iWqkT; q.b_img2 = lw.iW1bT;
+        q.relu_src = xA; q.relu_ld = D;
         RUN(pfo_gemm_launch(q, s));
       } else {
-        PfoGemm q = g_nn(w.dh1, D, p.w1 + E, E + D, dx, D, N, D, D);
+        PfoGemm q = g_nn(dh1, D, W1b_l, W1b_ld, dx, D, N, D, D);
         q.b_img = lw.iW1bT;
         RUN(pfo_gemm_launch(q, s));
-        q = g_nn(w.dQK, HCp, lw.Wqk, D, dx, D, N, D, HCp);
+        q = g_nn(w.dQK, HCp, Wqk_l, D, dx, D, N, D, HCp);
         q.accumulate = 1; q.b_img = lw.iWqkT;
+        q.relu_src = xA; q.relu_ld = D;
         RUN(pfo_gemm_launch(q, s));
       }
-      set_tn(tn[3], w.dQK, HCp, xA, D, x_idx, HCp, D, lw.dWqk, D, lw.gqk);
-      tn[3].c_accumulate = 0; tn[3].bias_accumulate = 0;
-      RUN(pfo_gemm_tn_group_launch(tn, 4, N, nullptr, w.slabs, w.slab_floats, s));
+      set_tn(tn[ntn], w.dQK, HCp, xA, D, x_idx, HCp, D, dWqk_l, D, gqk_l);
+      tn[ntn].c_accumulate = 0; tn[ntn].bias_accumulate = 0;
+      ++ntn;
+      RUN(pfo_gemm_tn_group_launch(tn, ntn, N, nullptr, w.slabs, w.slab_floats, s));
     }
 
-    // ---- chain the composite-weight gradients back to the parameters (tiny products, side streams).  Half A hangs off
-    // dW1ovT (the weight gradients over the instances), half B off dWqk / gqk (those over the table rows).  At layer 1 the
-    // two sources finish ~100 us apart on the side stream, so half A gets a stream of its own and is done before half B starts.
+    // ---- chain the composite-weight gradients back to the parameters (tiny products, side streams).
+    if (folded) {
+      // First undo the fc2 fold (notation of pfo_tgn_forward: A, b = W2, b2 of layer l-1; Q = Wqk, V = W1ovT, per head):
+      //   dT1_node = A dQ_f,node      dT1_edge|time = dQ_f,edge|time         dt likewise from gqk_f
+      //   dV_node  = A dV_f,node + b (x) dV_f[C]         dV elsewhere = dV_f
+      //   dW1b     = dW1b_f A^T + db1_f (x) b            db1 += db1_f
+      //   dQ       = dT1 A^T + dt (x) b                  d cqk = dt
+      //   dA       = sum_h ( T1_node dQ_f,node^T + t_node (x) gqk_f,node + V_node dV_f,node^T ) + W1b^T dW1b_f + Q^T dT1
+      //   db       = sum_h V_node dV_f[C]^T + W1b^T db1_f + Q^T dt
+      // The dA / db terms are written to slabs (several heads add to one matrix) and summed once.
+      const auto& gp = G.l[l - 1];
+      const float* A = P.l[l - 1].w2;
+      const float* bv = P.l[l - 1].b2;
+      const int64_t HCpD = (int64_t)HCp * D, CpD = (int64_t)Cp * D, DD = (int64_t)D * D;
+      HIPOK(hipEventRecord(sd.layer[l], s), "event record failed");
+      // (on the second side stream: the first one must stay free for layer 1's weight gradients over the instances)
+      hipStream_t sf = sd.s2;
+      HIPOK(hipStreamWaitEvent(sf, sd.layer[l], 0), "event wait failed");
+      HIPOK(hipMemcpyAsync(lw.dT1, lw.dWqk_f, HCpD * sizeof(float), hipMemcpyDeviceToDevice, sf), "copy failed");
+      HIPOK(hipMemcpyAsync(lw.gqk, lw.gqk_f, (size_t)HCp * sizeof(float), hipMemcpyDeviceToDevice, sf), "copy failed");
+      HIPOK(hipMemcpyAsync(lw.dW1ovT, lw.dW1ovT_f, HCpD * sizeof(float), hipMemcpyDeviceToDevice, sf), "copy failed");
+      float* sl = lw.fold_slabs;
+      float* vs = lw.fold_vslabs;
+      {
+        PfoGemm u[9];
+        u[0] = g_nn(A, D, lw.dWqk_f, D, lw.dT1, D, D, D, D);                                  // dT1_node = A dQ_f,node
+        u[0].batch = H; u[0].b_bs[0] = CpD; u[0].c_bs = CpD;
+        u[1] = g_nt(lw.gqk_f, D, nullptr, A, D, lw.gqk, D, 1, D, D, nullptr);                 // dt_node = A gqk_f,node
+        u[1].batch = H; u[1].a_bs[0] = Cp; u[1].c_bs = Cp;
+        u[2] = g_nt(lw.T1, D, nullptr, lw.dWqk_f, D, sl, D, D, D, D, nullptr);                // slab h: T1_node dQ_f,node^T
+        u[2].batch = H; u[2].a_bs[0] = CpD; u[2].b_bs[0] = CpD; u[2].c_bs = DD;
+        u[3] = g_nt(lw.W1ovT, D, nullptr, lw.dW1ovT_f, D, sl + H * DD, D, D, D, D, nullptr);  // slab H+h: V_node dV_f,node^T
+        u[3].batch = H; u[3].a_bs[0] = CpD; u[3].b_bs[0] = CpD; u[3].c_bs = DD;
+        u[4] = g_nn(p.w1 + E, E + D, lw.dW1b_f, D, sl + 2 * H * DD, D, D, D, D);              // slab 2H: W1b^T dW1b_f
+        u[4].a_kmajor = 1;
+        u[5] = g_nn(A, D, lw.dW1ovT_f, D, lw.dW1ovT, D, D, D, D);                             // dV_node = A dV_f,node
+        u[5].batch = H; u[5].b_bs[0] = CpD; u[5].c_bs = CpD;
+        u[6] = g_nt(lw.dW1ovT_f + (int64_t)C * D, D, nullptr, lw.W1ovT, D, vs, D, 1, D, D, nullptr);   // vslab h: V_node dV_f[C]^T
+        u[6].batch = H; u[6].a_bs[0] = CpD; u[6].b_bs[0] = CpD; u[6].c_bs = D;
+        u[7] = g_nn(lw.db1_f, D, p.w1 + E, E + D, vs + H * D, D, 1, D, D);                    // vslab H: W1b^T db1_f
+        u[8] = g_nt(lw.dW1b_f, D, nullptr, A, D, g.w1 + E, E + D, D, D, D, nullptr);          // dW1[:, E:] += dW1b_f A^T
+        u[8].accumulate = 1;
+        RUN(pfo_gemm_multi_launch(u, 9, sf));
+      }
+      {
+        PfoGemm u[3];
+        u[0] = g_nt(lw.dT1, D, nullptr, A, D, lw.dWqk, D, HCp, D, D, nullptr);                // dQ = dT1 A^T
+        u[1] = g_nn(lw.Wqk, D, lw.dT1, D, sl + (2 * H + 1) * DD, D, D, D, HCp);               // slab 2H+1: Q^T dT1 (all heads' rows)
+        u[1].a_kmajor = 1;
+        u[2] = g_nn(lw.gqk, HCp, lw.Wqk, D, vs + (H + 1) * D, D, 1, D, HCp);                  // vslab H+1: Q^T dt
+        RUN(pfo_gemm_multi_launch(u, 3, sf));
+      }
+      {
+        PFO_REQUIRE(H + 3 <= PFO_RANK1_MAX, "too many heads");
+        PfoRank1 r[PFO_RANK1_MAX];
+        int nr = 0;
+        r[nr].u = lw.gqk; r[nr].v = bv; r[nr].M = HCp; r[nr].N = D; r[nr].out = lw.dWqk; r[nr].ldo = D; ++nr;                    // dQ += dt (x) b
+        r[nr].u = lw.db1_f; r[nr].v = bv; r[nr].M = D; r[nr].N = D; r[nr].out = g.w1 + E; r[nr].ldo = E + D; ++nr;               // dW1[:, E:] += db1_f (x) b
+        for (int h = 0; h < H; ++h) {                                                                                             // dV_node += b (x) dV_f[C]
+          r[nr].u = bv; r[nr].v = lw.dW1ovT_f + ((int64_t)h * Cp + C) * D; r[nr].M = D; r[nr].N = D;
+          r[nr].out = lw.dW1ovT + (int64_t)h * CpD; r[nr].ldo = D; ++nr;
+        }
+        RUN(pfo_rank1_multi_launch(r, nr, sf));
+        PfoSumSlabs q[3];
+        q[0].dst = gp.w2; q[0].src = sl; q[0].stride = DD; q[0].count = DD; q[0].n_slabs = 2 * H + 2;                             // dA
+        q[1].dst = gp.b2; q[1].src = vs; q[1].stride = D; q[1].count = D; q[1].n_slabs = H + 2;                                   // db
+        q[2].dst = g.b1; q[2].src = lw.db1_f; q[2].stride = 0; q[2].count = D; q[2].n_slabs = 1;                                  // db1 += db1_f
+        RUN(pfo_sum_slabs_launch(q, 3, sf));
+        PfoRank1 ta;                                                                                                              // dA += sum_h t_node (x) gqk_f,node
+        ta.u = lw.tq; ta.v = lw.gqk_f; ta.M = D; ta.N = D; ta.out = gp.w2; ta.ldo = D; ta.reps = H; ta.u_rs = Cp; ta.v_rs = Cp;
+        RUN(pfo_rank1_multi_launch(&ta, 1, sf));
+      }
+    }
+    // Half A hangs off dW1ovT (the weight gradients over the instances), half B off dWqk / gqk (those over the table rows).
+    // At layer 1 the two sources finish ~100 us apart on the side stream, so half A gets a stream of its own and is done
+    // before half B starts.
     {
       PfoGemm ca[3], cb[3], c2[3];
       ca[0] = g_nn(p.wv, C, lw.dW1ovT, D, lw.dW1oT, D, dh, D, C);                          // dW1oT_h = Wv_h dW1ovT_h
@@ -750,21 +929,18 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
         rb[h].M = dh; rb[h].N = C; rb[h].out = g.wk + (int64_t)h * dh * C; rb[h].ldo = C;
       }
       ra[H].u = dc; ra[H].ldu = 1; ra[H].v = p.bo; ra[H].ldv = 1; ra[H].M = D; ra[H].N = E; ra[H].out = g.w1; ra[H].ldo = E + D;
-      hipStream_t sa = ss;
+      hipStream_t sa = sd.s2, sb = sd.s2;
       if (l == 1) {
         // both sources were launched on side streams (or, bracketed for profiling, the first on the main stream): no need to
         // hold the chain behind the main stream's d h0 contraction
-        sa = sd.s2;
+        sb = ss;
         HIPOK(hipStreamWaitEvent(sa, sd.tn_a_done, 0), "event wait failed");
-      } else {
-        HIPOK(hipEventRecord(sd.layer[l], s), "event record failed");
-        HIPOK(hipStreamWaitEvent(ss, sd.layer[l], 0), "event wait failed");
       }
       RUN(pfo_gemm_multi_launch(ca, 3, sa));
       RUN(pfo_rank1_multi_launch(ra, H + 1, sa));
       RUN(pfo_gemm_multi_launch(c2, 3, sa));
-      RUN(pfo_gemm_multi_launch(cb, 3, ss));
-      RUN(pfo_rank1_multi_launch(rb, H, ss));
+      RUN(pfo_gemm_multi_launch(cb, 3, sb));
+      RUN(pfo_rank1_multi_launch(rb, H, sb));
     }
   }
 
