@@ -91,18 +91,23 @@ __device__ __forceinline__ float4 ld4(const float* p, int nv, const float* safe)
 template <bool A_KM, bool B_KM, int TILE, bool VEC>
 __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const int by, int zb, const int split_in,
                                           float* __restrict__ lds_a, float* __restrict__ lds_b) {
-  constexpr bool SMALL = (TILE == 1);
+  constexpr bool TINY = (TILE == 2);           // 32 x 64 tile: the multi-problem launches (see gemm_multi_kernel)
+  constexpr bool SMALL = (TILE == 1) || TINY;
   constexpr int TBM = SMALL ? 32 : BM;
-  constexpr int NJ = SMALL ? 3 : 11;
+  constexpr int TBN = TINY ? 64 : BN;          // columns of the tile
+  constexpr int NB4 = TBN / 4;                 // float4 per k-row of a k-major B tile
+  constexpr int NBL = (TBN * 8 + 255) / 256;   // float4 of the B tile per thread
+  constexpr int NJ = TINY ? 1 : (SMALL ? 3 : 11);
   constexpr int NI = 2;                        // 16-row strips per wavefront
   constexpr int NA = TBM / 32;                 // float4 per thread for the A tile
-  constexpr int LDAK = LDA_KM;                 // k-major A row stride, = 16 mod 32
+  constexpr int LDAK = TINY ? 48 : LDA_KM;     // k-major A row stride, = 16 mod 32
+  constexpr int LDBK = TINY ? 80 : LDB_KM;     // k-major B row stride, = 16 mod 32
   float* const As[1] = {lds_a};
   float* const Bs[1] = {lds_b};
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int m0 = bx * TBM, n0 = by * BN;
+  const int m0 = bx * TBM, n0 = by * TBN;
   const int split = split_in;
 
   int Mlim = p.M;
@@ -133,16 +138,17 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
   const int T1 = (p.K[1] > 0 && p.A[1]) ? (p.K[1] + BK - 1) / BK : 0;
   const int T = T0 + T1;
 
-  float4 a_reg[NA], b_reg[6];
+  float4 a_reg[NA], b_reg[NBL];
+  float4 a_reg2[TINY ? NA : 1], b_reg2[TINY ? NBL : 1];   // TINY: second staging set (loads two tiles ahead)
   const float* a_row[NA];
-  const float* b_row[6];
-  bool a_ok[NA], b_ok[6];
+  const float* b_row[NBL];
+  bool a_ok[NA], b_ok[NBL];
   const float *Ab = nullptr, *Bb = nullptr;
   int64_t lda = 0, ldb = 0;
   int Ks = 0, cur_src = -1;
   const float* safe = p.A[0];
 
-  auto bind_src = [&](int src) {
+  auto bind_src = [&](int src) __attribute__((always_inline)) {
     cur_src = src;
     Ks = (src == 0) ? kend0 : p.K[1];
     Ab = p.A[src] + zb * p.a_bs[src];
@@ -160,15 +166,15 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
     }
     if (!B_KM) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < NBL; ++i) {
         const int f = tid + 256 * i;
         const int gn = n0 + (f >> 3);
-        b_ok[i] = (f < BN * 8) && gn < p.N;
+        b_ok[i] = (f < TBN * 8) && gn < p.N;
         b_row[i] = Bb + (int64_t)(b_ok[i] ? gn : 0) * ldb;
       }
     }
   };
-  auto load_tile = [&](int t) {
+  auto load_tile = [&](int t, auto& a_reg, auto& b_reg) __attribute__((always_inline)) {
     const int src = t < T0 ? 0 : 1;
     if (src != cur_src) bind_src(src);
     const int k0 = (src == 0) ? kbeg + t * BK : (t - T0) * BK;
@@ -189,18 +195,18 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
     }
     if (!B_KM) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < NBL; ++i) {
         const int k = k0 + 4 * ((tid + 256 * i) & 7);
         b_reg[i] = ld4<VEC>(b_row[i] + k, b_ok[i] ? Ks - k : 0, safe);
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < NBL; ++i) {
         const int f = tid + 256 * i;
-        const int kr = f / 44;
+        const int kr = f / NB4;
         const int k = k0 + kr;
-        const int n = n0 + 4 * (f - kr * 44);
-        const bool ok = (f < BK * 44) && k < Ks && n < p.N;
+        const int n = n0 + 4 * (f - kr * NB4);
+        const bool ok = (f < BK * NB4) && k < Ks && n < p.N;
         int64_t krow = ok ? k : 0;
         if (ok && p.b_idx && src == 0) krow = p.b_idx[k];
         b_reg[i] = ld4<VEC>(Bb + krow * ldb + n, ok ? p.n_real - n : 0, safe);
@@ -215,7 +221,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
       }
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const auto& a_reg, const auto& b_reg) __attribute__((always_inline)) {
     float* as = As[buf];
     float* bs = Bs[buf];
     if (!A_KM) {
@@ -235,9 +241,9 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
     }
     if (!B_KM) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < NBL; ++i) {
         const int f = tid + 256 * i;
-        if (f < BN * 8) {
+        if (f < TBN * 8) {
           float* d = bs + (f >> 3) * LDA_RM + 4 * (f & 7);
           *reinterpret_cast<float2*>(d) = float2{b_reg[i].x, b_reg[i].y};
           *reinterpret_cast<float2*>(d + 2) = float2{b_reg[i].z, b_reg[i].w};
@@ -245,41 +251,41 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < NBL; ++i) {
         const int f = tid + 256 * i;
-        if (f < BK * 44) {
-          const int kr = f / 44;
-          *reinterpret_cast<float4*>(bs + kr * LDB_KM + 4 * (f - kr * 44)) = b_reg[i];
+        if (f < BK * NB4) {
+          const int kr = f / NB4;
+          *reinterpret_cast<float4*>(bs + kr * LDBK + 4 * (f - kr * NB4)) = b_reg[i];
         }
       }
     }
   };
   // fragments of k-step s (lane (r, g) holds A[row r][k = 4s + g], B[k = 4s + g][col r])
-  auto load_frags = [&](const float* as, const float* bs, int s, float (&a)[NI], float (&b)[NJ]) {
+  auto load_frags = [&](const float* as, const float* bs, int s, float (&a)[NI], float (&b)[NJ]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
       a[i] = A_KM ? as[(4 * s + g) * LDAK + wrow + 16 * i + r] : as[(wrow + 16 * i + r) * LDA_RM + 4 * s + g];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int col = wcol + (SMALL ? 64 : 16) * j + r;
-      b[j] = B_KM ? bs[(4 * s + g) * LDB_KM + col] : bs[col * LDA_RM + 4 * s + g];
+      b[j] = B_KM ? bs[(4 * s + g) * LDBK + col] : bs[col * LDA_RM + 4 * s + g];
     }
   };
   // a wavefront whose 16-row strip lies entirely beyond M issues no MFMAs for it (172-row weight-gradient tiles:
   // the matrix pipe of its SIMD is left to the co-resident workgroup)
   const bool strip_on[2] = {m0 + wrow < p.M, m0 + wrow + 16 < p.M};
-  auto mma = [&](const float (&a)[NI], const float (&b)[NJ]) {
+  auto mma = [&](const float (&a)[NI], const float (&b)[NJ]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
       if (strip_on[i])
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
-        if (!SMALL || wcol + 64 * j < BN)
+        if (!SMALL || wcol + 64 * j < TBN)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
   };
   // all 8 k-steps of a tile; LDS beyond K holds zeros, so the K tail needs no guard.  Fragment reads of step
   // s+1 are issued ahead of the MFMAs of step s.
-  auto compute_tile = [&](int buf) {
+  auto compute_tile = [&](int buf) __attribute__((always_inline)) {
     const float* as = As[buf];
     const float* bs = Bs[buf];
     float a0[NI], b0[NJ], a1[NI], b1[NJ];
@@ -293,16 +299,40 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
     }
   };
 
-  if (T > 0) {
-    load_tile(0);
-    store_tile(0);
+  if constexpr (TINY && GEMM_EXP == 0) {
+    // The small problems (composite weights, their gradient chains) are a handful of workgroups beside the step's large
+    // launches: a k-tile costs one memory round trip, not its 16 MFMAs per wavefront.  Two tiles of loads stay in flight
+    // (two register sets; the loop is unrolled by two so that the sets are compile-time names).
+    if (T > 0) {
+      load_tile(0, a_reg, b_reg);
+      if (T > 1) load_tile(1, a_reg2, b_reg2);
+      store_tile(0, a_reg, b_reg);
+      __syncthreads();
+      for (int t = 0; t < T; t += 2) {
+        if (t + 2 < T) load_tile(t + 2, a_reg, b_reg);
+        compute_tile(0);
+        __syncthreads();
+        if (t + 1 < T) store_tile(0, a_reg2, b_reg2);
+        __syncthreads();
+        if (t + 1 < T) {
+          if (t + 3 < T) load_tile(t + 3, a_reg2, b_reg2);
+          compute_tile(0);
+          __syncthreads();
+          if (t + 2 < T) store_tile(0, a_reg, b_reg);
+          __syncthreads();
+        }
+      }
+    }
+  } else if (T > 0) {
+    load_tile(0, a_reg, b_reg);
+    store_tile(0, a_reg, b_reg);
     __syncthreads();
     for (int t = 0; t < T; ++t) {
       const bool more = (GEMM_EXP == 1 || GEMM_EXP == 3) ? false : (t + 1 < T);
-      if (more) load_tile(t + 1);                // global loads in flight during the MFMAs below
+      if (more) load_tile(t + 1, a_reg, b_reg);  // global loads in flight during the MFMAs below
       if (GEMM_EXP != 2) compute_tile(0);
       if (GEMM_EXP != 3) __syncthreads();        // every wavefront is done reading the tile
-      if (more) store_tile(0);
+      if (more) store_tile(0, a_reg, b_reg);
       if (GEMM_EXP != 3) __syncthreads();
     }
   }
@@ -331,7 +361,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDev& p, const int bx, const 
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int col = n0 + wcol + (SMALL ? 64 : 16) * j + r;
-        if (col >= p.N || (SMALL && wcol + 64 * j >= BN)) continue;
+        if (col >= p.N || (SMALL && wcol + 64 * j >= TBN)) continue;
         float v = acc[i][j][reg];
         if (!plain) {
           if (p.accumulate) v += Cb[(int64_t)row * ldc + col];
@@ -1159,7 +1189,7 @@ __global__ __launch_bounds__(256) void bimg_kernel(const BimgDev g) {
 
 // ---------------------------------------------------------------------------------------------
 // Several SMALL independent contractions in one launch (the composite-weight products of a layer and their
-// gradient chain: each is far too small to fill the chip or to amortise a launch).  32-row tiles; the operand
+// gradient chain: each is far too small to fill the chip or to amortise a launch).  32 x 64 tiles; the operand
 // layout is a per-problem switch (wavefront-uniform).
 #define MULTI_MAX PFO_GEMM_MULTI_MAX
 struct MultiDev {
@@ -1171,7 +1201,10 @@ struct MultiDev {
 };
 template <bool VEC>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_multi_kernel(const MultiDev g) {
-  GEMM_LDS_DECL;
+  // the 32 x 64 tile's staging: A max(32 * 34, 32 * 48), B max(64 * 34, 32 * 80) floats - 16 KB, so these launches take
+  // little room beside the large ones they run next to
+  __shared__ __attribute__((aligned(16))) float lds_a[1536];
+  __shared__ __attribute__((aligned(16))) float lds_b[2560];
   int q = 0;
 #pragma unroll
   for (int i = 1; i < MULTI_MAX; ++i)
@@ -1181,12 +1214,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_multi_kernel(const MultiDev
   const int zb = t / per_batch;
   t -= zb * per_batch;
   const int bx = t / g.tn[q], by = t % g.tn[q];
-  const GemmDev& p = g.p[q];
+  const GemmDev p = g.p[q];                       // a copy: indexing the by-value argument through a reference costs scratch
   switch (g.layout[q]) {
-    case 0: gemm_tile<false, false, 1, VEC>(p, bx, by, zb, 0, lds_a, lds_b); break;
-    case 1: gemm_tile<false, true, 1, VEC>(p, bx, by, zb, 0, lds_a, lds_b); break;
-    case 2: gemm_tile<true, false, 1, VEC>(p, bx, by, zb, 0, lds_a, lds_b); break;
-    default: gemm_tile<true, true, 1, VEC>(p, bx, by, zb, 0, lds_a, lds_b); break;
+    case 0: gemm_tile<false, false, 2, VEC>(p, bx, by, zb, 0, lds_a, lds_b); break;
+    case 1: gemm_tile<false, true, 2, VEC>(p, bx, by, zb, 0, lds_a, lds_b); break;
+    case 2: gemm_tile<true, false, 2, VEC>(p, bx, by, zb, 0, lds_a, lds_b); break;
+    default: gemm_tile<true, true, 2, VEC>(p, bx, by, zb, 0, lds_a, lds_b); break;
   }
 }
 
@@ -1580,7 +1613,7 @@ int pfo_gemm_multi_launch(const PfoGemm* list, int n, hipStream_t stream) {
       to_dev(s, g.p[i]);
       g.layout[i] = (s.a_kmajor ? 2 : 0) + (s.b_kmajor ? 1 : 0);
       g.tm[i] = (int)pfo_ceil_div(s.M, 32);
-      g.tn[i] = (int)pfo_ceil_div(s.N, BN);
+      g.tn[i] = (int)pfo_ceil_div(s.N, 64);            // gemm_tile's TINY shape: 32 x 64
       g.tile_begin[i] = tiles;
       tiles += g.tm[i] * g.tn[i] * s.batch;
       vec = vec && gemm_vec_ok(s);
