@@ -45,21 +45,29 @@ __device__ __forceinline__ unsigned attn_keep_bits(uint64_t seed, uint64_t offse
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
+#ifndef FWD_WAVES
+#define FWD_WAVES(NR, H) ((NR) * (H) <= 6 ? 5 : 2)      // registers per lane the compiler may use: 96 for D <= 192 with two heads
+#endif
 template <int NR, int H>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD_WAVES(NR, H)))) void attn_fwd_kernel(const AttnDev a) {
+  // the time-encoder parameters live in LDS, not in six registers per lane: with them the kernel fits 96 registers = 5
+  // wavefronts per SIMD instead of 4
+  __shared__ float s_tw[NR * 64], s_tb[NR * 64];
+  for (int c = threadIdx.x; c < NR * 64; c += 256) {
+    s_tw[c] = c < a.D ? a.tw[c] : 0.f;
+    s_tb[c] = c < a.D ? a.tb[c] : 0.f;
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t n = (int64_t)blockIdx.x * 4 + wave;     // one instance per wavefront (a grid-stride form was measured: the
   if (n >= a.N) return;                                 // loop-carried state cost 32 VGPRs = 2 waves/SIMD and 25 % of the time)
   const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef, Cp = a.Cp;   // Cp: per-head row stride (C + 2 extra columns, padded)
 
-  float tw[NR], tb[NR];
   float qn[H][NR], qt[H][NR], qe[H];
   const float* qk = a.QK + (a.qk_row ? (int64_t)a.qk_row[n] : n) * a.qk_ld;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int c = lane + 64 * r;
-    tw[r] = c < D ? a.tw[c] : 0.f;
-    tb[r] = c < D ? a.tb[c] : 0.f;
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       qn[h][r] = c < D ? qk[h * Cp + c] : 0.f;
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnDev a) {
     for (int c = 0; c < KC_FWD; ++c)
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        arg[c][r] = pfo_time_arg(dtv[c], tw[r], tb[r]);
+        arg[c][r] = pfo_time_arg(dtv[c], s_tw[lane + 64 * r], s_tb[lane + 64 * r]);
         big = big || !(fabsf(arg[c][r]) < 2.0e7f);
       }
     const bool any_big = __ballot(big) != 0ull;
