@@ -816,30 +816,36 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_areg_kernel(const Gem
 // CUs idle and every workgroup is latency-bound): 32 rows x 176 columns per workgroup, wavefront w owns the column
 // tiles w, w+4, w+8 of all 32 rows; two LDS buffers, ONE barrier per k-tile, and two register stages so that the
 // global loads of k-tiles t+2 and t+3 are in flight while tile t is multiplied.  Pre-split B image only.
+// NT = column tiles (of 16) per workgroup: 11 (the whole 176-column block of the image) or 4 - launches with a few dozen
+// row tiles (layer 2 at C2: 80) put three times the workgroups on the chip, each staging a third of the image per k-tile.
 #define SK_ROWS 32
 #define SK_A_PIECE (SK_ROWS * 64)
-#define SK_BUF_BYTES (3 * SK_A_PIECE + 3 * BX_B_PIECE)
+template <int NT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const GemmDev p) {
+  constexpr int SK_B_PIECE = NT * 16 * 64;                     // bytes of one piece of the staged B slice
+  constexpr int SK_BUF_BYTES = 3 * SK_A_PIECE + 3 * SK_B_PIECE;
+  constexpr int NU = (3 * (SK_B_PIECE / 16) + 255) / 256;      // 16-byte units of the B slice per thread
+  constexpr int NJW = (NT + 3) / 4;                            // column tiles per wavefront
   __shared__ __attribute__((aligned(16))) char lds[2 * SK_BUF_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * SK_ROWS, n0 = blockIdx.y * BN;
+  const int m0 = blockIdx.x * SK_ROWS, n0 = blockIdx.y * (NT * 16);
   int Mlim = p.M;
   if (p.m_dev) Mlim = min(Mlim, *p.m_dev);
   if (m0 >= Mlim) return;
   const int T0 = (p.K[0] + BK - 1) / BK;
   const int T1 = (p.K[1] > 0 && p.A[1]) ? (p.K[1] + BK - 1) / BK : 0;     // optional second K-concatenated source
   const int T = T0 + T1;
-  f32x4 acc[2][3];
+  f32x4 acc[2][NJW];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int jj = 0; jj < 3; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int jj = 0; jj < NJW; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // staging: one float4 of A (row tid >> 3, k quad tid & 7) and nine 16-byte units of the B image per thread and stage
+  // staging: one float4 of A (row tid >> 3, k quad tid & 7) and NU 16-byte units of the B image per thread and stage
   float4 a_st[2];
-  f32x4 i_st[2][9];
+  f32x4 i_st[2][NU];
   const int a_r = tid >> 3, a_c4 = tid & 7;
   const bool a_ok = m0 + a_r < Mlim;
   int64_t ridx0 = a_ok ? m0 + a_r : 0, ridx1 = ridx0;
@@ -851,6 +857,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const G
   const char* img0 = reinterpret_cast<const char*>(p.b_img) + (int64_t)n0 * 64;
   const char* img1 = T1 > 0 ? reinterpret_cast<const char*>(p.b_img2) + (int64_t)n0 * 64 : img0;
   const int64_t img_piece = (int64_t)p.b_img_rows * 64;
+  const int img_units_left = min(SK_B_PIECE / 16, (p.b_img_rows - n0) * 4);      // 16-byte units of this slice inside the image
   auto load_global = [&](int t, auto sc) {
     constexpr int st = decltype(sc)::value;
     const bool second = t >= T0;
@@ -858,11 +865,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const G
     const int k = ts * BK + 4 * a_c4;
     a_st[st] = ld4<true>((second ? a_row1 : a_row0) + k, a_ok ? (second ? p.K[1] : p.K[0]) - k : 0, safe);
     const char* tile = (second ? img1 : img0) + (int64_t)ts * 3 * img_piece;
-    bx_for<9>([&](auto uc) {
+    bx_for<NU>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
-      const int unit = min(tid + 256 * u, 3 * (BX_B_PIECE / 16) - 1);
-      const int q = (unit >= 2 * (BX_B_PIECE / 16)) ? 2 : (unit >= BX_B_PIECE / 16 ? 1 : 0);
-      i_st[st][u] = *reinterpret_cast<const f32x4*>(tile + q * img_piece + (unit - q * (BX_B_PIECE / 16)) * 16);
+      const int unit = min(tid + 256 * u, 3 * (SK_B_PIECE / 16) - 1);
+      const int q = (unit >= 2 * (SK_B_PIECE / 16)) ? 2 : (unit >= SK_B_PIECE / 16 ? 1 : 0);
+      // the last 64-column slice of a 176-row image block is 48 rows: rows beyond the image are clamped (their columns are never stored)
+      const int in_piece = min(unit - q * (SK_B_PIECE / 16), img_units_left - 1);
+      i_st[st][u] = *reinterpret_cast<const f32x4*>(tile + q * img_piece + in_piece * 16);
     });
   };
   auto store_lds = [&](int buf, auto sc) {
@@ -870,33 +879,33 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const G
     char* As = lds + buf * SK_BUF_BYTES;
     char* Bs = As + 3 * SK_A_PIECE;
     bx_split_store(As, SK_A_PIECE, a_r, a_c4, a_st[st]);
-    bx_for<9>([&](auto uc) {
+    bx_for<NU>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       const int unit = tid + 256 * u;
-      if (u < 8 || unit < 3 * (BX_B_PIECE / 16)) *reinterpret_cast<f32x4*>(Bs + unit * 16) = i_st[st][u];
+      if (256 * (u + 1) <= 3 * (SK_B_PIECE / 16) || unit < 3 * (SK_B_PIECE / 16)) *reinterpret_cast<f32x4*>(Bs + unit * 16) = i_st[st][u];
     });
   };
   const int frag_off = r * 64 + ((g ^ bx_swz(r)) << 4);
   auto compute = [&](int buf) {
     const char* As = lds + buf * SK_BUF_BYTES;
     const char* Bs = As + 3 * SK_A_PIECE;
-    bf16x8 a[2][3], b[3][3];
+    bf16x8 a[2][3], b[NJW][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(As + q * SK_A_PIECE + (16 * i) * 64 + frag_off);
 #pragma unroll
-    for (int jj = 0; jj < 3; ++jj)
+    for (int jj = 0; jj < NJW; ++jj)
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        const int j = min(wave + 4 * jj, 10);                 // wave 3 has no third tile: re-reads tile 10, result unused
-        b[jj][q] = *reinterpret_cast<const bf16x8*>(Bs + q * BX_B_PIECE + (16 * j) * 64 + frag_off);
+        const int j = min(wave + 4 * jj, NT - 1);             // NT = 11: wave 3 has no third tile, re-reads tile 10, result unused
+        b[jj][q] = *reinterpret_cast<const bf16x8*>(Bs + q * SK_B_PIECE + (16 * j) * 64 + frag_off);
       }
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
 #pragma unroll
     for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
-      for (int jj = 0; jj < 3; ++jj)
+      for (int jj = 0; jj < NJW; ++jj)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
           acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[jj][PB[t6]], a[i][PA[t6]], acc[i][jj], 0, 0, 0);
@@ -934,10 +943,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const G
     const bool zero = p.row_zero ? (p.row_zero[row] != 0) : false;
     const float* addrow = p.add_src ? p.add_src + (int64_t)(p.add_idx ? p.add_idx[row] : row) * p.add_ld : nullptr;
 #pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
+    for (int jj = 0; jj < NJW; ++jj) {
       const int j = wave + 4 * jj;
       const int col = n0 + 16 * j + 4 * g;
-      if (j < 11 && col < p.N) bx_store4(p, Cb, ldc, p.bias, rscale, zero, n4, row, col, acc[i][jj], addrow);
+      if (j < NT && col < p.N) bx_store4(p, Cb, ldc, p.bias, rscale, zero, n4, row, col, acc[i][jj], addrow);
     }
   }
 }
@@ -1557,7 +1566,14 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
     if (g.b_img && (g.K[1] == 0 || g.b_img2) && a_rowvec && (g.bx_force == 2 || (bx >= 1 && sk && !g.bx_force && force < 0 && big_tiles < bx_min_tiles))) {
       d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN); d.b_img2 = g.b_img2;
       if (!g.m_dev) kind = PFO_PROF_GEMM_BX_SKINNY;
-      hipLaunchKernelGGL(gemm_bx_skinny_kernel, dim3((unsigned)pfo_ceil_div(g.M, SK_ROWS), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
+      // few row tiles (< one per CU even with 176-column workgroups): 64-column workgroups fill the chip three times better
+      static const int narrow = getenv("PFO_SKINNY_NARROW") ? atoi(getenv("PFO_SKINNY_NARROW")) : 512;        // A/B switch: workgroup threshold, 0 = never
+      const int64_t sk_wgs = (int64_t)pfo_ceil_div(g.M, SK_ROWS) * tn;
+      if (sk_wgs < narrow)
+        hipLaunchKernelGGL(gemm_bx_skinny_kernel<4>, dim3((unsigned)pfo_ceil_div(g.M, SK_ROWS), (unsigned)pfo_ceil_div(g.N, 64), 1),
+                           dim3(GEMM_THREADS), 0, stream, d);
+      else
+        hipLaunchKernelGGL(gemm_bx_skinny_kernel<11>, dim3((unsigned)pfo_ceil_div(g.M, SK_ROWS), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
     } else if (g.b_img && (g.K[1] == 0 || g.b_img2) && a_rowvec && (g.bx_force || (bx >= 1 && big_tiles >= bx_min_tiles && force < 0))) {
       d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN); d.b_img2 = g.b_img2;
       if (!g.m_dev) kind = PFO_PROF_GEMM_BX;       // device-side row counts stay "time only"
