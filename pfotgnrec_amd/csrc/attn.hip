@@ -18,6 +18,7 @@ struct AttnDev {
   float* ctx; float* attw; uint8_t* inv;
   const float* dctx; float* dQK; float* d_nbr; int64_t d_nbr_ld; double* dtime_part;
   int64_t d_nbr_rep;  // DMODE 1: floats between the per-XCD replicas of the gradient table (0: one table)
+  int d_nbr_nrep;     // ... and how many of them are in use (a power of two)
   // run-merged layer-1 backward: instances in (table row, run key) order, seg_ptr[*n_rows] of them
   const int32_t* members; const int32_t* seg_ptr; const int32_t* n_rows;
   int abl;      // timing-only ablation switch (PFO_ATTN_ABL): 1 = spread the atomic destinations (wrong results)
@@ -258,7 +259,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
   // float atomics from all XCDs on one table make each cache line migrate between L2s (the 500 item rows take 77 % of
   // the adds); with one replica per XCD the atomics stay in the local L2.  The XCC id only picks the replica: a wrong
   // value would cost speed, never correctness (the atomics are device-coherent either way).
-  float* const d_nbr_x = (DMODE == 1) ? a.d_nbr + (int64_t)(__builtin_amdgcn_s_getreg(6164) & (PFO_GRAD_REPLICAS - 1)) * a.d_nbr_rep : a.d_nbr;   // hwreg(HW_REG_XCC_ID, 0, 4)
+  float* const d_nbr_x = (DMODE == 1) ? a.d_nbr + (int64_t)(__builtin_amdgcn_s_getreg(6164) & (a.d_nbr_nrep - 1)) * a.d_nbr_rep : a.d_nbr;   // hwreg(HW_REG_XCC_ID, 0, 4)
 
   for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < a.N; n += (int64_t)gridDim.x * 4) {
     float* dqk_out = a.dQK + n * H * Cp;
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
     s_tb[c] = c < D ? a.tb[c] : 0.f;
   }
   const float keep_scale = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
-  float* const d_nbr_x = a.d_nbr + (int64_t)(__builtin_amdgcn_s_getreg(6164) & (PFO_GRAD_REPLICAS - 1)) * a.d_nbr_rep;
+  float* const d_nbr_x = a.d_nbr + (int64_t)(__builtin_amdgcn_s_getreg(6164) & (a.d_nbr_nrep - 1)) * a.d_nbr_rep;
   const int M = a.seg_ptr[*a.n_rows];                            // members = instances that sit on a real node
   const int n_chunks = (M + RUN_CHUNK - 1) / RUN_CHUNK;
 
@@ -759,7 +760,7 @@ static void to_dev(const PfoAttn& a, AttnDev& d) {
   static const int abl = getenv("PFO_ATTN_ABL") ? atoi(getenv("PFO_ATTN_ABL")) : 0;
   d.abl = abl;
   d.ctx = a.ctx; d.attw = a.attw; d.inv = a.inv;
-  d.dctx = a.dctx; d.dQK = a.dQK; d.d_nbr = a.d_nbr; d.d_nbr_ld = a.d_nbr_ld; d.d_nbr_rep = a.d_nbr_rep;
+  d.dctx = a.dctx; d.dQK = a.dQK; d.d_nbr = a.d_nbr; d.d_nbr_ld = a.d_nbr_ld; d.d_nbr_rep = a.d_nbr_rep; d.d_nbr_nrep = a.d_nbr_nrep > 0 ? a.d_nbr_nrep : 1;
   d.dtime_part = a.dtime_part;
   d.members = a.members; d.seg_ptr = a.seg_ptr; d.n_rows = a.n_rows;
 }
@@ -816,9 +817,12 @@ int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream) {
   return PFO_OK;
 }
 
-bool pfo_attn_bwd_uses_runs(const PfoAttn& a) {
+bool pfo_attn_bwd_runs_possible(int K) {
   static const int runs_on = getenv("PFO_ATTN_RUNS") ? atoi(getenv("PFO_ATTN_RUNS")) : 1;                    // A/B switch
-  return a.d_nbr && a.nbr_row && runs_on && a.members && a.seg_ptr && a.n_rows && a.qk_row && a.K <= 64;
+  return runs_on && K <= 64;
+}
+bool pfo_attn_bwd_uses_runs(const PfoAttn& a) {
+  return a.d_nbr && a.nbr_row && pfo_attn_bwd_runs_possible(a.K) && a.members && a.seg_ptr && a.n_rows && a.qk_row;
 }
 
 int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {

@@ -46,7 +46,8 @@ struct PfoAttn {
   float* dQK = nullptr;             // [N, H*Cp]
   float* d_nbr = nullptr;           // rows of D floats: direct rows (nbr_row == null) or atomically added rows
   int64_t d_nbr_ld = 0;
-  int64_t d_nbr_rep = 0;            // atomically added rows: floats between the 8 per-XCD replicas of the table (0 = a single table)
+  int64_t d_nbr_rep = 0;            // atomically added rows: floats between the per-XCD replicas of the table (0 = a single table)
+  int d_nbr_nrep = 1;               // replicas in use (power of two <= PFO_GRAD_REPLICAS): XCD x adds into replica x & (n - 1)
   double* dtime_part = nullptr;     // [ATTN_TIME_BINS, 2*D] fp64 accumulators (dw | db) of the time encoder: ADDED to (zero them per step)
   // optional (layer 1 over the touched-node table, atomically added rows, most-recent sampling): the instances ordered by
   // (table row, run key) as built by pfo_seg_build_launch with key_src = eidx.  Consecutive members of a run share their K
@@ -63,3 +64,4 @@ int pfo_attn_bwd_max_parts();
 // true when pfo_attn_bwd_launch will take the run-merged kernel for `a`: dQK row m then belongs to the m-th MEMBER
 // (a.members[m]), not to instance m
 bool pfo_attn_bwd_uses_runs(const PfoAttn& a);
+bool pfo_attn_bwd_runs_possible(int K);   // the switch and the shape limit alone (known before the launch is described)

@@ -655,7 +655,10 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
   const int32_t* idx0 = w.idx0;
   const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
   const int64_t rep_stride = (int64_t)d.capP * D;             // floats between the per-XCD replicas of d_h0
-  if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_touched, capP, D, PFO_GRAD_REPLICAS, rep_stride, s));
+  // Per-XCD replicas of the level-0 gradient table pay off only for the per-instance atomics (uniform sampling: 4 replicas
+  // 0.537 -> 0.506 ms); the run-merged kernel issues 2-3x fewer and measures best on ONE table (1.656 vs 1.665 ms/step)
+  const int n_rep = (c->use_memory && !b->uniform && pfo_attn_bwd_runs_possible(K)) ? 1 : PFO_GRAD_REPLICAS;
+  if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_touched, capP, D, n_rep, rep_stride, s));
 
   const int Cp = d.Cp, HCp = H * d.Cp, WQ = HCp + D;
   Side& sd = side();
@@ -758,7 +761,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     a.scale = scale; a.dropout_p = b->dropout_p; a.seed = b->seed; a.offset = b->offset + 0x51ED0000ull + (uint64_t)l; a.offset_dev = b->offset_dev;
     a.ctx = lw.ctx; a.attw = lw.attw; a.inv = lw.inv;
     a.dctx = w.dctx; a.dQK = w.dQK;
-    if (l == 1) { a.d_nbr = c->use_memory ? w.d_h0 : nullptr; a.d_nbr_ld = D; a.d_nbr_rep = rep_stride; }
+    if (l == 1) { a.d_nbr = c->use_memory ? w.d_h0 : nullptr; a.d_nbr_ld = D; a.d_nbr_rep = rep_stride; a.d_nbr_nrep = n_rep; }
     else        { a.d_nbr = w.dH[l - 1]; a.d_nbr_ld = D; }
     a.dtime_part = w.dtime;
     int n_parts = 0;
@@ -946,7 +949,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
 
   // ---- GRU parameters (messages and stored memory are constants: SURVEY App. A-6)
   if (c->use_memory) {
-    RUN(pfo_gru_gates_bwd_launch(w.gi, w.gh, w.h_rows, w.hm, w.n_touched, capP, D, w.d_h0, PFO_GRAD_REPLICAS, rep_stride,
+    RUN(pfo_gru_gates_bwd_launch(w.gi, w.gh, w.h_rows, w.hm, w.n_touched, capP, D, w.d_h0, n_rep, rep_stride,
                                  w.dx_tab, s));
     {
       PfoTnProblem gp[2];
