@@ -427,6 +427,7 @@ def main():
                    "timed_seconds": round(elapsed, 3),
                    "block_ms_per_step": {"first": round(wl.block_ms[0], 4), "min": round(min(wl.block_ms), 4),
                                          "median": round(float(np.median(wl.block_ms)), 4), "last": round(wl.block_ms[-1], 4)},
+                   **({"block_ms_all": [round(x, 4) for x in wl.block_ms]} if os.environ.get("PFO_BENCH_BLOCKS") else {}),
                    "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4), "hip_graph": wl.graph_note,
                    "collective": ("%s all-reduce of the flat fp32 gradient, world %d"
                                   % ("rccl" if dist.get_backend() == "nccl" else dist.get_backend(), dist.get_world_size())) if world > 1 else None},
