@@ -251,6 +251,7 @@ PfoGemm g_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const int
   return g;
 }
 
+#define PFO_MAX_DEVICES 16
 // Internal side stream: the composite-weight products (forward) and their gradient chain (backward) are tiny
 // dependent launches; they run beside the main stream's work and are joined by events where their results are needed.
 struct Side {
@@ -261,7 +262,11 @@ struct Side {
   bool ok = false;
 };
 Side& side() {
-  static Side sd;
+  // one set per device (streams and events belong to the device that was current when they were made)
+  static Side sds[PFO_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PFO_MAX_DEVICES) dev = 0;
+  Side& sd = sds[dev];
   if (!sd.ok) {
     bool good = hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) == hipSuccess;
     good = good && hipStreamCreateWithFlags(&sd.s2, hipStreamNonBlocking) == hipSuccess;
