@@ -352,7 +352,7 @@ class Workload:
                    "%d/GPU" % self.per_gpu if self.scaling == "weak" else "%d global (fixed), %d shards" % (self.B, self.world)))
 
 
-def roofline_of(prof, n_prof_steps):
+def roofline_of(prof, n_prof_steps, profiled_workload=True):
     """Dominant kernel family by device time over the sampled steps.  Contractions on the bf16x3 kernels are priced against
     the dense bf16 MFMA peak divided by the six piece products one fp32 product costs; the fp32-MFMA kernels against the
     fp32 MFMA peak; the attention / sampling kernels against HBM."""
@@ -374,13 +374,16 @@ def roofline_of(prof, n_prof_steps):
         achieved = v["work"] / v["count"] / per_launch_s / 1e9
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}
-    roof["traffic"] = pmc_traffic(dom)
+    # the committed counter pass was taken on the default workload (C2, 512 interactions per launch): other shapes get null
+    roof["traffic"] = pmc_traffic(dom) if profiled_workload else None
     roof["kernel"] = dom
     roof["avg_launch_us"] = round(per_launch_s * 1e6, 2)
     roof["launches"] = int(v["count"])
     roof["sampled_steps"] = n_prof_steps
     roof["families_ms_per_step"] = {k: round(x["ms"] / max(1, n_prof_steps), 4) for k, x in prof.items() if x["count"] > 0}
-    tot = lambda ks: sum(prof[k]["work"] for k in ks if k in prof) / max(1e-9, sum(prof[k]["ms"] for k in ks if k in prof) * 1e-3)
+    # (families whose launches carry no work figure - device-side extents, "time only" - stay out of the rates)
+    tot = lambda ks: (sum(prof[k]["work"] for k in ks if k in prof and prof[k]["work"] > 0) /
+                      max(1e-9, sum(prof[k]["ms"] for k in ks if k in prof and prof[k]["work"] > 0) * 1e-3))
     roof["gemm_all_tflops"] = round(tot([k for k in prof if k.startswith("gemm")]) / 1e12, 2)
     roof["attn_all_gbs"] = round(tot([k for k in prof if k.startswith("attn")]) / 1e9, 1)
     return roof
@@ -433,7 +436,8 @@ def main():
                                   % ("rccl" if dist.get_backend() == "nccl" else dist.get_backend(), dist.get_world_size())) if world > 1 else None},
     }
     if prof is not None:
-        roof = roofline_of(prof, n_prof_steps)
+        roof = roofline_of(prof, n_prof_steps, profiled_workload=(cfg_name == "C2" and wl.mvs is None and
+                                                                    (wl.per_gpu if scaling == "weak" else wl.B // world) == 512))
         if roof:
             out["roofline"] = roof
 

@@ -1447,11 +1447,12 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
   else hipLaunchKernelGGL(gemm_tn_group_kernel<false>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   PFO_LAUNCH_CHECK();
   // the GEMM kernel alone; with a device-side K bound the host does not know the work: time only
-  if (use_bx) pfo_prof_end(k_dev ? PFO_PROF_GEMM_DEVM : PFO_PROF_GEMM_TN_BX, flops, stream);
+  // launches whose extent is a device-side count are "time only": the host knows only the capacity, not the work
+  if (use_bx) pfo_prof_end(k_dev ? PFO_PROF_GEMM_DEVM : PFO_PROF_GEMM_TN_BX, k_dev ? 0.0 : flops, stream);
   hipLaunchKernelGGL(tn_group_reduce_kernel, dim3((unsigned)std::min<int64_t>(1024, pfo_ceil_div(per_split, 256))), dim3(256), 0,
                      stream, g);
   PFO_LAUNCH_CHECK();
-  if (!use_bx) pfo_prof_end(k_dev ? PFO_PROF_GEMM_DEVM : PFO_PROF_GEMM_TN, flops, stream);
+  if (!use_bx) pfo_prof_end(k_dev ? PFO_PROF_GEMM_DEVM : PFO_PROF_GEMM_TN, k_dev ? 0.0 : flops, stream);
   return PFO_OK;
 }
 
@@ -1598,7 +1599,7 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
   }
 #undef GEMM_GO
   PFO_LAUNCH_CHECK();
-  pfo_prof_end(kind, flops, stream);
+  pfo_prof_end(kind, kind == PFO_PROF_GEMM_DEVM ? 0.0 : flops, stream);
   return PFO_OK;
 }
 
