@@ -125,14 +125,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD_WAVES(N
 #pragma unroll
     for (int c = 0; c < KC_FWD; ++c) {
       const int j = jj[c] < 0 ? 0 : jj[c];
-      const float* src = a.nbr_tab + (int64_t)rl_i(my_row, j) * a.nbr_ld;
+      const float* src = a.nbr_tab + (uint32_t)rl_i(my_row, j) * (uint32_t)a.nbr_ld;        // 32-bit element offsets (checked on the host): one scalar multiply
       const int e = rl_i(my_e, j);
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const int cc = lane + 64 * r;
         kk[c][r] = (jj[c] >= 0 && (r < NR - 1 || cc < D)) ? src[cc] : 0.f;
       }
-      ee[c] = (jj[c] >= 0 && lane < Ef) ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
+      ee[c] = (jj[c] >= 0 && lane < Ef) ? a.edge_feat[(uint32_t)e * (uint32_t)Ef + (uint32_t)lane] : 0.f;
     }
   };
   auto process = [&](const int (&js)[KC_FWD], const float (&kn)[KC_FWD][NR], const float (&ke)[KC_FWD]) {
@@ -345,7 +345,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
           const int cc = lane + 64 * r;
           kn[c][r] = (js[c] >= 0 && (r < NR - 1 || cc < D)) ? src[cc] : 0.f;
         }
-        ke[c] = (js[c] >= 0 && lane < Ef) ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
+        ke[c] = (js[c] >= 0 && lane < Ef) ? a.edge_feat[(uint32_t)e * (uint32_t)Ef + (uint32_t)lane] : 0.f;
       }
       float part[KC_BWD][H];
       // time encoding of the chunk: ONE out-of-range test for all its arguments (wave-wide), as in the forward kernel
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
 #pragma unroll
         for (int c = 0; c < KC_RUNS; ++c) {
           const int j = js[c] < 0 ? 0 : js[c];
-          const float* src = a.nbr_tab + (int64_t)rl_i(my_row, j) * a.nbr_ld;
+          const float* src = a.nbr_tab + (uint32_t)rl_i(my_row, j) * (uint32_t)a.nbr_ld;        // 32-bit element offsets (checked on the host): one scalar multiply
           const int e = rl_i(my_e, j);
           dtv[c] = rl_f(my_dt, j);
 #pragma unroll
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
             const int cc = lane + 64 * r;
             kn[c][r] = (js[c] >= 0 && (r < NR - 1 || cc < D)) ? src[cc] : 0.f;
           }
-          ke[c] = (js[c] >= 0 && lane < Ef) ? a.edge_feat[(int64_t)e * Ef + lane] : 0.f;
+          ke[c] = (js[c] >= 0 && lane < Ef) ? a.edge_feat[(uint32_t)e * (uint32_t)Ef + (uint32_t)lane] : 0.f;
         }
         float part[KC_RUNS][H];
         // time encoding of the chunk: ONE out-of-range test for all its arguments (wave-wide), as in the forward kernel
@@ -774,6 +774,9 @@ static int check_common(const PfoAttn& a) {
   PFO_REQUIRE(a.Ef == 0 || a.edge_feat, "null edge features");
   PFO_REQUIRE(a.dropout_p >= 0.f && a.dropout_p < 1.f, "dropout must be in [0, 1)");
   PFO_REQUIRE(a.Cp >= 2 * a.D + a.Ef + 2 && (a.Cp % 4) == 0, "Cp must hold C + 2 columns and be a multiple of 4");
+  // the kernels address the gathered rows with 32-bit element offsets
+  PFO_REQUIRE(a.nbr_rows > 0 && (uint64_t)a.nbr_rows * (uint64_t)a.nbr_ld < (1ull << 32), "neighbour table too large for 32-bit row offsets");
+  PFO_REQUIRE(a.Ef == 0 || (a.edge_rows > 0 && (uint64_t)a.edge_rows * (uint64_t)a.Ef < (1ull << 32)), "edge feature table too large for 32-bit row offsets");
   return PFO_OK;
 }
 

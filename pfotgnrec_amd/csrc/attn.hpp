@@ -26,6 +26,7 @@ struct PfoAttn {
   int64_t nbr_ld = 0;
   const int32_t* nbr_row = nullptr; // [N*K] row of nbr_tab per slot, or null: row = nbr_row_base + n*K + j
   int64_t nbr_row_base = 0;
+  int64_t nbr_rows = 0, edge_rows = 0;   // rows of nbr_tab / edge_feat (validated: the kernels use 32-bit element offsets)
   int nbr_relu = 0;                 // backward, plain-stored neighbour gradients: rows of nbr_tab are ReLU outputs, d row *= (row > 0)
   const int32_t* nbr_ids = nullptr; // [N*K] node ids; slot is padding iff id == 0 (embedding_module.py:154)
   const float* edge_feat = nullptr; // [E+1, Ef]

@@ -598,6 +598,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     a.N = N; a.K = K; a.D = D; a.Ef = Ef; a.H = H; a.Cp = Cp;
     a.QK = (l == 1) ? w.QX : lw.QK; a.qk_row = (l == 1) ? idx0 : nullptr; a.qk_ld = (l == 1) ? WQ : HCp;
     a.nbr_tab = xA; a.nbr_ld = D;
+    a.nbr_rows = (l == 1) ? capP : n[l - 1]; a.edge_rows = c->n_edges_p1;
     a.nbr_row = (l == 1) ? idx0 + N : nullptr;
     a.nbr_row_base = N;
     a.nbr_ids = w.nodes[l - 1] + N;
@@ -758,6 +759,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     a.N = N; a.K = K; a.D = D; a.Ef = Ef; a.H = H; a.Cp = Cp;
     a.QK = (l == 1) ? w.QX : lw.QK; a.qk_row = (l == 1) ? idx0 : nullptr; a.qk_ld = (l == 1) ? WQ : HCp;
     a.nbr_tab = xA; a.nbr_ld = D;
+    a.nbr_rows = (l == 1) ? capP : n[l - 1]; a.edge_rows = c->n_edges_p1;
     a.nbr_row = (l == 1) ? idx0 + N : nullptr;
     a.nbr_row_base = N;
     a.nbr_relu = folded ? 1 : 0;                               // the keys are h1 rows of the layer below: d row *= (row > 0)

@@ -189,6 +189,14 @@ def test_step_against_oracle(D, H, L, K, use_mem, uniform):
         rl, cache = T.bpr_loss(rse, rde.reshape(B, 1, -1), rne.reshape(B, 3, -1))
         ds, dp, dn = T.bpr_loss_backward(cache)
         rgrads = ref.backward(np.concatenate([ds, dp.reshape(B, -1), dn.reshape(3 * B, -1)]))
+        # A ReLU unit whose pre-activation sits within fp32 noise of zero may take the other branch here than in the oracle
+        # (the two forwards agree to ~1e-6; this loop's trajectory itself varies in its last bits from run to run because
+        # the level-0 scatter uses float atomics).  One flipped unit of a root's fc1 moves EVERY gradient below it by
+        # ~1/R (measured: 1-2.5 % at R = 200, in 1 of ~250 steps, always with the oracle's min |z1| < 1e-7, against
+        # ~1e-6 relative error otherwise - tools/probes/time_grad_error.py).  Such a step is checked with a bound that
+        # still catches a wrong formula but not the flip; tests/test_gpu_full_size.py holds the kink-free 2e-4 bound.
+        near_kink = _min_abs_z1(ref._ctx) < KINK_Z1
+        tol, tol_time = (RTOL_GRAD_KINK_STEP, RTOL_GRAD_KINK_STEP) if near_kink else (RTOL_GRAD_ORACLE_L2, RTOL_GRAD_TIME)
         for name, p in tgn.named_parameters():
             if name not in rgrads:
                 continue
@@ -198,7 +206,7 @@ def test_step_against_oracle(D, H, L, K, use_mem, uniform):
                 continue
             got = p.grad.cpu().numpy().astype(np.float64)
             e = np.linalg.norm(got - r) / (np.linalg.norm(r) + 1e-30)
-            assert e < (RTOL_GRAD_TIME if name.startswith("time_encoder") else RTOL_GRAD_ORACLE_L2), (step, name, e)
+            assert e < (tol_time if name.startswith("time_encoder") else tol), (step, name, e, near_kink)
         if use_mem:
             assert relerr(tgn.memory.memory.cpu().numpy(), ref.memory) < RTOL_EMB
             assert np.array_equal(tgn.memory.last_update.cpu().numpy(), ref.last_update)
@@ -208,6 +216,18 @@ def test_step_against_oracle(D, H, L, K, use_mem, uniform):
             assert np.array_equal(tgn.memory.msg_time.cpu().numpy()[has], mt[has])
             # layer-0 table of the touched nodes = lazily updated memory + node features (embedding_module.py:98)
         opt.step()
+
+
+KINK_Z1 = 5e-7               # an fc1 pre-activation this close to zero (oracle side) may flip between the two implementations
+RTOL_GRAD_KINK_STEP = 6e-2    # relative L2 bound of a step that holds such a unit
+
+
+def _min_abs_z1(ctx):
+    """Smallest |fc1 pre-activation| in the oracle's cached computation tree (embedding_module.py:110-175 recursion)."""
+    if ctx[0] == "leaf":
+        return np.inf
+    _, _, c_x, c_nb, cache, _, _ = ctx
+    return min(float(np.abs(cache["z1"]).min()), _min_abs_z1(c_x), _min_abs_z1(c_nb))
 
 
 def _legal_draws(onf, roots, ts, K, L, raw):
@@ -456,6 +476,8 @@ def test_step_against_oracle_on_a_general_graph_with_self_loops_and_ties():
         rl, cache = T.bpr_loss(rse, rde.reshape(B, 1, -1), rne.reshape(B, 3, -1))
         ds, dp, dn = T.bpr_loss_backward(cache)
         rgrads = ref.backward(np.concatenate([ds, dp.reshape(B, -1), dn.reshape(3 * B, -1)]))
+        near_kink = _min_abs_z1(ref._ctx) < KINK_Z1                 # see test_step_against_oracle
+        tol, tol_time = (RTOL_GRAD_KINK_STEP, RTOL_GRAD_KINK_STEP) if near_kink else (RTOL_GRAD_ORACLE_L2, RTOL_GRAD_TIME)
         for name, p in tgn.named_parameters():
             if name not in rgrads or np.abs(rgrads[name]).max() < 1e-7:
                 continue
@@ -465,7 +487,7 @@ def test_step_against_oracle_on_a_general_graph_with_self_loops_and_ties():
                 continue
             got = p.grad.cpu().numpy().astype(np.float64)
             e = np.linalg.norm(got - r) / (np.linalg.norm(r) + 1e-30)
-            assert e < (RTOL_GRAD_TIME if name.startswith("time_encoder") else RTOL_GRAD_ORACLE_L2), (step, name, e)
+            assert e < (tol_time if name.startswith("time_encoder") else tol), (step, name, e, near_kink)
         assert relerr(tgn.memory.memory.cpu().numpy(), ref.memory) < RTOL_EMB
         assert np.array_equal(tgn.memory.last_update.cpu().numpy(), ref.last_update)
         opt.step()
