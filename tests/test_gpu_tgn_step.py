@@ -144,7 +144,9 @@ def test_step_against_reference_golden(tag):
 @pytest.mark.parametrize("D,H,L,K,use_mem,uniform", [(32, 2, 1, 10, True, False), (172, 2, 2, 8, True, False),
                                                       (172, 4, 2, 6, False, True), (64, 1, 2, 5, True, False),
                                                       (24, 4, 3, 3, True, False), (36, 2, 2, 4, True, False),
-                                                      (52, 1, 1, 7, False, False)])
+                                                      (52, 1, 1, 7, False, False),
+                                                      (256, 4, 1, 12, True, False),      # widest rows the kernels take (NR = 4)
+                                                      (128, 2, 2, 20, True, False)])     # K = 20 through the run-merged backward
 def test_step_against_oracle(D, H, L, K, use_mem, uniform):
     torch.manual_seed(1234 + D + H)
     cfg = SyntheticConfig("t", 300, 25, 5000, D, L, K, H)
