@@ -348,24 +348,13 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
         ke[c] = (js[c] >= 0 && lane < Ef) ? a.edge_feat[(uint32_t)e * (uint32_t)Ef + (uint32_t)lane] : 0.f;
       }
       float part[KC_BWD][H];
-      // time encoding of the chunk: ONE out-of-range test for all its arguments (wave-wide), as in the forward kernel
-      float targ[KC_BWD][NR];
-      bool big = false;
-#pragma unroll
-      for (int c = 0; c < KC_BWD; ++c)
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          targ[c][r] = pfo_time_arg(dtv[c], tw[r], tb[r]);
-          big = big || !(fabsf(targ[c][r]) < 2.0e7f);
-        }
-      const bool any_big = __ballot(big) != 0ull;
 #pragma unroll
       for (int c = 0; c < KC_BWD; ++c) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           const int cc = lane + 64 * r;
-          const float u = __builtin_expect(any_big, 0) ? pfo_revolutions(targ[c][r]) : pfo_revolutions_fast(targ[c][r]);
-          const float sv = __builtin_amdgcn_sinf(u), cv = __builtin_amdgcn_cosf(u);
+          float sv, cv;
+          pfo_sincosf(pfo_time_arg(dtv[c], tw[r], tb[r]), sv, cv);
           const bool on = js[c] >= 0 && (r < NR - 1 || cc < D);     // select, not a branch (only the last r can be off)
           kt[c][r] = on ? cv : 0.f;
           ks[c][r] = on ? sv : 0.f;
@@ -803,9 +792,11 @@ static int check_common(const PfoAttn& a) {
     PFO_REQUIRE(done, "unsupported (D, H) combination");                                                      \
   }
 
-template <int NR, int H> __global__ __launch_bounds__(256, (H <= 2 && NR <= 3) ? 3 : 2) void attn_bwd_kernel_none(const AttnDev a) { attn_bwd_body<NR, H, 0>(a); }
-template <int NR, int H> __global__ __launch_bounds__(256, (H <= 2 && NR <= 3) ? 3 : 2) void attn_bwd_kernel(const AttnDev a) { attn_bwd_body<NR, H, 1>(a); }
-template <int NR, int H> __global__ __launch_bounds__(256, (H <= 2 && NR <= 3) ? 3 : 2) void attn_bwd_kernel_direct(const AttnDev a) { attn_bwd_body<NR, H, 2>(a); }
+// minimum wavefronts per SIMD the register allocation must allow: 3 where the kernel fits 168 VGPRs without spilling
+#define BWD_WAVES(NR, H, DMODE) (((H) <= 2 && (NR) <= 3) ? ((DMODE) == 1 ? 2 : 3) : (((H) == 4 && (NR) == 4) ? 1 : 2))
+template <int NR, int H> __global__ __launch_bounds__(256, BWD_WAVES(NR, H, 0)) void attn_bwd_kernel_none(const AttnDev a) { attn_bwd_body<NR, H, 0>(a); }
+template <int NR, int H> __global__ __launch_bounds__(256, BWD_WAVES(NR, H, 1)) void attn_bwd_kernel(const AttnDev a) { attn_bwd_body<NR, H, 1>(a); }
+template <int NR, int H> __global__ __launch_bounds__(256, BWD_WAVES(NR, H, 2)) void attn_bwd_kernel_direct(const AttnDev a) { attn_bwd_body<NR, H, 2>(a); }
 int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream) {
   if (int rc = check_common(a)) return rc;
   AttnDev d;
