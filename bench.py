@@ -58,6 +58,13 @@ def parse():
                     help="replay the step from a captured HIP graph (one launch per step instead of ~85).  auto (one GPU, per-GPU "
                          "batch <= 256): capture, time ten steps either way during set-up and keep the faster form - the graph "
                          "wins where the host's launch rate bounds the step (C1), the eager queue where the GPU does")
+    ap.add_argument("--allreduce", default="single", choices=["single", "buckets"],
+                    help="N > 1: one all-reduce of the flat gradient after the backward, or two pieces with the top layer's "
+                         "block reduced on a side stream while the lower layers are still being differentiated")
+    ap.add_argument("--emulate-ranks", default=None,
+                    help="ONE process, no collective: time rank 0's share of the step (its shard's roots + the global state "
+                         "update) for each listed world size, e.g. 1,2,4,8 - the compute-side ceiling of the scaling curve, "
+                         "measurable on one GPU.  Prints one JSON line with a per-world-size table")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="start the N ranks, rendezvous, all-reduce the rank ids and print a line; no GPU work (CPU test of the launcher)")
     ap.add_argument("--batch", type=int, default=0, help="interactions per GPU per step (default: the config's)")
@@ -151,31 +158,57 @@ def cpu_baseline(cfg, graph, batch, steps):
     return batch / float(np.median(times)), float(np.sum(times))
 
 
-def launch_ranks(n):
+def launch_ranks(n, poll_s=0.2, grace_s=10.0):
     """``python bench.py --gpus N`` without a launcher: start N ranks as CHILD processes (one per GPU, RCCL rendezvous
-    on 127.0.0.1) before this process has touched a GPU, relay rank 0's stdout, exit with the worst child status."""
+    on 127.0.0.1) before this process has touched a GPU, relay rank 0's stdout, exit with the worst child status.
+    A watchdog polls every child: on the first non-zero exit the rest are terminated (killed after a grace period) - a rank
+    that dies before or inside a collective would otherwise leave the others blocked in RCCL until its timeout."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    out_file = tempfile.TemporaryFile()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), PFO_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for q in procs[1:]:
-        rc = rc or q.wait()
-    sys.stdout.write(out.decode())
+                                      stdout=out_file if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    while True:
+        codes = [q.poll() for q in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            for q in procs:
+                if q.poll() is None:
+                    q.terminate()
+            t_end = time.time() + grace_s
+            for q in procs:
+                try:
+                    q.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    q.kill()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(poll_s)
+    for q in procs:
+        q.wait()
+    out_file.seek(0)
+    sys.stdout.write(out_file.read().decode())
     sys.stdout.flush()
+    if rc:
+        sys.stderr.write("bench.py: a rank exited with status %d; the remaining ranks were stopped\n" % rc)
     return rc
 
 
 def launcher_selftest(args):
+    if os.environ.get("PFO_SELFTEST_FAIL_RANK") == os.environ.get("RANK"):
+        sys.exit(7)                                          # watchdog test: this rank dies before the rendezvous
     import torch
     import torch.distributed as dist
     from pfotgnrec_amd.distributed import init_from_env
@@ -215,6 +248,8 @@ class Workload:
                                dropout=args.dropout, use_memory=cfg.use_memory, memory_dimension=cfg.dim,
                                message_function="identity", n_neighbors=cfg.n_neighbors)
         tgn.set_data_parallel(rank, world)
+        tgn.dp_bucketed = world > 1 and args.allreduce == "buckets"
+        self.emulate = False                                  # --emulate-ranks: a rank's compute without the collective
         broadcast_parameters(tgn.flat_parameters, world)
         if cfg.use_memory:
             steady_state_init(tgn, None)
@@ -273,7 +308,7 @@ class Workload:
         self.tgn.set_data_parallel(rank, world)
 
     def step(self, i):
-        from pfotgnrec_amd.distributed import allreduce_flat_grad
+        from pfotgnrec_amd.distributed import allreduce_flat_grad, allreduce_flat_grad_buckets
         P, torch, tgn, cfg, B, n_neg = self.P, self.torch, self.tgn, self.cfg, self.B, self.n_neg
         lo = self.start + (i * B) % self.span
         sl = slice(lo, lo + B)
@@ -284,16 +319,22 @@ class Workload:
             neg = self.sampler.sample(self.port_idx_all[sl], self.port_len_all[sl], n_neg, offset=i)            # utils.py:86-114
             emb, b = tgn.embed_device(self.src_all[sl], self.dst_all[sl], [neg.reshape(-1)], [n_neg], self.ts_all[sl],
                                       self.eidx_all[sl], cfg.n_neighbors)                                     # tgn.py:219-327
-            loss = P.bpr_loss(emb, b, n_neg, pos_block=1, grad_scale=tgn.dp_grad_scale)                         # main.py:364-381
+            pos_block = 1                                                                                      # main.py:364-381
         else:
             cand_neg = self.sampler.sample(self.port_idx_all[sl], self.port_len_all[sl], 20, offset=i)          # main.py:194-195
             cand = torch.cat([self.dst_all[sl].unsqueeze(1), cand_neg], 1).contiguous()                        # main.py:207
             p_pos, p_neg = self.mvs.select_device(self.day_all[sl], cand, self.port_idx_all[sl], self.port_len_all[sl])   # main.py:209-304
             emb, b = tgn.embed_device(self.src_all[sl], self.dst_all[sl], [p_pos.reshape(-1), p_neg.reshape(-1)], [1, 3],
                                       self.ts_all[sl], self.eidx_all[sl], cfg.n_neighbors)                    # tgn.py:102-217
-            loss = P.bpr_loss(emb, b, n_neg, pos_block=2, grad_scale=tgn.dp_grad_scale)                         # main.py:321-337
-        loss.backward()                                                                                        # main.py:388
-        allreduce_flat_grad(tgn.flat_grad, self.world)
+            pos_block = 2                                                                                      # main.py:321-337
+        # loss + loss.backward() (main.py:337,388) as two native calls: the loss kernel hands its gradient rows straight to
+        # the TGN backward (P.bpr_loss(...).backward() is the autograd spelling of the same thing, tests/test_gpu_round2.py)
+        loss = P.bpr_step(tgn, emb, b, n_neg, pos_block=pos_block)
+        if not self.emulate:
+            if self.args.allreduce == "buckets":
+                allreduce_flat_grad_buckets(tgn, self.world)
+            else:
+                allreduce_flat_grad(tgn.flat_grad, self.world)
         self.opt.step()                                                                                        # main.py:389
         self.opt.zero_grad(set_to_none=True)
         return loss
@@ -342,7 +383,7 @@ class Workload:
             blocks += 1
             if total >= min_seconds or blocks >= 10000:
                 break
-        return total, n_steps, blocks, float(loss.detach()), n_prof
+        return total, n_steps, blocks, float(loss.detach().reshape(-1)[0]), n_prof
 
     def describe(self):
         cfg = self.cfg
@@ -353,10 +394,11 @@ class Workload:
 
 
 def roofline_of(prof, n_prof_steps, profiled_workload=True):
-    """Dominant kernel family by device time over the sampled steps.  Contractions on the bf16x3 kernels are priced against
-    the dense bf16 MFMA peak divided by the six piece products one fp32 product costs; the fp32-MFMA kernels against the
-    fp32 MFMA peak; the attention / sampling kernels against HBM."""
-    fam = {k: v for k, v in prof.items() if v["count"] > 0 and v["work"] > 0}
+    """Dominant KERNEL by device time over the sampled steps: a family is all launches of one kernel (the library reads
+    the device-side row counts of the touched-table launches back, so every launch carries its work).  Contractions on the
+    bf16x3 kernels are priced against the dense bf16 MFMA peak divided by the six piece products one fp32 product costs;
+    the fp32-MFMA kernels against the fp32 MFMA peak; the attention / sampling kernels against HBM."""
+    fam = {k: v for k, v in prof.items() if v["count"] > 0}
     if not fam:
         return None
     dom = max(fam, key=lambda k: fam[k]["ms"])
@@ -377,19 +419,46 @@ def roofline_of(prof, n_prof_steps, profiled_workload=True):
     # the committed counter pass was taken on the default workload (C2, 512 interactions per launch): other shapes get null
     roof["traffic"] = pmc_traffic(dom) if profiled_workload else None
     roof["kernel"] = dom
+    roof["kernel_name"] = PMC_KERNEL.get(dom, dom)
     roof["avg_launch_us"] = round(per_launch_s * 1e6, 2)
     roof["launches"] = int(v["count"])
+    roof["launches_per_step"] = round(v["count"] / max(1, n_prof_steps), 2)
     roof["sampled_steps"] = n_prof_steps
     roof["families_ms_per_step"] = {k: round(x["ms"] / max(1, n_prof_steps), 4) for k, x in prof.items() if x["count"] > 0}
-    # (families whose launches carry no work figure - device-side extents, "time only" - stay out of the rates)
-    tot = lambda ks: (sum(prof[k]["work"] for k in ks if k in prof and prof[k]["work"] > 0) /
-                      max(1e-9, sum(prof[k]["ms"] for k in ks if k in prof and prof[k]["work"] > 0) * 1e-3))
+    rate = lambda x, unit: round(x["work"] / max(1e-12, x["ms"] * 1e-3) / unit, 2)
+    roof["families_rate"] = {k: rate(x, 1e12 if k.startswith("gemm") else 1e9) for k, x in prof.items() if x["count"] > 0}
+    tot = lambda ks: (sum(prof[k]["work"] for k in ks if k in prof) / max(1e-9, sum(prof[k]["ms"] for k in ks if k in prof) * 1e-3))
     roof["gemm_all_tflops"] = round(tot([k for k in prof if k.startswith("gemm")]) / 1e12, 2)
     roof["attn_all_gbs"] = round(tot([k for k in prof if k.startswith("attn")]) / 1e9, 1)
     return roof
 
 
-BX_FAMILIES = ("gemm_bx", "gemm_tn_bx", "gemm_bx_skinny", "gemm_gru")
+BX_FAMILIES = ("gemm_bx", "gemm_tn_bx", "gemm_bx_skinny")
+
+
+def emulate_ranks(args, dev):
+    """Compute-side ceiling of the data-parallel scaling curve on ONE GPU: for each world size N the step of rank 0 -
+    sampler / forward / loss / backward for its B/N interactions, the state update and the lazy GRU rows of ALL B global
+    positives, Adam - without the all-reduce.  Strong scaling (the config's batch is fixed), default C4 at 4096."""
+    import torch
+    cfg_name = args.config or "C4"
+    worlds = [int(x) for x in args.emulate_ranks.split(",")]
+    args.graph = "off"
+    wl = Workload(args, cfg_name, dev, 0, 1, "strong")
+    wl.emulate = True
+    rows = []
+    for n in worlds:
+        wl.set_world(0, n)
+        el, nt, _, _, _ = wl.timed(args.steps, args.warmup, min(args.min_seconds, 1.0), 0, first_step=1000 * n, collective=False)
+        ms = 1e3 * el / nt
+        rows.append({"world": n, "rank": 0, "local_batch": wl.B // n, "ms_per_step": round(ms, 4),
+                     "interactions_per_s_if_all_ranks_like_this": round(wl.B / (ms * 1e-3), 1),
+                     "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4)})
+    base = rows[0]["ms_per_step"] * rows[0]["world"]
+    for r in rows:
+        r["compute_scaling_efficiency_vs_first"] = round(base / (r["ms_per_step"] * r["world"]), 4)
+    print(json.dumps({"emulated_ranks": True, "workload": wl.describe(), "global_batch": wl.B, "collective": "none (stubbed)",
+                      "device": torch.cuda.get_device_name(dev), "table": rows}), flush=True)
 
 
 def main():
@@ -412,6 +481,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    if args.emulate_ranks:
+        return emulate_ranks(args, dev)
     cfg_name = args.config or ("C2" if world == 1 else "C4")
     scaling = args.scaling or ("strong" if (cfg_name == "C4" and world > 1) else "weak")
     wl = Workload(args, cfg_name, dev, rank, world, scaling)

@@ -141,6 +141,10 @@ int pfo_roots_assemble(const int32_t* src, const int32_t* dst, const double* ts,
  */
 int pfo_bpr_loss(const float* emb, int64_t B, int32_t D, int64_t pos_off, int64_t neg_off, int32_t n_neg,
                  int64_t R, float scale, float* loss_out, float* d_emb, float* workspace, void* stream);
+/* The same in ONE launch: the workgroup that finishes last takes the mean (index order: reproducible).  ticket i32[1]: zero
+ * before the first use, resets itself; workspace f32[B]. */
+int pfo_bpr_loss_fused(const float* emb, int64_t B, int32_t D, int64_t pos_off, int64_t neg_off, int32_t n_neg,
+                       int64_t R, float scale, float* loss_out, float* d_emb, float* workspace, int32_t* ticket, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Ranking metrics of evaluation.py:114-145 for one positive per interaction.
@@ -263,6 +267,18 @@ int pfo_tgn_forward(const pfo_tgn_config* cfg, const pfo_tgn_state* st, const pf
 /* Gradients of everything pfo_tgn_forward (training=1) computed, given d_emb f32[R,D]; ACCUMULATES into grad (flat). */
 int pfo_tgn_backward(const pfo_tgn_config* cfg, const pfo_tgn_state* st, const pfo_tgn_batch* batch,
                      void* workspace, const float* d_emb, float* grad, void* stream);
+/* The same with two options for the training loop:
+ *   zero_grad_first  != 0: `grad` is cleared by this call (on its side stream, off the critical path) before anything is added -
+ *                          replaces the caller's memset of the 6 MB flat buffer (optimizer.zero_grad(), main.py:386)
+ *   top_ready_event  (hipEvent_t as void*, may be NULL): recorded, on an internal stream, at the point where every gradient of
+ *                          the TOP layer's parameter block - elements [pfo_tgn_grad_split(cfg), layout.total) of `grad` - is
+ *                          final, ~half a step before the call's last kernel: a data-parallel caller makes its communication
+ *                          stream wait for it and all-reduces that block beside the rest of the backward.  Only
+ *                          with n_layers >= 2 (pfo_tgn_grad_split returns layout.total otherwise and the event is not recorded). */
+int pfo_tgn_backward_ev(const pfo_tgn_config* cfg, const pfo_tgn_state* st, const pfo_tgn_batch* batch,
+                        void* workspace, const float* d_emb, float* grad, int32_t zero_grad_first, void* top_ready_event,
+                        void* stream);
+int pfo_tgn_grad_split(const pfo_tgn_config* cfg, int64_t* split);
 /* Persist memory for the positives, clear their pending messages, build and store the new raw messages with
  * last-wins semantics (tgn.py:290-317, memory_updater.py:18-33, memory.py:35-37,73-75, tgn.py:357-378).
  * src/dst i32[B], ts f64[B], eidx i32[B]; needs the workspace of the forward call that preceded it. */
@@ -287,11 +303,11 @@ int pfo_tgn_debug_views(const pfo_tgn_config* cfg, void* workspace, pfo_tgn_debu
 #define PFO_PROF_GEMM_NT 0   /* C = A B^T (+bias...)  forward projections                */
 #define PFO_PROF_GEMM_NN 1   /* C = A B             backward-data, folded key projection */
 #define PFO_PROF_GEMM_TN 2   /* dW = A^T B          weight gradients (split-K + reduce)  */
-#define PFO_PROF_GEMM_DEVM 3 /* GEMMs whose row count lives on the device (GRU): time only */
+#define PFO_PROF_GEMM_DEVM 3 /* fp32-MFMA contractions whose extent is a device-side count (work = per-row flops x the count read back) */
 #define PFO_PROF_ATTN_FWD 4
 #define PFO_PROF_ATTN_BWD 5
 #define PFO_PROF_SAMPLER 6
-#define PFO_PROF_GEMM_BX 7   /* row-major contractions taken by the bf16x3 kernel (flops = 2MNK)  */
+#define PFO_PROF_GEMM_BX 7   /* gemm_bx_areg_kernel: every row-major bf16x3 launch, device-side row counts included (flops = 2MNK, M read back) */
 #define PFO_PROF_GEMM_TN_BX 8 /* grouped weight gradients on the bf16x3 kernel (GEMM kernel only)  */
 #define PFO_PROF_GEMM_BX_SKINNY 9 /* the 32-row bf16x3 kernel of the short (layer-2) launches           */
 #define PFO_PROF_ATTN_BWD_RUNS 10 /* layer-1 attention backward, run-merged kernel (attn_bwd_runs_kernel)  */

@@ -69,6 +69,8 @@ PROTOTYPES = {
                                      _VP, _VP, _VP]),
     "pfo_bpr_loss": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_float, _VP,
                                _VP, _VP, _VP]),
+    "pfo_bpr_loss_fused": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_float, _VP,
+                                     _VP, _VP, _VP, _VP]),
     "pfo_rank_metrics": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP]),
     "pfo_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                 _VP]),
@@ -83,6 +85,9 @@ PROTOTYPES = {
     "pfo_tgn_workspace_bytes": (C.c_int64, [C.POINTER(TgnConfig)]),
     "pfo_tgn_forward": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP]),
     "pfo_tgn_backward": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP, _VP]),
+    "pfo_tgn_backward_ev": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP, C.c_int32,
+                                      _VP, _VP]),
+    "pfo_tgn_grad_split": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(C.c_int64)]),
     "pfo_tgn_update_state": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), _VP, _VP, _VP, _VP, C.c_int32, _VP,
                                        _VP]),
     "pfo_tgn_debug_views": (C.c_int, [C.POINTER(TgnConfig), _VP, C.POINTER(TgnDebug)]),

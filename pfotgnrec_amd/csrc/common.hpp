@@ -31,6 +31,8 @@ void pfo_set_error(const char* fmt, ...);
 bool pfo_prof_on();   // while on, the step keeps its large launches on ONE stream so that every bracket times its kernel alone
 void pfo_prof_begin(hipStream_t s);
 void pfo_prof_end(int kind, double work, hipStream_t s);
+// work = work_per_unit * min(*units_dev, units_cap): launches whose extent is a device-side count (read back at collect time)
+void pfo_prof_end_dev(int kind, double work_per_unit, const int32_t* units_dev, int units_cap, hipStream_t s);
 
 static inline int64_t pfo_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t pfo_align_up(int64_t a, int64_t b) { return pfo_ceil_div(a, b) * b; }

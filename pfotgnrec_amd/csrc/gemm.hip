@@ -1446,13 +1446,12 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
   else if (vec) hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   else hipLaunchKernelGGL(gemm_tn_group_kernel<false>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   PFO_LAUNCH_CHECK();
-  // the GEMM kernel alone; with a device-side K bound the host does not know the work: time only
-  // launches whose extent is a device-side count are "time only": the host knows only the capacity, not the work
-  if (use_bx) pfo_prof_end(k_dev ? PFO_PROF_GEMM_DEVM : PFO_PROF_GEMM_TN_BX, k_dev ? 0.0 : flops, stream);
+  // the GEMM kernel alone; with a device-side K bound the work is (flops per k-row) x the count read back at collect time
+  if (use_bx) pfo_prof_end_dev(PFO_PROF_GEMM_TN_BX, flops / (double)K, k_dev, K, stream);
   hipLaunchKernelGGL(tn_group_reduce_kernel, dim3((unsigned)std::min<int64_t>(1024, pfo_ceil_div(per_split, 256))), dim3(256), 0,
                      stream, g);
   PFO_LAUNCH_CHECK();
-  if (!use_bx) pfo_prof_end(k_dev ? PFO_PROF_GEMM_DEVM : PFO_PROF_GEMM_TN, k_dev ? 0.0 : flops, stream);
+  if (!use_bx) pfo_prof_end_dev(PFO_PROF_GEMM_TN, flops / (double)K, k_dev, K, stream);
   return PFO_OK;
 }
 
@@ -1566,7 +1565,7 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
     static const int sk = getenv("PFO_GEMM_SKINNY") ? atoi(getenv("PFO_GEMM_SKINNY")) : 1;                  // A/B switch
     if (g.b_img && (g.K[1] == 0 || g.b_img2) && a_rowvec && (g.bx_force == 2 || (bx >= 1 && sk && !g.bx_force && force < 0 && big_tiles < bx_min_tiles))) {
       d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN); d.b_img2 = g.b_img2;
-      if (!g.m_dev) kind = PFO_PROF_GEMM_BX_SKINNY;
+      kind = PFO_PROF_GEMM_BX_SKINNY;
       // few row tiles (< one per CU even with 176-column workgroups): 64-column workgroups fill the chip three times better
       static const int narrow = getenv("PFO_SKINNY_NARROW") ? atoi(getenv("PFO_SKINNY_NARROW")) : 512;        // A/B switch: workgroup threshold, 0 = never
       const int64_t sk_wgs = (int64_t)pfo_ceil_div(g.M, SK_ROWS) * tn;
@@ -1577,7 +1576,7 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
         hipLaunchKernelGGL(gemm_bx_skinny_kernel<11>, dim3((unsigned)pfo_ceil_div(g.M, SK_ROWS), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
     } else if (g.b_img && (g.K[1] == 0 || g.b_img2) && a_rowvec && (g.bx_force || (bx >= 1 && big_tiles >= bx_min_tiles && force < 0))) {
       d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN); d.b_img2 = g.b_img2;
-      if (!g.m_dev) kind = PFO_PROF_GEMM_BX;       // device-side row counts stay "time only"
+      kind = PFO_PROF_GEMM_BX;
       static const int areg = getenv("PFO_GEMM_AREG") ? atoi(getenv("PFO_GEMM_AREG")) : PFO_DEFAULT_AREG;    // A/B switch
       if (areg && g.batch == 1)
         hipLaunchKernelGGL(gemm_bx_areg_kernel, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
@@ -1599,7 +1598,9 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
   }
 #undef GEMM_GO
   PFO_LAUNCH_CHECK();
-  pfo_prof_end(kind, kind == PFO_PROF_GEMM_DEVM ? 0.0 : flops, stream);
+  // a device-side extent (rows, or the K of a k-major A) scales the work: read back when the records are collected
+  if (g.m_dev) pfo_prof_end_dev(kind, flops / (double)(g.a_kmajor ? g.K[0] : g.M), g.m_dev, g.a_kmajor ? g.K[0] : g.M, stream);
+  else pfo_prof_end(kind, flops, stream);
   return PFO_OK;
 }
 

@@ -18,21 +18,6 @@ __global__ void touch_mark_kernel(const int32_t* __restrict__ nodes0, int64_t n0
   }
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void scan_count_kernel(const int32_t* __restrict__ slot, int n_nodes,
-                                                                int32_t* __restrict__ block_counts) {
-  __shared__ int s_cnt[SCAN_BLOCK / 64];
-  const int v = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  const bool f = v < n_nodes && slot[v] != 0;
-  const unsigned long long bal = __ballot(f);
-  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(bal);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int t = 0;
-    for (int w = 0; w < SCAN_BLOCK / 64; ++w) t += s_cnt[w];
-    block_counts[blockIdx.x] = t;
-  }
-}
-
 __global__ __launch_bounds__(1024) void scan_blocks_kernel(int32_t* __restrict__ block_counts, int n_blocks,
                                                            int32_t* __restrict__ n_touched) {
   // exclusive scan of block_counts in place, by one workgroup, 1024 entries per sweep
@@ -63,45 +48,72 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(int32_t* __restrict__
   if (threadIdx.x == 0) *n_touched = s_carry;
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void scan_scatter_kernel(int32_t* __restrict__ slot, int n_nodes,
-                                                                  const int32_t* __restrict__ block_offsets,
-                                                                  int32_t* __restrict__ touched_ids) {
+// ---------------------------------------------------------------------------------------------
+// The compaction in ONE launch (round 2: count / scan of the counts / scatter = three).  Block b counts its flags, publishes the count (+1: zero = not yet there) in flags[b], then sums the published counts of all blocks
+// before it - no chain: every block only waits for earlier blocks to PUBLISH, which depends on nothing.  Earlier blocks are
+// dispatched first, so they make progress whatever the occupancy (the forward-progress assumption of every look-back scan).
+// flags[] must be zero when the kernel starts: they sit behind slot[] in the workspace and are cleared by the same memset.
+// (Block b reads b flags: quadratic in n_nodes / 1024, 0.1 M reads at C4's 500 k nodes, ~50 M at 10 M nodes.)
+__global__ __launch_bounds__(SCAN_BLOCK) void compact_onepass_kernel(int32_t* __restrict__ slot, int n_nodes, int32_t* flags,
+                                                                     int32_t* __restrict__ touched_ids,
+                                                                     int32_t* __restrict__ n_touched) {
   __shared__ int s_cnt[SCAN_BLOCK / 64];
-  const int v = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  __shared__ int s_off[SCAN_BLOCK / 64];
+  const int b = blockIdx.x;
+  const int v = b * SCAN_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool f = v < n_nodes && slot[v] != 0;
   const unsigned long long bal = __ballot(f);
   if (lane == 0) s_cnt[wave] = __popcll(bal);
   __syncthreads();
-  int woff = 0;
-  for (int w = 0; w < wave; ++w) woff += s_cnt[w];
-  const int pos = block_offsets[blockIdx.x] + woff + __popcll(bal & ((1ull << lane) - 1ull));
+  int cnt = 0, woff = 0;
+  for (int w = 0; w < SCAN_BLOCK / 64; ++w) { if (w == wave) woff = cnt; cnt += s_cnt[w]; }
+  if (threadIdx.x == 0) __hip_atomic_store(&flags[b], cnt + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  // counts of the blocks before this one
+  int part = 0;
+  for (int t = threadIdx.x; t < b; t += SCAN_BLOCK) {
+    int c;
+    do { c = __hip_atomic_load(&flags[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (c == 0);
+    part += c - 1;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if (lane == 0) s_off[wave] = part;
+  __syncthreads();
+  int off = 0;
+  for (int w = 0; w < SCAN_BLOCK / 64; ++w) off += s_off[w];
+  const int pos = off + woff + __popcll(bal & ((1ull << lane) - 1ull));
   if (v < n_nodes) {
     slot[v] = f ? pos : -1;
     if (f) touched_ids[pos] = v;
   }
+  if (b == (int)gridDim.x - 1 && threadIdx.x == 0) *n_touched = off + cnt;
 }
 
 int64_t pfo_compact_scratch_ints(int n_nodes) { return pfo_ceil_div(n_nodes, SCAN_BLOCK) + 8; }
 
 int pfo_touch_compact_launch(const int32_t* nodes0, int64_t n0, const int32_t* extra, int64_t n_extra, int n_nodes,
                              int32_t* slot, int32_t* touched_ids, int32_t* n_touched, int32_t* scratch,
-                             bool slot_is_zero, hipStream_t stream) {
-  PFO_REQUIRE(nodes0 && slot && touched_ids && n_touched && scratch && n0 > 0 && n_nodes > 0, "bad arguments");
+                             bool slot_is_zero, bool marked, hipStream_t stream) {
+  PFO_REQUIRE(slot && touched_ids && n_touched && scratch && n_nodes > 0, "bad arguments");
+  PFO_REQUIRE(marked || (nodes0 && n0 > 0), "no node list to mark");
+  const int nb = (int)pfo_ceil_div(n_nodes, SCAN_BLOCK);
   if (!slot_is_zero) {
+    PFO_REQUIRE(!marked, "marked flags need a cleared table");
     hipError_t e = hipMemsetAsync(slot, 0, (size_t)n_nodes * sizeof(int32_t), stream);
     PFO_REQUIRE(e == hipSuccess, "memset failed");
+    e = hipMemsetAsync(scratch, 0, (size_t)nb * sizeof(int32_t), stream);
+    PFO_REQUIRE(e == hipSuccess, "memset failed");
   }
-  const int nb = (int)pfo_ceil_div(n_nodes, SCAN_BLOCK);
-  const int mb = (int)std::min<int64_t>(2048, pfo_ceil_div(n0, 256));
-  hipLaunchKernelGGL(touch_mark_kernel, dim3(mb), dim3(256), 0, stream, nodes0, n0, n_nodes, slot);
+  if (!marked) {
+    const int mb = (int)std::min<int64_t>(2048, pfo_ceil_div(n0, 256));
+    hipLaunchKernelGGL(touch_mark_kernel, dim3(mb), dim3(256), 0, stream, nodes0, n0, n_nodes, slot);
+  }
   if (extra && n_extra > 0) {
     const int eb = (int)std::min<int64_t>(2048, pfo_ceil_div(n_extra, 256));
     hipLaunchKernelGGL(touch_mark_kernel, dim3(eb), dim3(256), 0, stream, extra, n_extra, n_nodes, slot);
   }
-  hipLaunchKernelGGL(scan_count_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, slot, n_nodes, scratch);
-  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, scratch, nb, n_touched);
-  hipLaunchKernelGGL(scan_scatter_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, slot, n_nodes, scratch, touched_ids);
+  hipLaunchKernelGGL(compact_onepass_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, slot, n_nodes, scratch, touched_ids, n_touched);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -294,31 +306,47 @@ int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, cons
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ void pack_rows_kernel(const float* __restrict__ msg_table, int M, const float* __restrict__ memory, int D,
-                                 const uint8_t* __restrict__ has_msg, const int32_t* __restrict__ touched_ids,
-                                 const int32_t* __restrict__ n_touched, float* __restrict__ msg_rows,
-                                 float* __restrict__ h_rows, uint8_t* __restrict__ hm) {
+// Two independent jobs that both wait for the compaction, in ONE launch: blocks [0, row_blocks) copy the touched nodes' rows
+// out of the full tables (msg_table may be null: no-memory models copy node features only), the blocks behind them translate
+// the level-0 node list into table rows (idx0[i] = slot[nodes0[i]]).
+__global__ void pack_remap_kernel(const float* __restrict__ msg_table, int M, const float* __restrict__ memory, int D,
+                                  const uint8_t* __restrict__ has_msg, const int32_t* __restrict__ touched_ids,
+                                  const int32_t* __restrict__ n_touched, float* __restrict__ msg_rows,
+                                  float* __restrict__ h_rows, uint8_t* __restrict__ hm, int row_blocks,
+                                  const int32_t* __restrict__ nodes0, int64_t n0, const int32_t* __restrict__ slot,
+                                  int32_t* __restrict__ idx0) {
+  if ((int)blockIdx.x >= row_blocks) {
+    const int64_t nb = gridDim.x - row_blocks;
+    for (int64_t i = (int64_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x; i < n0; i += nb * blockDim.x)
+      idx0[i] = slot[nodes0[i]];
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int nt = *n_touched;
-  for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < nt; s += (gridDim.x * blockDim.x) >> 6) {
+  for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < nt; s += (row_blocks * blockDim.x) >> 6) {
     const int id = touched_ids[s];
-    const float4* src = reinterpret_cast<const float4*>(msg_table + (int64_t)id * M);
-    float4* dst = reinterpret_cast<float4*>(msg_rows + (int64_t)s * M);
-    for (int c = lane; c < M / 4; c += 64) dst[c] = src[c];
+    if (msg_table) {
+      const float4* src = reinterpret_cast<const float4*>(msg_table + (int64_t)id * M);
+      float4* dst = reinterpret_cast<float4*>(msg_rows + (int64_t)s * M);
+      for (int c = lane; c < M / 4; c += 64) dst[c] = src[c];
+    }
     const float4* hs = reinterpret_cast<const float4*>(memory + (int64_t)id * D);
     float4* hd = reinterpret_cast<float4*>(h_rows + (int64_t)s * D);
     for (int c = lane; c < D / 4; c += 64) hd[c] = hs[c];
-    if (lane == 0) hm[s] = has_msg[id];
+    if (hm && lane == 0) hm[s] = has_msg[id];
   }
 }
 
-int pfo_pack_rows_launch(const float* msg_table, int M, const float* memory, int D, const uint8_t* has_msg,
-                         const int32_t* touched_ids, const int32_t* n_touched, int cap, float* msg_rows, float* h_rows,
-                         uint8_t* hm, hipStream_t stream) {
+int pfo_pack_remap_launch(const float* msg_table, int M, const float* memory, int D, const uint8_t* has_msg,
+                          const int32_t* touched_ids, const int32_t* n_touched, int cap, float* msg_rows, float* h_rows,
+                          uint8_t* hm, const int32_t* nodes0, int64_t n0, const int32_t* slot, int32_t* idx0, hipStream_t stream) {
   PFO_REQUIRE((M % 4) == 0 && (D % 4) == 0, "row lengths must be multiples of 4");
-  const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div(cap, 4));
-  hipLaunchKernelGGL(pack_rows_kernel, dim3(nb), dim3(256), 0, stream, msg_table, M, memory, D, has_msg, touched_ids,
-                     n_touched, msg_rows, h_rows, hm);
+  PFO_REQUIRE(memory && h_rows && touched_ids && n_touched && nodes0 && slot && idx0 && n0 > 0, "bad arguments");
+  PFO_REQUIRE(!msg_table || (msg_rows && has_msg && hm), "null message buffers");
+  const int rb = (int)std::min<int64_t>(4096, std::max<int64_t>(1, pfo_ceil_div(cap, 4)));
+  const int mb = (int)std::min<int64_t>(2048, pfo_ceil_div(n0, 256));
+  hipLaunchKernelGGL(pack_remap_kernel, dim3(rb + mb), dim3(256), 0, stream, msg_table, M, memory, D, has_msg, touched_ids,
+                     n_touched, msg_rows, h_rows, hm, rb, nodes0, n0, slot, idx0);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -410,7 +438,7 @@ __global__ void persist_kernel(const int32_t* __restrict__ src, const int32_t* _
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (wave >= 2 * B) return;
   const int id = wave < B ? src[wave] : dst[wave - B];
-  if (lane == 0) winner[id] = -1;              // reset for the raw-message pass that follows (msg_winner_max_kernel)
+  if (winner && lane == 0) winner[id] = -1;    // large batches: reset for the atomicMax pass that follows (msg_winner_max_kernel)
   if (!has_msg[id]) return;
   const int s = slot[id];
   if (s < 0) return;
@@ -435,6 +463,10 @@ __global__ void msg_winner_max_kernel(const int32_t* __restrict__ src, const int
   if (e >= 2 * B) return;
   atomicMax(&winner[e < B ? src[e] : dst[e - B]], e);
 }
+// winner == null: event e finds out by itself whether a LATER event of the batch names its node (64 ids per step over the
+// 2B - e - 1 later events: the id lists are cache-resident) - no table, no atomics, no extra launch.  Used up to
+// MSG_INLINE_MAX events; beyond that the quadratic scan loses to the atomicMax table.
+#define MSG_INLINE_MAX 16384
 __global__ void msg_write_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                  const double* __restrict__ ts, const int32_t* __restrict__ eidx, int B,
                                  const float* __restrict__ memory, const float* __restrict__ last_update,
@@ -447,7 +479,13 @@ __global__ void msg_write_kernel(const int32_t* __restrict__ src, const int32_t*
   const int i = e < B ? e : e - B;
   const int X = e < B ? src[i] : dst[i];
   const int O = e < B ? dst[i] : src[i];
-  if (winner[X] != e) return;
+  if (winner) {
+    if (winner[X] != e) return;
+  } else {
+    bool later = false;
+    for (int e2 = e + 1 + lane; e2 < 2 * B; e2 += 64) later = later || ((e2 < B ? src[e2] : dst[e2 - B]) == X);
+    if (__ballot(later) != 0ull) return;
+  }
   const int M = 3 * D + Ef;
   float* out = msg_table + (int64_t)X * M;
   const float t = (float)ts[i];                       // tgn.py:359
@@ -464,12 +502,18 @@ __global__ void msg_write_kernel(const int32_t* __restrict__ src, const int32_t*
   }
 }
 
+bool pfo_msg_store_needs_winner(int B) { return 2 * (int64_t)B > MSG_INLINE_MAX; }
 int pfo_msg_store_launch(const int32_t* src, const int32_t* dst, const double* ts, const int32_t* eidx, int B,
                          const float* memory, const float* last_update, const float* edge_feat, const float* tw,
                          const float* tb, int D, int Ef, float* msg_table, float* msg_time, uint8_t* has_msg,
                          int32_t* winner, hipStream_t stream) {
-  const unsigned nb = (unsigned)pfo_ceil_div(2 * B, 256);
-  hipLaunchKernelGGL(msg_winner_max_kernel, dim3(nb), dim3(256), 0, stream, src, dst, B, winner);
+  if (pfo_msg_store_needs_winner(B)) {
+    PFO_REQUIRE(winner, "large batches need the winner table");
+    const unsigned nb = (unsigned)pfo_ceil_div(2 * B, 256);
+    hipLaunchKernelGGL(msg_winner_max_kernel, dim3(nb), dim3(256), 0, stream, src, dst, B, winner);
+  } else {
+    winner = nullptr;
+  }
   hipLaunchKernelGGL(msg_write_kernel, dim3((unsigned)pfo_ceil_div(2 * B, 4)), dim3(256), 0, stream, src, dst, ts, eidx,
                      B, memory, last_update, edge_feat, tw, tb, D, Ef, msg_table, msg_time, has_msg, winner);
   PFO_LAUNCH_CHECK();

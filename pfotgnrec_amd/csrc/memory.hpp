@@ -7,13 +7,16 @@
 int64_t pfo_compact_scratch_ints(int n_nodes);
 int pfo_touch_compact_launch(const int32_t* nodes0, int64_t n0, const int32_t* extra, int64_t n_extra, int n_nodes,
                              int32_t* slot, int32_t* touched_ids, int32_t* n_touched, int32_t* scratch,
-                             bool slot_is_zero, hipStream_t stream);
-// packs the rows backward still needs after the state update overwrites them:
+                             bool slot_is_zero, bool marked, hipStream_t stream);
+// (slot_is_zero also covers scratch[0, n_nodes / 1024]: the one-pass scan's block flags; marked: the flags slot[v] = 1 were
+//  already set by the sampler (pfo_tnbr_sample_dev `mark`), only `extra` is marked here)
+// packs the rows backward still needs after the state update overwrites them (pfo_pack_remap_launch):
 //   msg_rows[s] = msg_table[id], h_rows[s] = memory[id], hm[s] = has_msg[id]   (id = touched_ids[s])
-int pfo_pack_rows_launch(const float* msg_table, int M, const float* memory, int D, const uint8_t* has_msg,
-                         const int32_t* touched_ids, const int32_t* n_touched, int cap, float* msg_rows, float* h_rows,
-                         uint8_t* hm, hipStream_t stream);
 int pfo_remap_launch(const int32_t* nodes0, int64_t n0, const int32_t* slot, int32_t* idx0, hipStream_t stream);
+// both in one launch (msg_table == null: only `memory` rows are copied, e.g. node features of a no-memory model)
+int pfo_pack_remap_launch(const float* msg_table, int M, const float* memory, int D, const uint8_t* has_msg,
+                          const int32_t* touched_ids, const int32_t* n_touched, int cap, float* msg_rows, float* h_rows,
+                          uint8_t* hm, const int32_t* nodes0, int64_t n0, const int32_t* slot, int32_t* idx0, hipStream_t stream);
 
 // --- GRU gates (memory_updater.py:60; torch.nn.GRUCell gate order r, z, n)
 // forward: per touched slot s (id = touched_ids[s]): h' = hm[s] ? GRU(gi[s], gh[s], h_rows[s]) : h_rows[s];
@@ -48,6 +51,8 @@ int pfo_zero_rows_launch(float* dst, const int32_t* n_rows, int cap_rows, int D,
 int pfo_persist_launch(const int32_t* src, const int32_t* dst, int B, const int32_t* slot, const float* upd_mem,
                        const uint8_t* has_msg, const float* msg_time, float* memory, float* last_update, int D, int32_t* winner,
                        hipStream_t stream);
+// winner (i32[n_nodes]) is only used when pfo_msg_store_needs_winner(B): persist then resets it, the store takes an atomicMax pass
+bool pfo_msg_store_needs_winner(int B);
 int pfo_msg_store_launch(const int32_t* src, const int32_t* dst, const double* ts, const int32_t* eidx, int B,
                          const float* memory, const float* last_update, const float* edge_feat, const float* tw,
                          const float* tb, int D, int Ef, float* msg_table, float* msg_time, uint8_t* has_msg,
@@ -56,8 +61,12 @@ int pfo_msg_store_launch(const int32_t* src, const int32_t* dst, const double* t
 // --- small ops (misc.hip)
 // cq = Wq[:, D:2D] cos(b) + bq folded query bias: backward of that term
 //   gq[E] = colsum(dQ);  d bq += gq;  d Wq[:, D:] += gq (x) cosb;  d tb += -sin(tb) * (Wq[:, D:]^T gq)
+// tb_part != null: the time-bias term is STORED there instead of added to d_tb (a partial launch; a later launch passes it as
+// tb_add).  dtime != null (final launch only): the step's fp64 time-encoder partial sums [n_bins][2D] are folded into
+// d_tw / d_tb by the same launch (fixed order).
 int pfo_cq_backward_launch(const float* const* gq, const float* const* Wq, int n_layers, const float* tb, int D, float* const* d_bq,
-                           float* const* d_Wq, float* d_tb, hipStream_t stream);
+                           float* const* d_Wq, float* d_tb, float* tb_part, const float* tb_add, const double* dtime, int n_bins,
+                           float* d_tw, hipStream_t stream);
 // scratch: pfo_fold_parts_scratch_doubles(n) doubles; tickets: 64 ints, zero before the first use (self-resetting)
 int64_t pfo_fold_parts_scratch_doubles(int n);
 int pfo_fold_parts_launch(const double* parts, int n_parts, int n, float* out, int accumulate, double* scratch, int* tickets,

@@ -19,11 +19,16 @@ extern "C" const char* pfo_last_error(void) { return g_err; }
 // event-pair profiler
 #include <vector>
 namespace {
-struct ProfRec { int kind; double work; hipEvent_t a, b; };
+// `pin` >= 0: the launch's extent is a device-side count (touched rows); it is copied to slot `pin` of a pinned host ring
+// right behind the kernel and the record's work is work * min(count, cap), evaluated in pfo_prof_collect
+struct ProfRec { int kind; double work; hipEvent_t a, b; int pin; int cap; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t g_pending = nullptr;
+const int PIN_SLOTS = 8192;
+int32_t* g_pin = nullptr;
+int g_pin_next = 0;
 hipEvent_t prof_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;
@@ -42,7 +47,24 @@ void pfo_prof_end(int kind, double work, hipStream_t s) {
   hipEvent_t b = prof_event();
   if (!b) return;
   (void)hipEventRecord(b, s);
-  g_recs.push_back(ProfRec{kind, work, g_pending, b});
+  g_recs.push_back(ProfRec{kind, work, g_pending, b, -1, 0});
+  g_pending = nullptr;
+}
+void pfo_prof_end_dev(int kind, double work_per_unit, const int32_t* units_dev, int units_cap, hipStream_t s) {
+  if (!g_prof_on || !g_pending) return;
+  if (!units_dev) { pfo_prof_end(kind, work_per_unit * units_cap, s); return; }
+  hipEvent_t b = prof_event();
+  if (!b) return;
+  (void)hipEventRecord(b, s);
+  if (!g_pin && hipHostMalloc(reinterpret_cast<void**>(&g_pin), PIN_SLOTS * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) g_pin = nullptr;
+  int pin = -1;
+  if (g_pin && g_pin_next < PIN_SLOTS) {
+    pin = g_pin_next++;
+    g_pin[pin] = -1;
+    if (hipMemcpyAsync(&g_pin[pin], units_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) pin = -1;
+  }
+  // (ring exhausted or copy refused: the record keeps its time and counts zero work)
+  g_recs.push_back(ProfRec{kind, pin >= 0 ? work_per_unit : 0.0, g_pending, b, pin, units_cap});
   g_pending = nullptr;
 }
 extern "C" int pfo_prof_enable(int32_t on) {
@@ -52,14 +74,23 @@ extern "C" int pfo_prof_enable(int32_t on) {
 extern "C" int pfo_prof_collect(double* ms, double* work, int64_t* count) {
   PFO_REQUIRE(ms && work && count, "null output");
   for (int k = 0; k < PFO_PROF_KINDS; ++k) { ms[k] = 0; work[k] = 0; count[k] = 0; }
+  bool synced = false;
   for (auto& r : g_recs) {
     if (hipEventSynchronize(r.b) != hipSuccess) { pfo_set_error("pfo_prof_collect: event sync failed"); return PFO_ERR_HIP; }
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
-    ms[r.kind] += t; work[r.kind] += r.work; count[r.kind] += 1;
+    double w = r.work;
+    if (r.pin >= 0) {
+      // the count's copy was queued behind event b on the same stream: one device-wide wait covers all of them
+      if (!synced) { (void)hipDeviceSynchronize(); synced = true; }
+      const int units = g_pin[r.pin];
+      w = units >= 0 ? r.work * (double)(units < r.cap ? units : r.cap) : 0.0;
+    }
+    ms[r.kind] += t; work[r.kind] += w; count[r.kind] += 1;
     g_pool.push_back(r.a); g_pool.push_back(r.b);
   }
   g_recs.clear();
+  g_pin_next = 0;
   return PFO_OK;
 }
 extern "C" int pfo_abi_version(void) { return 2; }
@@ -87,11 +118,33 @@ extern "C" int pfo_time_encode(const float* t, int64_t n, const float* w, const 
 
 // ---------------------------------------------------------------------------------------------
 // BPR (main.py:321-337): one wavefront per interaction
-__global__ void bpr_kernel(const float* __restrict__ emb, int64_t B, int D, int64_t pos_off, int64_t neg_off, int n_neg,
-                           int64_t R, float scale, float* __restrict__ loss_part, float* __restrict__ d_emb) {
+// ticket != null: the workgroup that finishes LAST also takes the mean of the per-interaction losses, in index order
+// (reproducible) - no second launch.  The ticket word is zero before the first use and resets itself.
+__device__ __forceinline__ void bpr_mean_tail(const float* loss_part, int64_t B, float* loss_out, int* ticket) {
+  __shared__ int s_last;
+  __shared__ float s_sum[4];
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < B; i += 256) s += __hip_atomic_load(&loss_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  s = pfo_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *loss_out = ((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3])) / (float)B;
+    *ticket = 0;
+  }
+}
+__global__ __launch_bounds__(256) void bpr_kernel(const float* __restrict__ emb, int64_t B, int D, int64_t pos_off, int64_t neg_off, int n_neg,
+                           int64_t R, float scale, float* __restrict__ loss_part, float* __restrict__ d_emb,
+                           float* __restrict__ loss_out, int* ticket) {
   const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  if (b >= B) return;
+  if (b < B) {
   const float* s = emb + b * D;
   const float* p = emb + (pos_off + b) * D;
   float pos = 0.f;
@@ -129,6 +182,8 @@ __global__ void bpr_kernel(const float* __restrict__ emb, int64_t B, int D, int6
       for (int d = lane; d < D; d += 64) d_emb[row * D + d] = 0.f;
     }
   }
+  }
+  if (ticket) bpr_mean_tail(loss_part, B, loss_out, ticket);
 }
 __global__ void bpr_mean_kernel(const float* __restrict__ loss_part, int64_t B, float* __restrict__ loss_out) {
   // single wavefront, fixed order: deterministic
@@ -137,17 +192,27 @@ __global__ void bpr_mean_kernel(const float* __restrict__ loss_part, int64_t B, 
   s = pfo_wave_sum(s);
   if (threadIdx.x == 0) *loss_out = s / (float)B;
 }
-extern "C" int pfo_bpr_loss(const float* emb, int64_t B, int32_t D, int64_t pos_off, int64_t neg_off, int32_t n_neg,
-                            int64_t R, float scale, float* loss_out, float* d_emb, float* workspace, void* stream) {
+static int bpr_launch(const float* emb, int64_t B, int32_t D, int64_t pos_off, int64_t neg_off, int32_t n_neg, int64_t R,
+                      float scale, float* loss_out, float* d_emb, float* workspace, int32_t* ticket, void* stream) {
   PFO_REQUIRE(emb && loss_out && workspace, "null input");
   PFO_REQUIRE(B > 0 && D > 0 && n_neg > 0, "bad sizes");
   PFO_REQUIRE(pos_off >= B && pos_off + B <= R && neg_off + B * n_neg <= R && neg_off >= pos_off + B, "bad offsets");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bpr_kernel, dim3((unsigned)pfo_ceil_div(B, 4)), dim3(256), 0, s, emb, B, (int)D, pos_off, neg_off,
-                     (int)n_neg, R, scale, workspace, d_emb);
-  hipLaunchKernelGGL(bpr_mean_kernel, dim3(1), dim3(64), 0, s, workspace, B, loss_out);
+                     (int)n_neg, R, scale, workspace, d_emb, loss_out, ticket);
+  if (!ticket) hipLaunchKernelGGL(bpr_mean_kernel, dim3(1), dim3(64), 0, s, workspace, B, loss_out);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
+}
+extern "C" int pfo_bpr_loss(const float* emb, int64_t B, int32_t D, int64_t pos_off, int64_t neg_off, int32_t n_neg,
+                            int64_t R, float scale, float* loss_out, float* d_emb, float* workspace, void* stream) {
+  return bpr_launch(emb, B, D, pos_off, neg_off, n_neg, R, scale, loss_out, d_emb, workspace, nullptr, stream);
+}
+extern "C" int pfo_bpr_loss_fused(const float* emb, int64_t B, int32_t D, int64_t pos_off, int64_t neg_off, int32_t n_neg,
+                                  int64_t R, float scale, float* loss_out, float* d_emb, float* workspace, int32_t* ticket,
+                                  void* stream) {
+  PFO_REQUIRE(ticket, "null ticket");
+  return bpr_launch(emb, B, D, pos_off, neg_off, n_neg, R, scale, loss_out, d_emb, workspace, ticket, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -300,12 +365,18 @@ extern "C" int pfo_adam_step_ranges_dev(float* param, const float* grad, float* 
 }
 
 // one workgroup per time dimension d, every layer in turn: d Wq[:, D+d] += gq * cos(b_d);  d tb[d] += -sin(b_d) * sum_e Wq[e, D+d] gq[e]
+// The time-bias term either goes to `tb_part` (stored: a partial launch for the top layer, whose other gradients are then
+// final - see pfo_tgn_backward_ev) or is added to d_tb together with an earlier launch's `tb_add`.  `dtime` (optional):
+// the step's fp64 time-encoder partial sums [n_bins][2D] (attention backward), folded here in bin order into d_tw / d_tb.
 struct CqBwdDev {
   const float* gq[PFO_MAX_LAYERS]; const float* Wq[PFO_MAX_LAYERS]; float* d_bq[PFO_MAX_LAYERS]; float* d_Wq[PFO_MAX_LAYERS];
   int n;
 };
-__global__ __launch_bounds__(256) void cq_backward_kernel(const CqBwdDev q, const float* __restrict__ tb, int D, float* __restrict__ d_tb) {
+__global__ __launch_bounds__(256) void cq_backward_kernel(const CqBwdDev q, const float* __restrict__ tb, int D, float* __restrict__ d_tb,
+                                                          float* __restrict__ tb_part, const float* __restrict__ tb_add,
+                                                          const double* __restrict__ dtime, int n_bins, float* __restrict__ d_tw) {
   __shared__ float s_part[4];
+  __shared__ double s_bins[2][4];
   const int d = blockIdx.x, E = 2 * D;
   float sb, cb;
   pfo_sincosf(tb[d], sb, cb);                                     // query time feature is cos(fma(0, w, b)) = cos(b)
@@ -328,15 +399,43 @@ __global__ __launch_bounds__(256) void cq_backward_kernel(const CqBwdDev q, cons
     __syncthreads();
     if (threadIdx.x == 0) total += (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
   }
-  if (threadIdx.x == 0) d_tb[d] += -sb * total;
+  // time-encoder partial sums of this column: wavefront 0 folds the d_tw bins, wavefront 1 the d_tb bins, each in four
+  // interleaved chains of ascending bins and a fixed tree (reproducible)
+  double fold_w = 0.0, fold_b = 0.0;
+  if (dtime) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < 2 && lane < 4) {
+      double acc = 0.0;
+      for (int p = lane; p < n_bins; p += 4) acc += dtime[(int64_t)p * 2 * D + wave * D + d];
+      s_bins[wave][lane] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      fold_w = (s_bins[0][0] + s_bins[0][1]) + (s_bins[0][2] + s_bins[0][3]);
+      fold_b = (s_bins[1][0] + s_bins[1][1]) + (s_bins[1][2] + s_bins[1][3]);
+    }
+  }
+  if (threadIdx.x == 0) {
+    const float mine = -sb * total;
+    if (tb_part) tb_part[d] = mine;
+    else {
+      if (dtime) {
+        d_tw[d] = (float)((double)d_tw[d] + fold_w);
+        d_tb[d] = (float)((double)d_tb[d] + fold_b);
+      }
+      d_tb[d] += mine + (tb_add ? tb_add[d] : 0.f);
+    }
+  }
 }
 int pfo_cq_backward_launch(const float* const* gq, const float* const* Wq, int n_layers, const float* tb, int D, float* const* d_bq,
-                           float* const* d_Wq, float* d_tb, hipStream_t stream) {
+                           float* const* d_Wq, float* d_tb, float* tb_part, const float* tb_add, const double* dtime, int n_bins,
+                           float* d_tw, hipStream_t stream) {
   PFO_REQUIRE(n_layers >= 1 && n_layers <= PFO_MAX_LAYERS, "bad layer count");
+  PFO_REQUIRE(!dtime || (d_tw && !tb_part), "the time-partial fold belongs to the final launch");
   CqBwdDev q;
   q.n = n_layers;
   for (int l = 0; l < n_layers; ++l) { q.gq[l] = gq[l]; q.Wq[l] = Wq[l]; q.d_bq[l] = d_bq[l]; q.d_Wq[l] = d_Wq[l]; }
-  hipLaunchKernelGGL(cq_backward_kernel, dim3(D), dim3(256), 0, stream, q, tb, D, d_tb);
+  hipLaunchKernelGGL(cq_backward_kernel, dim3(D), dim3(256), 0, stream, q, tb, D, d_tb, tb_part, tb_add, dtime, n_bins, d_tw);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

@@ -16,7 +16,10 @@ __global__ __launch_bounds__(256) void tnbr_sample_kernel(
     const double* __restrict__ adj_ts, int64_t n_nodes, const int32_t* __restrict__ q_nodes,
     const double* __restrict__ q_ts, int64_t n_q, int K, const int64_t* __restrict__ draws, uint64_t seed,
     uint64_t offset, const uint64_t* __restrict__ offset_dev, int32_t* __restrict__ out_nbr, int32_t* __restrict__ out_eidx,
-    float* __restrict__ out_et, float* __restrict__ out_dt, int32_t* __restrict__ next_nodes, double* __restrict__ next_ts) {
+    float* __restrict__ out_et, float* __restrict__ out_dt, int32_t* __restrict__ next_nodes, double* __restrict__ next_ts,
+    int32_t* __restrict__ mark) {
+  // mark (optional, with next_nodes): mark[v] = 1 for every node written to the next level - the touched-node flags of the
+  // step's compaction, set here instead of by a pass of their own over the level-0 list
   if (MODE == 2 && offset_dev) offset += *offset_dev;
   __shared__ float s_time[16][PFO_MAX_NEIGHBORS];   // uniform modes: per-group sort scratch
   const int lane = threadIdx.x & 63;
@@ -65,6 +68,7 @@ __global__ __launch_bounds__(256) void tnbr_sample_kernel(
   if (active && sub == 0 && next_nodes) {
     next_nodes[q] = node;
     if (next_ts) next_ts[q] = t;
+    if (mark && node >= 0 && (int64_t)node < n_nodes) mark[node] = 1;
   }
 
   if (MODE == 0) {
@@ -87,6 +91,7 @@ __global__ __launch_bounds__(256) void tnbr_sample_kernel(
       if (next_nodes) {
         next_nodes[n_q + o] = v;
         if (next_ts) next_ts[n_q + o] = t;
+        if (mark && (uint64_t)(uint32_t)v < (uint64_t)n_nodes) mark[v] = 1;
       }
     }
   } else {
@@ -133,6 +138,7 @@ __global__ __launch_bounds__(256) void tnbr_sample_kernel(
           if (next_nodes) {
             next_nodes[n_q + o] = v[u];
             if (next_ts) next_ts[n_q + o] = t;
+            if (mark && (uint64_t)(uint32_t)v[u] < (uint64_t)n_nodes) mark[v[u]] = 1;
           }
         }
       }
@@ -143,7 +149,9 @@ __global__ __launch_bounds__(256) void tnbr_sample_kernel(
 int pfo_tnbr_sample_dev(const int64_t* indptr, const int32_t* adj_nbr, const int32_t* adj_eidx, const double* adj_ts,
                         int64_t n_nodes, const int32_t* q_nodes, const double* q_ts, int64_t n_q, int32_t K, int32_t mode,
                         const int64_t* draws, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int32_t* out_nbr,
-                        int32_t* out_eidx, float* out_et, float* out_dt, int32_t* next_nodes, double* next_ts, void* stream) {
+                        int32_t* out_eidx, float* out_et, float* out_dt, int32_t* next_nodes, double* next_ts, int32_t* mark,
+                        void* stream) {
+  PFO_REQUIRE(mark == nullptr || next_nodes != nullptr, "mark needs next_nodes");
   PFO_REQUIRE(K >= 1 && K <= PFO_MAX_NEIGHBORS, "K must be in [1, 64]");
   PFO_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0, 1 or 2");
   PFO_REQUIRE(mode != 1 || draws != nullptr, "mode 1 needs injected draws");
@@ -157,7 +165,7 @@ int pfo_tnbr_sample_dev(const int64_t* indptr, const int32_t* adj_nbr, const int
 #define LAUNCH(M)                                                                                                   \
   hipLaunchKernelGGL(tnbr_sample_kernel<M>, dim3((unsigned)blocks), dim3(threads), 0, s, indptr, adj_nbr, adj_eidx, \
                      adj_ts, n_nodes, q_nodes, q_ts, n_q, (int)K, draws, seed, offset, offset_dev, out_nbr, out_eidx,  \
-                     out_et, out_dt, next_nodes, next_ts)
+                     out_et, out_dt, next_nodes, next_ts, mark)
   pfo_prof_begin(s);
   if (mode == 0) LAUNCH(0);
   else if (mode == 1) LAUNCH(1);
@@ -175,7 +183,7 @@ extern "C" int pfo_tnbr_sample(const int64_t* indptr, const int32_t* adj_nbr, co
                                uint64_t offset, int32_t* out_nbr, int32_t* out_eidx, float* out_et, float* out_dt,
                                int32_t* next_nodes, double* next_ts, void* stream) {
   return pfo_tnbr_sample_dev(indptr, adj_nbr, adj_eidx, adj_ts, n_nodes, q_nodes, q_ts, n_q, K, mode, draws, seed, offset,
-                             nullptr, out_nbr, out_eidx, out_et, out_dt, next_nodes, next_ts, stream);
+                             nullptr, out_nbr, out_eidx, out_et, out_dt, next_nodes, next_ts, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -17,7 +17,7 @@
 
 int pfo_tnbr_sample_dev(const int64_t*, const int32_t*, const int32_t*, const double*, int64_t, const int32_t*, const double*,
                         int64_t, int32_t, int32_t, const int64_t*, uint64_t, uint64_t, const uint64_t*, int32_t*, int32_t*,
-                        float*, float*, int32_t*, double*, void*);
+                        float*, float*, int32_t*, double*, int32_t*, void*);
 
 namespace {
 
@@ -41,7 +41,7 @@ struct Ws {
   int32_t *slot, *touched, *n_touched, *scan, *idx0, *winner;
   float *gi, *gh, *upd_mem, *h0_tab, *d_h0, *msg_rows, *h_rows;
   uint8_t* hm;
-  float *cosb, *zero;
+  float *cosb, *zero, *tb_part;
   void *iWih, *iWhh;
   // layer 1 works on the touched-node table: QX[s] = h0_tab[s] [Wqk ; W1[:, E:]]^T + [cqk | 0] for every touched row s
   // (the query-side projections of all instances that sit on node s), Dq = per-row sums of the instances' gradients
@@ -55,7 +55,7 @@ struct Ws {
   double *dtime, *fold_scratch;
   int32_t* tickets;
   int64_t slab_floats;
-  size_t zero_bytes;
+  size_t zero_bytes, mark_bytes;
   int64_t bytes;
 };
 
@@ -113,12 +113,15 @@ Ws carve(const pfo_tgn_config* c, void* base) {
   w.dtime = take<double>(p, (int64_t)pfo_attn_bwd_max_parts() * 2 * d.D);      // time-encoder gradient bins, also cleared per step
   w.zero_bytes = (size_t)(p - reinterpret_cast<char*>(w.zero));
   w.cosb = take<float>(p, d.D);
+  w.tb_part = take<float>(p, d.D);
   {
     const int WQ = d.H * d.Cp + d.D;
+    // one memset per step clears [touched-node flags | block flags of the one-pass compaction]
     w.slot = take<int32_t>(p, c->n_nodes);
+    w.scan = take<int32_t>(p, pfo_compact_scratch_ints(c->n_nodes));
+    w.mark_bytes = (size_t)(p - reinterpret_cast<char*>(w.slot));
     w.touched = take<int32_t>(p, d.capP);
     w.n_touched = take<int32_t>(p, 64);
-    w.scan = take<int32_t>(p, pfo_compact_scratch_ints(c->n_nodes));
     w.idx0 = take<int32_t>(p, d.ncap[0]);
     w.h0_tab = take<float>(p, d.capP * d.D);
     w.QX = take<float>(p, d.capP * WQ);
@@ -256,7 +259,7 @@ PfoGemm g_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const int
 // dependent launches; they run beside the main stream's work and are joined by events where their results are needed.
 struct Side {
   hipStream_t s = nullptr, s2 = nullptr;
-  hipEvent_t tn_a_done = nullptr, done2 = nullptr;
+  hipEvent_t tn_a_done = nullptr, done2 = nullptr, grad0 = nullptr;
   hipEvent_t fork = nullptr, done = nullptr, gru_fork = nullptr, gru_join = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr, slot0 = nullptr, fold_done = nullptr;
   hipEvent_t layer[PFO_MAX_LAYERS + 1] = {};
   bool ok = false;
@@ -272,6 +275,7 @@ Side& side() {
     good = good && hipStreamCreateWithFlags(&sd.s2, hipStreamNonBlocking) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.tn_a_done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.done2, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.grad0, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.gru_fork, hipEventDisableTiming) == hipSuccess;
@@ -388,7 +392,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
   // the compaction's flags are cleared beside the sampling launches rather than between them and the marking pass
-  HIPOK(hipMemsetAsync(w.slot, 0, (size_t)c->n_nodes * sizeof(int32_t), ss), "memset failed");
+  HIPOK(hipMemsetAsync(w.slot, 0, w.mark_bytes, ss), "memset failed");
   HIPOK(hipEventRecord(sd.slot0, ss), "event record failed");
   // ---- frontier expansion: K1 per level (utils.py:163-219 called from embedding_module.py:125).  Enqueued before the
   // side-stream work below: it depends on nothing else, and the GPU samples while the host is still enqueueing
@@ -398,9 +402,13 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     // level L reads the caller's roots directly; every level writes [its own nodes | their neighbours] as the next one
     const int32_t* lvl_nodes = (l == L) ? b->roots : w.nodes[l];
     const double* lvl_ts = (l == L) ? b->root_ts : w.ts[l];
+    // the last launch writes the whole level-0 list [S_1 ; neighbours(S_1)]: it also sets the touched-node flags (cleared on
+    // the side stream meanwhile), so the compaction needs no marking pass
+    if (l == 1) HIPOK(hipStreamWaitEvent(s, sd.slot0, 0), "event wait failed");
     RUN(pfo_tnbr_sample_dev(st->indptr, st->adj_nbr, st->adj_eidx, st->adj_ts, c->n_nodes, lvl_nodes, lvl_ts, n[l], K,
                             b->uniform, dr, b->seed, b->offset + (uint64_t)l * 0x100000000ull, b->offset_dev, nullptr,
-                            w.eidx[l], nullptr, w.dt[l], w.nodes[l - 1], l > 1 ? w.ts[l - 1] : nullptr, stream));
+                            w.eidx[l], nullptr, w.dt[l], w.nodes[l - 1], l > 1 ? w.ts[l - 1] : nullptr, l == 1 ? w.slot : nullptr,
+                            stream));
   }
 
   if (c->use_memory) {
@@ -520,16 +528,15 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   // slot[v] = row of v in the per-step tables, idx0[i] = row of the i-th level-0 reference
   PFO_REQUIRE(b->n_extra >= 0 && b->n_extra <= 2 * c->max_batch, "n_extra exceeds 2 * max_batch");
   PFO_REQUIRE(b->n_extra == 0 || b->extra_nodes, "null extra_nodes");
-  HIPOK(hipStreamWaitEvent(s, sd.slot0, 0), "event wait failed");
-  RUN(pfo_touch_compact_launch(w.nodes[0], n[0], b->extra_nodes, b->n_extra, c->n_nodes, w.slot, w.touched, w.n_touched,
-                               w.scan, true, s));
-  RUN(pfo_remap_launch(w.nodes[0], n[0], w.slot, w.idx0, s));
+  RUN(pfo_touch_compact_launch(nullptr, 0, b->extra_nodes, b->n_extra, c->n_nodes, w.slot, w.touched, w.n_touched,
+                               w.scan, true, true, s));
   const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
   // ---- level-0 rows of the touched nodes: memory' + node features (embedding_module.py:93-98), memory' = the lazily
-  // updated memory (tgn.py:251; memory_updater.py:35-53)
+  // updated memory (tgn.py:251; memory_updater.py:35-53).  One launch copies the rows the GRU reads (and the backward reads
+  // again after the state update has overwritten the tables) and translates the level-0 list into table rows.
   if (c->use_memory) {
-    RUN(pfo_pack_rows_launch(st->msg_table, d.M, st->memory, D, st->has_msg, w.touched, w.n_touched, capP, w.msg_rows,
-                             w.h_rows, w.hm, s));
+    RUN(pfo_pack_remap_launch(st->msg_table, d.M, st->memory, D, st->has_msg, w.touched, w.n_touched, capP, w.msg_rows,
+                              w.h_rows, w.hm, w.nodes[0], n[0], w.slot, w.idx0, s));
     HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");         // images of W_ih / W_hh
     // the two GRU contractions are independent and each fills only ~55 % of the chip (touched rows / 128 x 3 column
     // tiles = ~280 workgroups): the hidden-state one runs beside the message one on the side stream
@@ -546,7 +553,8 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     RUN(pfo_gru_gates_fwd_launch(w.gi, w.gh, w.h_rows, st->node_feat, w.hm, w.touched, w.n_touched, capP, D, w.upd_mem,
                                  w.h0_tab, s));
   } else {
-    RUN(pfo_gather_rows_launch(st->node_feat, D, w.touched, w.n_touched, capP, w.h0_tab, s));
+    RUN(pfo_pack_remap_launch(nullptr, d.M, st->node_feat, D, nullptr, w.touched, w.n_touched, capP, nullptr, w.h0_tab, nullptr,
+                              w.nodes[0], n[0], w.slot, w.idx0, s));
   }
   const float* tab0 = w.h0_tab;
   const int32_t* idx0 = w.idx0;
@@ -640,8 +648,22 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
 }
 
 // =============================================================================================
+extern "C" int pfo_tgn_grad_split(const pfo_tgn_config* c, int64_t* split) {
+  if (int rc = check_cfg(c)) return rc;
+  PFO_REQUIRE(split != nullptr, "null output");
+  pfo_tgn_layout lay;
+  RUN(pfo_tgn_param_layout(c, &lay));
+  *split = c->n_layers >= 2 ? lay.layer[c->n_layers - 1].wq : lay.total;
+  return PFO_OK;
+}
+
 extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st, const pfo_tgn_batch* b, void* workspace,
                                 const float* d_emb, float* grad, void* stream) {
+  return pfo_tgn_backward_ev(c, st, b, workspace, d_emb, grad, 0, nullptr, stream);
+}
+
+extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state* st, const pfo_tgn_batch* b, void* workspace,
+                                   const float* d_emb, float* grad, int32_t zero_grad_first, void* top_ready_event, void* stream) {
   if (int rc = check_cfg(c)) return rc;
   PFO_REQUIRE(st && workspace && d_emb && grad && st->params, "null argument");
   int64_t n[PFO_MAX_LAYERS + 1];
@@ -664,16 +686,23 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
   // Per-XCD replicas of the level-0 gradient table pay off only for the per-instance atomics (uniform sampling: 4 replicas
   // 0.537 -> 0.506 ms); the run-merged kernel issues 2-3x fewer and measures best on ONE table (1.656 vs 1.665 ms/step)
   const int n_rep = (c->use_memory && !b->uniform && pfo_attn_bwd_runs_possible(K)) ? 1 : PFO_GRAD_REPLICAS;
-  if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_touched, capP, D, n_rep, rep_stride, s));
 
   const int Cp = d.Cp, HCp = H * d.Cp, WQ = HCp + D;
   Side& sd = side();
   PFO_REQUIRE(sd.ok, "could not create the side stream");
   hipStream_t ss = sd.s;
   // layer-1 instances grouped by the touched-table row they sit on (needed only when the layer-1 gradients are summed
-  // per row, late in this call): built on the side stream, beside the layer-L .. 2 work
+  // per row, late in this call): built on the side stream, beside the layer-L .. 2 work.  The same stream first clears what
+  // this call accumulates into: the level-0 gradient rows (layer 1's attention backward waits for seg_done) and, on request,
+  // the caller's flat gradient buffer (its first writer waits for grad0)
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
+  if (zero_grad_first) {
+    HIPOK(hipMemsetAsync(grad, 0, (size_t)lay.total * sizeof(float), ss), "memset failed");
+    HIPOK(hipEventRecord(sd.grad0, ss), "event record failed");
+    HIPOK(hipStreamWaitEvent(sd.s2, sd.grad0, 0), "event wait failed");
+  }
+  if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_touched, capP, D, n_rep, rep_stride, ss));
   RUN(pfo_seg_build_launch(idx0, w.nodes[0], (int)n[1], capP, b->uniform ? nullptr : w.eidx[1], K, w.seg_ptr, w.seg_cur,
                            w.seg_tmp, w.seg_mem, w.seg_scratch, ss));
   HIPOK(hipEventRecord(sd.seg_done, ss), "event record failed");
@@ -713,6 +742,7 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       q.relu_src = lw.h1; q.relu_ld = D;                     // ReLU backward
       q.b_img = lw.iW2T;
       RUN(pfo_gemm_launch(q, s));
+      if (zero_grad_first) HIPOK(hipStreamWaitEvent(s, sd.grad0, 0), "event wait failed");   // long done: the buffer is clear
       dh1 = w.dh1;
     } else {
       // below the top the layer above wrote d h1 directly, ReLU mask applied by its producers (attention backward's key
@@ -772,9 +802,9 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
     else        { a.d_nbr = w.dH[l - 1]; a.d_nbr_ld = D; }
     a.dtime_part = w.dtime;
     int n_parts = 0;
+    if (l == 1 && c->use_memory) HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");   // d_h0 is clear, the groups exist
     if (l == 1 && c->use_memory && !b->uniform) {
       // key-side gradients of instances with identical neighbour lists leave as one set of atomics (attn.hip)
-      HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");
       a.members = w.seg_mem; a.seg_ptr = w.seg_ptr; a.n_rows = w.n_touched;
     }
     const int dqk_by_member = pfo_attn_bwd_uses_runs(a) ? 1 : 0;
@@ -951,6 +981,16 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       RUN(pfo_gemm_multi_launch(c2, 3, sa));
       RUN(pfo_gemm_multi_launch(cb, 3, sb));
       RUN(pfo_rank1_multi_launch(rb, H, sb));
+      if (l == L && L >= 2) {
+        // The top layer's folded query-bias backward runs here, on the stream of its chain, with its time-bias term parked in
+        // tb_part (the final launch adds it): from this point every gradient of the top layer's parameter block
+        // [layer[L-1].wq, total) is FINAL - a data-parallel caller starts all-reducing that block while layers L-1 .. 1 are
+        // still being differentiated (pfo_tgn_grad_split, distributed.py)
+        const float* gq1[1] = {lw.gq}; const float* wq1[1] = {p.wq};
+        float* dbq1[1] = {g.b_in}; float* dwq1[1] = {g.wq};
+        RUN(pfo_cq_backward_launch(gq1, wq1, 1, P.tb, D, dbq1, dwq1, G.tb, w.tb_part, nullptr, nullptr, 0, nullptr, sb));
+        if (top_ready_event) HIPOK(hipEventRecord((hipEvent_t)top_ready_event, sb), "event record failed");
+      }
     }
   }
 
@@ -967,10 +1007,9 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
       RUN(pfo_gemm_tn_group_launch(gp, 2, capP, w.n_touched, w.slabs, w.slab_floats, s));
     }
   }
-  // the time-encoder partial sums of the attention backwards fold while the side streams are still chaining (time_w, time_b
-  // adjacent; measured: on a side stream of its own, right after the attention backward, this fold costs 30 us/step);
-  // then join: the folded query-bias backward accumulates into the same time_b gradient, so it comes after both
-  RUN(pfo_fold_parts_launch(w.dtime, pfo_attn_bwd_max_parts(), 2 * D, G.tw, 1, w.fold_scratch, w.tickets, s));
+  // join the side streams, then ONE launch finishes the time-encoder gradients: the folded query-bias backward of layers
+  // 1 .. L-1 (the top layer's ran with its chain), + its parked time-bias term, + the fold of the attention backwards' fp64
+  // partial sums into time_w / time_b (fixed order)
   HIPOK(hipEventRecord(sd.done, ss), "event record failed");
   HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
   HIPOK(hipEventRecord(sd.done2, sd.s2), "event record failed");
@@ -978,8 +1017,10 @@ extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st
   {
     const float *gq[PFO_MAX_LAYERS], *wq[PFO_MAX_LAYERS];
     float *dbq[PFO_MAX_LAYERS], *dwq[PFO_MAX_LAYERS];
-    for (int l = 1; l <= L; ++l) { gq[l - 1] = w.layer[l].gq; wq[l - 1] = P.l[l].wq; dbq[l - 1] = G.l[l].b_in; dwq[l - 1] = G.l[l].wq; }
-    RUN(pfo_cq_backward_launch(gq, wq, L, P.tb, D, dbq, dwq, G.tb, s));                  // cq = Wq[:, D:] cos(b) + bq
+    const int nl = L >= 2 ? L - 1 : L;
+    for (int l = 1; l <= nl; ++l) { gq[l - 1] = w.layer[l].gq; wq[l - 1] = P.l[l].wq; dbq[l - 1] = G.l[l].b_in; dwq[l - 1] = G.l[l].wq; }
+    RUN(pfo_cq_backward_launch(gq, wq, nl, P.tb, D, dbq, dwq, G.tb, nullptr, L >= 2 ? w.tb_part : nullptr, w.dtime,
+                               pfo_attn_bwd_max_parts(), G.tw, s));                   // cq = Wq[:, D:] cos(b) + bq
   }
   return PFO_OK;
 }
@@ -997,8 +1038,10 @@ extern "C" int pfo_tgn_update_state(const pfo_tgn_config* c, const pfo_tgn_state
   RUN(pfo_tgn_param_layout(c, &lay));
   const float* tw = st->params + lay.time_w;
   const float* tb = st->params + lay.time_b;
-  RUN(pfo_persist_launch(src, dst, B, w.slot, w.upd_mem, st->has_msg, st->msg_time, st->memory, st->last_update, c->D, w.winner, s));
+  // (the last-message-wins test needs the per-node table only for very large batches: memory.hip MSG_INLINE_MAX)
+  int32_t* winner = pfo_msg_store_needs_winner(B) ? w.winner : nullptr;
+  RUN(pfo_persist_launch(src, dst, B, w.slot, w.upd_mem, st->has_msg, st->msg_time, st->memory, st->last_update, c->D, winner, s));
   RUN(pfo_msg_store_launch(src, dst, ts, eidx, B, st->memory, st->last_update, st->edge_feat, tw, tb, c->D, c->Ef,
-                           st->msg_table, st->msg_time, st->has_msg, w.winner, s));
+                           st->msg_table, st->msg_time, st->has_msg, winner, s));
   return PFO_OK;
 }

@@ -44,6 +44,36 @@ def allreduce_flat_grad(flat_grad, world):
     return flat_grad
 
 
+_COMM_STREAMS = {}
+
+
+def allreduce_flat_grad_buckets(tgn, world, force=False):
+    """The same sum in TWO pieces, the first one beside the backward.  With ``tgn.dp_bucketed`` set, the native backward
+    records an event when the top layer's gradient block ``flat_grad[tgn.grad_split:]`` is final - layers L-1 .. 1 and the
+    GRU are still being differentiated then (roughly the second half of the backward at L = 2).  A communication stream
+    waits for that event and reduces the block; the rest is reduced on the caller's stream after the backward; the
+    caller's stream then waits for the communication stream.  Element-wise sums do not depend on how the buffer is cut, so
+    the result is bit-identical to ``allreduce_flat_grad``.  ``force``: run the collectives at world 1 too (tests)."""
+    g = tgn.flat_grad
+    if g is None or (world <= 1 and not force):
+        return g
+    split = tgn.grad_split
+    if not (tgn.dp_bucketed and tgn._bucket_event_fresh and 0 < split < g.numel()):
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)            # no event this step (empty shard, one layer): one piece
+        return g
+    tgn._bucket_event_fresh = False
+    main = torch.cuda.current_stream(g.device)
+    side = _COMM_STREAMS.get(g.device)
+    if side is None:
+        side = _COMM_STREAMS[g.device] = torch.cuda.Stream(device=g.device)
+    side.wait_event(tgn._bucket_event)
+    with torch.cuda.stream(side):
+        dist.all_reduce(g[split:], op=dist.ReduceOp.SUM)
+    dist.all_reduce(g[:split], op=dist.ReduceOp.SUM)
+    main.wait_stream(side)
+    return g
+
+
 def broadcast_parameters(flat_params, world, src=0):
     if world > 1:
         dist.broadcast(flat_params, src=src)

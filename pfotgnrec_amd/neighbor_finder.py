@@ -10,6 +10,15 @@ import numpy as np
 from . import _lib
 
 
+def _dev_key(device):
+    """'cuda' and 'cuda:<current>' name the same device: one cache entry for both spellings."""
+    import torch
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return str(d)
+
+
 def build_csr(sources, destinations, edge_idxs, timestamps, max_node_idx=None):
     """Per-node adjacency, stable-sorted by timestamp (utils/utils.py:117-142).
 
@@ -55,7 +64,19 @@ def build_csr_device(sources, destinations, edge_idxs, timestamps, device, max_n
     E = int(src.shape[0])
     if max_node_idx is None:
         max_node_idx = int(max(int(np.max(sources)), int(np.max(destinations)))) if E else 0
+    _check_ids(sources, destinations, max_node_idx)
     return _csr_build_native(src, dst, eid, ts, max_node_idx + 1, dev)
+
+
+def _check_ids(sources, destinations, max_node_idx):
+    """The device build sorts entries by the low bits of the owner id and counts only owners inside the table: an id outside
+    [0, max_node_idx] would yield a silently corrupt CSR (the host build raises from np.bincount / the index store)."""
+    if len(sources) == 0:
+        return
+    lo = min(int(np.min(sources)), int(np.min(destinations)))
+    hi = max(int(np.max(sources)), int(np.max(destinations)))
+    if lo < 0 or hi > max_node_idx:
+        raise ValueError("node ids must lie in [0, %d]: found %d .. %d" % (max_node_idx, lo, hi))
 
 
 def _csr_build_native(src, dst, eid, ts, n_nodes, dev):
@@ -74,28 +95,71 @@ def _csr_build_native(src, dst, eid, ts, n_nodes, dev):
 
 class NeighborFinder:
     """Drop-in for utils/utils.py:130.  ``adj_list`` is the reference's list of per-node
-    ``[(neighbor, edge_idx, timestamp), ...]`` lists; ``from_arrays`` skips that detour."""
+    ``[(neighbor, edge_idx, timestamp), ...]`` lists; ``from_arrays`` skips that detour.
 
-    def __init__(self, adj_list=None, uniform=False, seed=None, _csr=None):
-        if _csr is None:
-            owner, nbr, eidx, ts = [], [], [], []
-            for node, lst in enumerate(adj_list):
-                lst = sorted(lst, key=lambda x: x[2])
-                owner.extend([node] * len(lst))
-                nbr.extend(x[0] for x in lst)
-                eidx.extend(x[1] for x in lst)
-                ts.extend(x[2] for x in lst)
-            counts = np.bincount(np.asarray(owner, np.int64), minlength=len(adj_list))
-            indptr = np.zeros(len(adj_list) + 1, np.int64)
-            np.cumsum(counts, out=indptr[1:])
-            _csr = (indptr, np.asarray(nbr, np.int32), np.asarray(eidx, np.int32), np.asarray(ts, np.float64))
-        self.indptr, self.nbr, self.eidx, self.ts = _csr
-        self.n_nodes = len(self.indptr) - 1
+    The host arrays ``indptr / nbr / eidx / ts`` are MIRRORS of the device CSR: after a device-side build or ``append`` they
+    are stale and are fetched only when something reads them (a 10 M-edge adjacency is 0.5 GB of D2H per refresh)."""
+
+    def __init__(self, adj_list=None, uniform=False, seed=None, _csr=None, _dev_csr=None, _device=None):
+        self._host = None
+        self._dev = {}
+        if _dev_csr is not None:
+            self._dev[_dev_key(_device)] = _dev_csr
+            self.n_nodes = int(_dev_csr[0].shape[0]) - 1
+            self._max_nbr, self._max_eidx = None, None
+        else:
+            if _csr is None:
+                owner, nbr, eidx, ts = [], [], [], []
+                for node, lst in enumerate(adj_list):
+                    lst = sorted(lst, key=lambda x: x[2])
+                    owner.extend([node] * len(lst))
+                    nbr.extend(x[0] for x in lst)
+                    eidx.extend(x[1] for x in lst)
+                    ts.extend(x[2] for x in lst)
+                counts = np.bincount(np.asarray(owner, np.int64), minlength=len(adj_list))
+                indptr = np.zeros(len(adj_list) + 1, np.int64)
+                np.cumsum(counts, out=indptr[1:])
+                _csr = (indptr, np.asarray(nbr, np.int32), np.asarray(eidx, np.int32), np.asarray(ts, np.float64))
+            self._host = tuple(_csr)
+            self.n_nodes = len(self._host[0]) - 1
+            self._max_nbr = int(np.max(self._host[1], initial=0))
+            self._max_eidx = int(np.max(self._host[2], initial=0))
         self.uniform = uniform
         self.seed = 0 if seed is None else int(seed)
         self._calls = 0
-        self._dev = {}
         self._version = 0          # bumped whenever the adjacency changes (append): consumers re-fetch the device arrays
+
+    # ---- host mirrors (lazy)
+    def _host_arrays(self):
+        if self._host is None:
+            dev_csr = next(iter(self._dev.values()))
+            self._host = tuple(a.cpu().numpy() for a in dev_csr)
+        return self._host
+
+    indptr = property(lambda self: self._host_arrays()[0])
+    nbr = property(lambda self: self._host_arrays()[1])
+    eidx = property(lambda self: self._host_arrays()[2])
+    ts = property(lambda self: self._host_arrays()[3])
+
+    def max_neighbor_id(self):
+        """Largest neighbour id in the adjacency (tracked incrementally; one device reduction after a device-side build)."""
+        if self._max_nbr is None:
+            a = next(iter(self._dev.values()))[1]
+            self._max_nbr = int(a.max().item()) if a.numel() else 0
+        return self._max_nbr
+
+    def max_edge_idx(self):
+        if self._max_eidx is None:
+            a = next(iter(self._dev.values()))[2]
+            self._max_eidx = int(a.max().item()) if a.numel() else 0
+        return self._max_eidx
+
+    def rows_end(self, n_rows):
+        """indptr[n_rows] and indptr[-1] without materialising the host mirror."""
+        if self._host is not None:
+            return int(self._host[0][n_rows]), int(self._host[0][-1])
+        p = next(iter(self._dev.values()))[0]
+        return int(p[n_rows].item()), int(p[-1].item())
 
     @classmethod
     def from_arrays(cls, sources, destinations, edge_idxs, timestamps, uniform=False, max_node_idx=None, seed=None,
@@ -104,19 +168,19 @@ class NeighborFinder:
         if device is None:
             return cls(uniform=uniform, seed=seed, _csr=build_csr(sources, destinations, edge_idxs, timestamps, max_node_idx))
         dev_csr = build_csr_device(sources, destinations, edge_idxs, timestamps, device, max_node_idx)
-        obj = cls(uniform=uniform, seed=seed, _csr=tuple(a.cpu().numpy() for a in dev_csr))
-        import torch
-        obj._dev[str(torch.device(device))] = dev_csr
+        obj = cls(uniform=uniform, seed=seed, _dev_csr=dev_csr, _device=device)
+        if len(sources):                       # the extrema are known from the inputs: no device read-back later
+            obj._max_nbr = int(max(int(np.max(sources)), int(np.max(destinations))))
+            obj._max_eidx = int(np.max(edge_idxs))
         return obj
 
     def device_arrays(self, device):
         """CSR tensors resident on ``device`` (uploaded once)."""
         import torch
-        key = str(device)
+        key = _dev_key(device)
         if key not in self._dev:
             _lib.require_gpu(device)
-            self._dev[key] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device)
-                                   for a in (self.indptr, self.nbr, self.eidx, self.ts))
+            self._dev[key] = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in self._host_arrays())
         return self._dev[key]
 
     def append(self, sources, destinations, edge_idxs, timestamps, device=None):
@@ -136,6 +200,9 @@ class NeighborFinder:
         if m == 0:
             return self
         n_nodes = max(self.n_nodes, int(max(int(np.max(sources)), int(np.max(destinations)))) + 1)
+        _check_ids(sources, destinations, n_nodes - 1)
+        if int(np.max(edge_idxs)) >= 2 ** 31:
+            raise ValueError("edge ids must fit in int32")
         o_ptr, o_nbr, o_eid, o_ts = self.device_arrays(dev)
         a_ptr, a_nbr, a_eid, a_ts = _csr_build_native(src, dst, eid, ts, n_nodes, dev)
         total = int(o_nbr.shape[0]) + 2 * m
@@ -146,8 +213,11 @@ class NeighborFinder:
         _lib.call("pfo_csr_append", _lib.ptr(o_ptr), _lib.ptr(o_nbr), _lib.ptr(o_eid), _lib.ptr(o_ts), self.n_nodes,
                   _lib.ptr(a_ptr), _lib.ptr(a_nbr), _lib.ptr(a_eid), _lib.ptr(a_ts), n_nodes, _lib.ptr(n_ptr), _lib.ptr(n_nbr),
                   _lib.ptr(n_eid), _lib.ptr(n_ts), _lib.stream_ptr())
-        self._dev = {str(dev): (n_ptr, n_nbr, n_eid, n_ts)}
-        self.indptr, self.nbr, self.eidx, self.ts = (a.cpu().numpy() for a in (n_ptr, n_nbr, n_eid, n_ts))
+        # extrema tracked from the appended batch; the host mirrors go stale and are refetched only if somebody reads them
+        self._max_nbr = max(self.max_neighbor_id(), int(max(int(np.max(sources)), int(np.max(destinations)))))
+        self._max_eidx = max(self.max_edge_idx(), int(np.max(edge_idxs)))
+        self._dev = {_dev_key(dev): (n_ptr, n_nbr, n_eid, n_ts)}
+        self._host = None
         self.n_nodes = n_nodes
         self._version += 1
         return self

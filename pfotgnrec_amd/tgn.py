@@ -136,6 +136,9 @@ class TGN(nn.Module):
         self._step = 0
         self.seed = 0
         self.dp_rank, self.dp_world = 0, 1
+        self.dp_bucketed = False          # ask the backward for the "top layer's gradients are final" event (two-bucket all-reduce)
+        self._bucket_event, self._bucket_event_fresh, self._grad_split = None, False, None
+        self._zero_next = False
         self.eval_chunk_roots = 16384     # roots per forward-only pass (evaluation.py scores B*(2+N_ITEMS) roots per batch)
         self.eval_dedup = True            # forward-only passes embed every distinct (node, time) root once
         # memory_updater.py:25,41 assert that no pending message is older than its node's last update; the check reads
@@ -331,10 +334,14 @@ class TGN(nn.Module):
             return self._adj_cache[2]
         indptr, nbr, eidx, ts = nf.device_arrays(self.device)
         max_nbr = nf.max_neighbor_id() if hasattr(nf, "max_neighbor_id") else int(np.max(nf.nbr, initial=0))
-        if max_nbr >= self.n_nodes or nf.n_nodes > self.n_nodes and int(nf.indptr[-1]) != int(nf.indptr[self.n_nodes]):
+        extra_rows_used = False
+        if nf.n_nodes > self.n_nodes:                    # rows beyond this model's node table must be empty
+            end_mine, end_all = nf.rows_end(self.n_nodes) if hasattr(nf, "rows_end") else (int(nf.indptr[self.n_nodes]), int(nf.indptr[-1]))
+            extra_rows_used = end_mine != end_all
+        if max_nbr >= self.n_nodes or extra_rows_used:
             raise ValueError("neighbour finder references node ids >= n_nodes (%d): node features have %d rows"
                              % (max(max_nbr, nf.n_nodes - 1), self.n_nodes))
-        max_eidx = int(np.max(nf.eidx, initial=0))
+        max_eidx = nf.max_edge_idx() if hasattr(nf, "max_edge_idx") else int(np.max(nf.eidx, initial=0))
         if max_eidx >= self.edge_raw_features.shape[0]:
             raise ValueError("neighbour finder references edge index %d but edge features have %d rows"
                              % (max_eidx, self.edge_raw_features.shape[0]))
@@ -383,16 +390,23 @@ class TGN(nn.Module):
         self._last_ws = (call.cfg, call.ws)
         return emb
 
-    def _attach_grads(self, gru_applied=True):
+    def _attach_grads(self, gru_applied=True, defer_zero=False):
         """Every ``p.grad`` becomes a view of the flat gradient buffer the native backward accumulates into.  When the
         GRU was not applied in the forward (no node held a pending message: the first batch after ``__init_memory__``)
         the reference's autograd leaves the four GRU tensors' ``.grad`` at None (memory_updater.py:38-40 returns before
-        the cell is called) and torch.optim.Adam skips them; the same is done here."""
+        the cell is called) and torch.optim.Adam skips them; the same is done here.
+
+        Returns True when the WHOLE buffer still has to be cleared and ``defer_zero`` asked to leave that to the native
+        backward (which does it on its side stream, off the critical path)."""
         if self._flat_grad is None:
             self._flat_grad = torch.zeros_like(self._flat)
         missing = [v for v in self._views if v[0].grad is None]
+        deferred = False
         if len(missing) == len(self._views):
-            self._flat_grad.zero_()
+            if defer_zero:
+                deferred = True
+            else:
+                self._flat_grad.zero_()
         else:
             for _, off, n, _ in missing:
                 self._flat_grad[off:off + n].zero_()
@@ -400,12 +414,37 @@ class TGN(nn.Module):
             if not gru_applied and p in self._gru_params:
                 continue
             p.grad = self._flat_grad[off:off + n].view(shape)
+        return deferred
 
     def _native_backward(self, call, d_emb):
-        self._attach_grads(call.gru_applied)
+        zero_first = self._attach_grads(call.gru_applied, defer_zero=True) or self._zero_next
+        self._zero_next = False
         st = self._state_struct()
-        _lib.call("pfo_tgn_backward", ctypes.byref(call.cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
-                  call.ws.data_ptr(), d_emb.data_ptr(), self._flat_grad.data_ptr(), _lib.stream_ptr())
+        ev = None
+        if self.dp_bucketed and self.grad_split < self._layout.total:
+            # the top layer's gradient block is final when this event fires (distributed.allreduce_flat_grad_buckets)
+            if self._bucket_event is None:
+                self._bucket_event = torch.cuda.Event()
+                self._bucket_event.record()                       # materialises the underlying hipEvent_t
+            ev = self._bucket_event.cuda_event
+            self._bucket_event_fresh = True
+        _lib.call("pfo_tgn_backward_ev", ctypes.byref(call.cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
+                  call.ws.data_ptr(), d_emb.data_ptr(), self._flat_grad.data_ptr(), 1 if zero_first else 0, ev,
+                  _lib.stream_ptr())
+
+    def request_zero_grad(self):
+        """``optimizer.zero_grad()`` without a launch of its own: the NEXT native backward clears the flat gradient buffer
+        itself (on its side stream) before accumulating; the ``.grad`` views stay attached."""
+        self._zero_next = True
+
+    @property
+    def grad_split(self):
+        """Element offset of the top layer's parameter block in the flat buffers (``pfo_tgn_grad_split``)."""
+        if self._grad_split is None:
+            v = ctypes.c_int64(0)
+            _lib.call("pfo_tgn_grad_split", ctypes.byref(self._cfg), ctypes.byref(v))
+            self._grad_split = int(v.value)
+        return self._grad_split
 
     def _native_update_state(self, call, src, dst, ts, eidx):
         self.memory._any_msg = True
@@ -478,6 +517,7 @@ class TGN(nn.Module):
             call.release()
             if grad_mode:
                 self._attach_grads(self._gru_applied_now)         # this rank still joins the all-reduce: with a zero gradient
+                self._bucket_event_fresh = False                  # ... in one piece (no backward ran to record the event)
             # a leaf that requires grad: the caller's loss.backward() is a no-op instead of an error
             return torch.zeros((0, D), dtype=torch.float32, device=self.device, requires_grad=grad_mode), 0
         if grad_mode:

@@ -191,7 +191,32 @@ def g3():
         r = run_mv_block(g, d.destinations[:2400], sl, lam)
         for k, v in r.items():
             out["lam%02d_%s" % (int(lam * 10), k)] = v
+    out.update(_g3_layout_arrays(g, sl))
     save("g3_mv", **out)
+
+
+def _g3_layout_arrays(g, sl):
+    """The file-format side of the g3 inputs, as data: the ``time_feature`` day key of every interaction
+    (``str(ts)[:8]``, main.py:212 - the keys run_mv_block builds its dict with), the stock codes in item order (the pickle's
+    inner keys / ``map_item_id``) and the batch's portfolios as the code lists ``ml_transaction.json`` holds ('' = empty)."""
+    d = g.data
+    keys = np.array([str(ts)[:8] for ts in d.timestamps[sl]])
+    W = max(len(p) for p in d.portfolios[sl])
+    ports = np.array([list(p) + [""] * (W - len(p)) for p in d.portfolios[sl]])
+    return dict(day_keys=keys, codes=np.array(g.codes), port_codes=ports)
+
+
+def g3_layout():
+    """Adds the layout arrays above to the committed g3 fixture WITHOUT re-running the reference (every other array is kept
+    byte for byte): they are inputs derived from the synthetic graph, not reference outputs."""
+    cfg = SyntheticConfig("g3", 200, 40, 3000, 8, 1, 10, 2, n_days=8)
+    g = make_graph(cfg)
+    path = os.path.join(OUT, "g3_mv.npz")
+    old = dict(np.load(path, allow_pickle=False))
+    assert np.array_equal(old["ts"], g.data.timestamps[1500:1564]) and np.array_equal(old["prices"], g.prices)
+    old.update(_g3_layout_arrays(g, slice(1500, 1564)))
+    np.savez_compressed(path, **old)
+    print("augmented %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
 
 
 # ------------------------------------------------------------------ G4: modules (fwd + autograd grads)
