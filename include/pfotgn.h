@@ -145,6 +145,10 @@ int pfo_bpr_loss(const float* emb, int64_t B, int32_t D, int64_t pos_off, int64_
  * before the first use, resets itself; workspace f32[B]. */
 int pfo_bpr_loss_fused(const float* emb, int64_t B, int32_t D, int64_t pos_off, int64_t neg_off, int32_t n_neg,
                        int64_t R, float scale, float* loss_out, float* d_emb, float* workspace, int32_t* ticket, void* stream);
+/* Only the per-interaction losses loss_parts f32[B] (-log sigmoid of the mean score difference) and the gradient rows; the
+ * mean over the batch is left to the caller (pfo_tgn_backward_ev takes it on its side stream). */
+int pfo_bpr_loss_parts(const float* emb, int64_t B, int32_t D, int64_t pos_off, int64_t neg_off, int32_t n_neg,
+                       int64_t R, float scale, float* loss_parts, float* d_emb, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Ranking metrics of evaluation.py:114-145 for one positive per interaction.
@@ -274,10 +278,13 @@ int pfo_tgn_backward(const pfo_tgn_config* cfg, const pfo_tgn_state* st, const p
  *                          the TOP layer's parameter block - elements [pfo_tgn_grad_split(cfg), layout.total) of `grad` - is
  *                          final, ~half a step before the call's last kernel: a data-parallel caller makes its communication
  *                          stream wait for it and all-reduces that block beside the rest of the backward.  Only
- *                          with n_layers >= 2 (pfo_tgn_grad_split returns layout.total otherwise and the event is not recorded). */
+ *                          with n_layers >= 2 (pfo_tgn_grad_split returns layout.total otherwise and the event is not recorded).
+ *   mean_src / mean_n / mean_out (may be NULL / 0 / NULL): out[0] = mean(mean_src[0 .. mean_n)) is taken on this call's side
+ *                          stream, beside the backward, and is complete when the call's work is (pfo_bpr_loss_parts leaves the
+ *                          loss's final reduction to it: the loss VALUE is not an input of the backward) */
 int pfo_tgn_backward_ev(const pfo_tgn_config* cfg, const pfo_tgn_state* st, const pfo_tgn_batch* batch,
                         void* workspace, const float* d_emb, float* grad, int32_t zero_grad_first, void* top_ready_event,
-                        void* stream);
+                        const float* mean_src, int64_t mean_n, float* mean_out, void* stream);
 int pfo_tgn_grad_split(const pfo_tgn_config* cfg, int64_t* split);
 /* Persist memory for the positives, clear their pending messages, build and store the new raw messages with
  * last-wins semantics (tgn.py:290-317, memory_updater.py:18-33, memory.py:35-37,73-75, tgn.py:357-378).

@@ -71,6 +71,8 @@ PROTOTYPES = {
                                _VP, _VP, _VP]),
     "pfo_bpr_loss_fused": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_float, _VP,
                                      _VP, _VP, _VP, _VP]),
+    "pfo_bpr_loss_parts": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_float, _VP,
+                                     _VP, _VP]),
     "pfo_rank_metrics": (C.c_int, [_VP, C.c_int64, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP]),
     "pfo_adam_step": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                 _VP]),
@@ -86,7 +88,7 @@ PROTOTYPES = {
     "pfo_tgn_forward": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP]),
     "pfo_tgn_backward": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP, _VP]),
     "pfo_tgn_backward_ev": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP, C.c_int32,
-                                      _VP, _VP]),
+                                      _VP, _VP, C.c_int64, _VP, _VP]),
     "pfo_tgn_grad_split": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(C.c_int64)]),
     "pfo_tgn_update_state": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), _VP, _VP, _VP, _VP, C.c_int32, _VP,
                                        _VP]),

@@ -662,15 +662,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
 // straight in MFMA fragment order (lane (r, g): row r, k = 8g..8g+7 = two float4), splits them in registers into the
 // three bf16x8 fragments, and only the shared B image goes through LDS - double-buffered, so a k-tile costs ONE barrier
 // and the copy of tile t+1 into the other buffer runs beside the MFMAs of tile t.
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_areg_kernel(const GemmDev p) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 3 * BX_B_PIECE];
+__device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   int Mlim = p.M;
   if (p.m_dev) Mlim = min(Mlim, *p.m_dev);
-  if (m0 >= Mlim) return;
+  if (m0 >= Mlim || n0 >= p.N) return;
   const int wrow = 32 * wave;
 
   f32x4 acc[2][11];
@@ -809,6 +808,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_areg_kernel(const Gem
       if (col < p.N) bx_store4(p, Cb, ldc, bias, rscale, zero, n4, row, col, acc[i][j], addrow);
     }
   }
+}
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_areg_kernel(const GemmDev p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 3 * BX_B_PIECE];
+  bx_areg_body(p, lds);
+}
+// Two independent contractions in ONE launch (blockIdx.z picks): the GRU's message and hidden-state projections.  They used
+// to run on two streams; a cross-stream event wait costs the waiting stream 5-15 us on this part even when the event has long
+// fired, and the side stream was busy with the composite-weight chain anyway.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_areg_pair_kernel(const GemmDev p0, const GemmDev p1) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 3 * BX_B_PIECE];
+  if (blockIdx.z == 0) bx_areg_body(p0, lds); else bx_areg_body(p1, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1601,6 +1611,27 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
   // a device-side extent (rows, or the K of a k-major A) scales the work: read back when the records are collected
   if (g.m_dev) pfo_prof_end_dev(kind, flops / (double)(g.a_kmajor ? g.K[0] : g.M), g.m_dev, g.a_kmajor ? g.K[0] : g.M, stream);
   else pfo_prof_end(kind, flops, stream);
+  return PFO_OK;
+}
+
+int pfo_gemm_pair_launch(const PfoGemm& g0, const PfoGemm& g1, hipStream_t stream) {
+  const PfoGemm* gs[2] = {&g0, &g1};
+  GemmDev d[2];
+  double flops_per_row = 0;
+  for (int i = 0; i < 2; ++i) {
+    const PfoGemm& g = *gs[i];
+    PFO_REQUIRE(g.M > 0 && g.N > 0 && g.K[0] > 0 && g.K[1] == 0 && g.batch == 1 && g.A[0] && g.B[0] && g.C && g.b_img, "bad pair problem");
+    PFO_REQUIRE(!g.a_kmajor && aligned4(g.A[0]) && (g.lda[0] % 4) == 0 && (g.K[0] % 4) == 0, "pair launch: row-major 16-byte aligned A");
+    PFO_REQUIRE(g.M == g0.M && g.m_dev == g0.m_dev, "pair launch: both problems share the row extent");
+    to_dev(g, d[i]);
+    d[i].b_img = g.b_img; d[i].b_img_rows = (int)pfo_align_up(g.N, BN);
+    flops_per_row += 2.0 * g.N * g.K[0];
+  }
+  const unsigned tn = (unsigned)std::max(pfo_ceil_div(g0.N, BN), pfo_ceil_div(g1.N, BN));
+  pfo_prof_begin(stream);
+  hipLaunchKernelGGL(gemm_bx_areg_pair_kernel, dim3((unsigned)pfo_ceil_div(g0.M, BM), tn, 2), dim3(GEMM_THREADS), 0, stream, d[0], d[1]);
+  PFO_LAUNCH_CHECK();
+  pfo_prof_end_dev(PFO_PROF_GEMM_BX, flops_per_row, g0.m_dev, g0.M, stream);
   return PFO_OK;
 }
 

@@ -51,6 +51,9 @@ int64_t pfo_bimg_bytes(int N, int K);
 int pfo_bimg_launch(const PfoBimg* list, int n, hipStream_t stream);
 
 int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream);
+// two single-source row-major contractions with weight images and the SAME row extent (M, m_dev) in one launch of the 128-row
+// bf16x3 kernel (grid.z = 2)
+int pfo_gemm_pair_launch(const PfoGemm& g0, const PfoGemm& g1, hipStream_t stream);
 // true when a row-major launch of this size (aligned operands, images supplied) takes a bf16x3 kernel: those accept two
 // K-concatenated sources whose B operands differ in layout
 bool pfo_gemm_takes_bx(int M, int N);

@@ -59,6 +59,8 @@ int pfo_msg_store_launch(const int32_t* src, const int32_t* dst, const double* t
                          int32_t* winner, hipStream_t stream);
 
 // --- small ops (misc.hip)
+// out[0] = mean(src[0 .. n)), one wavefront, fixed order
+int pfo_mean_launch(const float* src, int64_t n, float* out, hipStream_t stream);
 // cq = Wq[:, D:2D] cos(b) + bq folded query bias: backward of that term
 //   gq[E] = colsum(dQ);  d bq += gq;  d Wq[:, D:] += gq (x) cosb;  d tb += -sin(tb) * (Wq[:, D:]^T gq)
 // tb_part != null: the time-bias term is STORED there instead of added to d_tb (a partial launch; a later launch passes it as

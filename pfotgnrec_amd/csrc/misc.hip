@@ -192,6 +192,11 @@ __global__ void bpr_mean_kernel(const float* __restrict__ loss_part, int64_t B, 
   s = pfo_wave_sum(s);
   if (threadIdx.x == 0) *loss_out = s / (float)B;
 }
+int pfo_mean_launch(const float* src, int64_t n, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(bpr_mean_kernel, dim3(1), dim3(64), 0, stream, src, n, out);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
 static int bpr_launch(const float* emb, int64_t B, int32_t D, int64_t pos_off, int64_t neg_off, int32_t n_neg, int64_t R,
                       float scale, float* loss_out, float* d_emb, float* workspace, int32_t* ticket, void* stream) {
   PFO_REQUIRE(emb && loss_out && workspace, "null input");
@@ -213,6 +218,16 @@ extern "C" int pfo_bpr_loss_fused(const float* emb, int64_t B, int32_t D, int64_
                                   void* stream) {
   PFO_REQUIRE(ticket, "null ticket");
   return bpr_launch(emb, B, D, pos_off, neg_off, n_neg, R, scale, loss_out, d_emb, workspace, ticket, stream);
+}
+extern "C" int pfo_bpr_loss_parts(const float* emb, int64_t B, int32_t D, int64_t pos_off, int64_t neg_off, int32_t n_neg,
+                                  int64_t R, float scale, float* loss_parts, float* d_emb, void* stream) {
+  PFO_REQUIRE(emb && loss_parts && d_emb, "null input");
+  PFO_REQUIRE(B > 0 && D > 0 && n_neg > 0, "bad sizes");
+  PFO_REQUIRE(pos_off >= B && pos_off + B <= R && neg_off + B * n_neg <= R && neg_off >= pos_off + B, "bad offsets");
+  hipLaunchKernelGGL(bpr_kernel, dim3((unsigned)pfo_ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, emb, B, (int)D, pos_off,
+                     neg_off, (int)n_neg, R, scale, loss_parts, d_emb, (float*)nullptr, (int*)nullptr);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -259,8 +259,8 @@ PfoGemm g_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const int
 // dependent launches; they run beside the main stream's work and are joined by events where their results are needed.
 struct Side {
   hipStream_t s = nullptr, s2 = nullptr;
-  hipEvent_t tn_a_done = nullptr, done2 = nullptr, grad0 = nullptr;
-  hipEvent_t fork = nullptr, done = nullptr, gru_fork = nullptr, gru_join = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr, slot0 = nullptr, fold_done = nullptr;
+  hipEvent_t tn_a_done = nullptr, done2 = nullptr;
+  hipEvent_t fork = nullptr, done = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr, fold_done = nullptr;
   hipEvent_t layer[PFO_MAX_LAYERS + 1] = {};
   bool ok = false;
 };
@@ -275,15 +275,11 @@ Side& side() {
     good = good && hipStreamCreateWithFlags(&sd.s2, hipStreamNonBlocking) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.tn_a_done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.done2, hipEventDisableTiming) == hipSuccess;
-    good = good && hipEventCreateWithFlags(&sd.grad0, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.done, hipEventDisableTiming) == hipSuccess;
-    good = good && hipEventCreateWithFlags(&sd.gru_fork, hipEventDisableTiming) == hipSuccess;
-    good = good && hipEventCreateWithFlags(&sd.gru_join, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.seg_done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.tn_a, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.tn_b, hipEventDisableTiming) == hipSuccess;
-    good = good && hipEventCreateWithFlags(&sd.slot0, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.fold_done, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; l <= PFO_MAX_LAYERS; ++l) good = good && hipEventCreateWithFlags(&sd.layer[l], hipEventDisableTiming) == hipSuccess;
     sd.ok = good;
@@ -391,9 +387,9 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   // it are what the main stream is waiting for.  All layers share each launch.
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
-  // the compaction's flags are cleared beside the sampling launches rather than between them and the marking pass
-  HIPOK(hipMemsetAsync(w.slot, 0, w.mark_bytes, ss), "memset failed");
-  HIPOK(hipEventRecord(sd.slot0, ss), "event record failed");
+  // The compaction's flags are cleared on THIS stream (4 us): a wait for a side-stream memset costs the waiting stream 5-17 us
+  // on this part (r3 timeline), more than the memset itself.  Same reasoning for the GRU's two weight images below.
+  HIPOK(hipMemsetAsync(w.slot, 0, w.mark_bytes, s), "memset failed");
   // ---- frontier expansion: K1 per level (utils.py:163-219 called from embedding_module.py:125).  Enqueued before the
   // side-stream work below: it depends on nothing else, and the GPU samples while the host is still enqueueing
   for (int l = L; l >= 1; --l) {
@@ -402,9 +398,8 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     // level L reads the caller's roots directly; every level writes [its own nodes | their neighbours] as the next one
     const int32_t* lvl_nodes = (l == L) ? b->roots : w.nodes[l];
     const double* lvl_ts = (l == L) ? b->root_ts : w.ts[l];
-    // the last launch writes the whole level-0 list [S_1 ; neighbours(S_1)]: it also sets the touched-node flags (cleared on
-    // the side stream meanwhile), so the compaction needs no marking pass
-    if (l == 1) HIPOK(hipStreamWaitEvent(s, sd.slot0, 0), "event wait failed");
+    // the last launch writes the whole level-0 list [S_1 ; neighbours(S_1)]: it also sets the touched-node flags, so the
+    // compaction needs no marking pass
     RUN(pfo_tnbr_sample_dev(st->indptr, st->adj_nbr, st->adj_eidx, st->adj_ts, c->n_nodes, lvl_nodes, lvl_ts, n[l], K,
                             b->uniform, dr, b->seed, b->offset + (uint64_t)l * 0x100000000ull, b->offset_dev, nullptr,
                             w.eidx[l], nullptr, w.dt[l], w.nodes[l - 1], l > 1 ? w.ts[l - 1] : nullptr, l == 1 ? w.slot : nullptr,
@@ -412,12 +407,11 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   }
 
   if (c->use_memory) {
-    // the GRU contractions come first on the main stream: their two weight images get their own launch and event
+    // the GRU contractions come first on the main stream: their two weight images are made there too (one 4 us launch)
     PfoBimg im[2];
     im[0].src = P.w_ih; im[0].ld = d.M; im[0].N = 3 * D; im[0].K = d.M; im[0].trans = 0; im[0].dst = w.iWih;
     im[1].src = P.w_hh; im[1].ld = D; im[1].N = 3 * D; im[1].K = D; im[1].trans = 0; im[1].dst = w.iWhh;
-    RUN(pfo_bimg_launch(im, 2, ss));
-    HIPOK(hipEventRecord(sd.done, ss), "event record failed");
+    RUN(pfo_bimg_launch(im, 2, s));
   }
   PFO_REQUIRE(hipMemsetAsync(w.zero, 0, w.zero_bytes, ss) == hipSuccess, "memset failed");   // w.zero, w.tickets, Wqk / W1ovT / cqk of every layer
   RUN(pfo_time_encode(w.zero, 1, P.tw, P.tb, D, w.cosb, ss));                  // cos(fma(0, w, b)) (embedding_module.py:92)
@@ -537,19 +531,13 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   if (c->use_memory) {
     RUN(pfo_pack_remap_launch(st->msg_table, d.M, st->memory, D, st->has_msg, w.touched, w.n_touched, capP, w.msg_rows,
                               w.h_rows, w.hm, w.nodes[0], n[0], w.slot, w.idx0, s));
-    HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");         // images of W_ih / W_hh
     // the two GRU contractions are independent and each fills only ~55 % of the chip (touched rows / 128 x 3 column
-    // tiles = ~280 workgroups): the hidden-state one runs beside the message one on the side stream
+    // tiles = ~280 workgroups): both in ONE launch
     PfoGemm gi = g_nt(w.msg_rows, d.M, nullptr, P.w_ih, d.M, w.gi, 3 * D, capP, 3 * D, d.M, P.b_ih);
     gi.m_dev = w.n_touched; gi.b_img = w.iWih;
     PfoGemm gh = g_nt(w.h_rows, D, nullptr, P.w_hh, D, w.gh, 3 * D, capP, 3 * D, D, P.b_hh);
     gh.m_dev = w.n_touched; gh.b_img = w.iWhh;
-    HIPOK(hipEventRecord(sd.gru_fork, s), "event record failed");
-    HIPOK(hipStreamWaitEvent(ss, sd.gru_fork, 0), "event wait failed");
-    RUN(pfo_gemm_launch(gh, ss));
-    HIPOK(hipEventRecord(sd.gru_join, ss), "event record failed");
-    RUN(pfo_gemm_launch(gi, s));
-    HIPOK(hipStreamWaitEvent(s, sd.gru_join, 0), "event wait failed");
+    RUN(pfo_gemm_pair_launch(gi, gh, s));
     RUN(pfo_gru_gates_fwd_launch(w.gi, w.gh, w.h_rows, st->node_feat, w.hm, w.touched, w.n_touched, capP, D, w.upd_mem,
                                  w.h0_tab, s));
   } else {
@@ -659,13 +647,15 @@ extern "C" int pfo_tgn_grad_split(const pfo_tgn_config* c, int64_t* split) {
 
 extern "C" int pfo_tgn_backward(const pfo_tgn_config* c, const pfo_tgn_state* st, const pfo_tgn_batch* b, void* workspace,
                                 const float* d_emb, float* grad, void* stream) {
-  return pfo_tgn_backward_ev(c, st, b, workspace, d_emb, grad, 0, nullptr, stream);
+  return pfo_tgn_backward_ev(c, st, b, workspace, d_emb, grad, 0, nullptr, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state* st, const pfo_tgn_batch* b, void* workspace,
-                                   const float* d_emb, float* grad, int32_t zero_grad_first, void* top_ready_event, void* stream) {
+                                   const float* d_emb, float* grad, int32_t zero_grad_first, void* top_ready_event,
+                                   const float* mean_src, int64_t mean_n, float* mean_out, void* stream) {
   if (int rc = check_cfg(c)) return rc;
   PFO_REQUIRE(st && workspace && d_emb && grad && st->params, "null argument");
+  PFO_REQUIRE(!mean_src || (mean_n > 0 && mean_out), "bad deferred mean");
   int64_t n[PFO_MAX_LAYERS + 1];
   RUN(level_sizes(c, b, n));
   const Dims d = dims_of(c);
@@ -693,15 +683,12 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   hipStream_t ss = sd.s;
   // layer-1 instances grouped by the touched-table row they sit on (needed only when the layer-1 gradients are summed
   // per row, late in this call): built on the side stream, beside the layer-L .. 2 work.  The same stream first clears what
-  // this call accumulates into: the level-0 gradient rows (layer 1's attention backward waits for seg_done) and, on request,
-  // the caller's flat gradient buffer (its first writer waits for grad0)
+  // this call accumulates into: the level-0 gradient rows (layer 1's attention backward waits for seg_done)
+  // (the gradient buffer is cleared on the caller's stream, before the fork: every writer on any stream comes after it)
+  if (zero_grad_first) HIPOK(hipMemsetAsync(grad, 0, (size_t)lay.total * sizeof(float), s), "memset failed");
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
-  if (zero_grad_first) {
-    HIPOK(hipMemsetAsync(grad, 0, (size_t)lay.total * sizeof(float), ss), "memset failed");
-    HIPOK(hipEventRecord(sd.grad0, ss), "event record failed");
-    HIPOK(hipStreamWaitEvent(sd.s2, sd.grad0, 0), "event wait failed");
-  }
+  if (mean_src) RUN(pfo_mean_launch(mean_src, mean_n, mean_out, ss));     // (a reduction the caller left to this call's side stream)
   if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_touched, capP, D, n_rep, rep_stride, ss));
   RUN(pfo_seg_build_launch(idx0, w.nodes[0], (int)n[1], capP, b->uniform ? nullptr : w.eidx[1], K, w.seg_ptr, w.seg_cur,
                            w.seg_tmp, w.seg_mem, w.seg_scratch, ss));
@@ -742,7 +729,6 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       q.relu_src = lw.h1; q.relu_ld = D;                     // ReLU backward
       q.b_img = lw.iW2T;
       RUN(pfo_gemm_launch(q, s));
-      if (zero_grad_first) HIPOK(hipStreamWaitEvent(s, sd.grad0, 0), "event wait failed");   // long done: the buffer is clear
       dh1 = w.dh1;
     } else {
       // below the top the layer above wrote d h1 directly, ReLU mask applied by its producers (attention backward's key
@@ -815,7 +801,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       // in the per-instance gradients (dqk', dh1) and otherwise depends on x only - the data gradient of x and the two
       // weight gradients against x - is taken AFTER summing those gradients per table row: contractions over the
       // ~11 k touched rows instead of the ~54 k instances.
-      HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");
+      if (!c->use_memory) HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");   // (with memory: awaited before the attention backward)
       RUN(pfo_segsum_launch(w.dQK, HCp, dh1, D, w.seg_ptr, w.seg_mem, w.n_touched, capP, dqk_by_member, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
       // the weight gradients over the table rows go to the side stream too (beside d h0 / the GRU backward on this one)
       HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
@@ -1010,10 +996,11 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   // join the side streams, then ONE launch finishes the time-encoder gradients: the folded query-bias backward of layers
   // 1 .. L-1 (the top layer's ran with its chain), + its parked time-bias term, + the fold of the attention backwards' fp64
   // partial sums into time_w / time_b (fixed order)
+  // (chained: the first side stream waits for the second, the caller's stream for the first - one wait on the critical path)
+  HIPOK(hipEventRecord(sd.done2, sd.s2), "event record failed");
+  HIPOK(hipStreamWaitEvent(ss, sd.done2, 0), "event wait failed");
   HIPOK(hipEventRecord(sd.done, ss), "event record failed");
   HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
-  HIPOK(hipEventRecord(sd.done2, sd.s2), "event record failed");
-  HIPOK(hipStreamWaitEvent(s, sd.done2, 0), "event wait failed");
   {
     const float *gq[PFO_MAX_LAYERS], *wq[PFO_MAX_LAYERS];
     float *dbq[PFO_MAX_LAYERS], *dwq[PFO_MAX_LAYERS];

@@ -56,7 +56,8 @@ def bpr_loss(emb, batch, n_neg, pos_block=1, grad_scale=1.0):
 def bpr_step(tgn, emb, batch, n_neg, pos_block=1, grad_scale=None):
     """``loss = bpr_loss(...); loss.backward()`` (main.py:321-337 + 388) as two native calls and no torch kernel: the loss
     kernel writes the already scaled gradient rows and the TGN backward is called on them directly, skipping autograd's
-    seed fill and ``d_emb * g`` multiply (three ~6 us launches on the critical path of a 1.5 ms step).  ``emb`` must be the
+    seed fill and ``d_emb * g`` multiply (three ~6 us launches on the critical path of a 1.5 ms step); the batch mean of the
+    per-interaction losses - an input of nothing - is taken beside the backward.  ``emb`` must be the
     tensor ``TGN.embed_device`` returned under autograd; anything else (an empty shard, a view) takes the autograd route.
     Returns the detached loss."""
     call = getattr(emb.grad_fn, "call", None) if emb.grad_fn is not None else None
@@ -65,8 +66,14 @@ def bpr_step(tgn, emb, batch, n_neg, pos_block=1, grad_scale=None):
         loss.backward()
         return loss.detach()
     scale = tgn.dp_grad_scale if grad_scale is None else grad_scale
-    loss, d_emb = bpr_loss_and_grad(emb.detach(), batch, pos_block * batch, (pos_block + 1) * batch, n_neg, scale)
-    tgn._native_backward(call, d_emb)
+    e = emb.detach().contiguous()
+    R, D = e.shape
+    parts = torch.empty(batch, dtype=torch.float32, device=e.device)
+    d_emb = torch.empty_like(e)
+    loss = torch.empty(1, dtype=torch.float32, device=e.device)
+    _lib.call("pfo_bpr_loss_parts", e.data_ptr(), batch, D, pos_block * batch, (pos_block + 1) * batch, n_neg, R, float(scale),
+              parts.data_ptr(), d_emb.data_ptr(), _lib.stream_ptr())
+    tgn._native_backward(call, d_emb, mean=(parts, loss))     # the batch mean of the losses: on the backward's side stream
     call.release()
     return loss[0]
 

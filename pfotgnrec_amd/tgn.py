@@ -416,7 +416,8 @@ class TGN(nn.Module):
             p.grad = self._flat_grad[off:off + n].view(shape)
         return deferred
 
-    def _native_backward(self, call, d_emb):
+    def _native_backward(self, call, d_emb, mean=None):
+        """``mean`` = (src f32[n], out f32[1]): a mean the backward takes on its side stream (the BPR loss value)."""
         zero_first = self._attach_grads(call.gru_applied, defer_zero=True) or self._zero_next
         self._zero_next = False
         st = self._state_struct()
@@ -430,7 +431,8 @@ class TGN(nn.Module):
             self._bucket_event_fresh = True
         _lib.call("pfo_tgn_backward_ev", ctypes.byref(call.cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
                   call.ws.data_ptr(), d_emb.data_ptr(), self._flat_grad.data_ptr(), 1 if zero_first else 0, ev,
-                  _lib.stream_ptr())
+                  mean[0].data_ptr() if mean else None, int(mean[0].shape[0]) if mean else 0,
+                  mean[1].data_ptr() if mean else None, _lib.stream_ptr())
 
     def request_zero_grad(self):
         """``optimizer.zero_grad()`` without a launch of its own: the NEXT native backward clears the flat gradient buffer
