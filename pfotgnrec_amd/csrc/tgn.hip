@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 int pfo_tnbr_sample_dev(const int64_t*, const int32_t*, const int32_t*, const double*, int64_t, const int32_t*, const double*,
                         int64_t, int32_t, int32_t, const int64_t*, uint64_t, uint64_t, const uint64_t*, int32_t*, int32_t*,
@@ -996,9 +997,10 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   // join the side streams, then ONE launch finishes the time-encoder gradients: the folded query-bias backward of layers
   // 1 .. L-1 (the top layer's ran with its chain), + its parked time-bias term, + the fold of the attention backwards' fp64
   // partial sums into time_w / time_b (fixed order)
-  // (chained: the first side stream waits for the second, the caller's stream for the first - one wait on the critical path)
+  // (both side streams are joined by the caller's stream itself: chaining them - the first side stream waiting for the second,
+  //  the caller's for the first, one wait fewer on the critical path - makes hipStreamEndCapture of ROCm 7.0 segfault)
   HIPOK(hipEventRecord(sd.done2, sd.s2), "event record failed");
-  HIPOK(hipStreamWaitEvent(ss, sd.done2, 0), "event wait failed");
+  HIPOK(hipStreamWaitEvent(s, sd.done2, 0), "event wait failed");
   HIPOK(hipEventRecord(sd.done, ss), "event record failed");
   HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
   {
