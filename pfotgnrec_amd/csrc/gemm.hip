@@ -662,11 +662,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
 // straight in MFMA fragment order (lane (r, g): row r, k = 8g..8g+7 = two float4), splits them in registers into the
 // three bf16x8 fragments, and only the shared B image goes through LDS - double-buffered, so a k-tile costs ONE barrier
 // and the copy of tile t+1 into the other buffer runs beside the MFMAs of tile t.
+template <int WAVES>
 __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
+  constexpr int NTHR = 64 * WAVES;                   // threads per workgroup; 32 rows per wavefront
+  constexpr int NDMA = (3 * (BX_B_PIECE / 16) + NTHR - 1) / NTHR;   // rounds of 16-byte units of the B image tile per thread
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = blockIdx.x * (32 * WAVES), n0 = blockIdx.y * BN;
   int Mlim = p.M;
   if (p.m_dev) Mlim = min(Mlim, *p.m_dev);
   if (m0 >= Mlim || n0 >= p.N) return;
@@ -717,13 +720,13 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
         a_raw[i][h] = ld4<true>(a_row[src][i] + ts * BK + 4 * h, a_ok[i] ? Ks - (k + 4 * h) : 0, safe);
     const char* tile = img[src] + (int64_t)ts * 3 * img_piece;
     char* Bs = lds + buf * 3 * BX_B_PIECE;
-    bx_for<9>([&](auto uc) {
+    bx_for<NDMA>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
-      if (u < 8 || wave == 0) {                              // 2112 units of 16 bytes: the 9th round is wavefront 0 only
-        const int unit = tid + 256 * u;
+      if (u < NDMA - 1 || wave == 0) {                       // 2112 units of 16 bytes: the last round is wavefront 0 only
+        const int unit = tid + NTHR * u;
         const int q = (unit >= 2 * (BX_B_PIECE / 16)) ? 2 : (unit >= BX_B_PIECE / 16 ? 1 : 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(tile + q * img_piece + (unit - q * (BX_B_PIECE / 16)) * 16),
-                                         (lptr_t)(Bs + (64 * wave + 256 * u) * 16), 16, 0, 0);
+                                         (lptr_t)(Bs + (64 * wave + NTHR * u) * 16), 16, 0, 0);
       }
     });
   };
@@ -811,14 +814,14 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
 }
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_areg_kernel(const GemmDev p) {
   __shared__ __attribute__((aligned(16))) char lds[2 * 3 * BX_B_PIECE];
-  bx_areg_body(p, lds);
+  bx_areg_body<4>(p, lds);
 }
 // Two independent contractions in ONE launch (blockIdx.z picks): the GRU's message and hidden-state projections.  They used
 // to run on two streams; a cross-stream event wait costs the waiting stream 5-15 us on this part even when the event has long
 // fired, and the side stream was busy with the composite-weight chain anyway.
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_areg_pair_kernel(const GemmDev p0, const GemmDev p1) {
   __shared__ __attribute__((aligned(16))) char lds[2 * 3 * BX_B_PIECE];
-  if (blockIdx.z == 0) bx_areg_body(p0, lds); else bx_areg_body(p1, lds);
+  if (blockIdx.z == 0) bx_areg_body<4>(p0, lds); else bx_areg_body<4>(p1, lds);
 }
 
 // ---------------------------------------------------------------------------------------------

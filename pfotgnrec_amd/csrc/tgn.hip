@@ -383,9 +383,8 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   PFO_REQUIRE(sd.ok, "could not create the side stream");
   hipStream_t ss = sd.s;
   const int Cp = d.Cp, HCp = H * d.Cp;
-  // Everything here depends on the parameters only, so the side stream starts at once (after whatever the main
-  // stream did before this call) and the host enqueues it in six calls: the sampling / compaction launches behind
-  // it are what the main stream is waiting for.  All layers share each launch.
+  // Everything on the side stream depends on the parameters only, so it may start at once (after whatever the main
+  // stream did before this call); all layers share each launch.
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
   // The compaction's flags are cleared on THIS stream (4 us): a wait for a side-stream memset costs the waiting stream 5-17 us
@@ -414,6 +413,37 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     im[1].src = P.w_hh; im[1].ld = D; im[1].N = 3 * D; im[1].K = D; im[1].trans = 0; im[1].dst = w.iWhh;
     RUN(pfo_bimg_launch(im, 2, s));
   }
+  bool composites_awaited = false;
+
+  // ---- the nodes this step reads (roots and every sampled neighbour, all levels; + the caller's extra nodes), compacted:
+  // slot[v] = row of v in the per-step tables, idx0[i] = row of the i-th level-0 reference
+  PFO_REQUIRE(b->n_extra >= 0 && b->n_extra <= 2 * c->max_batch, "n_extra exceeds 2 * max_batch");
+  PFO_REQUIRE(b->n_extra == 0 || b->extra_nodes, "null extra_nodes");
+  RUN(pfo_touch_compact_launch(nullptr, 0, b->extra_nodes, b->n_extra, c->n_nodes, w.slot, w.touched, w.n_touched,
+                               w.scan, true, true, s));
+  const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
+  // ---- level-0 rows of the touched nodes: memory' + node features (embedding_module.py:93-98), memory' = the lazily
+  // updated memory (tgn.py:251; memory_updater.py:35-53).  One launch copies the rows the GRU reads (and the backward reads
+  // again after the state update has overwritten the tables) and translates the level-0 list into table rows.
+  if (c->use_memory) {
+    RUN(pfo_pack_remap_launch(st->msg_table, d.M, st->memory, D, st->has_msg, w.touched, w.n_touched, capP, w.msg_rows,
+                              w.h_rows, w.hm, w.nodes[0], n[0], w.slot, w.idx0, s));
+    // the two GRU contractions are independent and each fills only ~55 % of the chip (touched rows / 128 x 3 column
+    // tiles = ~280 workgroups): both in ONE launch
+    PfoGemm gi = g_nt(w.msg_rows, d.M, nullptr, P.w_ih, d.M, w.gi, 3 * D, capP, 3 * D, d.M, P.b_ih);
+    gi.m_dev = w.n_touched; gi.b_img = w.iWih;
+    PfoGemm gh = g_nt(w.h_rows, D, nullptr, P.w_hh, D, w.gh, 3 * D, capP, 3 * D, D, P.b_hh);
+    gh.m_dev = w.n_touched; gh.b_img = w.iWhh;
+    RUN(pfo_gemm_pair_launch(gi, gh, s));
+    RUN(pfo_gru_gates_fwd_launch(w.gi, w.gh, w.h_rows, st->node_feat, w.hm, w.touched, w.n_touched, capP, D, w.upd_mem,
+                                 w.h0_tab, s));
+  } else {
+    RUN(pfo_pack_remap_launch(nullptr, d.M, st->node_feat, D, nullptr, w.touched, w.n_touched, capP, nullptr, w.h0_tab, nullptr,
+                              w.nodes[0], n[0], w.slot, w.idx0, s));
+  }
+  // ---- composite weights of every layer and their bf16x3 images: side stream.  Enqueued HERE, after the sampling / compaction /
+  // GRU launches of the caller's stream (which need none of it): when the host is the slower side (small batches, profilers)
+  // the critical chain is already queued while these ~14 launches are being issued; layer 1 waits for them below.
   PFO_REQUIRE(hipMemsetAsync(w.zero, 0, w.zero_bytes, ss) == hipSuccess, "memset failed");   // w.zero, w.tickets, Wqk / W1ovT / cqk of every layer
   RUN(pfo_time_encode(w.zero, 1, P.tw, P.tb, D, w.cosb, ss));                  // cos(fma(0, w, b)) (embedding_module.py:92)
   {
@@ -516,34 +546,6 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
       for (int i = 0; i < mi; i += PFO_BIMG_MAX) RUN(pfo_bimg_launch(fim + i, std::min(PFO_BIMG_MAX, mi - i), ss));
       HIPOK(hipEventRecord(sd.fold_done, ss), "event record failed");
     }
-  }
-  bool composites_awaited = false;
-
-  // ---- the nodes this step reads (roots and every sampled neighbour, all levels; + the caller's extra nodes), compacted:
-  // slot[v] = row of v in the per-step tables, idx0[i] = row of the i-th level-0 reference
-  PFO_REQUIRE(b->n_extra >= 0 && b->n_extra <= 2 * c->max_batch, "n_extra exceeds 2 * max_batch");
-  PFO_REQUIRE(b->n_extra == 0 || b->extra_nodes, "null extra_nodes");
-  RUN(pfo_touch_compact_launch(nullptr, 0, b->extra_nodes, b->n_extra, c->n_nodes, w.slot, w.touched, w.n_touched,
-                               w.scan, true, true, s));
-  const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
-  // ---- level-0 rows of the touched nodes: memory' + node features (embedding_module.py:93-98), memory' = the lazily
-  // updated memory (tgn.py:251; memory_updater.py:35-53).  One launch copies the rows the GRU reads (and the backward reads
-  // again after the state update has overwritten the tables) and translates the level-0 list into table rows.
-  if (c->use_memory) {
-    RUN(pfo_pack_remap_launch(st->msg_table, d.M, st->memory, D, st->has_msg, w.touched, w.n_touched, capP, w.msg_rows,
-                              w.h_rows, w.hm, w.nodes[0], n[0], w.slot, w.idx0, s));
-    // the two GRU contractions are independent and each fills only ~55 % of the chip (touched rows / 128 x 3 column
-    // tiles = ~280 workgroups): both in ONE launch
-    PfoGemm gi = g_nt(w.msg_rows, d.M, nullptr, P.w_ih, d.M, w.gi, 3 * D, capP, 3 * D, d.M, P.b_ih);
-    gi.m_dev = w.n_touched; gi.b_img = w.iWih;
-    PfoGemm gh = g_nt(w.h_rows, D, nullptr, P.w_hh, D, w.gh, 3 * D, capP, 3 * D, D, P.b_hh);
-    gh.m_dev = w.n_touched; gh.b_img = w.iWhh;
-    RUN(pfo_gemm_pair_launch(gi, gh, s));
-    RUN(pfo_gru_gates_fwd_launch(w.gi, w.gh, w.h_rows, st->node_feat, w.hm, w.touched, w.n_touched, capP, D, w.upd_mem,
-                                 w.h0_tab, s));
-  } else {
-    RUN(pfo_pack_remap_launch(nullptr, d.M, st->node_feat, D, nullptr, w.touched, w.n_touched, capP, nullptr, w.h0_tab, nullptr,
-                              w.nodes[0], n[0], w.slot, w.idx0, s));
   }
   const float* tab0 = w.h0_tab;
   const int32_t* idx0 = w.idx0;

@@ -6,9 +6,12 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pfotgnrec_amd import _lib
 
-SHAPES = [(53760, 348, 172, "QK' nt"), (53760, 172, 696, "h_pre nt"), (53760, 172, 172, "fc2 nt"),
-          (53760, 172, 516, "fc1 nt"), (12000, 516, 520, "GRU ih nt"), (12000, 516, 172, "GRU hh nt"),
-          (4099, 171, 44, "ragged")]
+SHAPES = [(53760, 172, 704, "h1 nt"), (53760, 704, 172, "dctx' nt"), (12000, 876, 172, "QX nt"),
+          (12000, 516, 520, "GRU ih nt"), (12000, 516, 172, "GRU hh nt"), (4099, 171, 44, "ragged")]
+if os.environ.get("BX_SHAPES") == "old":
+    SHAPES = [(53760, 348, 172, "QK' nt"), (53760, 172, 696, "h_pre nt"), (53760, 172, 172, "fc2 nt"),
+              (53760, 172, 516, "fc1 nt"), (12000, 516, 520, "GRU ih nt"), (12000, 516, 172, "GRU hh nt"),
+              (4099, 171, 44, "ragged")]
 dev = "cuda:0"
 torch.manual_seed(0)
 ws = torch.empty(1 << 20, device=dev)
