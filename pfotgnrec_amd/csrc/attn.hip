@@ -9,6 +9,7 @@
 // ctx_h = sum_j a_jh key_j; both projections become plain GEMMs on [N, C] operands.
 #include "attn.hpp"
 #include <algorithm>
+#include <type_traits>
 
 struct AttnDev {
   int N, K, D, Ef, H, Cp;
@@ -20,7 +21,7 @@ struct AttnDev {
   int64_t d_nbr_rep;  // DMODE 1: floats between the per-XCD replicas of the gradient table (0: one table)
   int d_nbr_nrep;     // ... and how many of them are in use (a power of two)
   // run-merged layer-1 backward: instances in (table row, run key) order, seg_ptr[*n_rows] of them
-  const int32_t* members; const int32_t* seg_ptr; const int32_t* n_rows;
+  const int32_t* members; const int32_t* seg_ptr; const int32_t* n_rows; const int32_t* run_cnt;
   int abl;      // timing-only ablation switch (PFO_ATTN_ABL): 1 = spread the atomic destinations (wrong results)
 };
 
@@ -442,62 +443,84 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Layer-1 backward with RUN MERGING.  The level-0 gradient scatter is bound by the float-atomic rate of the part (~1.3 TB/s of
-// added bytes: 454 MB per launch at C2; without the atomics the same kernel takes 0.35 instead of 0.49 ms).  Instances
-// arrive ordered by (touched-table row, run key) - memory.hpp pfo_seg_build_launch - so consecutive instances of a run sit
-// on the same node and have the SAME K neighbour rows.  One wavefront (a 64-thread workgroup) walks a chunk of RUN_CHUNK
-// consecutive members and the key-side gradient rows of a run leave as ONE set of float atomics when the run or the chunk
-// ends - 2-3x fewer atomic bytes.
+// Layer-1 backward with SHIFT MERGING.  The level-0 gradient scatter is bound by the float-atomic rate of the part (~1.3 TB/s of
+// added bytes chip-wide, MI355X_MICROARCH.md: one 256-byte wave instruction per ~50 ns per CU); everything else in this kernel
+// hides behind it.  Instances arrive ordered by (touched-table row, entries of the row's history before the instance's time) -
+// memory.hpp pfo_seg_build_launch - so consecutive members of a row walk its history forwards, and under most-recent sampling
+// slot j of an instance holds history entry cnt - K + j: the neighbour lists of two instances of one node are SHIFTS of each
+// other by the difference of their counts (identical when the counts are equal - every ~4 instances of a user in a batch;
+// shifted by one or two entries for the instances of an item, whose history grows inside the batch window).
+// One wavefront (a 64-thread workgroup) walks a chunk of RUN_CHUNK consecutive members.  Lane q stands for history entry
+// cnt0 - K + q of the group's first instance; an instance whose count is cnt0 + d puts its slot j on lane j + d.  The key-side
+// gradient rows of a group leave as ONE set of float atomics, one row per distinct history entry, when the row, the lane range
+// (K + d <= 64) or the chunk ends.  Round 2 merged only identical lists (d = 0): at C2 that left the ~12 k item instances, 55 %
+// of the atomic instructions, unmerged.
 //
-// The rows are not accumulated while the instances are walked.  The gradient of neighbour row j summed over a run is
-//     sum_i sum_h ( cA_ihj * g_ih  +  cB_ihj * q_h )        g_ih = d ctx'_h (node part) of instance i,  q_h = the node's query
-// with wave-uniform scalars cA (post-dropout weight) and cB (d score * scale), and q_h is the same for every instance of
-// the run.  So the walk only keeps the SCALARS - lane j holds cA of key j for each of the run's <= RUN_CHUNK instances and
-// the running sum of cB - and the rows are formed once per run from the re-read g rows (just used: cache hits): per key
-// (RUN_CHUNK + 1) * H FMAs per column instead of 2H FMAs plus an LDS read-modify-write per column PER INSTANCE.  The first
-// version of this kernel summed the rows in a wavefront-private LDS image [K][D] (13.8 KB): that image, not the work,
-// set the speed - 11 wavefronts per CU, and the kernel's time is inversely proportional to its occupancy (measured by
-// padding the allocation: 8 per CU 459 us, 5 per CU 765 us against 383 us).
+// The rows are not accumulated while the instances are walked.  The gradient of a neighbour row summed over a group is
+//     sum_i sum_h ( cA_ih * g_ih  +  cB_ih * q_h )        g_ih = d ctx'_h (node part) of instance i,  q_h = the node's query
+// with wave-uniform scalars cA (post-dropout weight) and cB (d score * scale), and q_h is the same for every instance of the
+// node.  So the walk only keeps the SCALARS - per instance and slot cA (LDS), per lane the running sum of cB (a register) - and
+// the rows are formed once per group from the re-read g rows (just used: cache hits).
 #ifndef RUN_CHUNK
-#define RUN_CHUNK 4     // measured at C2: 4 -> 1.86 ms/step, 8 -> 1.88, 16 -> 2.00 (a wavefront walks its chunk serially: long
-#endif                  // chunks merge more atomics but leave a tail), per-instance kernel 1.91
+#define RUN_CHUNK 4     // measured at C2 (round 2): 2: 399, 3: 370, 4: 365, 6: 402, 8: 417 us (a wavefront walks its chunk serially:
+#endif                  // long chunks merge more atomics but leave a tail)
 
 #ifndef KC_RUNS
-#define KC_RUNS 2      // keys in flight per wavefront: 2 costs 14 registers, and occupancy is worth more here than ILP
+#define KC_RUNS 2      // keys in flight per wavefront
 #endif
 #ifndef RUNS_WAVES
 #define RUNS_WAVES(NR, H) ((NR) * (H) <= 6 ? 3 : 2)
 #endif
+// How a wavefront spends its cycles (round 3; measured against the round-2 loop, 357 vs 363 us at equal atomics - the atomic
+// rate, not the issue rate, bounds this kernel):
+//  * the gathers of key chunk c+1 are issued before chunk c is scored (two register sets used alternately, as in the forward);
+//  * no exec-mask region and no select in the key loop: gathers read clamped addresses (the last 64-column group re-reads
+//    column D-1, the edge lanes column Ef-1) instead of being predicated, and the lanes they feed carry zero query / gradient
+//    values or are never stored; the time-encoder parameters are zero beyond D, so the encodings there are cos(0), sin(0);
+//  * the "argument too large for the fp32 range reduction" test is taken once per INSTANCE from max|dt| * max|w| + max|b|
+//    (wave-uniform), not per chunk on every argument;
+//  * the per-key softmax-backward scalars of a chunk are reduced together (one interleaved DPP tree for KC*H sums), the running
+//    sum of cB per key lives in a register (select on lane == key) instead of an LDS read-modify-write.
 template <int NR, int H>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(NR, H)))) void attn_bwd_runs_kernel(const AttnDev a) {
-  // Registers decide this kernel's speed (see above), so everything that is not touched every few instructions lives in
-  // the wavefront's 4 KB of LDS: the time-encoder parameters and the run's per-key scalars.
   __shared__ float s_tw[NR * 64], s_tb[NR * 64];
-  __shared__ float s_cA[RUN_CHUNK][H][64], s_sB[H][64];
+  __shared__ float s_cA[RUN_CHUNK][H][64];     // [instance of the group][head][slot]: cA of that key; zero where the slot is empty
+  __shared__ int s_delta[RUN_CHUNK];            // [instance of the group]: its shift (count - the group's first count)
   const int lane = threadIdx.x;
   const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef, Cp = a.Cp;
+  float wmax = 0.f, bmax = 0.f;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int c = lane + 64 * r;
-    s_tw[c] = c < D ? a.tw[c] : 0.f;
-    s_tb[c] = c < D ? a.tb[c] : 0.f;
+    const float w = c < D ? a.tw[c] : 0.f, b = c < D ? a.tb[c] : 0.f;
+    s_tw[c] = w; s_tb[c] = b;
+    wmax = fmaxf(wmax, fabsf(w)); bmax = fmaxf(bmax, fabsf(b));
   }
+  wmax = pfo_wave_max(wmax); bmax = pfo_wave_max(bmax);
+  // clamped column of this lane in each 64-column group, and the edge column
+  int colr[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) colr[r] = min(lane + 64 * r, D - 1);
+  const int cole = min(lane, max(Ef, 1) - 1);
   const float keep_scale = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
   float* const d_nbr_x = a.d_nbr + (int64_t)(__builtin_amdgcn_s_getreg(6164) & (a.d_nbr_nrep - 1)) * a.d_nbr_rep;
   const int M = a.seg_ptr[*a.n_rows];                            // members = instances that sit on a real node
   const int n_chunks = (M + RUN_CHUNK - 1) / RUN_CHUNK;
+  const uint64_t rng_off = a.offset + (a.offset_dev ? *a.offset_dev : 0ull);
+  const float* const nbr_tab = a.nbr_tab;
+  const float* const edge_feat = a.edge_feat;
+  const uint32_t nbr_ld = (uint32_t)a.nbr_ld;
 
   for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    // the time-encoder gradient of a chunk (<= RUN_CHUNK * K terms per column) is summed in fp32 and added to the fp64 bins
-    // once (the reference's autograd sums everything in fp32)
     float dwc[NR], dbc[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) { dwc[r] = 0.f; dbc[r] = 0.f; }
-    // the current run: s_cA[i][h][j] = cA of key j for the run's i-th instance, s_sB[h][j] = sum of cB over its instances
-    int run_slot = -1, run_key = 0, run_rows = 0, run_len = 0, run_first = 0;
-    unsigned long long run_valid = 0ull;
+    // the current group: lane q <-> history entry cnt0 - K + q of the node run_slot
+    int run_slot = -1, run_cnt0 = 0, run_rows = 0, run_len = 0, run_first = 0;
+    unsigned long long run_valid = 0ull;                           // lanes whose history entry exists and was seen
+    float sBr[H];                                                  // lane q: sum of cB over the group's instances that hold entry q
 #pragma unroll
-    for (int h = 0; h < H; ++h) s_sB[h][lane] = 0.f;
+    for (int h = 0; h < H; ++h) sBr[h] = 0.f;
     auto flush = [&]() {                                           // the run's rows: one float atomic per element
       if (run_valid != 0ull && run_len > 0) {
         const float* qk = a.QK + (int64_t)run_slot * a.qk_ld;
@@ -509,14 +532,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
             const int c = lane + 64 * r;
             qn[h][r] = c < D ? qk[h * Cp + c] : 0.f;
           }
-        float cAr[RUN_CHUNK][H], sB[H];                              // lane j: key j's scalars
+        float cAr[RUN_CHUNK][H];                                   // lane q: cA of the slot instance i has on history entry q
 #pragma unroll
         for (int i = 0; i < RUN_CHUNK; ++i) {
           const bool on = i < run_len;                             // wave-uniform
           const float* dc = a.dctx + (int64_t)a.members[on ? run_first + i : run_first] * H * Cp;
+          const int sl = lane - (on ? s_delta[i] : 0);             // the instance's slot on this lane (may lie outside [0, K): zero)
 #pragma unroll
           for (int h = 0; h < H; ++h) {
-            cAr[i][h] = on ? s_cA[i][h][lane] : 0.f;
+            cAr[i][h] = (on && sl >= 0) ? s_cA[i][h][sl < 0 ? 0 : sl] : 0.f;
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
               const int c = lane + 64 * r;
@@ -524,8 +548,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
             }
           }
         }
-#pragma unroll
-        for (int h = 0; h < H; ++h) sB[h] = s_sB[h][lane];
         unsigned long long vmask = run_valid;
         while (vmask) {
           const int j = __ffsll((long long)vmask) - 1;
@@ -536,7 +558,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
           for (int r = 0; r < NR; ++r) row[r] = 0.f;
 #pragma unroll
           for (int h = 0; h < H; ++h) {
-            const float sb = rl_f(sB[h], j);
+            const float sb = rl_f(sBr[h], j);
 #pragma unroll
             for (int r = 0; r < NR; ++r) row[r] = fmaf(sb, qn[h][r], row[r]);
 #pragma unroll
@@ -554,7 +576,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         }
       }
 #pragma unroll
-      for (int h = 0; h < H; ++h) s_sB[h][lane] = 0.f;
+      for (int h = 0; h < H; ++h) sBr[h] = 0.f;
       run_len = 0;
     };
 
@@ -570,20 +592,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
       const float my_dt = inK ? a.dt[slot0 + lane] : 0.f;
       const unsigned long long valid = __ballot(inK && my_id != 0);
       const int slot = a.qk_row[n];
-      const int e_new = rl_i(my_e, K - 1);                       // common.hpp pfo_run_key: equal keys <=> identical neighbour lists
-      const int key = e_new * 2 + ((K >= 2 && e_new != 0 && rl_i(my_e, K >= 2 ? K - 2 : 0) == e_new) ? 1 : 0);
-      if (slot != run_slot || key != run_key) {                  // a new run: the previous one's rows leave
+      const int cnt_n = a.run_cnt[n];
+      int delta = cnt_n - run_cnt0;                              // members of a row arrive by ascending count
+      if (slot != run_slot || delta < 0 || delta > 64 - K) {     // another node, or the lanes run out: the group's rows leave
         flush();
-        run_slot = slot; run_key = key; run_rows = my_row; run_valid = valid;
+        run_slot = slot; run_cnt0 = cnt_n; run_rows = 0; run_valid = 0ull;
+        delta = 0;
+      }
+      {
+        // this instance's slots move to lanes j + delta: row indices and validity join the group's
+        const int rows_sh = __builtin_amdgcn_ds_bpermute((lane - delta) << 2, my_row);
+        const unsigned long long vs = valid << delta;
+        run_rows = ((vs >> lane) & 1ull) ? rows_sh : run_rows;
+        run_valid |= vs;
       }
       if (valid == 0ull) {
         for (int c = lane; c < H * Cp; c += 64) dqk_out[c] = 0.f;
         continue;
       }
-      if (run_len == 0) run_first = m;                           // the run's instances are consecutive members
-      const int run_i = run_len;
+      if (run_len == 0) run_first = m;                           // the group's instances with a neighbour are consecutive members
+      const int run_i = run_len;                                 // (an instance without history has count 0: first of its row)
       run_len += 1;
-      float qn[H][NR], qt[H][NR], qe[H], gn[H][NR], gt[H][NR], ge[H], t[H], dsb[H];
+      s_delta[run_i] = delta;
+#pragma unroll
+      for (int h = 0; h < H; ++h) s_cA[run_i][h][lane] = 0.f;
+      float qt[H][NR], gn[H][NR], gt[H][NR], ge[H], tds[2 * H];
       float dqn[H][NR], dqt[H][NR], dqe[H];
       const float* qk = a.QK + (int64_t)slot * a.qk_ld;
       const float* dc = a.dctx + n * H * Cp;
@@ -595,106 +628,90 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         for (int r = 0; r < NR; ++r) {
           const int c = lane + 64 * r;
           const bool ok = c < D;
-          qn[h][r] = ok ? qk[h * Cp + c] : 0.f;
           qt[h][r] = ok ? qk[h * Cp + D + Ef + c] : 0.f;
           gn[h][r] = ok ? dc[h * Cp + c] : 0.f;
           gt[h][r] = ok ? dc[h * Cp + D + Ef + c] : 0.f;
           if (ok) part = fmaf(gn[h][r], cx[h * Cp + c], fmaf(gt[h][r], cx[h * Cp + D + Ef + c], part));
           dqn[h][r] = 0.f; dqt[h][r] = 0.f;
         }
-        qe[h] = lane < Ef ? qk[h * Cp + D + lane] : 0.f;
         ge[h] = lane < Ef ? dc[h * Cp + D + lane] : 0.f;
         if (lane < Ef) part = fmaf(ge[h], cx[h * Cp + D + lane], part);
         dqe[h] = 0.f;
-        t[h] = part;
-        dsb[h] = dc[h * Cp + C];
+        tds[h] = part;
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int h = 0; h < H; ++h) t[h] += __shfl_xor(t[h], o, 64);
+      pfo_wave_sum_scalar_n<H>(reinterpret_cast<float(&)[H]>(tds));     // delta_h = dctx_h . ctx_h (+ the extra column below)
+      float t[H], dsb[H];
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        t[h] = fmaf(dsb[h], cx[h * Cp + C], t[h]);
-        t[h] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(t[h])));          // wave-uniform: scalar registers
-        dsb[h] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(dsb[h])));
+        dsb[h] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(dc[h * Cp + C])));
+        t[h] = fmaf(dsb[h], __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cx[h * Cp + C]))), tds[h]);
       }
-      const unsigned keep = attn_keep_bits(a.seed, a.offset + (a.offset_dev ? *a.offset_dev : 0ull), n, lane, a.dropout_p);
+      const unsigned keep = attn_keep_bits(a.seed, rng_off, n, lane, a.dropout_p);
       float my_a[H];
 #pragma unroll
       for (int h = 0; h < H; ++h) my_a[h] = inK ? a.attw[(n * H + h) * K + lane] : 0.f;
+      // one range test per instance: |fma(dt, w, b)| <= max|dt| max|w| + max|b| < 2e7 -> the fp32 reduction holds for every key
+      const bool fast = fmaf(pfo_wave_max(fabsf(my_dt)), wmax, bmax) < 2.0e7f;
 
+      auto walk = [&](auto fast_c) {
+      constexpr bool FAST = decltype(fast_c)::value;
       unsigned long long vm = valid;
-      while (vm) {
-        int js[KC_RUNS];
+      int jsA[KC_RUNS], jsB[KC_RUNS];
+      float knA[KC_RUNS][NR], keA[KC_RUNS], knB[KC_RUNS][NR], keB[KC_RUNS];
+      auto pick = [&](int (&jj)[KC_RUNS]) {
 #pragma unroll
         for (int c = 0; c < KC_RUNS; ++c) {
-          js[c] = vm ? (__ffsll((long long)vm) - 1) : -1;
+          jj[c] = vm ? (__ffsll((long long)vm) - 1) : -1;
           vm &= vm - 1ull;
         }
-        float kn[KC_RUNS][NR], kt[KC_RUNS][NR], ks[KC_RUNS][NR], ke[KC_RUNS], dtv[KC_RUNS];
+      };
+      auto gather = [&](const int (&jj)[KC_RUNS], float (&kk)[KC_RUNS][NR], float (&ee)[KC_RUNS]) {
 #pragma unroll
         for (int c = 0; c < KC_RUNS; ++c) {
-          const int j = js[c] < 0 ? 0 : js[c];
-          const float* src = a.nbr_tab + (uint32_t)rl_i(my_row, j) * (uint32_t)a.nbr_ld;        // 32-bit element offsets (checked on the host): one scalar multiply
-          const int e = rl_i(my_e, j);
-          dtv[c] = rl_f(my_dt, j);
+          const int j = jj[c] < 0 ? 0 : jj[c];                   // an absent key re-reads slot 0's row: never used
+          const float* src = nbr_tab + (uint32_t)rl_i(my_row, j) * nbr_ld;
+          const uint32_t e = (uint32_t)rl_i(my_e, j);
 #pragma unroll
-          for (int r = 0; r < NR; ++r) {
-            const int cc = lane + 64 * r;
-            kn[c][r] = (js[c] >= 0 && (r < NR - 1 || cc < D)) ? src[cc] : 0.f;
-          }
-          ke[c] = (js[c] >= 0 && lane < Ef) ? a.edge_feat[(uint32_t)e * (uint32_t)Ef + (uint32_t)lane] : 0.f;
+          for (int r = 0; r < NR; ++r) kk[c][r] = src[colr[r]];
+          ee[c] = Ef > 0 ? edge_feat[e * (uint32_t)Ef + (uint32_t)cole] : 0.f;
         }
-        float part[KC_RUNS][H];
-        // time encoding of the chunk: ONE out-of-range test for all its arguments (wave-wide), as in the forward kernel
-        float targ[KC_RUNS][NR];
-        bool big = false;
-#pragma unroll
-        for (int c = 0; c < KC_RUNS; ++c)
-#pragma unroll
-          for (int r = 0; r < NR; ++r) {
-            targ[c][r] = pfo_time_arg(dtv[c], s_tw[lane + 64 * r], s_tb[lane + 64 * r]);
-            big = big || !(fabsf(targ[c][r]) < 2.0e7f);
-          }
-        const bool any_big = __ballot(big) != 0ull;
+      };
+      auto process = [&](const int (&js)[KC_RUNS], const float (&kn)[KC_RUNS][NR], const float (&ke)[KC_RUNS]) {
+        float kt[KC_RUNS][NR], ks[KC_RUNS][NR], dtv[KC_RUNS], part[KC_RUNS * H];
 #pragma unroll
         for (int c = 0; c < KC_RUNS; ++c) {
+          dtv[c] = rl_f(my_dt, js[c] < 0 ? 0 : js[c]);
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
-            const int cc = lane + 64 * r;
-            const float u = __builtin_expect(any_big, 0) ? pfo_revolutions(targ[c][r]) : pfo_revolutions_fast(targ[c][r]);
-            const float sv = __builtin_amdgcn_sinf(u), cv = __builtin_amdgcn_cosf(u);
-            const bool on = js[c] >= 0 && (r < NR - 1 || cc < D);
-            kt[c][r] = on ? cv : 0.f;
-            ks[c][r] = on ? sv : 0.f;
+            const float arg = pfo_time_arg(dtv[c], s_tw[lane + 64 * r], s_tb[lane + 64 * r]);
+            const float u = FAST ? pfo_revolutions_fast(arg) : pfo_revolutions(arg);
+            ks[c][r] = __builtin_amdgcn_sinf(u);
+            kt[c][r] = __builtin_amdgcn_cosf(u);
           }
 #pragma unroll
           for (int h = 0; h < H; ++h) {
             float pp = ke[c] * ge[h];
 #pragma unroll
             for (int r = 0; r < NR; ++r) pp = fmaf(kn[c][r], gn[h][r], fmaf(kt[c][r], gt[h][r], pp));
-            part[c][h] = pp;
+            part[c * H + h] = pp;
           }
         }
-#pragma unroll
-        for (int c = 0; c < KC_RUNS; ++c)
-#pragma unroll
-          for (int h = 0; h < H; ++h) part[c][h] = pfo_wave_sum_scalar(part[c][h]);
+        pfo_wave_sum_scalar_n<KC_RUNS * H>(part);
 #pragma unroll
         for (int c = 0; c < KC_RUNS; ++c) {
           if (js[c] < 0) continue;
           const unsigned kb = (unsigned)rl_i((int)keep, js[c]);
+          const bool mine = lane == js[c] + delta;              // the lane of this key's history entry
           float cA[H], cB[H];
 #pragma unroll
           for (int h = 0; h < H; ++h) {
             const float ks_h = ((kb >> h) & 1u) ? keep_scale : 0.f;
-            const float da = (part[c][h] + dsb[h]) * ks_h;
+            const float da = (part[c * H + h] + dsb[h]) * ks_h;
             const float aj = rl_f(my_a[h], js[c]);
             const float dscore = aj * (da - t[h]);
             cA[h] = aj * ks_h;
             cB[h] = dscore * a.scale;
-            if (lane == js[c]) { s_cA[run_i][h][lane] = cA[h]; s_sB[h][lane] += cB[h]; }   // key js[c]'s share of the run's rows (flush)
+            sBr[h] = mine ? sBr[h] + cB[h] : sBr[h];               // key js[c]'s share of the run's rows (flush)
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
               dqn[h][r] = fmaf(cB[h], kn[c][r], dqn[h][r]);
@@ -702,17 +719,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
             }
             dqe[h] = fmaf(cB[h], ke[c], dqe[h]);
           }
+          if (lane == js[c]) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) s_cA[run_i][h][lane] = cA[h];
+          }
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
             float dkt = 0.f;
 #pragma unroll
             for (int h = 0; h < H; ++h) dkt = fmaf(cA[h], gt[h][r], fmaf(cB[h], qt[h][r], dkt));
-            const float gsin = -ks[c][r] * dkt;                 // d/d(arg) cos(arg) = -sin(arg); ks = 0 on lanes beyond D
+            const float gsin = -ks[c][r] * dkt;                 // d/d(arg) cos(arg) = -sin(arg); sin(0) = 0 on lanes beyond D
             dwc[r] = fmaf(gsin, dtv[c], dwc[r]);
             dbc[r] += gsin;
           }
         }
+      };
+      pick(jsA);
+      gather(jsA, knA, keA);
+      while (true) {
+        pick(jsB);
+        if (jsB[0] >= 0) gather(jsB, knB, keB);
+        process(jsA, knA, keA);
+        if (jsB[0] < 0) break;
+        pick(jsA);
+        if (jsA[0] >= 0) gather(jsA, knA, keA);
+        process(jsB, knB, keB);
+        if (jsA[0] < 0) break;
       }
+      };
+      if (fast) walk(std::true_type{}); else walk(std::false_type{});
 #pragma unroll
       for (int h = 0; h < H; ++h) {
 #pragma unroll
@@ -728,7 +763,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
       }
     }
     flush();                                                     // the chunk's last run
-    // time-encoder partials: this chunk's sums into the shared fp64 bins
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int c = lane + 64 * r;
@@ -751,7 +785,7 @@ static void to_dev(const PfoAttn& a, AttnDev& d) {
   d.ctx = a.ctx; d.attw = a.attw; d.inv = a.inv;
   d.dctx = a.dctx; d.dQK = a.dQK; d.d_nbr = a.d_nbr; d.d_nbr_ld = a.d_nbr_ld; d.d_nbr_rep = a.d_nbr_rep; d.d_nbr_nrep = a.d_nbr_nrep > 0 ? a.d_nbr_nrep : 1;
   d.dtime_part = a.dtime_part;
-  d.members = a.members; d.seg_ptr = a.seg_ptr; d.n_rows = a.n_rows;
+  d.members = a.members; d.seg_ptr = a.seg_ptr; d.n_rows = a.n_rows; d.run_cnt = a.run_cnt;
 }
 
 static int check_common(const PfoAttn& a) {
@@ -816,7 +850,7 @@ bool pfo_attn_bwd_runs_possible(int K) {
   return runs_on && K <= 64;
 }
 bool pfo_attn_bwd_uses_runs(const PfoAttn& a) {
-  return a.d_nbr && a.nbr_row && pfo_attn_bwd_runs_possible(a.K) && a.members && a.seg_ptr && a.n_rows && a.qk_row;
+  return a.d_nbr && a.nbr_row && pfo_attn_bwd_runs_possible(a.K) && a.members && a.seg_ptr && a.n_rows && a.qk_row && a.run_cnt;
 }
 
 int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {

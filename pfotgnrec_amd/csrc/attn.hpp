@@ -51,11 +51,14 @@ struct PfoAttn {
   int d_nbr_nrep = 1;               // replicas in use (power of two <= PFO_GRAD_REPLICAS): XCD x adds into replica x & (n - 1)
   double* dtime_part = nullptr;     // [ATTN_TIME_BINS, 2*D] fp64 accumulators (dw | db) of the time encoder: ADDED to (zero them per step)
   // optional (layer 1 over the touched-node table, atomically added rows, most-recent sampling): the instances ordered by
-  // (table row, run key) as built by pfo_seg_build_launch with key_src = eidx.  Consecutive members of a run share their K
-  // neighbour rows, so their key-side gradients are summed on chip and added once per run.
+  // (table row, entries before the instance's time) as built by pfo_seg_build_launch with key_src = run_cnt.  Consecutive
+  // members of a row have neighbour lists that are shifts of each other, so their key-side gradients are summed on chip by
+  // row entry and added once per group.
   const int32_t* members = nullptr; // [seg_ptr[*n_rows]]
   const int32_t* seg_ptr = nullptr; // [rows + 1]
   const int32_t* n_rows = nullptr;  // device-side row count
+  const int32_t* run_cnt = nullptr; // [N] entries of the instance's row before its time (sampler.hip out_cnt): members of one
+                                    // row whose counts differ by d have neighbour lists shifted by d slots
 };
 
 int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream);

@@ -111,15 +111,6 @@ __device__ __forceinline__ uint32_t pfo_u4_get(const pfo_u4& v, int i) {
   return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
-// Run key of a layer-1 instance under most-recent sampling: its K neighbour slots are the last K entries of the node's row
-// before the root time, so two instances of one node have IDENTICAL slot lists iff their newest entry is the same row
-// entry.  Edge ids identify row entries except for a self-loop (both of its entries carry one edge id, adjacent in the
-// row): the low bit tells whether the slot before the newest holds the same edge id.  0 = no neighbour at all.
-__device__ __forceinline__ int pfo_run_key(const int32_t* __restrict__ eidx_row, int K) {
-  const int e = eidx_row[K - 1];
-  return e * 2 + ((K >= 2 && e != 0 && eidx_row[K - 2] == e) ? 1 : 0);
-}
-
 // Wave-wide sum delivered as a wave-uniform scalar: 6 DPP adds (quad xor 1/2, row_ror 4/8, row_bcast 15/31) and
 // one v_readlane instead of 6 ds_bpermute round trips through the LDS crossbar.
 template <int CTRL, int ROW_MASK>

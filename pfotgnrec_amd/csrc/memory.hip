@@ -195,22 +195,23 @@ __global__ void seg_place_kernel(const int32_t* __restrict__ idx, const int32_t*
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n < N && nodes[n] != 0) members[atomicAdd(&cursor[idx[n]], 1)] = n;
 }
-// one wavefront per group: members ordered by (run key, instance index).  The run key of an instance (common.hpp
-// pfo_run_key) names the newest entry of its neighbour list: equal keys <=> identical neighbour lists under most-recent
-// sampling.  When `key_src` is null (uniform sampling: lists are random) the key is the instance index itself.  Instance indices are distinct, so ranks are too; the order is reproducible.
+// one wavefront per group: members ordered by (key, instance index).  key = key_src[instance]: under most-recent sampling the
+// number of row entries before the instance's time (sampler.hip out_cnt) - equal keys <=> identical neighbour lists, and a
+// group in this order walks its node's history forwards.  key_src == null (uniform sampling: lists are random): the instance
+// index itself.  Instance indices are distinct, so ranks are too; the order is reproducible.
 __global__ void seg_sort_kernel(const int32_t* __restrict__ seg_ptr, int n_seg, const int32_t* __restrict__ in,
-                                const int32_t* __restrict__ key_src, int K, int32_t* __restrict__ out) {
+                                const int32_t* __restrict__ key_src, int32_t* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < n_seg; s += (gridDim.x * blockDim.x) >> 6) {
     const int lo = seg_ptr[s], cnt = seg_ptr[s + 1] - lo;
     if (cnt <= 0) continue;
     for (int i = lane; i < cnt; i += 64) {
       const int x = in[lo + i];
-      const int kx = key_src ? pfo_run_key(key_src + (int64_t)x * K, K) : x;
+      const int kx = key_src ? key_src[x] : x;
       int rank = 0;
       for (int j = 0; j < cnt; ++j) {
         const int y = in[lo + j];
-        const int ky = key_src ? pfo_run_key(key_src + (int64_t)y * K, K) : y;
+        const int ky = key_src ? key_src[y] : y;
         rank += (ky < kx) || (ky == kx && y < x);
       }
       out[lo + rank] = x;
@@ -228,7 +229,7 @@ int pfo_iscan_launch(const int32_t* in, int64_t n, int32_t* out, int32_t* scratc
 }
 
 int64_t pfo_seg_scratch_ints(int cap_rows) { return pfo_ceil_div(cap_rows + 1, SCAN_BLOCK) + 8; }
-int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int cap_rows, const int32_t* key_src, int K,
+int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int cap_rows, const int32_t* key_src,
                          int32_t* seg_ptr, int32_t* cursor, int32_t* tmp, int32_t* members, int32_t* scratch,
                          hipStream_t stream) {
   PFO_REQUIRE(idx && nodes && seg_ptr && cursor && tmp && members && scratch && N > 0 && cap_rows > 0, "bad arguments");
@@ -241,7 +242,7 @@ int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int ca
   hipLaunchKernelGGL(iscan_add_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, seg_ptr, n, scratch, cursor);
   hipLaunchKernelGGL(seg_place_kernel, dim3((unsigned)pfo_ceil_div(N, 256)), dim3(256), 0, stream, idx, nodes, N, cursor, tmp);
   hipLaunchKernelGGL(seg_sort_kernel, dim3((unsigned)std::min<int64_t>(4096, pfo_ceil_div(cap_rows, 4))), dim3(256), 0, stream,
-                     seg_ptr, cap_rows, tmp, key_src, K, members);
+                     seg_ptr, cap_rows, tmp, key_src, members);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

@@ -36,9 +36,9 @@ int pfo_gather_rows_launch(const float* src, int D, const int32_t* touched_ids, 
 int pfo_iscan_launch(const int32_t* in, int64_t n, int32_t* out, int32_t* scratch, hipStream_t stream);
 // --- instances grouped by the touched-table row they read: seg_ptr[cap_rows + 1], members[N] (ascending inside a group)
 int64_t pfo_seg_scratch_ints(int cap_rows);
-// inside a group the members are ordered by (run key, instance): key = key_src[n*K + K-1] (the newest neighbour's edge id:
-// equal keys <=> identical most-recent neighbour lists) or the instance index when key_src is null
-int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int cap_rows, const int32_t* key_src, int K,
+// inside a group the members are ordered by (key_src[instance], instance): key = the number of row entries before the
+// instance's time (equal keys <=> identical most-recent neighbour lists), or the instance index when key_src is null
+int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int cap_rows, const int32_t* key_src,
                          int32_t* seg_ptr, int32_t* cursor, int32_t* tmp, int32_t* members, int32_t* scratch,
                          hipStream_t stream);
 // out[s] = [ sum_{n in group s} src0[n] | sum_{n in group s} src1[n] ]  (row widths W0, W1; s < *n_rows).

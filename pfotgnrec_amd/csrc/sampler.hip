@@ -17,9 +17,12 @@ __global__ __launch_bounds__(256) void tnbr_sample_kernel(
     const double* __restrict__ q_ts, int64_t n_q, int K, const int64_t* __restrict__ draws, uint64_t seed,
     uint64_t offset, const uint64_t* __restrict__ offset_dev, int32_t* __restrict__ out_nbr, int32_t* __restrict__ out_eidx,
     float* __restrict__ out_et, float* __restrict__ out_dt, int32_t* __restrict__ next_nodes, double* __restrict__ next_ts,
-    int32_t* __restrict__ mark) {
+    int32_t* __restrict__ mark, int32_t* __restrict__ out_cnt) {
   // mark (optional, with next_nodes): mark[v] = 1 for every node written to the next level - the touched-node flags of the
   // step's compaction, set here instead of by a pass of their own over the level-0 list
+  // out_cnt (optional): entries of the node's row strictly before the query time.  Under most-recent sampling slot j of the
+  // query holds row entry cnt - K + j, so two queries on one node have neighbour lists that are SHIFTS of each other by the
+  // difference of their counts (the layer-1 attention backward merges their key-side gradients by row entry)
   if (MODE == 2 && offset_dev) offset += *offset_dev;
   __shared__ float s_time[16][PFO_MAX_NEIGHBORS];   // uniform modes: per-group sort scratch
   const int lane = threadIdx.x & 63;
@@ -64,6 +67,7 @@ __global__ __launch_bounds__(256) void tnbr_sample_kernel(
     }
   }
   const int64_t cnt = lo - row_lo;   // entries strictly before t
+  if (out_cnt && active && sub == 0) out_cnt[q] = (int32_t)(cnt < 0x7fffffff ? cnt : 0x7fffffff);
 
   if (active && sub == 0 && next_nodes) {
     next_nodes[q] = node;
@@ -150,7 +154,7 @@ int pfo_tnbr_sample_dev(const int64_t* indptr, const int32_t* adj_nbr, const int
                         int64_t n_nodes, const int32_t* q_nodes, const double* q_ts, int64_t n_q, int32_t K, int32_t mode,
                         const int64_t* draws, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int32_t* out_nbr,
                         int32_t* out_eidx, float* out_et, float* out_dt, int32_t* next_nodes, double* next_ts, int32_t* mark,
-                        void* stream) {
+                        int32_t* out_cnt, void* stream) {
   PFO_REQUIRE(mark == nullptr || next_nodes != nullptr, "mark needs next_nodes");
   PFO_REQUIRE(K >= 1 && K <= PFO_MAX_NEIGHBORS, "K must be in [1, 64]");
   PFO_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0, 1 or 2");
@@ -165,7 +169,7 @@ int pfo_tnbr_sample_dev(const int64_t* indptr, const int32_t* adj_nbr, const int
 #define LAUNCH(M)                                                                                                   \
   hipLaunchKernelGGL(tnbr_sample_kernel<M>, dim3((unsigned)blocks), dim3(threads), 0, s, indptr, adj_nbr, adj_eidx, \
                      adj_ts, n_nodes, q_nodes, q_ts, n_q, (int)K, draws, seed, offset, offset_dev, out_nbr, out_eidx,  \
-                     out_et, out_dt, next_nodes, next_ts, mark)
+                     out_et, out_dt, next_nodes, next_ts, mark, out_cnt)
   pfo_prof_begin(s);
   if (mode == 0) LAUNCH(0);
   else if (mode == 1) LAUNCH(1);
@@ -183,7 +187,7 @@ extern "C" int pfo_tnbr_sample(const int64_t* indptr, const int32_t* adj_nbr, co
                                uint64_t offset, int32_t* out_nbr, int32_t* out_eidx, float* out_et, float* out_dt,
                                int32_t* next_nodes, double* next_ts, void* stream) {
   return pfo_tnbr_sample_dev(indptr, adj_nbr, adj_eidx, adj_ts, n_nodes, q_nodes, q_ts, n_q, K, mode, draws, seed, offset,
-                             nullptr, out_nbr, out_eidx, out_et, out_dt, next_nodes, next_ts, nullptr, stream);
+                             nullptr, out_nbr, out_eidx, out_et, out_dt, next_nodes, next_ts, nullptr, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@
 
 int pfo_tnbr_sample_dev(const int64_t*, const int32_t*, const int32_t*, const double*, int64_t, const int32_t*, const double*,
                         int64_t, int32_t, int32_t, const int64_t*, uint64_t, uint64_t, const uint64_t*, int32_t*, int32_t*,
-                        float*, float*, int32_t*, double*, int32_t*, void*);
+                        float*, float*, int32_t*, double*, int32_t*, int32_t*, void*);
 
 namespace {
 
@@ -49,6 +49,7 @@ struct Ws {
   float *QX, *Dq, *dx_tab, *l1_bias;
   void* iQX;
   int32_t *seg_ptr, *seg_cur, *seg_tmp, *seg_mem, *seg_scratch;
+  int32_t* cnt1;               // per layer-1 instance: entries of its node's row before its time (the run key, sampler.hip)
   LayerWs layer[PFO_MAX_LAYERS + 1];
   float *dh1, *dctx, *dQK;
   float* dH[PFO_MAX_LAYERS + 1];
@@ -134,6 +135,7 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     w.seg_tmp = take<int32_t>(p, d.ncap[1]);
     w.seg_mem = take<int32_t>(p, d.ncap[1]);
     w.seg_scratch = take<int32_t>(p, pfo_seg_scratch_ints((int)d.capP));
+    w.cnt1 = take<int32_t>(p, d.ncap[1]);
   }
   if (c->use_memory) {
     w.winner = take<int32_t>(p, c->n_nodes);
@@ -403,7 +405,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     RUN(pfo_tnbr_sample_dev(st->indptr, st->adj_nbr, st->adj_eidx, st->adj_ts, c->n_nodes, lvl_nodes, lvl_ts, n[l], K,
                             b->uniform, dr, b->seed, b->offset + (uint64_t)l * 0x100000000ull, b->offset_dev, nullptr,
                             w.eidx[l], nullptr, w.dt[l], w.nodes[l - 1], l > 1 ? w.ts[l - 1] : nullptr, l == 1 ? w.slot : nullptr,
-                            stream));
+                            l == 1 ? w.cnt1 : nullptr, stream));
   }
 
   if (c->use_memory) {
@@ -693,7 +695,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
   if (mean_src) RUN(pfo_mean_launch(mean_src, mean_n, mean_out, ss));     // (a reduction the caller left to this call's side stream)
   if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_touched, capP, D, n_rep, rep_stride, ss));
-  RUN(pfo_seg_build_launch(idx0, w.nodes[0], (int)n[1], capP, b->uniform ? nullptr : w.eidx[1], K, w.seg_ptr, w.seg_cur,
+  RUN(pfo_seg_build_launch(idx0, w.nodes[0], (int)n[1], capP, b->uniform ? nullptr : w.cnt1, w.seg_ptr, w.seg_cur,
                            w.seg_tmp, w.seg_mem, w.seg_scratch, ss));
   HIPOK(hipEventRecord(sd.seg_done, ss), "event record failed");
   for (int l = L; l >= 1; --l) {
@@ -794,7 +796,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     if (l == 1 && c->use_memory) HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");   // d_h0 is clear, the groups exist
     if (l == 1 && c->use_memory && !b->uniform) {
       // key-side gradients of instances with identical neighbour lists leave as one set of atomics (attn.hip)
-      a.members = w.seg_mem; a.seg_ptr = w.seg_ptr; a.n_rows = w.n_touched;
+      a.members = w.seg_mem; a.seg_ptr = w.seg_ptr; a.n_rows = w.n_touched; a.run_cnt = w.cnt1;
     }
     const int dqk_by_member = pfo_attn_bwd_uses_runs(a) ? 1 : 0;
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
