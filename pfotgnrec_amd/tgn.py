@@ -533,11 +533,8 @@ class TGN(nn.Module):
         # roots.  Those are embedded once and gathered back.
         inverse = None
         if self.eval_dedup and draws is None and R >= 4096:
-            uniq, inv = torch.unique(torch.stack([roots.to(torch.float64), root_ts], 1), dim=0, return_inverse=True)
-            if uniq.shape[0] < R:
-                inverse, R_full = inv, R
-                roots, root_ts = uniq[:, 0].to(torch.int32).contiguous(), uniq[:, 1].contiguous()
-                R = int(roots.shape[0])
+            roots, root_ts, inverse = self._dedup_roots(src[lo:hi], dst[lo:hi], edge_times[lo:hi], groups, lo, hi, B, roots, root_ts)
+            R = int(roots.shape[0])
         cap = int(self.eval_chunk_roots)
         if R <= cap or draws is not None:
             call = self._make_call(roots, root_ts, K, draws, dropout_p, extra, B)
@@ -560,6 +557,37 @@ class TGN(nn.Module):
         if inverse is not None:
             emb = emb.index_select(0, inverse)
         return emb, b
+
+    def _dedup_roots(self, src, dst, ts, groups, lo, hi, B, roots, root_ts):
+        """An embedding is a function of (node, time) only, and an evaluation batch scores the same few hundred items for
+        every interaction (evaluation.py:88-94: N_ITEMS draws from the item set per interaction, all at the interaction's
+        time).  Item-side structure: the distinct timestamps T of the batch (a sort of b values) and the
+        distinct nodes U of the extra groups (a presence bitmap over the node table, no sort) span a dense grid of T x U
+        roots; every extra root is a gather from it.  Taken when the grid is smaller than the list it replaces.
+        Returns (roots, root_ts, inverse) with ``inverse`` = None when nothing is saved."""
+        b = hi - lo
+        n_extra = sum(r for _, r in groups)
+        if b == 0 or n_extra == 0:
+            return roots, root_ts, None
+        uniq_t, tid = torch.unique(ts, return_inverse=True)                       # b values
+        present = torch.zeros(self.n_nodes, dtype=torch.bool, device=self.device)
+        cols = [t.view(B, r)[lo:hi] for t, r in groups]                             # this shard's rows of every group
+        for c in cols:
+            present[c.reshape(-1).long()] = True
+        uniq_n = present.nonzero().view(-1)
+        n_t, n_u = int(uniq_t.shape[0]), int(uniq_n.shape[0])                      # (one host read-back for both)
+        if n_t * n_u >= b * n_extra:
+            return roots, root_ts, None
+        col_of = torch.cumsum(present, 0, dtype=torch.int32) - 1                    # node id -> column of the grid
+        grid_nodes = uniq_n.to(torch.int32).repeat(n_t)
+        grid_ts = uniq_t.repeat_interleave(n_u)
+        new_roots = torch.cat([roots[:2 * b], grid_nodes]).contiguous()
+        new_ts = torch.cat([root_ts[:2 * b], grid_ts]).contiguous()
+        base = 2 * b + tid.to(torch.int64) * n_u                                     # [b] first grid row of the interaction's time
+        inv = [torch.arange(2 * b, device=self.device, dtype=torch.int64)]
+        for c in cols:
+            inv.append((base[:, None] + col_of[c.long()].to(torch.int64)).reshape(-1))
+        return new_roots, new_ts, torch.cat(inv)
 
     def _to_dev(self, a, dtype):
         return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=dtype)).to(self.device)

@@ -602,3 +602,128 @@ def test_c4_batch_4096_step_properties_and_state_machine(c4):
         if den < 1e-12:
             continue
         assert ((grads[1][n] / 4.0 - g1).abs().max().item() / den) < 2e-5, n
+
+
+def test_c4_kink_masked_gradients_of_a_64_interaction_slice(c4):
+    """C4 graph (500 k users, 10 M edges) at its table sizes: the gradient of a 64-interaction slice against the oracle with the
+    near-kink roots left out on both sides.  The graph's size is what this covers - 32-bit gather offsets
+    into a 500 k-row node table, the compaction over 500 k nodes, the shift-merged attention backward on long item histories
+    (10 000 edges per item before the batch) - at a batch the oracle finishes in seconds."""
+    cfg, g, nf, onf = c4
+    d = g.data
+    tgn = _model(cfg, g, nf, seed=12)
+    ref = _oracle_for(tgn, g, onf, cfg, True)
+    rs = np.random.RandomState(77)
+    B, K = 64, cfg.n_neighbors
+    s = cfg.n_edges // 2 + 12345
+    tgn.train()
+    # step 1 (state only) stores messages for 2B nodes, so that step 2 runs the lazy GRU and its backward on both sides
+    sb, db, tb, eb = d.sources[s:s + B], d.destinations[s:s + B], d.timestamps[s:s + B], d.edge_idxs[s:s + B]
+    neg = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * 3)
+    with torch.no_grad():
+        tgn.compute_temporal_embeddings(sb, db, neg, tb, eb, K)
+    ref.compute_temporal_embeddings(sb, db, neg, tb, eb, K)
+    db1 = db
+    s += B
+    sb, db, tb, eb = d.sources[s:s + B], d.destinations[s:s + B], d.timestamps[s:s + B], d.edge_idxs[s:s + B]
+    neg = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * 3)
+    neg[:8] = db1[:8]                                                # roots that certainly hold a pending message from step 1
+    for p in tgn.parameters():
+        p.grad = None
+    emb = torch.cat(tgn.compute_temporal_embeddings(sb, db, neg, tb, eb, K))
+    remb = np.concatenate(ref.compute_temporal_embeddings(sb, db, neg, tb, eb, K))
+    assert relerr(emb.detach().cpu().numpy(), remb) < RTOL_EMB
+    R = 5 * B
+    bad = _near_kink_roots(ref._ctx, R, K)
+    assert bad.sum() < R // 3, bad.sum()
+    W = rs.randn(R, cfg.dim).astype(np.float32) / R
+    W[bad] = 0
+    (emb * torch.from_numpy(W).to(DEV)).sum().backward()
+    checked, worst = _grad_compare(tgn, ref.backward(W), RTOL_GRAD_KINKFREE, RTOL_GRAD_TIME)
+    assert checked >= 20, checked
+
+
+def test_full_size_evaluation_batch_slice_against_oracle(c2):
+    """SURVEY 8(f-1) at size: evaluation.py:63-145 for 64 interactions of the C2 graph, every one scoring all 500 items
+    (R = 64 x 502 = 32 128 roots, 0.67 M layer-1 instances), forward only in eval mode, against the oracle: embeddings,
+    ranks / recall / NDCG (canonical tie policy) and the memory state machine.  Half of the interactions share their
+    timestamp pairwise (day-granular real data repeats whole blocks of (item, time) roots): the grid dedup engages and has to
+    give the same embeddings as the plain list; the chunked walk (16 384 roots per pass) has to equal one pass."""
+    cfg, g, nf = c2
+    d = g.data
+    tgn = _model(cfg, g, nf, seed=14)
+    rs = np.random.RandomState(5)
+    msgs, mem = _steady_state(tgn, g, cfg, rs)
+    onf = OracleNeighborFinder(*build_adjacency(d.sources, d.destinations, d.edge_idxs, d.timestamps), uniform=False)
+    ref = _oracle_for(tgn, g, onf, cfg, True)
+    for v in range(1, g.n_nodes):
+        ref.messages[v] = [(msgs[v], np.float32(0))]
+    ref.memory = mem.copy()
+    B, K, n_items = 64, cfg.n_neighbors, cfg.n_items
+    s = 900000
+    sb, db, eb = d.sources[s:s + B], d.destinations[s:s + B], d.edge_idxs[s:s + B]
+    tb = d.timestamps[s:s + B].copy()
+    tb[1::2] = tb[0::2]                                               # 32 distinct timestamps
+    items = np.arange(cfg.n_users + 1, cfg.n_users + 1 + n_items)
+    neg = np.tile(items, B)
+    neg.reshape(B, n_items)[:, :40] = rs.randint(cfg.n_users + 1, cfg.n_users + 1 + n_items, size=(B, 40))   # draws with replacement (utils.py:99-101)
+    snap = [t.clone() for t in (tgn.memory.memory.data, tgn.memory.last_update.data, tgn.memory.msg_table, tgn.memory.msg_time, tgn.memory.has_msg)]
+
+    def restore():
+        with torch.no_grad():
+            for dst_t, src_t in zip((tgn.memory.memory.data, tgn.memory.last_update.data, tgn.memory.msg_table, tgn.memory.msg_time,
+                                     tgn.memory.has_msg), snap):
+                dst_t.copy_(src_t)
+    tgn.eval()
+    outs = {}
+    for mode, dedup, chunk in (("grid", True, 16384), ("plain", False, 16384), ("one_pass", False, 1 << 20)):
+        restore()
+        tgn.eval_dedup, tgn.eval_chunk_roots = dedup, chunk
+        with torch.no_grad():
+            se, de, ne = tgn.compute_temporal_embeddings(sb, db, neg, tb, eb, K)
+        outs[mode] = torch.cat([se, de, ne])
+    assert torch.equal(outs["grid"], outs["plain"]) and torch.equal(outs["plain"], outs["one_pass"])
+    tgn.eval_dedup, tgn.eval_chunk_roots = True, 16384
+    emb = outs["grid"]
+    rank, hits, ndcg = P.rank_metrics(emb, B, n_items)
+    # ---- oracle: the lazily updated memory once, the roots in chunks of 2 560 (one training batch's worth of tensors each)
+    memory, _, _ = ref._get_updated_memory()
+    nodes = np.concatenate([sb, db, neg])
+    ts = np.concatenate([tb, tb, np.repeat(tb, n_items)]).astype(np.float64)
+    # (node, time) pairs repeat: embed the distinct ones (the oracle is a pure function of them)
+    pairs, inv = np.unique(np.stack([nodes.astype(np.float64), ts], 1), axis=0, return_inverse=True)
+    remb_u = np.empty((len(pairs), cfg.dim), np.float32)
+    for c0 in range(0, len(pairs), 2560):
+        out, _ = ref._embed(memory, pairs[c0:c0 + 2560, 0].astype(np.int64), pairs[c0:c0 + 2560, 1], cfg.n_layers, K, None)
+        remb_u[c0:c0 + 2560] = out
+    remb = remb_u[inv.reshape(-1)]
+    got = emb.cpu().numpy()
+    assert relerr(got, remb) < RTOL_EMB, relerr(got, remb)
+    # ranking (evaluation.py:114-145) on the oracle's embeddings, canonical tie policy.  The two sides' scores agree to ~1e-6
+    # relative, and 500 random-init items score close together: the device rank has to lie between the counts of negatives
+    # that beat the positive by more than / by at least minus that margin (equal on most rows), and recall / NDCG follow from it
+    rs_, rd_, rn_ = remb[:B], remb[B:2 * B], remb[2 * B:].reshape(B, n_items, -1)
+    pos = (rs_ * rd_).sum(1)
+    negs = np.einsum("bd,bkd->bk", rs_, rn_)
+    eps = 2e-5 * max(np.abs(negs).max(), np.abs(pos).max())
+    same = neg.reshape(B, n_items) == db[:, None]                     # the destination among its own negatives (utils.py:96): an
+    r_lo = ((negs > pos[:, None] + eps) & ~same).sum(1) + same.sum(1)   # exact tie, counted by the canonical policy on both sides
+    r_hi = ((negs >= pos[:, None] - eps) & ~same).sum(1) + same.sum(1)
+    gr = rank.cpu().numpy()
+    assert np.all((gr >= r_lo) & (gr <= r_hi)), (gr, r_lo, r_hi)
+    assert (r_lo == r_hi).sum() >= B // 2                              # ... and most rows leave no room at all
+    for i, k in enumerate((1, 3, 5)):
+        assert np.array_equal(hits.cpu().numpy()[:, i], (gr < k).astype(np.float32))
+        assert np.allclose(ndcg.cpu().numpy()[:, i], np.where(gr < k, 1.0 / np.log2(gr + 2.0), 0.0), atol=1e-6)
+    # memory state machine after the evaluation batch (tgn.py:290-317)
+    positives = np.concatenate([sb, db])
+    ref._update_memory(positives)
+    for nid in positives:
+        ref.messages[int(nid)] = []
+    ref._get_raw_messages(sb, db, tb, eb)
+    ref._get_raw_messages(db, sb, tb, eb)
+    assert relerr(tgn.memory.memory.cpu().numpy(), ref.memory) < RTOL_EMB
+    assert np.array_equal(tgn.memory.last_update.cpu().numpy(), ref.last_update)
+    tab, mt, has = ref.pending_table()
+    assert relerr(tgn.memory.msg_table.cpu().numpy()[has], tab[has]) < RTOL_EMB
+    assert np.array_equal(tgn.memory.msg_time.cpu().numpy()[has], mt[has])
