@@ -65,6 +65,8 @@ def parse():
                     help="ONE process, no collective: time rank 0's share of the step (its shard's roots + the global state "
                          "update) for each listed world size, e.g. 1,2,4,8 - the compute-side ceiling of the scaling curve, "
                          "measurable on one GPU.  Prints one JSON line with a per-world-size table")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="bitwise run-to-run reproducible backward (fixed-point level-0 gradient rows, slab-folded time partials)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="start the N ranks, rendezvous, all-reduce the rank ids and print a line; no GPU work (CPU test of the launcher)")
     ap.add_argument("--batch", type=int, default=0, help="interactions per GPU per step (default: the config's)")
@@ -86,7 +88,7 @@ PMC_KERNEL = {"gemm_bx": "gemm_bx_areg_kernel", "gemm_tn_bx": "gemm_tn_group_bx_
               "gemm_nn": "void gemm_f32_kernel<false, true, 0, true>",
               "gemm_tn": "void gemm_tn_group_kernel<true>",
               "attn_fwd": "void attn_fwd_kernel<3, 2>", "attn_bwd": "void attn_bwd_kernel_direct<3, 2>",
-              "attn_bwd_runs": "void attn_bwd_runs_kernel<3, 2>"}
+              "attn_bwd_runs": "void attn_bwd_runs_kernel<3, 2, false>"}
 
 
 def pmc_traffic(family):
@@ -248,6 +250,7 @@ class Workload:
                                dropout=args.dropout, use_memory=cfg.use_memory, memory_dimension=cfg.dim,
                                message_function="identity", n_neighbors=cfg.n_neighbors)
         tgn.set_data_parallel(rank, world)
+        tgn.deterministic = bool(args.deterministic)
         tgn.dp_bucketed = world > 1 and args.allreduce == "buckets"
         self.emulate = False                                  # --emulate-ranks: a rank's compute without the collective
         broadcast_parameters(tgn.flat_parameters, world)
@@ -502,7 +505,7 @@ def main():
                    "block_ms_per_step": {"first": round(wl.block_ms[0], 4), "min": round(min(wl.block_ms), 4),
                                          "median": round(float(np.median(wl.block_ms)), 4), "last": round(wl.block_ms[-1], 4)},
                    **({"block_ms_all": [round(x, 4) for x in wl.block_ms]} if os.environ.get("PFO_BENCH_BLOCKS") else {}),
-                   "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4), "hip_graph": wl.graph_note,
+                   "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4), "hip_graph": wl.graph_note, "deterministic_backward": bool(args.deterministic),
                    "collective": ("%s all-reduce of the flat fp32 gradient, world %d"
                                   % ("rccl" if dist.get_backend() == "nccl" else dist.get_backend(), dist.get_world_size())) if world > 1 else None},
     }

@@ -262,6 +262,11 @@ typedef struct pfo_tgn_batch {
   const uint64_t* offset_dev; /* optional device word ADDED to `offset` by every kernel that draws random numbers (dropout
                                  masks, Philox neighbour draws).  A step captured into a HIP graph keeps its kernel
                                  arguments: the per-step stream position then lives here and is advanced on the device */
+  int32_t deterministic;    /* != 0: pfo_tgn_backward is bitwise reproducible run to run.  The two order-dependent sums of the
+                                 default path - float atomics into the level-0 gradient rows, fp64 atomics into the time-encoder
+                                 partial bins - become order-free: the rows are added as 2^-40 fixed-point int64 (integer addition
+                                 is associative), the partials go to one slab row per workgroup and are folded in row order.
+                                 Costs ~4 % of a C2 step (8-byte atomics); every other sum of the step is ordered already */
 } pfo_tgn_batch;
 
 /* Lazy memory update for touched nodes (tgn.py:251, memory_updater.py:35-53) + L-layer temporal graph

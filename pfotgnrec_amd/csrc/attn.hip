@@ -22,8 +22,14 @@ struct AttnDev {
   int d_nbr_nrep;     // ... and how many of them are in use (a power of two)
   // run-merged layer-1 backward: instances in (table row, run key) order, seg_ptr[*n_rows] of them
   const int32_t* members; const int32_t* seg_ptr; const int32_t* n_rows; const int32_t* run_cnt;
+  int det; double* dtime_slab;   // deterministic mode (attn.hpp)
   int abl;      // timing-only ablation switch (PFO_ATTN_ABL): 1 = spread the atomic destinations (wrong results)
 };
+
+// deterministic mode: a gradient element is added as 2^-40 fixed point - integer addition does not depend on the order
+__device__ __forceinline__ void det_add(float* table, int64_t idx, float v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(table) + idx, (unsigned long long)__double2ll_rn((double)v * PFO_DET_SCALE));
+}
 
 // dropout keep-bits for slot `lane` of instance n: bit h = keep for head h (H <= 4)
 __device__ __forceinline__ unsigned attn_keep_bits(uint64_t seed, uint64_t offset, int64_t n, int lane, float p) {
@@ -235,6 +241,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD_WAVES(N
 #endif
 int pfo_attn_bwd_max_parts() { return ATTN_TIME_BINS; }
 
+// (DMODE 3: the deterministic form of 1 - int64 fixed-point atomics into one table, attn.hpp)
 // DMODE: what happens to the neighbour-row gradients - 0 none (layer 1 without memory: level-0 rows are constants),
 // 1 float atomics into the rows `nbr_row` names (layer 1 over the touched-node table), 2 plain stores (layers >= 2,
 // where every (instance, slot) owns its row).  A template parameter: as a run-time test it cost three scalar branch
@@ -392,7 +399,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
           }
           dqe[h] = fmaf(cB[h], ke[c], dqe[h]);
         }
-        float* dst = (DMODE != 0) ? d_nbr_x + (int64_t)rows[c] * a.d_nbr_ld : nullptr;
+        float* dst = (DMODE == 1 || DMODE == 2) ? d_nbr_x + (int64_t)rows[c] * a.d_nbr_ld : nullptr;
         if (DMODE == 1 && a.abl == 1) dst = d_nbr_x + (int64_t)((((unsigned)rows[c] * 2654435761u) + (unsigned)n * 40503u) % 8192u) * a.d_nbr_ld;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -406,6 +413,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
           if (r < NR - 1 || cc < D) {                    // 64 * (NR - 1) < D: only the last r needs the lane test
             if (DMODE == 2) dst[cc] = (a.nbr_relu && !(kn[c][r] > 0.f)) ? 0.f : dkn;   // the row is a ReLU output of the layer below
             else if (DMODE == 1 && a.abl != 2) atomicAdd(dst + cc, dkn);
+            else if (DMODE == 3) det_add(a.d_nbr, (int64_t)rows[c] * a.d_nbr_ld + cc, dkn);
           }
           const float gsin = -ks[c][r] * dkt;            // d/d(arg) cos(arg) = -sin(arg); ks = 0 on lanes beyond D
           dw[r] += (double)gsin * (double)dtv[c];
@@ -437,8 +445,10 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
   for (int c = threadIdx.x; c < 2 * D; c += 256) {
     const int which = c / D, cc = c - which * D;
     const double v = s_red[0][which][cc] + s_red[1][which][cc] + s_red[2][which][cc] + s_red[3][which][cc];
-    // fp64 atomics into one of ATTN_TIME_BINS accumulator rows (all layers of a step share them; folded once at the end)
-    atomicAdd(&a.dtime_part[(int64_t)(blockIdx.x & (ATTN_TIME_BINS - 1)) * 2 * D + c], v);
+    // fp64 atomics into one of ATTN_TIME_BINS accumulator rows (all layers of a step share them; folded once at the end);
+    // deterministic mode: this workgroup's own slab row (folded in row order)
+    if (a.det) a.dtime_slab[(int64_t)blockIdx.x * 2 * D + c] = v;     // (once per workgroup: a run-time test costs nothing here)
+    else atomicAdd(&a.dtime_part[(int64_t)(blockIdx.x & (ATTN_TIME_BINS - 1)) * 2 * D + c], v);
   }
 }
 
@@ -481,7 +491,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
 //    (wave-uniform), not per chunk on every argument;
 //  * the per-key softmax-backward scalars of a chunk are reduced together (one interleaved DPP tree for KC*H sums), the running
 //    sum of cB per key lives in a register (select on lane == key) instead of an LDS read-modify-write.
-template <int NR, int H>
+template <int NR, int H, bool DET>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(NR, H)))) void attn_bwd_runs_kernel(const AttnDev a) {
   __shared__ float s_tw[NR * 64], s_tb[NR * 64];
   __shared__ float s_cA[RUN_CHUNK][H][64];     // [instance of the group][head][slot]: cA of that key; zero where the slot is empty
@@ -552,7 +562,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         while (vmask) {
           const int j = __ffsll((long long)vmask) - 1;
           vmask &= vmask - 1ull;
-          float* dst = d_nbr_x + (int64_t)rl_i(run_rows, j) * a.d_nbr_ld;
+          const int64_t drow = (int64_t)rl_i(run_rows, j) * a.d_nbr_ld;
+          float* dst = d_nbr_x + drow;
           float row[NR];
 #pragma unroll
           for (int r = 0; r < NR; ++r) row[r] = 0.f;
@@ -571,7 +582,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
             const int cc = lane + 64 * r;
-            if ((r < NR - 1 || cc < D) && a.abl != 2) atomicAdd(dst + cc, row[r]);
+            if ((r < NR - 1 || cc < D) && a.abl != 2) {
+              if (DET) det_add(a.d_nbr, drow + cc, row[r]); else atomicAdd(dst + cc, row[r]);
+            }
           }
         }
       }
@@ -767,13 +780,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
     for (int r = 0; r < NR; ++r) {
       const int c = lane + 64 * r;
       if (c < D) {
-        double* bin = a.dtime_part + (int64_t)(chunk & (ATTN_TIME_BINS - 1)) * 2 * D;
-        atomicAdd(bin + c, (double)dwc[r]);
-        atomicAdd(bin + D + c, (double)dbc[r]);
+        if (DET) {
+          a.dtime_slab[(int64_t)chunk * 2 * D + c] = (double)dwc[r];
+          a.dtime_slab[(int64_t)chunk * 2 * D + D + c] = (double)dbc[r];
+        } else {
+          double* bin = a.dtime_part + (int64_t)(chunk & (ATTN_TIME_BINS - 1)) * 2 * D;
+          atomicAdd(bin + c, (double)dwc[r]);
+          atomicAdd(bin + D + c, (double)dbc[r]);
+        }
       }
     }
   }
+  // deterministic mode: the launch has one workgroup per POSSIBLE chunk; those beyond the members' count own a zero row
+  if (DET && (int)blockIdx.x >= n_chunks)
+    for (int c = lane; c < 2 * D; c += 64) a.dtime_slab[(int64_t)blockIdx.x * 2 * D + c] = 0.0;
 }
+
+int64_t pfo_attn_bwd_det_parts(int64_t N) { return std::max<int64_t>(pfo_ceil_div(N, RUN_CHUNK), std::min<int64_t>(ATTN_BWD_MAX_BLOCKS, pfo_ceil_div(N, 4))); }
 
 static void to_dev(const PfoAttn& a, AttnDev& d) {
   d.N = a.N; d.K = a.K; d.D = a.D; d.Ef = a.Ef; d.H = a.H; d.Cp = a.Cp;
@@ -785,6 +808,7 @@ static void to_dev(const PfoAttn& a, AttnDev& d) {
   d.ctx = a.ctx; d.attw = a.attw; d.inv = a.inv;
   d.dctx = a.dctx; d.dQK = a.dQK; d.d_nbr = a.d_nbr; d.d_nbr_ld = a.d_nbr_ld; d.d_nbr_rep = a.d_nbr_rep; d.d_nbr_nrep = a.d_nbr_nrep > 0 ? a.d_nbr_nrep : 1;
   d.dtime_part = a.dtime_part;
+  d.det = a.det; d.dtime_slab = a.dtime_slab;
   d.members = a.members; d.seg_ptr = a.seg_ptr; d.n_rows = a.n_rows; d.run_cnt = a.run_cnt;
 }
 
@@ -831,6 +855,7 @@ static int check_common(const PfoAttn& a) {
 template <int NR, int H> __global__ __launch_bounds__(256, BWD_WAVES(NR, H, 0)) void attn_bwd_kernel_none(const AttnDev a) { attn_bwd_body<NR, H, 0>(a); }
 template <int NR, int H> __global__ __launch_bounds__(256, BWD_WAVES(NR, H, 1)) void attn_bwd_kernel(const AttnDev a) { attn_bwd_body<NR, H, 1>(a); }
 template <int NR, int H> __global__ __launch_bounds__(256, BWD_WAVES(NR, H, 2)) void attn_bwd_kernel_direct(const AttnDev a) { attn_bwd_body<NR, H, 2>(a); }
+template <int NR, int H> __global__ __launch_bounds__(256, BWD_WAVES(NR, H, 1)) void attn_bwd_kernel_det(const AttnDev a) { attn_bwd_body<NR, H, 3>(a); }
 int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream) {
   if (int rc = check_common(a)) return rc;
   AttnDev d;
@@ -856,9 +881,11 @@ bool pfo_attn_bwd_uses_runs(const PfoAttn& a) {
 int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
   if (int rc = check_common(a)) return rc;
   PFO_REQUIRE(a.dctx && a.dQK && a.dtime_part, "null backward buffers");
+  PFO_REQUIRE(!a.det || a.dtime_slab, "deterministic mode needs the slab");
   AttnDev d;
   to_dev(a, d);
-  static const int bwd_blocks = getenv("PFO_ATTN_BWD_BLOCKS") ? atoi(getenv("PFO_ATTN_BWD_BLOCKS")) : ATTN_BWD_MAX_BLOCKS;
+  static const int bwd_blocks_env = getenv("PFO_ATTN_BWD_BLOCKS") ? atoi(getenv("PFO_ATTN_BWD_BLOCKS")) : ATTN_BWD_MAX_BLOCKS;
+  const int bwd_blocks = a.det ? ATTN_BWD_MAX_BLOCKS : bwd_blocks_env;          // (deterministic: the slab's row count is fixed)
   const int grid = (int)std::min<int64_t>(bwd_blocks, pfo_ceil_div(a.N, 4));
   // rows read again + their gradient rows written/added, qk + dctx + ctx in, dqk out
   const double C = 2.0 * a.D + a.Ef;
@@ -871,38 +898,35 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
     // grid is capped for an experiment)
     static const int rblocks = getenv("PFO_ATTN_RUNS_BLOCKS") ? atoi(getenv("PFO_ATTN_RUNS_BLOCKS")) : 0;
     const int64_t all_chunks = pfo_ceil_div(a.N, RUN_CHUNK);
-    const int rgrid = (int)(rblocks > 0 ? std::min<int64_t>(rblocks, all_chunks) : all_chunks);
+    const int rgrid = (int)((rblocks > 0 && !a.det) ? std::min<int64_t>(rblocks, all_chunks) : all_chunks);
     pfo_prof_begin(stream);
     const int NRv = (a.D + 63) / 64;
     const dim3 g((unsigned)rgrid), b(64);
     bool done = true;
+#define RUNS_GO(NRc, Hc)                                                                                              \
+  case NRc * 8 + Hc:                                                                                                  \
+    if (a.det) hipLaunchKernelGGL((attn_bwd_runs_kernel<NRc, Hc, true>), g, b, run_lds, stream, d);                   \
+    else hipLaunchKernelGGL((attn_bwd_runs_kernel<NRc, Hc, false>), g, b, run_lds, stream, d);                        \
+    break;
     switch (NRv * 8 + a.H) {
-      case 1 * 8 + 1: hipLaunchKernelGGL((attn_bwd_runs_kernel<1, 1>), g, b, run_lds, stream, d); break;
-      case 1 * 8 + 2: hipLaunchKernelGGL((attn_bwd_runs_kernel<1, 2>), g, b, run_lds, stream, d); break;
-      case 1 * 8 + 4: hipLaunchKernelGGL((attn_bwd_runs_kernel<1, 4>), g, b, run_lds, stream, d); break;
-      case 2 * 8 + 1: hipLaunchKernelGGL((attn_bwd_runs_kernel<2, 1>), g, b, run_lds, stream, d); break;
-      case 2 * 8 + 2: hipLaunchKernelGGL((attn_bwd_runs_kernel<2, 2>), g, b, run_lds, stream, d); break;
-      case 2 * 8 + 4: hipLaunchKernelGGL((attn_bwd_runs_kernel<2, 4>), g, b, run_lds, stream, d); break;
-      case 3 * 8 + 1: hipLaunchKernelGGL((attn_bwd_runs_kernel<3, 1>), g, b, run_lds, stream, d); break;
-      case 3 * 8 + 2: hipLaunchKernelGGL((attn_bwd_runs_kernel<3, 2>), g, b, run_lds, stream, d); break;
-      case 3 * 8 + 4: hipLaunchKernelGGL((attn_bwd_runs_kernel<3, 4>), g, b, run_lds, stream, d); break;
-      case 4 * 8 + 1: hipLaunchKernelGGL((attn_bwd_runs_kernel<4, 1>), g, b, run_lds, stream, d); break;
-      case 4 * 8 + 2: hipLaunchKernelGGL((attn_bwd_runs_kernel<4, 2>), g, b, run_lds, stream, d); break;
-      case 4 * 8 + 4: hipLaunchKernelGGL((attn_bwd_runs_kernel<4, 4>), g, b, run_lds, stream, d); break;
+      RUNS_GO(1, 1) RUNS_GO(1, 2) RUNS_GO(1, 4) RUNS_GO(2, 1) RUNS_GO(2, 2) RUNS_GO(2, 4)
+      RUNS_GO(3, 1) RUNS_GO(3, 2) RUNS_GO(3, 4) RUNS_GO(4, 1) RUNS_GO(4, 2) RUNS_GO(4, 4)
       default: done = false;
     }
+#undef RUNS_GO
     PFO_REQUIRE(done, "unsupported (D, H) combination");
     PFO_LAUNCH_CHECK();
     pfo_prof_end(PFO_PROF_ATTN_BWD_RUNS, bytes, stream);
-    if (n_parts) *n_parts = ATTN_TIME_BINS;
+    if (n_parts) *n_parts = a.det ? rgrid : ATTN_TIME_BINS;       // deterministic: slab rows written (one per workgroup)
     return PFO_OK;
   }
   pfo_prof_begin(stream);
   if (dmode == 0) { ATTN_DISPATCH(attn_bwd_kernel_none, grid); }
+  else if (dmode == 1 && a.det) { ATTN_DISPATCH(attn_bwd_kernel_det, grid); }
   else if (dmode == 1) { ATTN_DISPATCH(attn_bwd_kernel, grid); }
   else { ATTN_DISPATCH(attn_bwd_kernel_direct, grid); }
   PFO_LAUNCH_CHECK();
   pfo_prof_end(PFO_PROF_ATTN_BWD, bytes, stream);
-  if (n_parts) *n_parts = ATTN_TIME_BINS;
+  if (n_parts) *n_parts = a.det ? grid : ATTN_TIME_BINS;
   return PFO_OK;
 }

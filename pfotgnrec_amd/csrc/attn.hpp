@@ -50,6 +50,11 @@ struct PfoAttn {
   int64_t d_nbr_rep = 0;            // atomically added rows: floats between the per-XCD replicas of the table (0 = a single table)
   int d_nbr_nrep = 1;               // replicas in use (power of two <= PFO_GRAD_REPLICAS): XCD x adds into replica x & (n - 1)
   double* dtime_part = nullptr;     // [ATTN_TIME_BINS, 2*D] fp64 accumulators (dw | db) of the time encoder: ADDED to (zero them per step)
+  // deterministic mode (pfo_tgn_batch.deterministic): the time-encoder partials go to dtime_slab, one row of 2*D doubles per
+  // workgroup (pfo_attn_bwd_det_parts(N) rows, every row written), and atomically added neighbour rows are int64 fixed point
+  // (PFO_DET_SCALE) in a table of d_nbr_ld int64 per row at d_nbr
+  int det = 0;
+  double* dtime_slab = nullptr;
   // optional (layer 1 over the touched-node table, atomically added rows, most-recent sampling): the instances ordered by
   // (table row, entries before the instance's time) as built by pfo_seg_build_launch with key_src = run_cnt.  Consecutive
   // members of a row have neighbour lists that are shifts of each other, so their key-side gradients are summed on chip by
@@ -65,6 +70,8 @@ int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream);
 // *n_parts receives ATTN_TIME_BINS (rows of dtime_part that may hold contributions)
 int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream);
 int pfo_attn_bwd_max_parts();
+int64_t pfo_attn_bwd_det_parts(int64_t N);   // slab rows a deterministic backward launch over N instances writes (all of them)
+#define PFO_DET_SCALE 1099511627776.0       // 2^40: level-0 gradient rows as fixed point, resolution 9e-13, range +-8e6
 // true when pfo_attn_bwd_launch will take the run-merged kernel for `a`: dQK row m then belongs to the m-th MEMBER
 // (a.members[m]), not to instance m
 bool pfo_attn_bwd_uses_runs(const PfoAttn& a);

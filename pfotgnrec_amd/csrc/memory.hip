@@ -389,7 +389,7 @@ int pfo_gru_gates_fwd_launch(const float* gi, const float* gh, const float* h_ro
 __global__ void gru_gates_bwd_kernel(float* __restrict__ gi, float* __restrict__ gh, const float* __restrict__ h_rows,
                                      const uint8_t* __restrict__ hm, const int32_t* __restrict__ n_touched, int D,
                                      const float* __restrict__ d_h0, int n_rep, int64_t rep_stride,
-                                     const float* __restrict__ d_extra) {
+                                     const float* __restrict__ d_extra, int det) {
   const int64_t total = (int64_t)(*n_touched) * D;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int s = (int)(e / D), d = (int)(e - (int64_t)s * D);
@@ -403,6 +403,8 @@ __global__ void gru_gates_bwd_kernel(float* __restrict__ gi, float* __restrict__
       const float z = sigmoidf_acc(gis[D + d] + ghs[D + d]);
       const float nn = tanhf(gis[2 * D + d] + r * ghn);
       float dh = 0.f;                                  // the level-0 gradient is kept in one replica per XCD
+      if (det) dh = (float)((double)reinterpret_cast<const long long*>(d_h0)[e] * (1.0 / 1099511627776.0));   // 2^-40 fixed point (attn.hpp)
+      else
       for (int q = 0; q < n_rep; ++q) dh += d_h0[(int64_t)q * rep_stride + e];
       if (d_extra) dh += d_extra[e];                   // the rows' own (query-side) gradient, already summed per row
       const float dn = dh * (1.f - z);
@@ -420,10 +422,10 @@ __global__ void gru_gates_bwd_kernel(float* __restrict__ gi, float* __restrict__
 
 int pfo_gru_gates_bwd_launch(float* gi, float* gh, const float* h_rows, const uint8_t* hm, const int32_t* n_touched,
                              int cap, int D, const float* d_h0, int n_rep, int64_t rep_stride, const float* d_extra,
-                             hipStream_t stream) {
+                             int det, hipStream_t stream) {
   const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div((int64_t)cap * D, 256));
   hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(nb), dim3(256), 0, stream, gi, gh, h_rows, hm, n_touched, D, d_h0, n_rep, rep_stride,
-                     d_extra);
+                     d_extra, det);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

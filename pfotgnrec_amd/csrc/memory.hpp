@@ -28,7 +28,8 @@ int pfo_gru_gates_fwd_launch(const float* gi, const float* gh, const float* h_ro
 // d_extra (optional): one more [rows, D] addend of d h' (the rows' query-side gradient, layer 1)
 int pfo_gru_gates_bwd_launch(float* gi, float* gh, const float* h_rows, const uint8_t* hm, const int32_t* n_touched,
                              int cap, int D, const float* d_h0, int n_rep, int64_t rep_stride, const float* d_extra,
-                             hipStream_t stream);
+                             int det, hipStream_t stream);
+// (det: d_h0 is ONE table of int64 fixed-point sums, attn.hpp PFO_DET_SCALE)
 // dst[s] = src[touched_ids[s]], s < *n_touched
 int pfo_gather_rows_launch(const float* src, int D, const int32_t* touched_ids, const int32_t* n_touched, int cap, float* dst,
                            hipStream_t stream);
@@ -72,4 +73,5 @@ int pfo_cq_backward_launch(const float* const* gq, const float* const* Wq, int n
 // scratch: pfo_fold_parts_scratch_doubles(n) doubles; tickets: 64 ints, zero before the first use (self-resetting)
 int64_t pfo_fold_parts_scratch_doubles(int n);
 int pfo_fold_parts_launch(const double* parts, int n_parts, int n, float* out, int accumulate, double* scratch, int* tickets,
-                          hipStream_t stream);
+                          hipStream_t stream, double* out64 = nullptr);
+// (out64 != null: the sums are stored there as doubles instead of being cast into `out`)

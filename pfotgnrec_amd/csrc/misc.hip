@@ -461,7 +461,7 @@ int pfo_cq_backward_launch(const float* const* gq, const float* const* Wq, int n
 #define FOLD_SLICES 32
 __global__ __launch_bounds__(256) void fold_parts_kernel(const double* __restrict__ parts, int n_parts, int n,
                                                          float* __restrict__ out, int accumulate, double* scratch,
-                                                         int* tickets) {
+                                                         int* tickets, double* __restrict__ out64) {
   __shared__ double s_red[4][64];
   __shared__ int s_last;
   const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
@@ -499,16 +499,17 @@ __global__ __launch_bounds__(256) void fold_parts_kernel(const double* __restric
       t2 += scratch[(int64_t)(y + 2) * n + col]; t3 += scratch[(int64_t)(y + 3) * n + col];
     }
     const double t = (t0 + t1) + (t2 + t3);
-    out[col] = accumulate ? (float)((double)out[col] + t) : (float)t;
+    if (out64) out64[col] = t;
+    else out[col] = accumulate ? (float)((double)out[col] + t) : (float)t;
   }
   if (threadIdx.x == 0) tickets[blockIdx.x] = 0;
 }
 int64_t pfo_fold_parts_scratch_doubles(int n) { return (int64_t)FOLD_SLICES * n; }
 int pfo_fold_parts_launch(const double* parts, int n_parts, int n, float* out, int accumulate, double* scratch, int* tickets,
-                          hipStream_t stream) {
+                          hipStream_t stream, double* out64) {
   PFO_REQUIRE(n <= 64 * 64, "too many columns for the ticket array");
   hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)pfo_ceil_div(n, 64), FOLD_SLICES), dim3(256), 0, stream, parts, n_parts,
-                     n, out, accumulate, scratch, tickets);
+                     n, out, accumulate, scratch, tickets, out64);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

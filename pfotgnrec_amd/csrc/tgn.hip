@@ -54,7 +54,7 @@ struct Ws {
   float *dh1, *dctx, *dQK;
   float* dH[PFO_MAX_LAYERS + 1];
   float *slabs, *slabs2;      // split-K slabs of the weight-gradient launches: main stream / side stream
-  double *dtime, *fold_scratch;
+  double *dtime, *fold_scratch, *dtime_slab;
   int32_t* tickets;
   int64_t slab_floats;
   size_t zero_bytes, mark_bytes;
@@ -192,6 +192,12 @@ Ws carve(const pfo_tgn_config* c, void* base) {
   w.slabs = take<float>(p, w.slab_floats);
   w.slabs2 = take<float>(p, w.slab_floats);
   w.fold_scratch = take<double>(p, pfo_fold_parts_scratch_doubles(2 * d.D));
+  {
+    // deterministic mode: one slab row of time-encoder partials per attention-backward workgroup, all layers
+    int64_t rows = 0;
+    for (int l = 1; l <= d.L; ++l) rows += pfo_attn_bwd_det_parts(d.ncap[l]);
+    w.dtime_slab = take<double>(p, rows * 2 * d.D);
+  }
   w.bytes = p - reinterpret_cast<char*>(base);
   return w;
 }
@@ -680,7 +686,10 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   const int64_t rep_stride = (int64_t)d.capP * D;             // floats between the per-XCD replicas of d_h0
   // Per-XCD replicas of the level-0 gradient table pay off only for the per-instance atomics (uniform sampling: 4 replicas
   // 0.537 -> 0.506 ms); the run-merged kernel issues 2-3x fewer and measures best on ONE table (1.656 vs 1.665 ms/step)
-  const int n_rep = (c->use_memory && !b->uniform && pfo_attn_bwd_runs_possible(K)) ? 1 : PFO_GRAD_REPLICAS;
+  const int det = b->deterministic ? 1 : 0;
+  const int n_rep = (det || (c->use_memory && !b->uniform && pfo_attn_bwd_runs_possible(K))) ? 1 : PFO_GRAD_REPLICAS;
+  static_assert(PFO_GRAD_REPLICAS >= 2, "the deterministic int64 gradient table needs the room of two float replicas");
+  int64_t det_rows = 0;                                        // slab rows written so far (deterministic mode)
 
   const int Cp = d.Cp, HCp = H * d.Cp, WQ = HCp + D;
   Side& sd = side();
@@ -694,7 +703,8 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
   if (mean_src) RUN(pfo_mean_launch(mean_src, mean_n, mean_out, ss));     // (a reduction the caller left to this call's side stream)
-  if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_touched, capP, D, n_rep, rep_stride, ss));
+  // (deterministic: the table holds int64 fixed-point sums - rows of 2 D floats' worth)
+  if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_touched, capP, det ? 2 * D : D, n_rep, rep_stride, ss));
   RUN(pfo_seg_build_launch(idx0, w.nodes[0], (int)n[1], capP, b->uniform ? nullptr : w.cnt1, w.seg_ptr, w.seg_cur,
                            w.seg_tmp, w.seg_mem, w.seg_scratch, ss));
   HIPOK(hipEventRecord(sd.seg_done, ss), "event record failed");
@@ -792,6 +802,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     if (l == 1) { a.d_nbr = c->use_memory ? w.d_h0 : nullptr; a.d_nbr_ld = D; a.d_nbr_rep = rep_stride; a.d_nbr_nrep = n_rep; }
     else        { a.d_nbr = w.dH[l - 1]; a.d_nbr_ld = D; }
     a.dtime_part = w.dtime;
+    a.det = det; a.dtime_slab = w.dtime_slab + det_rows * 2 * D;
     int n_parts = 0;
     if (l == 1 && c->use_memory) HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");   // d_h0 is clear, the groups exist
     if (l == 1 && c->use_memory && !b->uniform) {
@@ -800,6 +811,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     }
     const int dqk_by_member = pfo_attn_bwd_uses_runs(a) ? 1 : 0;
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
+    if (det) det_rows += n_parts;
     // merged query/key projection: dx += dqk' Wqk, dWqk = dqk'^T x, gqk = colsum(dqk')
     if (l == 1) {
       // Layer 1: x is a row of the touched-node table shared by all instances on that node, so everything that is linear
@@ -988,7 +1000,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   // ---- GRU parameters (messages and stored memory are constants: SURVEY App. A-6)
   if (c->use_memory) {
     RUN(pfo_gru_gates_bwd_launch(w.gi, w.gh, w.h_rows, w.hm, w.n_touched, capP, D, w.d_h0, n_rep, rep_stride,
-                                 w.dx_tab, s));
+                                 w.dx_tab, det, s));
     {
       PfoTnProblem gp[2];
       gp[0].A = w.gi; gp[0].lda = 3 * D; gp[0].B = w.msg_rows; gp[0].ldb = d.M; gp[0].M = 3 * D; gp[0].N = d.M;
@@ -1001,6 +1013,8 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   // join the side streams, then ONE launch finishes the time-encoder gradients: the folded query-bias backward of layers
   // 1 .. L-1 (the top layer's ran with its chain), + its parked time-bias term, + the fold of the attention backwards' fp64
   // partial sums into time_w / time_b (fixed order)
+  // deterministic mode: the attention backwards' slab rows fold, in row order, into bin 0 of the (otherwise empty) fp64 bins
+  if (det) RUN(pfo_fold_parts_launch(w.dtime_slab, (int)det_rows, 2 * D, nullptr, 0, w.fold_scratch, w.tickets, s, w.dtime));
   // (both side streams are joined by the caller's stream itself: chaining them - the first side stream waiting for the second,
   //  the caller's for the first, one wait fewer on the critical path - makes hipStreamEndCapture of ROCm 7.0 segfault)
   HIPOK(hipEventRecord(sd.done2, sd.s2), "event record failed");

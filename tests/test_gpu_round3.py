@@ -129,3 +129,53 @@ def test_rccl_world1_allreduce_of_flat_gradient():
     out = subprocess.run(["timeout", "-k", "10", "300", sys.executable, "-c", _RCCL_CHILD % REPO, str(port)], env=env,
                          capture_output=True)
     assert out.returncode == 0 and b"RCCL_OK" in out.stdout, out.stderr.decode()[-3000:]
+
+
+# ------------------------------------------------------------------ deterministic backward
+@pytest.mark.parametrize("uniform", [False, True])
+def test_deterministic_backward_is_bitwise_reproducible(uniform):
+    """``tgn.deterministic = True`` (pfo_tgn_batch.deterministic): the same step from the same state gives bit-identical
+    gradients run after run - level-0 rows summed as 2^-40 fixed-point int64, time-encoder partials folded from per-workgroup
+    slab rows - and agrees with the default (float-atomic) backward to fp32 rounding.  Most-recent sampling takes the
+    shift-merged layer-1 kernel, uniform sampling the per-instance one."""
+    from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+    torch.manual_seed(3)
+    cfg = SyntheticConfig("det", 400, 30, 8000, 64, 2, 10, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    tgn = P.TGN(P.get_neighbor_finder(d, uniform), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=2, dropout=0.1,
+                use_memory=True, memory_dimension=64, message_function="identity", n_neighbors=10)
+    with torch.no_grad():
+        tgn.time_encoder.w.bias.normal_(0, 0.3)
+    rs = np.random.RandomState(1)
+    B = 96
+    tgn.train()
+    for s in (4000, 4096):                                              # populate memory and pending messages
+        neg = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * 3)
+        with torch.no_grad():
+            tgn.compute_temporal_embeddings(d.sources[s:s + B], d.destinations[s:s + B], neg, d.timestamps[s:s + B], d.edge_idxs[s:s + B], 10)
+    m = tgn.memory
+    snap = [t.clone() for t in (m.memory.data, m.last_update.data, m.msg_table, m.msg_time, m.has_msg)]
+    s = 4192
+    batch = (d.sources[s:s + B], d.destinations[s:s + B], rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * 3),
+             d.timestamps[s:s + B], d.edge_idxs[s:s + B])
+
+    def grad(det):
+        with torch.no_grad():
+            for dst_t, src_t in zip((m.memory.data, m.last_update.data, m.msg_table, m.msg_time, m.has_msg), snap):
+                dst_t.copy_(src_t)
+        tgn.deterministic = det
+        tgn._step = 1000                                                # same Philox stream position (dropout masks, draws)
+        tgn.zero_grad(set_to_none=True)
+        emb = torch.cat(tgn.compute_temporal_embeddings(*batch, 10))
+        P.bpr_loss(emb, B, 3).backward()
+        return tgn.flat_grad.clone()
+
+    g1, g2, g3 = grad(True), grad(True), grad(True)
+    assert torch.equal(g1, g2) and torch.equal(g2, g3)
+    g0 = grad(False)
+    D = 64
+    den = g0[2 * D:].abs().max().item()
+    assert (g1[2 * D:] - g0[2 * D:]).abs().max().item() <= 2e-5 * den       # same sums, different rounding order
+    assert (g1[:2 * D] - g0[:2 * D]).abs().max().item() <= 3e-3 * g0[:2 * D].abs().max().item()   # time encoder: cancellation-heavy
+    tgn.deterministic = False
