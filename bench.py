@@ -138,25 +138,32 @@ def cpu_baseline(cfg, graph, batch, steps):
     m = {k: np.zeros_like(v) for k, v in ref.P.items()}
     v2 = {k: np.zeros_like(v) for k, v in ref.P.items()}
     s = cfg.n_edges // 2
-    times = []
+    times, phases = [], []
     for it in range(steps + 1):
         sl = slice(s, s + batch)
         sb, db, tb, eb = d.sources[sl], d.destinations[sl], d.timestamps[sl], d.edge_idxs[sl]
         t0 = time.perf_counter()
         neg = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=batch * 3)
         se, de, ne = ref.compute_temporal_embeddings(sb, db, neg, tb, eb, cfg.n_neighbors)
+        t1 = time.perf_counter()
         loss, cache = T.bpr_loss(se, de.reshape(batch, 1, -1), ne.reshape(batch, 3, -1))
         ds, dp, dn = T.bpr_loss_backward(cache)
+        t2 = time.perf_counter()
         grads = ref.backward(np.concatenate([ds, dp.reshape(batch, -1), dn.reshape(3 * batch, -1)]))
+        t3 = time.perf_counter()
         for k in ref.P:                                   # Adam, main.py:123
             g = grads[k]
             m[k] = 0.9 * m[k] + 0.1 * g
             v2[k] = 0.999 * v2[k] + 0.001 * g * g
             ref.P[k] = ref.P[k] - 1e-4 * (m[k] / (1 - 0.9 ** (it + 1))) / (np.sqrt(v2[k] / (1 - 0.999 ** (it + 1))) + 1e-8)
-        dt = time.perf_counter() - t0
+        t4 = time.perf_counter()
         if it > 0:                                        # first step pays page-in / BLAS warm-up
-            times.append(dt)
+            times.append(t4 - t0)
+            phases.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))
         s += batch
+    ph = np.median(np.array(phases), axis=0)
+    cpu_baseline.phases = {"sampling+memory+forward_s": round(float(ph[0]), 3), "loss_s": round(float(ph[1]), 4),
+                           "backward_s": round(float(ph[2]), 3), "adam_s": round(float(ph[3]), 4)}
     return batch / float(np.median(times)), float(np.sum(times))
 
 
@@ -556,8 +563,12 @@ def main():
             v, spent = cpu_baseline(cfg, make_graph(cfg, with_prices=False), args.cpu_batch, args.cpu_steps)
             out["cpu_baseline"] = {"value": round(v, 2), "unit": "interactions/s", "cores": threads, "kind": "port",
                                    "sample": "%d step(s) of %d interactions of the same workload after one untimed step "
-                                             "(oracle/tgn_oracle.py: numpy fp32 + BLAS + C fmaf/cosf helper, steady-state "
-                                             "memory), median step, %.1f s timed" % (args.cpu_steps, args.cpu_batch, spent)}
+                                             "(oracle/tgn_oracle.py: numpy fp32 + BLAS + C fmaf/cosf helper; the attention layers' "
+                                             "53 760-instance calls run as 2 048-row chunks on a thread pool of min(64, cores) "
+                                             "workers with single-threaded BLAS inside, everything else on %d BLAS threads; "
+                                             "steady-state memory), median step, %.1f s timed"
+                                             % (args.cpu_steps, args.cpu_batch, threads, spent),
+                                   "phases_median_s": getattr(cpu_baseline, "phases", None)}
         except Exception as e:  # the baseline never blocks the measurement
             out["cpu_baseline"] = {"value": None, "unit": "interactions/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": "failed: %r" % (e,)}
