@@ -305,7 +305,15 @@ int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.f / (1.f + expf(-x)); }
+// sigmoid / tanh of the GRU gates on the hardware exponential (v_exp_f32 = 2^x, ~1 ulp) and v_rcp_f32: ~1e-7 absolute, against
+// ~40 instructions each for expf / tanhf (the two gate kernels are otherwise plain streaming passes)
+__device__ __forceinline__ float sigmoidf_acc(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x)); }
+__device__ __forceinline__ float tanhf_acc(float x) {
+  // tanh(x) = sign(x) (1 - e) / (1 + e), e = exp(-2|x|): no cancellation for small |x| (1 - e is exact to an ulp of e ~ 1)
+  const float e = __builtin_amdgcn_exp2f(-2.88539008177792681472f * fabsf(x));
+  const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
+  return copysignf(t, x);
+}
 
 // Two independent jobs that both wait for the compaction, in ONE launch: blocks [0, row_blocks) copy the touched nodes' rows
 // out of the full tables (msg_table may be null: no-memory models copy node features only), the blocks behind them translate
@@ -368,7 +376,7 @@ __global__ void gru_gates_fwd_kernel(const float* __restrict__ gi, const float* 
       const float* ghs = gh + (int64_t)s * 3 * D;
       const float r = sigmoidf_acc(gis[d] + ghs[d]);
       const float z = sigmoidf_acc(gis[D + d] + ghs[D + d]);
-      const float nn = tanhf(gis[2 * D + d] + r * ghs[2 * D + d]);
+      const float nn = tanhf_acc(gis[2 * D + d] + r * ghs[2 * D + d]);
       hn = (1.f - z) * nn + z * h;
     }
     upd_mem[e] = hn;
@@ -401,7 +409,7 @@ __global__ void gru_gates_bwd_kernel(float* __restrict__ gi, float* __restrict__
       const float ghn = ghs[2 * D + d];
       const float r = sigmoidf_acc(gis[d] + ghs[d]);
       const float z = sigmoidf_acc(gis[D + d] + ghs[D + d]);
-      const float nn = tanhf(gis[2 * D + d] + r * ghn);
+      const float nn = tanhf_acc(gis[2 * D + d] + r * ghn);
       float dh = 0.f;                                  // the level-0 gradient is kept in one replica per XCD
       if (det) dh = (float)((double)reinterpret_cast<const long long*>(d_h0)[e] * (1.0 / 1099511627776.0));   // 2^-40 fixed point (attn.hpp)
       else

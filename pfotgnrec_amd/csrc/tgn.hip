@@ -586,10 +586,12 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     const float* b1_l = (l == 1) ? p.b1 : lw.b1_f;
 
     if (!composites_awaited) {
-      HIPOK(hipStreamWaitEvent(s, sd.layer[0], 0), "event wait failed");   // composite weights are ready
+      // ONE wait for everything the side stream prepared (composite weights, images and, with several layers, the fc2-folded
+      // ones: its ~14 launches are done long before the sampling / GRU phase of this stream is) - every wait on another
+      // stream's event costs this stream ~5-15 us on this part, signalled or not
+      HIPOK(hipStreamWaitEvent(s, L >= 2 ? sd.fold_done : sd.layer[0], 0), "event wait failed");
       composites_awaited = true;
     }
-    if (l == 2) HIPOK(hipStreamWaitEvent(s, sd.fold_done, 0), "event wait failed");   // ... and the folded ones of the layers >= 2
     // ---- qk' = x Wqk^T + cqk.  Layer 1: x is a row of the touched-node table, shared by every instance that sits on
     // that node (~54 k instances on ~11 k nodes at C2): ONE projection of the table, [qk' | x W1[:, E:]^T] per row
     if (l == 1) {
@@ -1015,10 +1017,13 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   // partial sums into time_w / time_b (fixed order)
   // deterministic mode: the attention backwards' slab rows fold, in row order, into bin 0 of the (otherwise empty) fp64 bins
   if (det) RUN(pfo_fold_parts_launch(w.dtime_slab, (int)det_rows, 2 * D, nullptr, 0, w.fold_scratch, w.tickets, s, w.dtime));
-  // (both side streams are joined by the caller's stream itself: chaining them - the first side stream waiting for the second,
-  //  the caller's for the first, one wait fewer on the critical path - makes hipStreamEndCapture of ROCm 7.0 segfault)
+  // The side streams are joined in a chain - the first waits for the second, the caller's stream for the first: one wait on
+  // the critical path instead of two - except while the caller's stream is being captured into a HIP graph, where that
+  // topology makes hipStreamEndCapture of ROCm 7.0 segfault: there the caller's stream waits for both itself.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;
   HIPOK(hipEventRecord(sd.done2, sd.s2), "event record failed");
-  HIPOK(hipStreamWaitEvent(s, sd.done2, 0), "event wait failed");
+  HIPOK(hipStreamWaitEvent(cap == hipStreamCaptureStatusNone ? ss : s, sd.done2, 0), "event wait failed");
   HIPOK(hipEventRecord(sd.done, ss), "event record failed");
   HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
   {

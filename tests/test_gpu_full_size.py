@@ -17,8 +17,11 @@ from oracle.neighbor_finder import OracleNeighborFinder, build_adjacency
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 RTOL_EMB = 1e-4          # north_star: embeddings within 1e-4 relative
-RTOL_GRAD_L2 = 2e-3      # relative L2 of a parameter gradient (ReLU kinks flip for a handful of the 9 M hidden units)
+RTOL_GRAD_BPR_MASKED = 5e-4   # the BPR step's gradients with near-kink roots left out on both sides (test_gpu_tgn_step._masked_bpr_backward)
 RTOL_GRAD_TIME = 5e-3    # time-encoder gradients: sums of terms scaled by dt ~ 1e7 with heavy cancellation
+
+
+from test_gpu_tgn_step import _masked_bpr_backward  # noqa: E402
 
 
 def relerr(a, b):
@@ -86,23 +89,8 @@ def test_full_size_training_step_against_oracle(c2):
     remb = np.concatenate([rse, rde, rne])
     e = relerr(emb.detach().cpu().numpy(), remb)
     assert e < RTOL_EMB, e
-    loss = P.bpr_loss(emb, B, 3)
-    loss.backward()
-    rl, cache = T.bpr_loss(rse, rde.reshape(B, 1, -1), rne.reshape(B, 3, -1))
-    assert abs(float(loss.detach()) - float(rl)) < 1e-5
-    ds, dp, dn = T.bpr_loss_backward(cache)
-    rgrads = ref.backward(np.concatenate([ds, dp.reshape(B, -1), dn.reshape(3 * B, -1)]))
-    checked = 0
-    for name, p in tgn.named_parameters():
-        if name not in rgrads:
-            continue
-        r = rgrads[name].reshape(p.shape)
-        if np.abs(r).max() < 1e-7:
-            continue
-        got = p.grad.cpu().numpy().astype(np.float64)
-        err = np.linalg.norm(got - r) / (np.linalg.norm(r) + 1e-30)
-        assert err < (RTOL_GRAD_TIME if name.startswith("time_encoder") else RTOL_GRAD_L2), (name, err)
-        checked += 1
+    rgrads = _masked_bpr_backward(tgn, ref, emb, rse, rde, rne, B, K)       # loss value, d loss / d emb, then the masked backward
+    checked, _ = _grad_compare(tgn, rgrads, RTOL_GRAD_BPR_MASKED, RTOL_GRAD_TIME)
     assert checked >= 20
     # memory state machine: persisted rows, last_update, pending messages of the positives
     assert relerr(tgn.memory.memory.cpu().numpy(), ref.memory) < RTOL_EMB
@@ -357,13 +345,10 @@ def test_full_size_c5_tgat_uniform_step_against_oracle(c2):
     rse, rde, rne = ref.compute_temporal_embeddings(sb, db, neg, tb, eb, K, draws=list(odraws))
     remb = np.concatenate([rse, rde, rne])
     assert relerr(emb.detach().cpu().numpy(), remb) < RTOL_EMB
-    loss = P.bpr_loss(emb, B, 3)
-    loss.backward(retain_graph=False)
-    rl, cache = T.bpr_loss(rse, rde.reshape(B, 1, -1), rne.reshape(B, 3, -1))
-    assert abs(float(loss.detach()) - float(rl)) < 1e-5
-    ds, dp, dn = T.bpr_loss_backward(cache)
-    rgrads = ref.backward(np.concatenate([ds, dp.reshape(B, -1), dn.reshape(3 * B, -1)]))
-    checked, _ = _grad_compare(tgn, rgrads, RTOL_GRAD_L2, RTOL_GRAD_TIME)
+    # BPR loss and its gradients, the roots whose tree holds a near-kink ReLU unit left out on BOTH sides (round 3: the
+    # unmasked check needed a 2e-3 bound and still depended on which units happened to flip)
+    rgrads = _masked_bpr_backward(tgn, ref, emb, rse, rde, rne, B, K)
+    checked, _ = _grad_compare(tgn, rgrads, RTOL_GRAD_BPR_MASKED, RTOL_GRAD_TIME)
     assert checked >= 18
     # kink-free bound on the same forward
     for p in tgn.parameters():
@@ -462,12 +447,17 @@ def test_full_size_c3_p_path_step_against_oracle():
     remb = np.concatenate([rse, rde, rpe, rne])
     assert relerr(emb.detach().cpu().numpy(), remb) < RTOL_EMB
     loss = P.bpr_loss(emb, B, 3, pos_block=2)                       # main.py:321-337: positives = p_pos
-    loss.backward()
+    (d_emb,) = torch.autograd.grad(loss, emb, retain_graph=True)
     rl, cache = T.bpr_loss(rse, rpe.reshape(B, 1, -1), rne.reshape(B, 3, -1))
     assert abs(float(loss.detach()) - float(rl)) < 1e-5
     ds, dp, dn = T.bpr_loss_backward(cache)
-    d_all = np.concatenate([ds, np.zeros_like(rde), dp.reshape(B, -1), dn.reshape(3 * B, -1)])   # dst embeddings are unused on this path
-    checked, _ = _grad_compare(tgn, ref.backward(d_all), RTOL_GRAD_L2, RTOL_GRAD_TIME)
+    d_all = np.concatenate([ds, np.zeros_like(rde), dp.reshape(B, -1), dn.reshape(3 * B, -1)]).astype(np.float32)   # dst embeddings are unused on this path
+    assert np.abs(d_emb.cpu().numpy() - d_all).max() <= 2e-5 * np.abs(d_all).max() + 1e-9
+    bad = _near_kink_roots(ref._ctx, 6 * B, K)                      # near-kink roots: left out on both sides
+    assert bad.sum() < 2 * B
+    emb.backward(d_emb * torch.from_numpy((~bad).astype(np.float32)).to(DEV)[:, None])
+    d_all[bad] = 0
+    checked, _ = _grad_compare(tgn, ref.backward(d_all), RTOL_GRAD_BPR_MASKED, RTOL_GRAD_TIME)
     assert checked >= 20
     assert relerr(tgn.memory.memory.cpu().numpy(), ref.memory) < RTOL_EMB
     assert np.array_equal(tgn.memory.last_update.cpu().numpy(), ref.last_update)
