@@ -6,7 +6,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CSRC = os.path.join(HERE, "csrc")
+CSRC = os.environ.get("PFO_CSRC") or os.path.join(HERE, "csrc")     # override: A/B build of another checkout's kernels
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpfotgn.so")
 SOURCES = ["sampler.hip", "gemm.hip", "attn.hip", "memory.hip", "misc.hip", "csr.hip", "tgn.hip"]

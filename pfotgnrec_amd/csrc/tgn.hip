@@ -53,7 +53,7 @@ struct Ws {
   LayerWs layer[PFO_MAX_LAYERS + 1];
   float *dh1, *dctx, *dQK;
   float* dH[PFO_MAX_LAYERS + 1];
-  float *slabs, *slabs2;      // split-K slabs of the weight-gradient launches: main stream / side stream
+  float *slabs, *slabs2, *slabs3;   // split-K slabs of the weight-gradient launches: main stream / side stream / second side stream
   double *dtime, *fold_scratch, *dtime_slab;
   int32_t* tickets;
   int64_t slab_floats;
@@ -191,6 +191,7 @@ Ws carve(const pfo_tgn_config* c, void* base) {
   w.slab_floats = SLAB_FLOATS;
   w.slabs = take<float>(p, w.slab_floats);
   w.slabs2 = take<float>(p, w.slab_floats);
+  w.slabs3 = take<float>(p, w.slab_floats);
   w.fold_scratch = take<double>(p, pfo_fold_parts_scratch_doubles(2 * d.D));
   {
     // deterministic mode: one slab row of time-encoder partials per attention-backward workgroup, all layers
@@ -859,7 +860,8 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       set_tn(tn[ntn], w.dQK, HCp, xA, D, x_idx, HCp, D, dWqk_l, D, gqk_l);
       tn[ntn].c_accumulate = 0; tn[ntn].bias_accumulate = 0;
       ++ntn;
-      RUN(pfo_gemm_tn_group_launch(tn, ntn, N, nullptr, w.slabs, w.slab_floats, s));
+      // (launched below, on the second side stream in front of the layer's chain: nothing on this stream needs the weight
+      //  gradients of a layer >= 2 - 36 us of launch-latency-bound work off the critical path at C2)
     }
 
     // ---- chain the composite-weight gradients back to the parameters (tiny products, side streams).
@@ -880,6 +882,14 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       // (on the second side stream: the first one must stay free for layer 1's weight gradients over the instances)
       hipStream_t sf = sd.s2;
       HIPOK(hipStreamWaitEvent(sf, sd.layer[l], 0), "event wait failed");
+      if (pfo_prof_on()) {
+        // event-bracketed step (bench.py's roofline sample): on the caller's stream, so that the bracket times the kernel alone
+        RUN(pfo_gemm_tn_group_launch(tn, ntn, N, nullptr, w.slabs, w.slab_floats, s));
+        HIPOK(hipEventRecord(sd.layer[l], s), "event record failed");
+        HIPOK(hipStreamWaitEvent(sf, sd.layer[l], 0), "event wait failed");
+      } else {
+        RUN(pfo_gemm_tn_group_launch(tn, ntn, N, nullptr, w.slabs3, w.slab_floats, sf));
+      }
       HIPOK(hipMemcpyAsync(lw.dT1, lw.dWqk_f, HCpD * sizeof(float), hipMemcpyDeviceToDevice, sf), "copy failed");
       HIPOK(hipMemcpyAsync(lw.gqk, lw.gqk_f, (size_t)HCp * sizeof(float), hipMemcpyDeviceToDevice, sf), "copy failed");
       HIPOK(hipMemcpyAsync(lw.dW1ovT, lw.dW1ovT_f, HCpD * sizeof(float), hipMemcpyDeviceToDevice, sf), "copy failed");
@@ -1012,28 +1022,34 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       RUN(pfo_gemm_tn_group_launch(gp, 2, capP, w.n_touched, w.slabs, w.slab_floats, s));
     }
   }
-  // join the side streams, then ONE launch finishes the time-encoder gradients: the folded query-bias backward of layers
-  // 1 .. L-1 (the top layer's ran with its chain), + its parked time-bias term, + the fold of the attention backwards' fp64
-  // partial sums into time_w / time_b (fixed order)
-  // deterministic mode: the attention backwards' slab rows fold, in row order, into bin 0 of the (otherwise empty) fp64 bins
-  if (det) RUN(pfo_fold_parts_launch(w.dtime_slab, (int)det_rows, 2 * D, nullptr, 0, w.fold_scratch, w.tickets, s, w.dtime));
+  // ---- the last small launches go to the first side stream, beside the GRU's weight gradients on the caller's stream:
+  // [deterministic mode: the attention backwards' slab rows fold, in row order, into bin 0 of the (otherwise empty) fp64 bins]
+  // then ONE launch finishes the time-encoder gradients: the folded query-bias backward of layers 1 .. L-1 (the top layer's ran
+  // with its chain), + its parked time-bias term, + the fold of the fp64 partial sums into time_w / time_b (fixed order).
+  // That stream has seen every attention backward (it waited for tn_b, recorded behind layer 1's) and runs layer 1's chain.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;
+  const bool chained = cap == hipStreamCaptureStatusNone;
   // The side streams are joined in a chain - the first waits for the second, the caller's stream for the first: one wait on
   // the critical path instead of two - except while the caller's stream is being captured into a HIP graph, where that
   // topology makes hipStreamEndCapture of ROCm 7.0 segfault: there the caller's stream waits for both itself.
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;
   HIPOK(hipEventRecord(sd.done2, sd.s2), "event record failed");
-  HIPOK(hipStreamWaitEvent(cap == hipStreamCaptureStatusNone ? ss : s, sd.done2, 0), "event wait failed");
-  HIPOK(hipEventRecord(sd.done, ss), "event record failed");
-  HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
+  HIPOK(hipStreamWaitEvent(chained ? ss : s, sd.done2, 0), "event wait failed");
+  if (!chained) {                                             // (the launches below read the second side stream's results)
+    HIPOK(hipEventRecord(sd.tn_a, s), "event record failed");
+    HIPOK(hipStreamWaitEvent(ss, sd.tn_a, 0), "event wait failed");
+  }
+  if (det) RUN(pfo_fold_parts_launch(w.dtime_slab, (int)det_rows, 2 * D, nullptr, 0, w.fold_scratch, w.tickets, ss, w.dtime));
   {
     const float *gq[PFO_MAX_LAYERS], *wq[PFO_MAX_LAYERS];
     float *dbq[PFO_MAX_LAYERS], *dwq[PFO_MAX_LAYERS];
     const int nl = L >= 2 ? L - 1 : L;
     for (int l = 1; l <= nl; ++l) { gq[l - 1] = w.layer[l].gq; wq[l - 1] = P.l[l].wq; dbq[l - 1] = G.l[l].b_in; dwq[l - 1] = G.l[l].wq; }
     RUN(pfo_cq_backward_launch(gq, wq, nl, P.tb, D, dbq, dwq, G.tb, nullptr, L >= 2 ? w.tb_part : nullptr, w.dtime,
-                               pfo_attn_bwd_max_parts(), G.tw, s));                   // cq = Wq[:, D:] cos(b) + bq
+                               pfo_attn_bwd_max_parts(), G.tw, ss));                  // cq = Wq[:, D:] cos(b) + bq
   }
+  HIPOK(hipEventRecord(sd.done, ss), "event record failed");
+  HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
   return PFO_OK;
 }
 
