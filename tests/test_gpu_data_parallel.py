@@ -14,12 +14,12 @@ from conftest import REPO, has_gpu
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")]
 
 
-def _run(rank, world, port, out_dir, n_steps, B=48):
+def _run(rank, world, port, out_dir, n_steps, B=48, buckets=False, det=False):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import torch.distributed as dist
     import pfotgnrec_amd as P
-    from pfotgnrec_amd.distributed import init_from_env, allreduce_flat_grad, broadcast_parameters
+    from pfotgnrec_amd.distributed import init_from_env, allreduce_flat_grad, allreduce_flat_grad_buckets, broadcast_parameters
     from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
     init_from_env(backend="gloo")
     dev = torch.device("cuda:0")
@@ -30,6 +30,8 @@ def _run(rank, world, port, out_dir, n_steps, B=48):
     tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, dev, n_layers=2, n_heads=2, dropout=0.0,
                 use_memory=True, memory_dimension=32, message_function="identity")
     tgn.set_data_parallel(rank, world)
+    tgn.dp_bucketed = buckets
+    tgn.deterministic = det                                     # bitwise run-to-run reproducible backward (round 3)
     broadcast_parameters(tgn.flat_parameters, world)
     opt = P.FusedAdam(tgn, lr=1e-3)
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
@@ -44,14 +46,18 @@ def _run(rank, world, port, out_dir, n_steps, B=48):
         assert emb.shape[0] == 5 * b
         loss = P.bpr_loss(emb, b, 3, grad_scale=tgn.dp_grad_scale)      # local mean * (b / B): shard sums = global mean
         loss.backward()
-        allreduce_flat_grad(tgn.flat_grad, world)
+        if buckets:
+            assert tgn._bucket_event_fresh == (b > 0)               # the backward recorded the "top layer final" event
+            allreduce_flat_grad_buckets(tgn, world)
+        else:
+            allreduce_flat_grad(tgn.flat_grad, world)
         if step == 0:
             grad0 = tgn.flat_grad.cpu().numpy().copy()
             mem0 = tgn.memory.memory.cpu().numpy().copy()
         opt.step()
         opt.zero_grad(set_to_none=True)
     torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, "w%d_r%d_B%d.npz" % (world, rank, B)), params=tgn.flat_parameters.cpu().numpy(), grad0=grad0, mem0=mem0,
+    np.savez(os.path.join(out_dir, "w%d_r%d_B%d%s.npz" % (world, rank, B, "_buckets" if buckets else "")), params=tgn.flat_parameters.cpu().numpy(), grad0=grad0, mem0=mem0,
              memory=tgn.memory.memory.cpu().numpy(), last_update=tgn.memory.last_update.cpu().numpy(),
              msg=tgn.memory.msg_table.cpu().numpy(), msg_t=tgn.memory.msg_time.cpu().numpy(), has=tgn.memory.has_msg.cpu().numpy())
     if world > 1:
@@ -59,9 +65,9 @@ def _run(rank, world, port, out_dir, n_steps, B=48):
         dist.destroy_process_group()
 
 
-def _spawn(world, port, tmp_path, n_steps, B):
+def _spawn(world, port, tmp_path, n_steps, B, buckets=False, det=False):
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_run, args=(r, world, port, str(tmp_path), n_steps, B)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, str(tmp_path), n_steps, B, buckets, det)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -109,3 +115,18 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert np.array_equal(r0["last_update"], one["last_update"]) and np.array_equal(r0["has"], one["has"])
     assert np.array_equal(r0["msg_t"], one["msg_t"])
     assert rel(r0["params"], one["params"]) < 1e-2
+
+
+def test_two_bucket_allreduce_equals_the_single_one(tmp_path):
+    """SURVEY 8e / DESIGN 6: the top layer's gradient block reduced on a communication stream as soon as the backward's event
+    says it is final, the rest after the backward - element-wise sums do not depend on how the buffer is cut, so gradients,
+    parameters after Adam and the memory state are BIT-identical to the one-piece all-reduce (two ranks, gloo, one GPU)."""
+    port = 29950 + (os.getpid() % 40)
+    # (both runs with the deterministic backward: the default float-atomic scatter differs in its last bits from run to run,
+    #  which would hide - or fake - a difference between the two collectives)
+    _spawn(2, port, tmp_path, 3, 48, det=True)
+    _spawn(2, port + 1, tmp_path, 3, 48, buckets=True, det=True)
+    for r in (0, 1):
+        one, two = np.load(tmp_path / ("w2_r%d_B48.npz" % r)), np.load(tmp_path / ("w2_r%d_B48_buckets.npz" % r))
+        for k in one.files:
+            assert np.array_equal(one[k], two[k]), (r, k)
