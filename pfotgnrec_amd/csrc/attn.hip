@@ -23,6 +23,7 @@ struct AttnDev {
   // run-merged layer-1 backward: instances in (table row, run key) order, seg_ptr[*n_rows] of them
   const int32_t* members; const int32_t* seg_ptr; const int32_t* n_rows; const int32_t* run_cnt;
   int det; double* dtime_slab;   // deterministic mode (attn.hpp)
+  uint8_t* dqk_live;             // run-merged kernel: [members] 1 = dQK row m holds a sum, 0 = folded into a later row / nothing
   int abl;      // timing-only ablation switch (PFO_ATTN_ABL): 1 = spread the atomic destinations (wrong results)
 };
 
@@ -528,6 +529,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
     // the current group: lane q <-> history entry cnt0 - K + q of the node run_slot
     int run_slot = -1, run_cnt0 = 0, run_rows = 0, run_len = 0, run_first = 0;
     unsigned long long run_valid = 0ull;                           // lanes whose history entry exists and was seen
+    // The query-side gradient rows [dqk' (node | edge | time)] of consecutive members that sit on ONE table row are summed
+    // here, in registers, and stored once (row acc_m, flagged live): the per-row sum pass that follows (segsum) adds the
+    // members of a row anyway, and a chunk of 4 members holds ~2.5 per row at C2 - less than half the rows are written / re-read
+    float dqn[H][NR], dqt[H][NR], dqe[H];
+    int acc_m = -1;
+    auto acc_reset = [&]() {
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { dqn[h][r] = 0.f; dqt[h][r] = 0.f; }
+        dqe[h] = 0.f;
+      }
+    };
+    auto acc_store = [&]() {
+      if (acc_m >= 0) {
+        float* dqk_out = a.dQK + (int64_t)acc_m * H * Cp;          // row m, not n: the per-row sums then stream contiguous rows
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const int c = lane + 64 * r;
+            if (c < D) {
+              dqk_out[h * Cp + c] = dqn[h][r];
+              dqk_out[h * Cp + D + Ef + c] = dqt[h][r];
+            }
+          }
+          if (lane < Ef) dqk_out[h * Cp + D + lane] = dqe[h];
+          if (lane < Cp - C) dqk_out[h * Cp + C + lane] = 0.f;
+        }
+        if (lane == 0) a.dqk_live[acc_m] = 1;
+      }
+      acc_m = -1;
+      acc_reset();
+    };
+    acc_reset();
     float sBr[H];                                                  // lane q: sum of cB over the group's instances that hold entry q
 #pragma unroll
     for (int h = 0; h < H; ++h) sBr[h] = 0.f;
@@ -596,7 +632,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
     const int m_end = min(M, (chunk + 1) * RUN_CHUNK);
     for (int m = chunk * RUN_CHUNK; m < m_end; ++m) {
       const int64_t n = a.members[m];
-      float* dqk_out = a.dQK + (int64_t)m * H * Cp;             // row m, not n: the per-row sums then stream contiguous rows
       const int64_t slot0 = n * K;
       const bool inK = lane < K;
       const int my_id = inK ? a.nbr_ids[slot0 + lane] : 0;
@@ -608,6 +643,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
       const int cnt_n = a.run_cnt[n];
       int delta = cnt_n - run_cnt0;                              // members of a row arrive by ascending count
       if (slot != run_slot || delta < 0 || delta > 64 - K) {     // another node, or the lanes run out: the group's rows leave
+        acc_store();                                             // (the query-side sums too: never live across a flush)
         flush();
         run_slot = slot; run_cnt0 = cnt_n; run_rows = 0; run_valid = 0ull;
         delta = 0;
@@ -619,10 +655,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         run_rows = ((vs >> lane) & 1ull) ? rows_sh : run_rows;
         run_valid |= vs;
       }
-      if (valid == 0ull) {
-        for (int c = lane; c < H * Cp; c += 64) dqk_out[c] = 0.f;
-        continue;
-      }
+      if (lane == 0) a.dqk_live[m] = 0;                         // (set when this member's position receives a stored sum)
+      if (valid == 0ull) continue;                               // no neighbour: nothing to add to the row's sums
+      acc_m = m;
       if (run_len == 0) run_first = m;                           // the group's instances with a neighbour are consecutive members
       const int run_i = run_len;                                 // (an instance without history has count 0: first of its row)
       run_len += 1;
@@ -630,7 +665,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
 #pragma unroll
       for (int h = 0; h < H; ++h) s_cA[run_i][h][lane] = 0.f;
       float qt[H][NR], gn[H][NR], gt[H][NR], ge[H], tds[2 * H];
-      float dqn[H][NR], dqt[H][NR], dqe[H];
       const float* qk = a.QK + (int64_t)slot * a.qk_ld;
       const float* dc = a.dctx + n * H * Cp;
       const float* cx = a.ctx + n * H * Cp;
@@ -645,11 +679,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
           gn[h][r] = ok ? dc[h * Cp + c] : 0.f;
           gt[h][r] = ok ? dc[h * Cp + D + Ef + c] : 0.f;
           if (ok) part = fmaf(gn[h][r], cx[h * Cp + c], fmaf(gt[h][r], cx[h * Cp + D + Ef + c], part));
-          dqn[h][r] = 0.f; dqt[h][r] = 0.f;
         }
         ge[h] = lane < Ef ? dc[h * Cp + D + lane] : 0.f;
         if (lane < Ef) part = fmaf(ge[h], cx[h * Cp + D + lane], part);
-        dqe[h] = 0.f;
         tds[h] = part;
       }
       pfo_wave_sum_scalar_n<H>(reinterpret_cast<float(&)[H]>(tds));     // delta_h = dctx_h . ctx_h (+ the extra column below)
@@ -761,20 +793,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
       }
       };
       if (fast) walk(std::true_type{}); else walk(std::false_type{});
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          const int c = lane + 64 * r;
-          if (c < D) {
-            dqk_out[h * Cp + c] = dqn[h][r];
-            dqk_out[h * Cp + D + Ef + c] = dqt[h][r];
-          }
-        }
-        if (lane < Ef) dqk_out[h * Cp + D + lane] = dqe[h];
-        if (lane < Cp - C) dqk_out[h * Cp + C + lane] = 0.f;
-      }
     }
+    acc_store();                                                 // the chunk's last row sums
     flush();                                                     // the chunk's last run
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -808,7 +828,7 @@ static void to_dev(const PfoAttn& a, AttnDev& d) {
   d.ctx = a.ctx; d.attw = a.attw; d.inv = a.inv;
   d.dctx = a.dctx; d.dQK = a.dQK; d.d_nbr = a.d_nbr; d.d_nbr_ld = a.d_nbr_ld; d.d_nbr_rep = a.d_nbr_rep; d.d_nbr_nrep = a.d_nbr_nrep > 0 ? a.d_nbr_nrep : 1;
   d.dtime_part = a.dtime_part;
-  d.det = a.det; d.dtime_slab = a.dtime_slab;
+  d.det = a.det; d.dtime_slab = a.dtime_slab; d.dqk_live = a.dqk_live;
   d.members = a.members; d.seg_ptr = a.seg_ptr; d.n_rows = a.n_rows; d.run_cnt = a.run_cnt;
 }
 
@@ -875,7 +895,8 @@ bool pfo_attn_bwd_runs_possible(int K) {
   return runs_on && K <= 64;
 }
 bool pfo_attn_bwd_uses_runs(const PfoAttn& a) {
-  return a.d_nbr && a.nbr_row && pfo_attn_bwd_runs_possible(a.K) && a.members && a.seg_ptr && a.n_rows && a.qk_row && a.run_cnt;
+  return a.d_nbr && a.nbr_row && pfo_attn_bwd_runs_possible(a.K) && a.members && a.seg_ptr && a.n_rows && a.qk_row && a.run_cnt &&
+         a.dqk_live;
 }
 
 int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {

@@ -55,6 +55,8 @@ struct PfoAttn {
   // (PFO_DET_SCALE) in a table of d_nbr_ld int64 per row at d_nbr
   int det = 0;
   double* dtime_slab = nullptr;
+  uint8_t* dqk_live = nullptr;      // run-merged kernel (members given): [members] flags of the dQK rows that hold a sum - consecutive
+                                    // members on one table row are summed on chip and stored once (pfo_segsum_launch src0_live)
   // optional (layer 1 over the touched-node table, atomically added rows, most-recent sampling): the instances ordered by
   // (table row, entries before the instance's time) as built by pfo_seg_build_launch with key_src = run_cnt.  Consecutive
   // members of a row have neighbour lists that are shifts of each other, so their key-side gradients are summed on chip by

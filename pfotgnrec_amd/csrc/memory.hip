@@ -250,10 +250,12 @@ int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int ca
 // out[s][0:W0) = sum over the group's members n of src0[n][0:W0), out[s][W0:W0+W1) = ... of src1[n][0:W1), s < *n_rows;
 // groups without members get zeros.  One wavefront per group, fixed member order -> reproducible.
 #define SEGSUM_R 16
+// src0_live (optional, with src0_by_position): byte flags per position - a row whose flag is 0 holds nothing (its producer
+// folded it into a later row of the same group, attn.hip) and is not read
 __global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ src0, int W0, const float* __restrict__ src1, int W1,
                                                      const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ members,
                                                      const int32_t* __restrict__ n_rows, int src0_by_position,
-                                                     float* __restrict__ out) {
+                                                     const uint8_t* __restrict__ src0_live, float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int W = W0 + W1;
   const int nr = *n_rows;
@@ -267,12 +269,13 @@ __global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ s
       for (; m + 1 < hi; m += 2) {                       // two member rows in flight
         const int64_t na = members[m], nb = members[m + 1];
         const int64_t pa = src0_by_position ? m : na, pb = src0_by_position ? m + 1 : nb;
+        const bool la = !src0_live || src0_live[m] != 0, lb = !src0_live || src0_live[m + 1] != 0;   // wave-uniform
         float va[SEGSUM_R], vb[SEGSUM_R];
 #pragma unroll
         for (int r = 0; r < SEGSUM_R; ++r) {
           const int c = c0 + lane + 64 * r;
-          va[r] = c < W0 ? src0[pa * W0 + c] : (c < W ? src1[na * W1 + (c - W0)] : 0.f);
-          vb[r] = c < W0 ? src0[pb * W0 + c] : (c < W ? src1[nb * W1 + (c - W0)] : 0.f);
+          va[r] = c < W0 ? (la ? src0[pa * W0 + c] : 0.f) : (c < W ? src1[na * W1 + (c - W0)] : 0.f);
+          vb[r] = c < W0 ? (lb ? src0[pb * W0 + c] : 0.f) : (c < W ? src1[nb * W1 + (c - W0)] : 0.f);
         }
 #pragma unroll
         for (int r = 0; r < SEGSUM_R; ++r) acc[r] = (acc[r] + va[r]) + vb[r];
@@ -280,10 +283,11 @@ __global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ s
       if (m < hi) {
         const int64_t na = members[m];
         const int64_t pa = src0_by_position ? m : na;
+        const bool la = !src0_live || src0_live[m] != 0;
 #pragma unroll
         for (int r = 0; r < SEGSUM_R; ++r) {
           const int c = c0 + lane + 64 * r;
-          acc[r] += c < W0 ? src0[pa * W0 + c] : (c < W ? src1[na * W1 + (c - W0)] : 0.f);
+          acc[r] += c < W0 ? (la ? src0[pa * W0 + c] : 0.f) : (c < W ? src1[na * W1 + (c - W0)] : 0.f);
         }
       }
 #pragma unroll
@@ -295,11 +299,13 @@ __global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ s
   }
 }
 int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, const int32_t* seg_ptr, const int32_t* members,
-                      const int32_t* n_rows, int cap_rows, int src0_by_position, float* out, hipStream_t stream) {
+                      const int32_t* n_rows, int cap_rows, int src0_by_position, const uint8_t* src0_live, float* out,
+                      hipStream_t stream) {
   PFO_REQUIRE(src0 && src1 && seg_ptr && members && n_rows && out && W0 > 0 && W1 > 0, "bad arguments");
+  PFO_REQUIRE(!src0_live || src0_by_position, "row flags go with rows stored by position");
   const int nb = (int)std::min<int64_t>(8192, std::max<int64_t>(1, pfo_ceil_div(cap_rows, 4)));
   hipLaunchKernelGGL(segsum_kernel, dim3(nb), dim3(256), 0, stream, src0, W0, src1, W1, seg_ptr, members, n_rows,
-                     src0_by_position, out);
+                     src0_by_position, src0_live, out);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

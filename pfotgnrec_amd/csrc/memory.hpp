@@ -45,7 +45,9 @@ int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int ca
 // out[s] = [ sum_{n in group s} src0[n] | sum_{n in group s} src1[n] ]  (row widths W0, W1; s < *n_rows).
 // src0_by_position: src0's rows are stored in MEMBER order (row m belongs to members[m]) - contiguous per group
 int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, const int32_t* seg_ptr, const int32_t* members,
-                      const int32_t* n_rows, int cap_rows, int src0_by_position, float* out, hipStream_t stream);
+                      const int32_t* n_rows, int cap_rows, int src0_by_position, const uint8_t* src0_live, float* out,
+                      hipStream_t stream);
+// (src0_live: optional byte flags per position; rows flagged 0 are not read)
 int pfo_zero_rows_launch(float* dst, const int32_t* n_rows, int cap_rows, int D, int n_rep, int64_t rep_stride, hipStream_t stream);
 
 // --- state update (tgn.py:290-317)

@@ -49,6 +49,7 @@ struct Ws {
   float *QX, *Dq, *dx_tab, *l1_bias;
   void* iQX;
   int32_t *seg_ptr, *seg_cur, *seg_tmp, *seg_mem, *seg_scratch;
+  uint8_t* dqk_live;           // per layer-1 member position: does dQK row m hold a sum (attn.hip, run-merged backward)
   int32_t* cnt1;               // per layer-1 instance: entries of its node's row before its time (the run key, sampler.hip)
   LayerWs layer[PFO_MAX_LAYERS + 1];
   float *dh1, *dctx, *dQK;
@@ -136,6 +137,7 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     w.seg_mem = take<int32_t>(p, d.ncap[1]);
     w.seg_scratch = take<int32_t>(p, pfo_seg_scratch_ints((int)d.capP));
     w.cnt1 = take<int32_t>(p, d.ncap[1]);
+    w.dqk_live = take<uint8_t>(p, d.ncap[1]);
   }
   if (c->use_memory) {
     w.winner = take<int32_t>(p, c->n_nodes);
@@ -810,7 +812,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     if (l == 1 && c->use_memory) HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");   // d_h0 is clear, the groups exist
     if (l == 1 && c->use_memory && !b->uniform) {
       // key-side gradients of instances with identical neighbour lists leave as one set of atomics (attn.hip)
-      a.members = w.seg_mem; a.seg_ptr = w.seg_ptr; a.n_rows = w.n_touched; a.run_cnt = w.cnt1;
+      a.members = w.seg_mem; a.seg_ptr = w.seg_ptr; a.n_rows = w.n_touched; a.run_cnt = w.cnt1; a.dqk_live = w.dqk_live;
     }
     const int dqk_by_member = pfo_attn_bwd_uses_runs(a) ? 1 : 0;
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
@@ -822,7 +824,8 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       // weight gradients against x - is taken AFTER summing those gradients per table row: contractions over the
       // ~11 k touched rows instead of the ~54 k instances.
       if (!c->use_memory) HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");   // (with memory: awaited before the attention backward)
-      RUN(pfo_segsum_launch(w.dQK, HCp, dh1, D, w.seg_ptr, w.seg_mem, w.n_touched, capP, dqk_by_member, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
+      RUN(pfo_segsum_launch(w.dQK, HCp, dh1, D, w.seg_ptr, w.seg_mem, w.n_touched, capP, dqk_by_member,
+                            dqk_by_member ? w.dqk_live : nullptr, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
       // the weight gradients over the table rows go to the side stream too (beside d h0 / the GRU backward on this one)
       HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
       HIPOK(hipStreamWaitEvent(ss, sd.tn_b, 0), "event wait failed");
