@@ -816,12 +816,207 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_areg_kernel(const Gem
   __shared__ __attribute__((aligned(16))) char lds[2 * 3 * BX_B_PIECE];
   bx_areg_body<4>(p, lds);
 }
-// Two independent contractions in ONE launch (blockIdx.z picks): the GRU's message and hidden-state projections.  They used
-// to run on two streams; a cross-stream event wait costs the waiting stream 5-15 us on this part even when the event has long
-// fired, and the side stream was busy with the composite-weight chain anyway.
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_areg_pair_kernel(const GemmDev p0, const GemmDev p1) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 3 * BX_B_PIECE];
-  if (blockIdx.z == 0) bx_areg_body<4>(p0, lds); else bx_areg_body<4>(p1, lds);
+// ---------------------------------------------------------------------------------------------
+// The lazy GRU of the touched rows in ONE launch (memory_updater.py:18-61: torch.nn.GRUCell on [message | memory]): both
+// contractions - message rows x W_ih^T (K = 3D + Ef) and memory rows x W_hh^T (K = D), K-concatenated - with the gate math in
+// the epilogue, so the pre-activations gi / gh (2 x 3D floats per row) never go to HBM.  What makes that possible is the ORDER
+// of the image rows (bimg_gate_row): a column block holds, for two groups of 16 hidden units, the four tiles r | z | n_i | n_h.
+// In the operand-swapped accumulator layout lane (r, g) owns columns 4g .. 4g+3 of EVERY tile of row r: the r, z, n_i and n_h
+// pre-activations of hidden units 16 q + 4g .. + 3 sit in one lane, in four accumulator tiles.  n_i takes only the message
+// part and n_h only the memory part (n = tanh(n_i + r * n_h), torch GRUCell): their tiles skip the other source's k-tiles
+// instead of multiplying zero rows, so no MFMA is spent that the two separate launches did not spend.
+// Same staging as gemm_bx_areg_kernel: A rows straight to registers in fragment order and split there, the B image tile (128
+// rows x 3 pieces = 24 KB) DMA'd into a double-buffered LDS image, one barrier per k-tile.
+#define GF_NJ 8
+#define GF_BN (GF_NJ * 16)
+#define GF_B_PIECE (GF_BN * 64)
+struct GruFusedDev {
+  const float* msg_rows; int64_t ld_msg; int K0;
+  const float* h_rows; int64_t ld_h; int K1;
+  const void* img0; const void* img1; int img_rows;
+  const float* b_ih; const float* b_hh;
+  const uint8_t* hm; const int32_t* touched; const float* node_feat;
+  float* upd_mem; float* h0_tab; float* gates;
+  int D, M; const int32_t* m_dev;
+};
+int pfo_gru_img_rows(int D) { return (int)pfo_ceil_div(D, 32) * GF_BN; }
+int64_t pfo_gru_img_bytes(int D, int K) { return (int64_t)pfo_ceil_div(K, 32) * 3 * pfo_gru_img_rows(D) * 64; }
+
+__device__ __forceinline__ float gf_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x)); }
+__device__ __forceinline__ float gf_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(-2.88539008177792681472f * fabsf(x));
+  return copysignf((1.f - e) * __builtin_amdgcn_rcpf(1.f + e), x);
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFusedDev p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 3 * GF_B_PIECE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * GF_BN;
+  const int Mlim = min(p.M, p.m_dev ? *p.m_dev : p.M);
+  if (m0 >= Mlim) return;
+  const int wrow = 32 * wave;
+  f32x4 acc[2][GF_NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < GF_NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int T0 = (p.K0 + BK - 1) / BK, T1 = (p.K1 + BK - 1) / BK, T = T0 + T1;
+  const float* safe = p.msg_rows;
+  const int64_t img_piece = (int64_t)p.img_rows * 64;
+  const float* a_row[2][2];
+  bool a_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int gm = m0 + wrow + 16 * i + r;
+    a_ok[i] = gm < Mlim;
+    const int64_t ridx = a_ok[i] ? gm : 0;
+    a_row[0][i] = p.msg_rows + ridx * p.ld_msg + 8 * g;
+    a_row[1][i] = p.h_rows + ridx * p.ld_h + 8 * g;
+  }
+  const char* img[2] = {reinterpret_cast<const char*>(p.img0) + (int64_t)n0 * 64, reinterpret_cast<const char*>(p.img1) + (int64_t)n0 * 64};
+  float4 a_raw[2][2];
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto load_global = [&](int t, int buf) {
+    const int src = t < T0 ? 0 : 1;
+    const int ts = src == 0 ? t : t - T0;
+    const int k = ts * BK + 8 * g;
+    const int Ks = src == 0 ? p.K0 : p.K1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        a_raw[i][h] = ld4<true>(a_row[src][i] + ts * BK + 4 * h, a_ok[i] ? Ks - (k + 4 * h) : 0, safe);
+    const char* tile = img[src] + (int64_t)ts * 3 * img_piece;
+    char* Bs = lds + buf * 3 * GF_B_PIECE;
+    bx_for<6>([&](auto uc) {                                   // 3 pieces x 512 units of 16 bytes = 6 rounds of 256 threads
+      constexpr int u = decltype(uc)::value;
+      const int unit = tid + 256 * u;
+      const int q = unit >> 9;                                 // 512 units per piece
+      __builtin_amdgcn_global_load_lds((gptr_t)(tile + q * img_piece + (unit - (q << 9)) * 16),
+                                       (lptr_t)(Bs + (64 * wave + 256 * u) * 16), 16, 0, 0);
+    });
+  };
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  bf16x8 a[2][3];
+  auto split_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      uint2 lo[3], hi[3];
+      bx_split4(a_raw[i][0], lo[0], lo[1], lo[2]);
+      bx_split4(a_raw[i][1], hi[0], hi[1], hi[2]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const u32x4 w = {lo[q].x, lo[q].y, hi[q].x, hi[q].y};
+        a[i][q] = __builtin_bit_cast(bf16x8, w);
+      }
+    }
+  };
+  const int frag_off = r * 64 + ((g ^ bx_swz(r)) << 4);
+  // tiles that take source SRC: the message part feeds r, z, n_i (tiles 0 1 2 | 4 5 6), the memory part r, z, n_h (0 1 3 | 4 5 7)
+  auto compute_tile = [&](int buf, auto src_c) {
+    constexpr int SRC = decltype(src_c)::value;
+    constexpr int act[6] = {0, 1, SRC == 0 ? 2 : 3, 4, 5, SRC == 0 ? 6 : 7};
+    const char* Bs = lds + buf * 3 * GF_B_PIECE;
+    auto ldb = [&](bf16x8 (&b)[3], int j) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) b[q] = *reinterpret_cast<const bf16x8*>(Bs + q * GF_B_PIECE + (16 * j) * 64 + frag_off);
+    };
+    auto mma = [&](const bf16x8 (&b)[3], int j) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f32x4 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][2], c, 0, 0, 0);   // operands swapped, smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[2], a[i][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[i][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[i][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+    };
+    bf16x8 b0[3], b1[3];
+    ldb(b0, act[0]);
+#pragma unroll
+    for (int q = 0; q < 6; q += 2) {
+      ldb(b1, act[q + 1]);
+      mma(b0, act[q]);
+      if (q + 2 < 6) ldb(b0, act[q + 2]);
+      mma(b1, act[q + 1]);
+    }
+  };
+  load_global(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  split_a();
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const bool more = t + 1 < T;
+    if (more) load_global(t + 1, (t + 1) & 1);
+    if (t < T0) compute_tile(t & 1, std::integral_constant<int, 0>{}); else compute_tile(t & 1, std::integral_constant<int, 1>{});
+    if (more) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      split_a();
+    }
+    __syncthreads();
+  }
+  // gates.  lane (r, g), strip i: row m0 + wrow + 16 i + r; group q: hidden units u0 .. u0 + 3, u0 = 32 by + 16 q + 4 g
+  const int D = p.D;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = m0 + wrow + 16 * i + r;
+    if (row >= Mlim) continue;
+    const bool has = p.hm[row] != 0;
+    const int64_t id = p.touched[row];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int u0 = 32 * (int)blockIdx.y + 16 * q + 4 * g;
+      if (u0 >= D) continue;                                    // D % 4 == 0: a lane's four units are all inside or all outside
+      const float4 h4 = *reinterpret_cast<const float4*>(p.h_rows + (int64_t)row * p.ld_h + u0);
+      const float4 nf = *reinterpret_cast<const float4*>(p.node_feat + id * D + u0);
+      const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
+      float rr[4], zz[4], nn[4], gh[4], hn[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int u = u0 + e;
+        const float pr = acc[i][4 * q + 0][e] + p.b_ih[u] + p.b_hh[u];
+        const float pz = acc[i][4 * q + 1][e] + p.b_ih[D + u] + p.b_hh[D + u];
+        const float pn = acc[i][4 * q + 2][e] + p.b_ih[2 * D + u];
+        gh[e] = acc[i][4 * q + 3][e] + p.b_hh[2 * D + u];
+        rr[e] = gf_sigmoid(pr);
+        zz[e] = gf_sigmoid(pz);
+        nn[e] = gf_tanh(pn + rr[e] * gh[e]);
+        hn[e] = has ? (1.f - zz[e]) * nn[e] + zz[e] * hv[e] : hv[e];      // no pending message: the memory row is kept
+      }
+      *reinterpret_cast<float4*>(p.upd_mem + (int64_t)row * D + u0) = float4{hn[0], hn[1], hn[2], hn[3]};
+      *reinterpret_cast<float4*>(p.h0_tab + (int64_t)row * D + u0) = float4{hn[0] + nf.x, hn[1] + nf.y, hn[2] + nf.z, hn[3] + nf.w};
+      float* gs = p.gates + (int64_t)row * 4 * D + u0;           // kept for the backward: r | z | n | gh_n
+      *reinterpret_cast<float4*>(gs) = float4{rr[0], rr[1], rr[2], rr[3]};
+      *reinterpret_cast<float4*>(gs + D) = float4{zz[0], zz[1], zz[2], zz[3]};
+      *reinterpret_cast<float4*>(gs + 2 * D) = float4{nn[0], nn[1], nn[2], nn[3]};
+      *reinterpret_cast<float4*>(gs + 3 * D) = float4{gh[0], gh[1], gh[2], gh[3]};
+    }
+  }
+}
+
+int pfo_gru_fused_launch(const PfoGruFused& f, hipStream_t stream) {
+  PFO_REQUIRE(f.msg_rows && f.h_rows && f.img_ih && f.img_hh && f.b_ih && f.b_hh && f.hm && f.touched && f.node_feat && f.upd_mem &&
+              f.h0_tab && f.gates, "null argument");
+  PFO_REQUIRE(f.D > 0 && (f.D % 4) == 0 && f.K_msg > 0 && (f.K_msg % 4) == 0 && f.cap_rows > 0, "bad sizes");
+  PFO_REQUIRE(aligned4(f.msg_rows) && aligned4(f.h_rows) && aligned4(f.node_feat) && aligned4(f.upd_mem) && aligned4(f.h0_tab) &&
+              aligned4(f.gates), "operands must be 16-byte aligned");
+  GruFusedDev d;
+  d.msg_rows = f.msg_rows; d.ld_msg = f.K_msg; d.K0 = f.K_msg; d.h_rows = f.h_rows; d.ld_h = f.D; d.K1 = f.D;
+  d.img0 = f.img_ih; d.img1 = f.img_hh; d.img_rows = pfo_gru_img_rows(f.D);
+  d.b_ih = f.b_ih; d.b_hh = f.b_hh; d.hm = f.hm; d.touched = f.touched; d.node_feat = f.node_feat;
+  d.upd_mem = f.upd_mem; d.h0_tab = f.h0_tab; d.gates = f.gates; d.D = f.D; d.M = f.cap_rows; d.m_dev = f.n_rows;
+  pfo_prof_begin(stream);
+  hipLaunchKernelGGL(gru_fused_kernel, dim3((unsigned)pfo_ceil_div(f.cap_rows, BM), (unsigned)pfo_ceil_div(f.D, 32), 1), dim3(GEMM_THREADS),
+                     0, stream, d);
+  PFO_LAUNCH_CHECK();
+  pfo_prof_end_dev(PFO_PROF_GEMM_BX, 2.0 * 3 * f.D * ((double)f.K_msg + f.D), f.n_rows, f.cap_rows, stream);   // per-row FLOPs of the two contractions
+  return PFO_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1170,7 +1365,20 @@ struct BimgDev {
   const float* src[PFO_BIMG_MAX]; int64_t ld[PFO_BIMG_MAX]; int N[PFO_BIMG_MAX], K[PFO_BIMG_MAX], trans[PFO_BIMG_MAX];
   void* dst[PFO_BIMG_MAX]; int rows[PFO_BIMG_MAX];      // rows: image rows this problem fills (incl. zero padding)
   int row0[PFO_BIMG_MAX], rows_total[PFO_BIMG_MAX];     // first image row of the problem, padded rows of the whole image
+  int gate[PFO_BIMG_MAX], gate_D[PFO_BIMG_MAX];         // GRU gate-ordered image (gemm.hpp PfoBimg::gate): 0 = plain
 };
+// Source row of image row n of a GRU gate-ordered image (gru_fused_kernel): blocks of GF_BN = 128 image rows = two groups of
+// four 16-row tiles (r, z, n_i, n_h) for 16 hidden units each.  gate 1: the message weights W_ih [3D, M] (no n_h rows),
+// gate 2: the hidden-state weights W_hh [3D, D] (no n_i rows).  -1: a zero row.
+__device__ __forceinline__ int bimg_gate_row(int n, int which, int D) {
+  const int b = n >> 7, t = (n & 127) >> 4, i = n & 15;
+  const int u = 32 * b + 16 * (t >> 2) + i, gt = t & 3;
+  if (u >= D) return -1;
+  if (gt == 0) return u;
+  if (gt == 1) return D + u;
+  if (gt == 2) return which == 1 ? 2 * D + u : -1;
+  return which == 2 ? 2 * D + u : -1;
+}
 __global__ __launch_bounds__(256) void bimg_kernel(const BimgDev g) {
   const int z = blockIdx.y;
   const int N = g.N[z], K = g.K[z], rows = g.rows[z];
@@ -1191,7 +1399,10 @@ __global__ __launch_bounds__(256) void bimg_kernel(const BimgDev g) {
       for (int h = 0; h < 2; ++h) {
         const int k = 32 * t + 8 * c + 2 * e2 + h;
         float x = 0.f;
-        if (n < N && k < K) x = g.trans[z] ? src[(int64_t)k * ld + n] : src[(int64_t)n * ld + k];
+        if (g.gate[z]) {
+          const int sr = bimg_gate_row(n, g.gate[z], g.gate_D[z]);
+          if (sr >= 0 && k < K) x = src[(int64_t)sr * ld + k];
+        } else if (n < N && k < K) x = g.trans[z] ? src[(int64_t)k * ld + n] : src[(int64_t)n * ld + k];
         const uint32_t b1 = __float_as_uint(x) & 0xFFFF0000u;
         const float r1 = x - __uint_as_float(b1);
         const uint32_t b2 = __float_as_uint(r1) & 0xFFFF0000u;
@@ -1498,6 +1709,14 @@ int pfo_bimg_launch(const PfoBimg* list, int n, hipStream_t stream) {
     d.src[i] = list[i].src; d.ld[i] = list[i].ld; d.N[i] = list[i].N; d.K[i] = list[i].K; d.trans[i] = list[i].trans;
     d.dst[i] = list[i].dst;
     d.row0[i] = list[i].row0;
+    d.gate[i] = list[i].gate; d.gate_D[i] = list[i].gate_D;
+    if (list[i].gate) {
+      // gate-ordered: the image has pfo_gru_img_rows(D) rows, all written by this problem (zero rows included); N = 3 D source rows
+      PFO_REQUIRE(list[i].gate_D > 0 && list[i].N == 3 * list[i].gate_D && !list[i].trans && list[i].rows_total == 0, "bad gate-ordered image");
+      d.rows_total[i] = d.rows[i] = pfo_gru_img_rows(list[i].gate_D);
+      most = std::max<int64_t>(most, (int64_t)pfo_ceil_div(list[i].K, 32) * d.rows[i] * 4);
+      continue;
+    }
     d.rows_total[i] = list[i].rows_total > 0 ? (int)pfo_align_up(list[i].rows_total, BN) : (int)pfo_align_up(list[i].N, BN);
     // rows this problem writes: a plain image and the last operand of a stack include the zero padding up to the padded end
     d.rows[i] = list[i].rows_total > 0 ? (list[i].last ? d.rows_total[i] - d.row0[i] : list[i].N) : d.rows_total[i];
@@ -1614,27 +1833,6 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
   // a device-side extent (rows, or the K of a k-major A) scales the work: read back when the records are collected
   if (g.m_dev) pfo_prof_end_dev(kind, flops / (double)(g.a_kmajor ? g.K[0] : g.M), g.m_dev, g.a_kmajor ? g.K[0] : g.M, stream);
   else pfo_prof_end(kind, flops, stream);
-  return PFO_OK;
-}
-
-int pfo_gemm_pair_launch(const PfoGemm& g0, const PfoGemm& g1, hipStream_t stream) {
-  const PfoGemm* gs[2] = {&g0, &g1};
-  GemmDev d[2];
-  double flops_per_row = 0;
-  for (int i = 0; i < 2; ++i) {
-    const PfoGemm& g = *gs[i];
-    PFO_REQUIRE(g.M > 0 && g.N > 0 && g.K[0] > 0 && g.K[1] == 0 && g.batch == 1 && g.A[0] && g.B[0] && g.C && g.b_img, "bad pair problem");
-    PFO_REQUIRE(!g.a_kmajor && aligned4(g.A[0]) && (g.lda[0] % 4) == 0 && (g.K[0] % 4) == 0, "pair launch: row-major 16-byte aligned A");
-    PFO_REQUIRE(g.M == g0.M && g.m_dev == g0.m_dev, "pair launch: both problems share the row extent");
-    to_dev(g, d[i]);
-    d[i].b_img = g.b_img; d[i].b_img_rows = (int)pfo_align_up(g.N, BN);
-    flops_per_row += 2.0 * g.N * g.K[0];
-  }
-  const unsigned tn = (unsigned)std::max(pfo_ceil_div(g0.N, BN), pfo_ceil_div(g1.N, BN));
-  pfo_prof_begin(stream);
-  hipLaunchKernelGGL(gemm_bx_areg_pair_kernel, dim3((unsigned)pfo_ceil_div(g0.M, BM), tn, 2), dim3(GEMM_THREADS), 0, stream, d[0], d[1]);
-  PFO_LAUNCH_CHECK();
-  pfo_prof_end_dev(PFO_PROF_GEMM_BX, flops_per_row, g0.m_dev, g0.M, stream);
   return PFO_OK;
 }
 

@@ -46,14 +46,29 @@ struct PfoBimg {
   // [row0, row0 + N) of an image of rows_total rows (padded to the tile width); the LAST operand of a stack sets `last`
   // and also writes the zero padding rows up to the padded end.  rows_total = 0: a plain single-operand image
   int row0 = 0, rows_total = 0, last = 0;
+  // GRU gate-ordered image for pfo_gru_fused_launch: src = the stacked [3D, K] weight (N = 3 D), gate = 1 (W_ih) or 2 (W_hh),
+  // gate_D = D; dst needs pfo_gru_img_bytes(D, K)
+  int gate = 0, gate_D = 0;
 };
+int pfo_gru_img_rows(int D);
+int64_t pfo_gru_img_bytes(int D, int K);
+
+// The lazy GRU of cap_rows (device count n_rows) packed rows in one launch: [msg_rows | h_rows] against the gate-ordered images,
+// gates in the epilogue.  upd_mem = h' (or h where hm == 0), h0_tab = h' + node_feat[touched], gates [rows, 4D] = r | z | n | gh_n.
+struct PfoGruFused {
+  const float* msg_rows = nullptr; int K_msg = 0;     // [rows, K_msg]
+  const float* h_rows = nullptr;                      // [rows, D]
+  const void* img_ih = nullptr; const void* img_hh = nullptr;
+  const float* b_ih = nullptr; const float* b_hh = nullptr;
+  const uint8_t* hm = nullptr; const int32_t* touched = nullptr; const float* node_feat = nullptr;
+  float* upd_mem = nullptr; float* h0_tab = nullptr; float* gates = nullptr;
+  int D = 0, cap_rows = 0; const int32_t* n_rows = nullptr;
+};
+int pfo_gru_fused_launch(const PfoGruFused& f, hipStream_t stream);
 int64_t pfo_bimg_bytes(int N, int K);
 int pfo_bimg_launch(const PfoBimg* list, int n, hipStream_t stream);
 
 int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream);
-// two single-source row-major contractions with weight images and the SAME row extent (M, m_dev) in one launch of the 128-row
-// bf16x3 kernel (grid.z = 2)
-int pfo_gemm_pair_launch(const PfoGemm& g0, const PfoGemm& g1, hipStream_t stream);
 // true when a row-major launch of this size (aligned operands, images supplied) takes a bf16x3 kernel: those accept two
 // K-concatenated sources whose B operands differ in layout
 bool pfo_gemm_takes_bx(int M, int N);

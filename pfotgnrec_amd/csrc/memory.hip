@@ -311,16 +311,6 @@ int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// sigmoid / tanh of the GRU gates on the hardware exponential (v_exp_f32 = 2^x, ~1 ulp) and v_rcp_f32: ~1e-7 absolute, against
-// ~40 instructions each for expf / tanhf (the two gate kernels are otherwise plain streaming passes)
-__device__ __forceinline__ float sigmoidf_acc(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x)); }
-__device__ __forceinline__ float tanhf_acc(float x) {
-  // tanh(x) = sign(x) (1 - e) / (1 + e), e = exp(-2|x|): no cancellation for small |x| (1 - e is exact to an ulp of e ~ 1)
-  const float e = __builtin_amdgcn_exp2f(-2.88539008177792681472f * fabsf(x));
-  const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
-  return copysignf(t, x);
-}
-
 // Two independent jobs that both wait for the compaction, in ONE launch: blocks [0, row_blocks) copy the touched nodes' rows
 // out of the full tables (msg_table may be null: no-memory models copy node features only), the blocks behind them translate
 // the level-0 node list into table rows (idx0[i] = slot[nodes0[i]]).
@@ -366,56 +356,22 @@ int pfo_pack_remap_launch(const float* msg_table, int M, const float* memory, in
   return PFO_OK;
 }
 
-__global__ void gru_gates_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
-                                     const float* __restrict__ h_rows, const float* __restrict__ node_feat,
-                                     const uint8_t* __restrict__ hm, const int32_t* __restrict__ touched_ids,
-                                     const int32_t* __restrict__ n_touched, int D, float* __restrict__ upd_mem,
-                                     float* __restrict__ h0_tab) {
+// GRU backward, gate part (torch.nn.GRUCell): from d h' and the gates the fused forward kept (gemm.hip gru_fused_kernel:
+// gates[s] = r | z | n | gh_n) to the gradients of the two pre-activation blocks, d gi = (dr', dz', dn'), d gh = (dr', dz', dn' r)
+// - the A operands of the GRU's weight-gradient launch.  d h' = the key-side rows the attention scattered (n_rep float replicas,
+// or ONE int64 fixed-point table in deterministic mode) + d_extra (the rows' query-side gradient, already summed per row).
+__global__ void gru_gates_bwd_kernel(const float* __restrict__ gates, float* __restrict__ dgi, float* __restrict__ dgh,
+                                     const float* __restrict__ h_rows, const uint8_t* __restrict__ hm,
+                                     const int32_t* __restrict__ n_touched, int D, const float* __restrict__ d_h0, int n_rep,
+                                     int64_t rep_stride, const float* __restrict__ d_extra, int det) {
   const int64_t total = (int64_t)(*n_touched) * D;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int s = (int)(e / D), d = (int)(e - (int64_t)s * D);
-    const int id = touched_ids[s];
-    const float h = h_rows[e];
-    float hn = h;
-    if (hm[s]) {
-      const float* gis = gi + (int64_t)s * 3 * D;
-      const float* ghs = gh + (int64_t)s * 3 * D;
-      const float r = sigmoidf_acc(gis[d] + ghs[d]);
-      const float z = sigmoidf_acc(gis[D + d] + ghs[D + d]);
-      const float nn = tanhf_acc(gis[2 * D + d] + r * ghs[2 * D + d]);
-      hn = (1.f - z) * nn + z * h;
-    }
-    upd_mem[e] = hn;
-    h0_tab[e] = hn + node_feat[(int64_t)id * D + d];
-  }
-}
-
-int pfo_gru_gates_fwd_launch(const float* gi, const float* gh, const float* h_rows, const float* node_feat,
-                             const uint8_t* hm, const int32_t* touched_ids, const int32_t* n_touched, int cap, int D,
-                             float* upd_mem, float* h0_tab, hipStream_t stream) {
-  const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div((int64_t)cap * D, 256));
-  hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(nb), dim3(256), 0, stream, gi, gh, h_rows, node_feat, hm,
-                     touched_ids, n_touched, D, upd_mem, h0_tab);
-  PFO_LAUNCH_CHECK();
-  return PFO_OK;
-}
-
-__global__ void gru_gates_bwd_kernel(float* __restrict__ gi, float* __restrict__ gh, const float* __restrict__ h_rows,
-                                     const uint8_t* __restrict__ hm, const int32_t* __restrict__ n_touched, int D,
-                                     const float* __restrict__ d_h0, int n_rep, int64_t rep_stride,
-                                     const float* __restrict__ d_extra, int det) {
-  const int64_t total = (int64_t)(*n_touched) * D;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int s = (int)(e / D), d = (int)(e - (int64_t)s * D);
-    float* gis = gi + (int64_t)s * 3 * D;
-    float* ghs = gh + (int64_t)s * 3 * D;
     float dpr = 0.f, dpz = 0.f, dpn = 0.f, dpnr = 0.f;
     if (hm[s]) {
+      const float* gs = gates + (int64_t)s * 4 * D;
       const float h = h_rows[e];
-      const float ghn = ghs[2 * D + d];
-      const float r = sigmoidf_acc(gis[d] + ghs[d]);
-      const float z = sigmoidf_acc(gis[D + d] + ghs[D + d]);
-      const float nn = tanhf_acc(gis[2 * D + d] + r * ghn);
+      const float r = gs[d], z = gs[D + d], nn = gs[2 * D + d], ghn = gs[3 * D + d];
       float dh = 0.f;                                  // the level-0 gradient is kept in one replica per XCD
       if (det) dh = (float)((double)reinterpret_cast<const long long*>(d_h0)[e] * (1.0 / 1099511627776.0));   // 2^-40 fixed point (attn.hpp)
       else
@@ -429,17 +385,19 @@ __global__ void gru_gates_bwd_kernel(float* __restrict__ gi, float* __restrict__
       dpz = dz * z * (1.f - z);
       dpnr = dpn * r;
     }
+    float* gis = dgi + (int64_t)s * 3 * D;
+    float* ghs = dgh + (int64_t)s * 3 * D;
     gis[d] = dpr; gis[D + d] = dpz; gis[2 * D + d] = dpn;
     ghs[d] = dpr; ghs[D + d] = dpz; ghs[2 * D + d] = dpnr;
   }
 }
 
-int pfo_gru_gates_bwd_launch(float* gi, float* gh, const float* h_rows, const uint8_t* hm, const int32_t* n_touched,
-                             int cap, int D, const float* d_h0, int n_rep, int64_t rep_stride, const float* d_extra,
-                             int det, hipStream_t stream) {
+int pfo_gru_gates_bwd_launch(const float* gates, float* dgi, float* dgh, const float* h_rows, const uint8_t* hm,
+                             const int32_t* n_touched, int cap, int D, const float* d_h0, int n_rep, int64_t rep_stride,
+                             const float* d_extra, int det, hipStream_t stream) {
   const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div((int64_t)cap * D, 256));
-  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(nb), dim3(256), 0, stream, gi, gh, h_rows, hm, n_touched, D, d_h0, n_rep, rep_stride,
-                     d_extra, det);
+  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(nb), dim3(256), 0, stream, gates, dgi, dgh, h_rows, hm, n_touched, D, d_h0, n_rep,
+                     rep_stride, d_extra, det);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

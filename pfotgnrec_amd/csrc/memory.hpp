@@ -18,18 +18,13 @@ int pfo_pack_remap_launch(const float* msg_table, int M, const float* memory, in
                           const int32_t* touched_ids, const int32_t* n_touched, int cap, float* msg_rows, float* h_rows,
                           uint8_t* hm, const int32_t* nodes0, int64_t n0, const int32_t* slot, int32_t* idx0, hipStream_t stream);
 
-// --- GRU gates (memory_updater.py:60; torch.nn.GRUCell gate order r, z, n)
-// forward: per touched slot s (id = touched_ids[s]): h' = hm[s] ? GRU(gi[s], gh[s], h_rows[s]) : h_rows[s];
-//          upd_mem[s] = h'; h0_tab[s] = h' + node_feat[id]          (embedding_module.py:98)
-int pfo_gru_gates_fwd_launch(const float* gi, const float* gh, const float* h_rows, const float* node_feat,
-                             const uint8_t* hm, const int32_t* touched_ids, const int32_t* n_touched, int cap, int D,
-                             float* upd_mem, float* h0_tab, hipStream_t stream);
-// backward: overwrites gi/gh with d gi / d gh given d h' = sum over the n_rep replicas of d_h0[s] (zeros where no message was applied)
-// d_extra (optional): one more [rows, D] addend of d h' (the rows' query-side gradient, layer 1)
-int pfo_gru_gates_bwd_launch(float* gi, float* gh, const float* h_rows, const uint8_t* hm, const int32_t* n_touched,
-                             int cap, int D, const float* d_h0, int n_rep, int64_t rep_stride, const float* d_extra,
-                             int det, hipStream_t stream);
-// (det: d_h0 is ONE table of int64 fixed-point sums, attn.hpp PFO_DET_SCALE)
+// --- GRU gates, backward (memory_updater.py:60; torch.nn.GRUCell gate order r, z, n).  The forward is gemm.hpp
+// pfo_gru_fused_launch (contractions + gates in one launch; it keeps gates[s] = r | z | n | gh_n).  Writes d gi / d gh [rows, 3D]
+// given d h' = sum over the n_rep replicas of d_h0[s] (+ d_extra: the rows' query-side gradient, layer 1); zeros where no
+// message was applied.  det: d_h0 is ONE table of int64 fixed-point sums (attn.hpp PFO_DET_SCALE)
+int pfo_gru_gates_bwd_launch(const float* gates, float* dgi, float* dgh, const float* h_rows, const uint8_t* hm,
+                             const int32_t* n_touched, int cap, int D, const float* d_h0, int n_rep, int64_t rep_stride,
+                             const float* d_extra, int det, hipStream_t stream);
 // dst[s] = src[touched_ids[s]], s < *n_touched
 int pfo_gather_rows_launch(const float* src, int D, const int32_t* touched_ids, const int32_t* n_touched, int cap, float* dst,
                            hipStream_t stream);

@@ -40,7 +40,7 @@ struct Ws {
   int32_t* eidx[PFO_MAX_LAYERS + 1];
   float* dt[PFO_MAX_LAYERS + 1];
   int32_t *slot, *touched, *n_touched, *scan, *idx0, *winner;
-  float *gi, *gh, *upd_mem, *h0_tab, *d_h0, *msg_rows, *h_rows;
+  float *gi, *gh, *gates, *upd_mem, *h0_tab, *d_h0, *msg_rows, *h_rows;   // gi / gh: backward only (d gi / d gh)
   uint8_t* hm;
   float *cosb, *zero, *tb_part;
   void *iWih, *iWhh;
@@ -143,13 +143,14 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     w.winner = take<int32_t>(p, c->n_nodes);
     w.gi = take<float>(p, d.capP * 3 * d.D);
     w.gh = take<float>(p, d.capP * 3 * d.D);
+    w.gates = take<float>(p, d.capP * 4 * d.D);
     w.upd_mem = take<float>(p, d.capP * d.D);
     w.d_h0 = take<float>(p, PFO_GRAD_REPLICAS * d.capP * d.D);     // one replica per XCD (attn.hip, DMODE 1)
     w.msg_rows = take<float>(p, d.capP * d.M);
     w.h_rows = take<float>(p, d.capP * d.D);
     w.hm = take<uint8_t>(p, d.capP);
-    w.iWih = take<char>(p, pfo_bimg_bytes(3 * d.D, d.M));
-    w.iWhh = take<char>(p, pfo_bimg_bytes(3 * d.D, d.D));
+    w.iWih = take<char>(p, pfo_gru_img_bytes(d.D, d.M));
+    w.iWhh = take<char>(p, pfo_gru_img_bytes(d.D, d.D));
   }
   for (int l = 1; l <= d.L; ++l) {
     const int64_t N = d.ncap[l];
@@ -422,6 +423,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     PfoBimg im[2];
     im[0].src = P.w_ih; im[0].ld = d.M; im[0].N = 3 * D; im[0].K = d.M; im[0].trans = 0; im[0].dst = w.iWih;
     im[1].src = P.w_hh; im[1].ld = D; im[1].N = 3 * D; im[1].K = D; im[1].trans = 0; im[1].dst = w.iWhh;
+    im[0].gate = 1; im[0].gate_D = D; im[1].gate = 2; im[1].gate_D = D;      // gate-ordered rows: r | z | n_i | n_h per 16 hidden units
     RUN(pfo_bimg_launch(im, 2, s));
   }
   bool composites_awaited = false;
@@ -439,15 +441,12 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   if (c->use_memory) {
     RUN(pfo_pack_remap_launch(st->msg_table, d.M, st->memory, D, st->has_msg, w.touched, w.n_touched, capP, w.msg_rows,
                               w.h_rows, w.hm, w.nodes[0], n[0], w.slot, w.idx0, s));
-    // the two GRU contractions are independent and each fills only ~55 % of the chip (touched rows / 128 x 3 column
-    // tiles = ~280 workgroups): both in ONE launch
-    PfoGemm gi = g_nt(w.msg_rows, d.M, nullptr, P.w_ih, d.M, w.gi, 3 * D, capP, 3 * D, d.M, P.b_ih);
-    gi.m_dev = w.n_touched; gi.b_img = w.iWih;
-    PfoGemm gh = g_nt(w.h_rows, D, nullptr, P.w_hh, D, w.gh, 3 * D, capP, 3 * D, D, P.b_hh);
-    gh.m_dev = w.n_touched; gh.b_img = w.iWhh;
-    RUN(pfo_gemm_pair_launch(gi, gh, s));
-    RUN(pfo_gru_gates_fwd_launch(w.gi, w.gh, w.h_rows, st->node_feat, w.hm, w.touched, w.n_touched, capP, D, w.upd_mem,
-                                 w.h0_tab, s));
+    // both GRU contractions and the gate math in ONE launch (gemm.hip gru_fused_kernel): gi / gh never exist in HBM
+    PfoGruFused f;
+    f.msg_rows = w.msg_rows; f.K_msg = d.M; f.h_rows = w.h_rows; f.img_ih = w.iWih; f.img_hh = w.iWhh;
+    f.b_ih = P.b_ih; f.b_hh = P.b_hh; f.hm = w.hm; f.touched = w.touched; f.node_feat = st->node_feat;
+    f.upd_mem = w.upd_mem; f.h0_tab = w.h0_tab; f.gates = w.gates; f.D = D; f.cap_rows = capP; f.n_rows = w.n_touched;
+    RUN(pfo_gru_fused_launch(f, s));
   } else {
     RUN(pfo_pack_remap_launch(nullptr, d.M, st->node_feat, D, nullptr, w.touched, w.n_touched, capP, nullptr, w.h0_tab, nullptr,
                               w.nodes[0], n[0], w.slot, w.idx0, s));
@@ -589,12 +588,13 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     const float* b1_l = (l == 1) ? p.b1 : lw.b1_f;
 
     if (!composites_awaited) {
-      // ONE wait for everything the side stream prepared (composite weights, images and, with several layers, the fc2-folded
-      // ones: its ~14 launches are done long before the sampling / GRU phase of this stream is) - every wait on another
-      // stream's event costs this stream ~5-15 us on this part, signalled or not
-      HIPOK(hipStreamWaitEvent(s, L >= 2 ? sd.fold_done : sd.layer[0], 0), "event wait failed");
+      HIPOK(hipStreamWaitEvent(s, sd.layer[0], 0), "event wait failed");   // composite weights and layer 1's images are ready
       composites_awaited = true;
     }
+    // ... and the fc2-folded ones of the layers >= 2.  (Round 3 tried ONE wait for both, on the later event: the side stream's
+    // chain - 14 small dependent launches, ~150 us - then ends about when this stream reaches layer 1, and the touched-table
+    // projection started 25 us late; layer 1 needs only the first ~90 us of that chain.)
+    if (l == 2) HIPOK(hipStreamWaitEvent(s, sd.fold_done, 0), "event wait failed");
     // ---- qk' = x Wqk^T + cqk.  Layer 1: x is a row of the touched-node table, shared by every instance that sits on
     // that node (~54 k instances on ~11 k nodes at C2): ONE projection of the table, [qk' | x W1[:, E:]^T] per row
     if (l == 1) {
@@ -1014,7 +1014,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
 
   // ---- GRU parameters (messages and stored memory are constants: SURVEY App. A-6)
   if (c->use_memory) {
-    RUN(pfo_gru_gates_bwd_launch(w.gi, w.gh, w.h_rows, w.hm, w.n_touched, capP, D, w.d_h0, n_rep, rep_stride,
+    RUN(pfo_gru_gates_bwd_launch(w.gates, w.gi, w.gh, w.h_rows, w.hm, w.n_touched, capP, D, w.d_h0, n_rep, rep_stride,
                                  w.dx_tab, det, s));
     {
       PfoTnProblem gp[2];
