@@ -24,6 +24,8 @@ namespace {
 
 struct LayerWs {
   float *QK, *attw, *ctx, *h1;             // activations kept for backward
+  float* dQK;                              // layers >= 2: their own d qk' rows - their weight-gradient launch reads them on a side
+                                           // stream while the caller's stream is already writing layer 1's
   float *cq, *Wqk, *cqk, *W1oT, *W1ovT;   // per-step composite weights (see the layer comment in pfo_tgn_forward)
   float *dWqk, *gqk, *dW1ovT, *dW1oT, *gq; // their gradients (per layer: the chain-back runs on the side stream)
   // layers >= 2 take the PREVIOUS layer's h1 rows as input, with that layer's fc2 (out = W2 h1 + b2) folded into their own
@@ -176,6 +178,7 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     lw.h1 = take<float>(p, N * d.D);
     if (l < d.L) w.dH[l] = take<float>(p, N * d.D);
     if (l >= 2) {
+      lw.dQK = take<float>(p, N * d.H * d.Cp);
       const int64_t HCpD = (int64_t)d.H * d.Cp * d.D, HCp = (int64_t)d.H * d.Cp, DD = (int64_t)d.D * d.D;
       lw.T1 = take<float>(p, HCpD);      lw.tq = take<float>(p, HCp);
       lw.Wqk_f = take<float>(p, HCpD);   lw.cqk_f = take<float>(p, HCp);
@@ -803,7 +806,8 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     a.edge_feat = st->edge_feat; a.eidx = w.eidx[l]; a.dt = w.dt[l]; a.tw = P.tw; a.tb = P.tb;
     a.scale = scale; a.dropout_p = b->dropout_p; a.seed = b->seed; a.offset = b->offset + 0x51ED0000ull + (uint64_t)l; a.offset_dev = b->offset_dev;
     a.ctx = lw.ctx; a.attw = lw.attw; a.inv = lw.inv;
-    a.dctx = w.dctx; a.dQK = w.dQK;
+    float* const dqk_l = (l == 1) ? w.dQK : lw.dQK;
+    a.dctx = w.dctx; a.dQK = dqk_l;
     if (l == 1) { a.d_nbr = c->use_memory ? w.d_h0 : nullptr; a.d_nbr_ld = D; a.d_nbr_rep = rep_stride; a.d_nbr_nrep = n_rep; }
     else        { a.d_nbr = w.dH[l - 1]; a.d_nbr_ld = D; }
     a.dtime_part = w.dtime;
@@ -824,7 +828,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       // weight gradients against x - is taken AFTER summing those gradients per table row: contractions over the
       // ~11 k touched rows instead of the ~54 k instances.
       if (!c->use_memory) HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");   // (with memory: awaited before the attention backward)
-      RUN(pfo_segsum_launch(w.dQK, HCp, dh1, D, w.seg_ptr, w.seg_mem, w.n_touched, capP, dqk_by_member,
+      RUN(pfo_segsum_launch(dqk_l, HCp, dh1, D, w.seg_ptr, w.seg_mem, w.n_touched, capP, dqk_by_member,
                             dqk_by_member ? w.dqk_live : nullptr, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
       // the weight gradients over the table rows go to the side stream too (beside d h0 / the GRU backward on this one)
       HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
@@ -846,7 +850,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       // d h1 of the layer below, self rows [0, N): [dqk' | dh1] [Q_f ; W1b_f], masked by that layer's ReLU
       if (pfo_gemm_takes_bx(N, D)) {
         // both sources in one launch, dx written once
-        PfoGemm q = g_nn(w.dQK, HCp, Wqk_l, D, dx, D, N, D, HCp);
+        PfoGemm q = g_nn(dqk_l, HCp, Wqk_l, D, dx, D, N, D, HCp);
         q.A[1] = dh1; q.lda[1] = D; q.B[1] = W1b_l; q.ldb[1] = W1b_ld; q.K[1] = D;
         q.b_img = lw.iWqkT; q.b_img2 = lw.iW1bT;
         q.relu_src = xA; q.relu_ld = D;
@@ -855,12 +859,12 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
         PfoGemm q = g_nn(dh1, D, W1b_l, W1b_ld, dx, D, N, D, D);
         q.b_img = lw.iW1bT;
         RUN(pfo_gemm_launch(q, s));
-        q = g_nn(w.dQK, HCp, Wqk_l, D, dx, D, N, D, HCp);
+        q = g_nn(dqk_l, HCp, Wqk_l, D, dx, D, N, D, HCp);
         q.accumulate = 1; q.b_img = lw.iWqkT;
         q.relu_src = xA; q.relu_ld = D;
         RUN(pfo_gemm_launch(q, s));
       }
-      set_tn(tn[ntn], w.dQK, HCp, xA, D, x_idx, HCp, D, dWqk_l, D, gqk_l);
+      set_tn(tn[ntn], dqk_l, HCp, xA, D, x_idx, HCp, D, dWqk_l, D, gqk_l);
       tn[ntn].c_accumulate = 0; tn[ntn].bias_accumulate = 0;
       ++ntn;
       // (launched below, on the second side stream in front of the layer's chain: nothing on this stream needs the weight
