@@ -11,10 +11,12 @@
 
 #define SCAN_BLOCK 1024
 
-__global__ void touch_mark_kernel(const int32_t* __restrict__ nodes0, int64_t n0, int n_nodes, int32_t* __restrict__ slot) {
+// mark[v] = value for every listed node; keep_set: nodes already marked (by the sampler: the step's own references) stay as they are
+__global__ void touch_mark_kernel(const int32_t* __restrict__ nodes0, int64_t n0, int n_nodes, int32_t* __restrict__ mark, int value,
+                                  int keep_set) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0; i += (int64_t)gridDim.x * blockDim.x) {
     const int v = nodes0[i];
-    if (v >= 0 && v < n_nodes) slot[v] = 1;
+    if (v >= 0 && v < n_nodes && !(keep_set && mark[v] != 0)) mark[v] = value;
   }
 }
 
@@ -54,15 +56,17 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(int32_t* __restrict__
 // dispatched first, so they make progress whatever the occupancy (the forward-progress assumption of every look-back scan).
 // flags[] must be zero when the kernel starts: they sit behind slot[] in the workspace and are cleared by the same memset.
 // (Block b reads b flags: quadratic in n_nodes / 1024, 0.1 M reads at C4's 500 k nodes, ~50 M at 10 M nodes.)
-__global__ __launch_bounds__(SCAN_BLOCK) void compact_onepass_kernel(int32_t* __restrict__ slot, int n_nodes, int32_t* flags,
-                                                                     int32_t* __restrict__ touched_ids,
-                                                                     int32_t* __restrict__ n_touched) {
+__global__ __launch_bounds__(SCAN_BLOCK) void compact_onepass_kernel(const int32_t* __restrict__ mark, int match, int32_t* __restrict__ slot,
+                                                                     int n_nodes, int32_t* flags, int32_t* __restrict__ touched_ids,
+                                                                     const int32_t* __restrict__ base_dev, int32_t* __restrict__ n_out,
+                                                                     int32_t* __restrict__ n_out2, int write_unmatched) {
   __shared__ int s_cnt[SCAN_BLOCK / 64];
   __shared__ int s_off[SCAN_BLOCK / 64];
   const int b = blockIdx.x;
   const int v = b * SCAN_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool f = v < n_nodes && slot[v] != 0;
+  const int mk = v < n_nodes ? mark[v] : 0;
+  const bool f = mk == match;
   const unsigned long long bal = __ballot(f);
   if (lane == 0) s_cnt[wave] = __popcll(bal);
   __syncthreads();
@@ -80,40 +84,54 @@ __global__ __launch_bounds__(SCAN_BLOCK) void compact_onepass_kernel(int32_t* __
   for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
   if (lane == 0) s_off[wave] = part;
   __syncthreads();
-  int off = 0;
+  int off = base_dev ? *base_dev : 0;                        // second class: slots continue behind the first one's
   for (int w = 0; w < SCAN_BLOCK / 64; ++w) off += s_off[w];
   const int pos = off + woff + __popcll(bal & ((1ull << lane) - 1ull));
   if (v < n_nodes) {
-    slot[v] = f ? pos : -1;
-    if (f) touched_ids[pos] = v;
+    if (f) { slot[v] = pos; touched_ids[pos] = v; }
+    else if (write_unmatched) slot[v] = -1;
   }
-  if (b == (int)gridDim.x - 1 && threadIdx.x == 0) *n_touched = off + cnt;
+  if (b == (int)gridDim.x - 1 && threadIdx.x == 0) {
+    *n_out = off + cnt;
+    if (n_out2) *n_out2 = off + cnt;
+  }
 }
 
-int64_t pfo_compact_scratch_ints(int n_nodes) { return pfo_ceil_div(n_nodes, SCAN_BLOCK) + 8; }
+int64_t pfo_compact_scratch_ints(int n_nodes) { return 2 * pfo_ceil_div(n_nodes, SCAN_BLOCK) + 8; }
 
-int pfo_touch_compact_launch(const int32_t* nodes0, int64_t n0, const int32_t* extra, int64_t n_extra, int n_nodes,
-                             int32_t* slot, int32_t* touched_ids, int32_t* n_touched, int32_t* scratch,
-                             bool slot_is_zero, bool marked, hipStream_t stream) {
-  PFO_REQUIRE(slot && touched_ids && n_touched && scratch && n_nodes > 0, "bad arguments");
+// Two CLASSES of touched nodes: those the step's levels reference (flag 1, set by the sampler or the marking pass here) get
+// slots [0, n_core); nodes only the caller's `extra` list names (flag 2: a data-parallel rank's global positives, whose lazily
+// updated memory the state update needs) get [n_core, n_touched).  Everything that is computed FOR the layers - the
+// touched-table projection, the per-row gradient sums, the GRU backward - then stops at n_core (n_counts[1]); the GRU forward
+// covers all n_touched (n_counts[0]) rows.  Without extras one pass, n_core == n_touched.
+int pfo_touch_compact_launch(const int32_t* nodes0, int64_t n0, const int32_t* extra, int64_t n_extra, int n_nodes, int32_t* mark,
+                             int32_t* slot, int32_t* touched_ids, int32_t* n_counts, int32_t* scratch, bool marks_are_zero,
+                             bool marked, hipStream_t stream) {
+  PFO_REQUIRE(mark && slot && touched_ids && n_counts && scratch && n_nodes > 0, "bad arguments");
   PFO_REQUIRE(marked || (nodes0 && n0 > 0), "no node list to mark");
   const int nb = (int)pfo_ceil_div(n_nodes, SCAN_BLOCK);
-  if (!slot_is_zero) {
+  if (!marks_are_zero) {
     PFO_REQUIRE(!marked, "marked flags need a cleared table");
-    hipError_t e = hipMemsetAsync(slot, 0, (size_t)n_nodes * sizeof(int32_t), stream);
+    hipError_t e = hipMemsetAsync(mark, 0, (size_t)n_nodes * sizeof(int32_t), stream);
     PFO_REQUIRE(e == hipSuccess, "memset failed");
-    e = hipMemsetAsync(scratch, 0, (size_t)nb * sizeof(int32_t), stream);
+    e = hipMemsetAsync(scratch, 0, (size_t)2 * nb * sizeof(int32_t), stream);
     PFO_REQUIRE(e == hipSuccess, "memset failed");
   }
   if (!marked) {
     const int mb = (int)std::min<int64_t>(2048, pfo_ceil_div(n0, 256));
-    hipLaunchKernelGGL(touch_mark_kernel, dim3(mb), dim3(256), 0, stream, nodes0, n0, n_nodes, slot);
+    hipLaunchKernelGGL(touch_mark_kernel, dim3(mb), dim3(256), 0, stream, nodes0, n0, n_nodes, mark, 1, 0);
   }
-  if (extra && n_extra > 0) {
+  const bool two = extra && n_extra > 0;
+  if (two) {
     const int eb = (int)std::min<int64_t>(2048, pfo_ceil_div(n_extra, 256));
-    hipLaunchKernelGGL(touch_mark_kernel, dim3(eb), dim3(256), 0, stream, extra, n_extra, n_nodes, slot);
+    hipLaunchKernelGGL(touch_mark_kernel, dim3(eb), dim3(256), 0, stream, extra, n_extra, n_nodes, mark, 2, 1);
   }
-  hipLaunchKernelGGL(compact_onepass_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, slot, n_nodes, scratch, touched_ids, n_touched);
+  // class 1 -> n_counts[1] (and n_counts[0] when it is the only class); class 2 continues behind it -> n_counts[0]
+  hipLaunchKernelGGL(compact_onepass_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, mark, 1, slot, n_nodes, scratch, touched_ids,
+                     (const int32_t*)nullptr, n_counts + 1, two ? (int32_t*)nullptr : n_counts, 1);
+  if (two)
+    hipLaunchKernelGGL(compact_onepass_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, mark, 2, slot, n_nodes, scratch + nb, touched_ids,
+                       (const int32_t*)(n_counts + 1), n_counts, (int32_t*)nullptr, 0);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

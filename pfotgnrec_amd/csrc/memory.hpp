@@ -2,14 +2,15 @@
 #pragma once
 #include "common.hpp"
 
-// --- touched-node compaction: slot[v] = rank of v among the nodes referenced this step, -1 otherwise
-// (slot_is_zero: the caller has already cleared slot[0, n_nodes) in stream order)
+// --- touched-node compaction: slot[v] = row of v in the per-step tables, -1 when the step does not touch v.  mark[] holds the
+// flags (1 = referenced by the step's levels: set by the sampler's `mark` output when `marked`, else from nodes0 here; 2 = named
+// only by `extra`), slot[] / touched_ids[] the result: class-1 nodes in id order first (n_counts[1] of them), class-2 nodes
+// behind (n_counts[0] = all).  marks_are_zero: the caller has cleared mark[0, n_nodes) and scratch[0, 2 n_nodes / 1024) in
+// stream order.
 int64_t pfo_compact_scratch_ints(int n_nodes);
-int pfo_touch_compact_launch(const int32_t* nodes0, int64_t n0, const int32_t* extra, int64_t n_extra, int n_nodes,
-                             int32_t* slot, int32_t* touched_ids, int32_t* n_touched, int32_t* scratch,
-                             bool slot_is_zero, bool marked, hipStream_t stream);
-// (slot_is_zero also covers scratch[0, n_nodes / 1024]: the one-pass scan's block flags; marked: the flags slot[v] = 1 were
-//  already set by the sampler (pfo_tnbr_sample_dev `mark`), only `extra` is marked here)
+int pfo_touch_compact_launch(const int32_t* nodes0, int64_t n0, const int32_t* extra, int64_t n_extra, int n_nodes, int32_t* mark,
+                             int32_t* slot, int32_t* touched_ids, int32_t* n_counts, int32_t* scratch, bool marks_are_zero,
+                             bool marked, hipStream_t stream);
 // packs the rows backward still needs after the state update overwrites them (pfo_pack_remap_launch):
 //   msg_rows[s] = msg_table[id], h_rows[s] = memory[id], hm[s] = has_msg[id]   (id = touched_ids[s])
 int pfo_remap_launch(const int32_t* nodes0, int64_t n0, const int32_t* slot, int32_t* idx0, hipStream_t stream);

@@ -41,7 +41,7 @@ struct Ws {
   double* ts[PFO_MAX_LAYERS + 1];
   int32_t* eidx[PFO_MAX_LAYERS + 1];
   float* dt[PFO_MAX_LAYERS + 1];
-  int32_t *slot, *touched, *n_touched, *scan, *idx0, *winner;
+  int32_t *mark, *slot, *touched, *n_touched, *n_core, *scan, *idx0, *winner;   // n_touched = counts[0] (all rows), n_core = counts[1]
   float *gi, *gh, *gates, *upd_mem, *h0_tab, *d_h0, *msg_rows, *h_rows;   // gi / gh: backward only (d gi / d gh)
   uint8_t* hm;
   float *cosb, *zero, *tb_part;
@@ -122,11 +122,13 @@ Ws carve(const pfo_tgn_config* c, void* base) {
   {
     const int WQ = d.H * d.Cp + d.D;
     // one memset per step clears [touched-node flags | block flags of the one-pass compaction]
-    w.slot = take<int32_t>(p, c->n_nodes);
+    w.mark = take<int32_t>(p, c->n_nodes);
     w.scan = take<int32_t>(p, pfo_compact_scratch_ints(c->n_nodes));
-    w.mark_bytes = (size_t)(p - reinterpret_cast<char*>(w.slot));
+    w.mark_bytes = (size_t)(p - reinterpret_cast<char*>(w.mark));
+    w.slot = take<int32_t>(p, c->n_nodes);
     w.touched = take<int32_t>(p, d.capP);
     w.n_touched = take<int32_t>(p, 64);
+    w.n_core = w.n_touched + 1;
     w.idx0 = take<int32_t>(p, d.ncap[0]);
     w.h0_tab = take<float>(p, d.capP * d.D);
     w.QX = take<float>(p, d.capP * WQ);
@@ -404,7 +406,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
   // The compaction's flags are cleared on THIS stream (4 us): a wait for a side-stream memset costs the waiting stream 5-17 us
   // on this part (r3 timeline), more than the memset itself.  Same reasoning for the GRU's two weight images below.
-  HIPOK(hipMemsetAsync(w.slot, 0, w.mark_bytes, s), "memset failed");
+  HIPOK(hipMemsetAsync(w.mark, 0, w.mark_bytes, s), "memset failed");
   // ---- frontier expansion: K1 per level (utils.py:163-219 called from embedding_module.py:125).  Enqueued before the
   // side-stream work below: it depends on nothing else, and the GPU samples while the host is still enqueueing
   for (int l = L; l >= 1; --l) {
@@ -417,7 +419,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     // compaction needs no marking pass
     RUN(pfo_tnbr_sample_dev(st->indptr, st->adj_nbr, st->adj_eidx, st->adj_ts, c->n_nodes, lvl_nodes, lvl_ts, n[l], K,
                             b->uniform, dr, b->seed, b->offset + (uint64_t)l * 0x100000000ull, b->offset_dev, nullptr,
-                            w.eidx[l], nullptr, w.dt[l], w.nodes[l - 1], l > 1 ? w.ts[l - 1] : nullptr, l == 1 ? w.slot : nullptr,
+                            w.eidx[l], nullptr, w.dt[l], w.nodes[l - 1], l > 1 ? w.ts[l - 1] : nullptr, l == 1 ? w.mark : nullptr,
                             l == 1 ? w.cnt1 : nullptr, stream));
   }
 
@@ -435,7 +437,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   // slot[v] = row of v in the per-step tables, idx0[i] = row of the i-th level-0 reference
   PFO_REQUIRE(b->n_extra >= 0 && b->n_extra <= 2 * c->max_batch, "n_extra exceeds 2 * max_batch");
   PFO_REQUIRE(b->n_extra == 0 || b->extra_nodes, "null extra_nodes");
-  RUN(pfo_touch_compact_launch(nullptr, 0, b->extra_nodes, b->n_extra, c->n_nodes, w.slot, w.touched, w.n_touched,
+  RUN(pfo_touch_compact_launch(nullptr, 0, b->extra_nodes, b->n_extra, c->n_nodes, w.mark, w.slot, w.touched, w.n_touched,
                                w.scan, true, true, s));
   const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
   // ---- level-0 rows of the touched nodes: memory' + node features (embedding_module.py:93-98), memory' = the lazily
@@ -602,7 +604,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     // that node (~54 k instances on ~11 k nodes at C2): ONE projection of the table, [qk' | x W1[:, E:]^T] per row
     if (l == 1) {
       PfoGemm g = g_nt(tab0, D, nullptr, lw.Wqk, D, w.QX, WQ, capP, WQ, D, w.l1_bias);
-      g.m_dev = w.n_touched; g.b_img = w.iQX;
+      g.m_dev = w.n_core; g.b_img = w.iQX;                 // (rows only the caller's extra list names are never queried)
       RUN(pfo_gemm_launch(g, s));
     } else {
       PfoGemm g = g_nt(xA, D, x_idx, Wqk_l, D, lw.QK, HCp, N, HCp, D, cqk_l);
@@ -712,7 +714,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
   if (mean_src) RUN(pfo_mean_launch(mean_src, mean_n, mean_out, ss));     // (a reduction the caller left to this call's side stream)
   // (deterministic: the table holds int64 fixed-point sums - rows of 2 D floats' worth)
-  if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_touched, capP, det ? 2 * D : D, n_rep, rep_stride, ss));
+  if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_core, capP, det ? 2 * D : D, n_rep, rep_stride, ss));
   RUN(pfo_seg_build_launch(idx0, w.nodes[0], (int)n[1], capP, b->uniform ? nullptr : w.cnt1, w.seg_ptr, w.seg_cur,
                            w.seg_tmp, w.seg_mem, w.seg_scratch, ss));
   HIPOK(hipEventRecord(sd.seg_done, ss), "event record failed");
@@ -816,7 +818,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     if (l == 1 && c->use_memory) HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");   // d_h0 is clear, the groups exist
     if (l == 1 && c->use_memory && !b->uniform) {
       // key-side gradients of instances with identical neighbour lists leave as one set of atomics (attn.hip)
-      a.members = w.seg_mem; a.seg_ptr = w.seg_ptr; a.n_rows = w.n_touched; a.run_cnt = w.cnt1; a.dqk_live = w.dqk_live;
+      a.members = w.seg_mem; a.seg_ptr = w.seg_ptr; a.n_rows = w.n_core; a.run_cnt = w.cnt1; a.dqk_live = w.dqk_live;
     }
     const int dqk_by_member = pfo_attn_bwd_uses_runs(a) ? 1 : 0;
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
@@ -828,7 +830,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       // weight gradients against x - is taken AFTER summing those gradients per table row: contractions over the
       // ~11 k touched rows instead of the ~54 k instances.
       if (!c->use_memory) HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");   // (with memory: awaited before the attention backward)
-      RUN(pfo_segsum_launch(dqk_l, HCp, dh1, D, w.seg_ptr, w.seg_mem, w.n_touched, capP, dqk_by_member,
+      RUN(pfo_segsum_launch(dqk_l, HCp, dh1, D, w.seg_ptr, w.seg_mem, w.n_core, capP, dqk_by_member,
                             dqk_by_member ? w.dqk_live : nullptr, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
       // the weight gradients over the table rows go to the side stream too (beside d h0 / the GRU backward on this one)
       HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
@@ -838,12 +840,12 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       tb[0].c_accumulate = 0; tb[0].bias_accumulate = 0;
       set_tn(tb[1], w.Dq + HCp, WQ, tab0, D, nullptr, D, D, g.w1 + E, E + D, g.b1);        // dW1[:, E:], db1
       // (the layer's chain-back on the side stream needs dWqk / gqk: this launch stays there also while profiling)
-      RUN(pfo_gemm_tn_group_launch(tb, 2, capP, w.n_touched, w.slabs2, w.slab_floats, ss));
+      RUN(pfo_gemm_tn_group_launch(tb, 2, capP, w.n_core, w.slabs2, w.slab_floats, ss));
       if (c->use_memory) {
         // d h0_tab (query side) = Dq [Wqk ; W1[:, E:]]; the GRU backward adds it to the key-side rows the attention scattered
         PfoGemm q = g_nn(w.Dq, WQ, lw.Wqk, D, w.dx_tab, D, capP, D, HCp);
         q.A[1] = w.Dq + HCp; q.lda[1] = WQ; q.B[1] = p.w1 + E; q.ldb[1] = E + D; q.K[1] = D;
-        q.b_img = lw.iWqkT; q.b_img2 = lw.iW1bT; q.m_dev = w.n_touched;
+        q.b_img = lw.iWqkT; q.b_img2 = lw.iW1bT; q.m_dev = w.n_core;
         RUN(pfo_gemm_launch(q, s));
       }
     } else {
@@ -1018,7 +1020,8 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
 
   // ---- GRU parameters (messages and stored memory are constants: SURVEY App. A-6)
   if (c->use_memory) {
-    RUN(pfo_gru_gates_bwd_launch(w.gates, w.gi, w.gh, w.h_rows, w.hm, w.n_touched, capP, D, w.d_h0, n_rep, rep_stride,
+    // (the GRU's backward covers the rows the layers read: rows only the extra list names carry no gradient)
+    RUN(pfo_gru_gates_bwd_launch(w.gates, w.gi, w.gh, w.h_rows, w.hm, w.n_core, capP, D, w.d_h0, n_rep, rep_stride,
                                  w.dx_tab, det, s));
     {
       PfoTnProblem gp[2];
@@ -1026,7 +1029,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       gp[0].C = G.w_ih; gp[0].ldc = d.M; gp[0].bias_out = G.b_ih;
       gp[1].A = w.gh; gp[1].lda = 3 * D; gp[1].B = w.h_rows; gp[1].ldb = D; gp[1].M = 3 * D; gp[1].N = D;
       gp[1].C = G.w_hh; gp[1].ldc = D; gp[1].bias_out = G.b_hh;
-      RUN(pfo_gemm_tn_group_launch(gp, 2, capP, w.n_touched, w.slabs, w.slab_floats, s));
+      RUN(pfo_gemm_tn_group_launch(gp, 2, capP, w.n_core, w.slabs, w.slab_floats, s));
     }
   }
   // ---- the last small launches go to the first side stream, beside the GRU's weight gradients on the caller's stream:
