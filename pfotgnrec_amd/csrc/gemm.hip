@@ -436,6 +436,117 @@ __device__ __forceinline__ void bx_split_store(char* base, int piece_bytes, int 
   *reinterpret_cast<uint2*>(base + 2 * piece_bytes + off) = o3;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second split format (FMT 1, "fp16x2"): every fp32 operand element is the sum of TWO fp16 pieces of its value times a power of
+// two, x * 2^s = h + l with h = fp16(x 2^s), l = fp16(x 2^s - h) (22 significant bits), and a 16x16x32 block takes THREE
+// v_mfma_f32_16x16x32_f16 (h.l + l.h + h.h) instead of the six bf16 products: half the matrix-pipe work and two thirds of the
+// staging traffic at the same accuracy on the fp64 test (tests/test_gpu_kernels.py).  fp16 has 5 exponent bits, so the power of
+// two is chosen per ROW of each operand, from the row's largest magnitude, so that the largest scaled value lies in
+// [2^14, 2^15): elements down to 2^-18 of their row's maximum keep all 22 bits, smaller ones an absolute error of 2^-40 of the
+// row maximum - far below the rounding of an fp32 accumulation, but a NORM-wise bound where bf16x3 (fp32's own exponent range)
+// gives a component-wise one.  Weight images carry the exponent of each image row behind the tiles (bimg_h_kernel); activation
+// rows are scaled by the consuming kernel from a RUNNING maximum over the k-tiles it has seen: when a later tile holds a larger
+// value the row's accumulators are multiplied by the (exact) power of two between the old and the new scale, the way an online
+// softmax rescales its sums.  Powers of two throughout: scaling and unscaling are exact.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define HX_EMIN 24            // clamp of the biased exponent of a row maximum: rows of zeros (and denormals) scale like 2^-103
+#define HX_EMAX 254
+#define HX_TOP 141            // scaled maximum in [2^14, 2^15): scale exponent = HX_TOP - E
+template <int FMT> struct BxFmt;
+template <> struct BxFmt<0> { static constexpr int NP = 3; };
+template <> struct BxFmt<1> { static constexpr int NP = 2; };
+// process-wide choice of the format of every pre-split image and of the kernels that read them (A/B switch: PFO_BX_FMT=0)
+#define PFO_DEFAULT_BX_FMT 1
+#ifndef BX_AREG_OCC
+#define BX_AREG_OCC 2
+#endif
+int pfo_bx_fmt() {
+  static const int f = getenv("PFO_BX_FMT") ? (atoi(getenv("PFO_BX_FMT")) != 0 ? 1 : 0) : PFO_DEFAULT_BX_FMT;
+  return f;
+}
+__device__ __forceinline__ int hx_exp_of(float m) {           // biased exponent of |m| (m >= 0), clamped
+  return min(max((int)(__float_as_uint(m) >> 23), HX_EMIN), HX_EMAX);
+}
+__device__ __forceinline__ int hx_exp_of_bits(uint32_t b) { return min(max((int)(b >> 23), HX_EMIN), HX_EMAX); }
+// maximum over the four lanes r, r + 16, r + 32, r + 48 (the four k-groups of one fragment row), in every one of them: two
+// lane-swap VALU instructions (gfx950), no LDS round trip.  Bits of non-negative floats order like unsigned integers.
+__device__ __forceinline__ uint32_t hx_max_over_g(uint32_t u) {
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = max(a[0], a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return max(b[0], b[1]);
+}
+__device__ __forceinline__ float hx_absmax8(const float4 a, const float4 b) {
+  return fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+               fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+}
+// four values times 2^se -> the two fp16 pieces, packed two per dword (element e in the low half of dword e/2)
+__device__ __forceinline__ void hx_split4(const float4 v, int se, uint2& oh, uint2& ol) {
+  const f32x2 p0 = {__builtin_amdgcn_ldexpf(v.x, se), __builtin_amdgcn_ldexpf(v.y, se)};
+  const f32x2 p1 = {__builtin_amdgcn_ldexpf(v.z, se), __builtin_amdgcn_ldexpf(v.w, se)};
+  const f16x2 h0 = __builtin_convertvector(p0, f16x2), h1 = __builtin_convertvector(p1, f16x2);
+  const f16x2 l0 = __builtin_convertvector(p0 - __builtin_convertvector(h0, f32x2), f16x2);   // residual exact in fp32
+  const f16x2 l1 = __builtin_convertvector(p1 - __builtin_convertvector(h1, f32x2), f16x2);
+  oh = uint2{__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1)};
+  ol = uint2{__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1)};
+}
+// the products of one 16x16x32 block, smallest terms first; x = the operand whose rows become accumulator COLUMNS (first MFMA
+// operand), y = the other one.  FMT 0: pieces hi | mid | lo (bf16), FMT 1: hi | lo (fp16)
+template <int FMT>
+__device__ __forceinline__ f32x4 bx_mma(const u32x4 (&x)[BxFmt<FMT>::NP], const u32x4 (&y)[BxFmt<FMT>::NP], f32x4 c) {
+  if constexpr (FMT == 0) {
+    typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+#define BXM(q, w) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8, x[q]), __builtin_bit_cast(v8, y[w]), c, 0, 0, 0)
+    BXM(0, 2); BXM(2, 0); BXM(1, 1); BXM(0, 1); BXM(1, 0); BXM(0, 0);
+#undef BXM
+  } else {
+#define BXM(q, w) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x[q]), __builtin_bit_cast(f16x8, y[w]), c, 0, 0, 0)
+    BXM(0, 1); BXM(1, 0); BXM(0, 0);
+#undef BXM
+  }
+  return c;
+}
+__device__ __forceinline__ f32x4 hx_scale4(const f32x4 a, const int4 e, int base) {          // a[c] * 2^(base + e[c])
+  return f32x4{__builtin_amdgcn_ldexpf(a[0], base + e.x), __builtin_amdgcn_ldexpf(a[1], base + e.y),
+               __builtin_amdgcn_ldexpf(a[2], base + e.z), __builtin_amdgcn_ldexpf(a[3], base + e.w)};
+}
+
+// The A fragments of one k-tile from the raw rows a lane holds ([strip][half]: 8 consecutive k of one row per strip).  FMT 1
+// keeps the running row scale (rowE) and moves the row's accumulators when a larger value arrives.
+template <int FMT, int NJ>
+__device__ __forceinline__ void bx_split_rows(const float4 (&a_raw)[2][2], u32x4 (&a)[2][BxFmt<FMT>::NP], int (&rowE)[2], f32x4 (&acc)[2][NJ]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if constexpr (FMT == 0) {
+      uint2 lo[3], hi[3];
+      bx_split4(a_raw[i][0], lo[0], lo[1], lo[2]);
+      bx_split4(a_raw[i][1], hi[0], hi[1], hi[2]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a[i][q] = u32x4{lo[q].x, lo[q].y, hi[q].x, hi[q].y};
+    } else {
+      // the row's maximum over this k-tile: 8 values here, the other 24 in the lanes 16 / 32 / 48 further on
+      const int e = hx_exp_of_bits(hx_max_over_g(__float_as_uint(hx_absmax8(a_raw[i][0], a_raw[i][1]))));
+      if (e > rowE[i]) {                                     // a larger value than any before: the sums so far move to the new scale
+        const int d = rowE[i] - e;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[i][j][c] = __builtin_amdgcn_ldexpf(acc[i][j][c], d);
+        rowE[i] = e;
+      }
+      const int se = HX_TOP - rowE[i];
+      uint2 h0, l0, h1, l1;
+      hx_split4(a_raw[i][0], se, h0, l0);
+      hx_split4(a_raw[i][1], se, h1, l1);
+      a[i][0] = u32x4{h0.x, h0.y, h1.x, h1.y};
+      a[i][1] = u32x4{l0.x, l0.y, l1.x, l1.y};
+    }
+  }
+}
+
 // epilogue of the operand-swapped bf16x3 kernels: four consecutive columns col..col+3 of one output row
 __device__ __forceinline__ void bx_store4(const GemmDev& p, float* Cb, int64_t ldc, const float* bias, float rscale, bool zero,
                                           bool n4, int row, int col, const f32x4 a, const float* addrow = nullptr) {
@@ -662,10 +773,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
 // straight in MFMA fragment order (lane (r, g): row r, k = 8g..8g+7 = two float4), splits them in registers into the
 // three bf16x8 fragments, and only the shared B image goes through LDS - double-buffered, so a k-tile costs ONE barrier
 // and the copy of tile t+1 into the other buffer runs beside the MFMAs of tile t.
-template <int WAVES>
+template <int WAVES, int FMT>
 __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
+  constexpr int NP = BxFmt<FMT>::NP;
   constexpr int NTHR = 64 * WAVES;                   // threads per workgroup; 32 rows per wavefront
-  constexpr int NDMA = (3 * (BX_B_PIECE / 16) + NTHR - 1) / NTHR;   // rounds of 16-byte units of the B image tile per thread
+  constexpr int UNITS = NP * (BX_B_PIECE / 16);      // 16-byte units of one B image tile (a multiple of 64)
+  constexpr int NDMA = (UNITS + NTHR - 1) / NTHR;    // rounds of 16-byte units per thread
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -702,13 +815,18 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
   }
   const char* img[2] = {reinterpret_cast<const char*>(p.b_img) + (int64_t)n0 * 64,
                         T1 > 0 ? reinterpret_cast<const char*>(p.b_img2) + (int64_t)n0 * 64 : nullptr};
+  // FMT 1: exponents of the image rows (this block's columns) behind the tiles of each image
+  const int32_t* bexp[2] = {reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.b_img) + (int64_t)T0 * NP * img_piece) + n0,
+                            T1 > 0 ? reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.b_img2) + (int64_t)T1 * NP * img_piece) + n0
+                                   : nullptr};
 
-  float4 a_raw[2][2];                 // [strip][half]: k = k0 + 8g + 4*half ..
+  float4 a_raw[2][2][2];              // [set][strip][half]: k = k0 + 8g + 4*half ..; tile t lives in set t & 1
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  // B image tile -> LDS by asynchronous global->LDS loads (the LDS image IS the global image: a lane-linear copy, no
-  // staging registers, no ds_write); `buf` is the buffer being filled for tile t
-  auto load_global = [&](int t, int buf) {
+  // A rows of tile t -> registers, two tiles ahead of the MFMAs (HBM latency under load exceeds one k-tile of MFMAs now that a
+  // tile is 66 of them)
+  auto load_a = [&](int t, auto setc) {
+    constexpr int set = decltype(setc)::value;
     const int src = t < T0 ? 0 : 1;
     const int ts = src == 0 ? t : t - T0;
     const int k = ts * BK + 8 * g;
@@ -717,55 +835,41 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
-        a_raw[i][h] = ld4<true>(a_row[src][i] + ts * BK + 4 * h, a_ok[i] ? Ks - (k + 4 * h) : 0, safe);
-    const char* tile = img[src] + (int64_t)ts * 3 * img_piece;
-    char* Bs = lds + buf * 3 * BX_B_PIECE;
+        a_raw[set][i][h] = ld4<true>(a_row[src][i] + ts * BK + 4 * h, a_ok[i] ? Ks - (k + 4 * h) : 0, safe);
+  };
+  // B image tile -> LDS by asynchronous global->LDS loads (the LDS image IS the global image: a lane-linear copy, no
+  // staging registers, no ds_write); `buf` is the buffer being filled for tile t
+  auto load_b = [&](int t, int buf) {
+    const int src = t < T0 ? 0 : 1;
+    const int ts = src == 0 ? t : t - T0;
+    const char* tile = img[src] + (int64_t)ts * NP * img_piece;
+    char* Bs = lds + buf * NP * BX_B_PIECE;
     bx_for<NDMA>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
-      if (u < NDMA - 1 || wave == 0) {                       // 2112 units of 16 bytes: the last round is wavefront 0 only
-        const int unit = tid + NTHR * u;
-        const int q = (unit >= 2 * (BX_B_PIECE / 16)) ? 2 : (unit >= BX_B_PIECE / 16 ? 1 : 0);
+      const int unit0 = 64 * wave + NTHR * u;                  // the last round covers some of the wavefronts only (wave-uniform)
+      if (unit0 < UNITS) {
+        const int unit = unit0 + lane;
+        const int q = unit / (BX_B_PIECE / 16);
         __builtin_amdgcn_global_load_lds((gptr_t)(tile + q * img_piece + (unit - q * (BX_B_PIECE / 16)) * 16),
-                                         (lptr_t)(Bs + (64 * wave + NTHR * u) * 16), 16, 0, 0);
+                                         (lptr_t)(Bs + unit0 * 16), 16, 0, 0);
       }
     });
   };
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  bf16x8 a[2][3];
-  auto split_a = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      uint2 lo[3], hi[3];
-      bx_split4(a_raw[i][0], lo[0], lo[1], lo[2]);
-      bx_split4(a_raw[i][1], hi[0], hi[1], hi[2]);
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const u32x4 w = {lo[q].x, lo[q].y, hi[q].x, hi[q].y};
-        a[i][q] = __builtin_bit_cast(bf16x8, w);
-      }
-    }
-  };
+  u32x4 a[2][NP];
+  int rowE[2] = {HX_EMIN, HX_EMIN};    // FMT 1: biased exponent of the running maximum of this lane's two rows
+  auto split_a = [&](auto setc) { bx_split_rows<FMT, 11>(a_raw[decltype(setc)::value], a, rowE, acc); };
   const int frag_off = r * 64 + ((g ^ bx_swz(r)) << 4);
   auto compute_tile = [&](int buf) {
-    const char* Bs = lds + buf * 3 * BX_B_PIECE;
-    auto ldb = [&](bf16x8 (&b)[3], int j) {
+    const char* Bs = lds + buf * NP * BX_B_PIECE;
+    auto ldb = [&](u32x4 (&b)[NP], int j) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) b[q] = *reinterpret_cast<const bf16x8*>(Bs + q * BX_B_PIECE + (16 * j) * 64 + frag_off);
+      for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const u32x4*>(Bs + q * BX_B_PIECE + (16 * j) * 64 + frag_off);
     };
-    auto mma = [&](const bf16x8 (&b)[3], int j) {
+    auto mma = [&](const u32x4 (&b)[NP], int j) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        f32x4 c = acc[i][j];
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][2], c, 0, 0, 0);   // operands swapped, smallest terms first
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[2], a[i][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[i][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[i][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][0], c, 0, 0, 0);
-        acc[i][j] = c;
-      }
+      for (int i = 0; i < 2; ++i) acc[i][j] = bx_mma<FMT>(b, a[i], acc[i][j]);     // operands swapped: image rows = accumulator columns
     };
-    bf16x8 b0[3], b1[3];
+    u32x4 b0[NP], b1[NP];
     ldb(b0, 0);
 #pragma unroll
     for (int j = 0; j < 11; j += 2) {
@@ -776,20 +880,44 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
     }
   };
 
-  if (T > 0) {
-    load_global(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    split_a();
-    __syncthreads();
-    for (int t = 0; t < T; ++t) {
-      const bool more = t + 1 < T;
-      if (more) load_global(t + 1, (t + 1) & 1);   // A rows to registers, B image tile to the other LDS buffer: in flight
-      compute_tile(t & 1);                         // during the MFMAs of this tile
-      if (more) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA is ordered only by the issuing wave's vmcnt + the barrier
-        split_a();                                 // this wavefront's own fragments for tile t+1
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  // one k-tile: the fragments of tile t are in `a`; queue the image of t+1 and the rows of t+2, multiply, split the rows of t+1
+  auto step = [&](int t, auto curc) {
+    constexpr int cur = decltype(curc)::value;                 // == t & 1
+    const bool more = t + 1 < T, more2 = t + 2 < T;
+    if (more) load_b(t + 1, (t + 1) & 1);
+    if (more2) load_a(t + 2, curc);                            // (the raw rows of tile t were split before this call)
+    if constexpr (FMT == 1) {
+      if (t == T0 && T1 > 0) {                     // second source: its image rows have their own scales - move the sums over
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+          const int4 e1 = *reinterpret_cast<const int4*>(bexp[0] + 16 * j + 4 * g);
+          const int4 e2 = *reinterpret_cast<const int4*>(bexp[1] + 16 * j + 4 * g);
+          const int4 d = {e1.x - e2.x, e1.y - e2.y, e1.z - e2.z, e1.w - e2.w};
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][j] = hx_scale4(acc[i][j], d, 0);
+        }
       }
-      __syncthreads();
+    }
+    compute_tile(cur);
+    if (more) {
+      // the DMA is ordered only by the issuing wave's vmcnt + the barrier; the four row loads of tile t+2 were issued last
+      if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      split_a(std::integral_constant<int, 1 - cur>{});         // this wavefront's own fragments for tile t+1
+    }
+    __syncthreads();
+  };
+  if (T > 0) {
+    load_a(0, C0{});
+    load_b(0, 0);
+    if (T > 1) { load_a(1, C1{}); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    split_a(C0{});
+    __syncthreads();
+    for (int t = 0; t < T; t += 2) {
+      step(t, C0{});
+      if (t + 1 < T) step(t + 1, C1{});
     }
   }
 
@@ -798,6 +926,7 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
   const float* bias = p.bias;
   const float* rs = p.row_scale;
   const bool n4 = bx_n4(p, Cb, ldc, bias);
+  const int32_t* bexp_last = T1 > 0 ? bexp[1] : bexp[0];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = m0 + wrow + 16 * i + r;
@@ -808,13 +937,18 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
 #pragma unroll
     for (int j = 0; j < 11; ++j) {
       const int col = n0 + 16 * j + 4 * g;
-      if (col < p.N) bx_store4(p, Cb, ldc, bias, rscale, zero, n4, row, col, acc[i][j], addrow);
+      if (col < p.N) {
+        f32x4 v = acc[i][j];
+        if constexpr (FMT == 1) v = hx_scale4(v, *reinterpret_cast<const int4*>(bexp_last + 16 * j + 4 * g), rowE[i] - 2 * HX_TOP);
+        bx_store4(p, Cb, ldc, bias, rscale, zero, n4, row, col, v, addrow);
+      }
     }
   }
 }
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_areg_kernel(const GemmDev p) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 3 * BX_B_PIECE];
-  bx_areg_body<4>(p, lds);
+template <int FMT>
+__global__ __launch_bounds__(GEMM_THREADS, FMT == 1 ? BX_AREG_OCC : 2) void gemm_bx_areg_kernel(const GemmDev p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * BxFmt<FMT>::NP * BX_B_PIECE];
+  bx_areg_body<4, FMT>(p, lds);
 }
 // ---------------------------------------------------------------------------------------------
 // The lazy GRU of the touched rows in ONE launch (memory_updater.py:18-61: torch.nn.GRUCell on [message | memory]): both
@@ -848,8 +982,10 @@ __device__ __forceinline__ float gf_tanh(float x) {
   return copysignf((1.f - e) * __builtin_amdgcn_rcpf(1.f + e), x);
 }
 
+template <int FMT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFusedDev p) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 3 * GF_B_PIECE];
+  constexpr int NP = BxFmt<FMT>::NP;
+  __shared__ __attribute__((aligned(16))) char lds[2 * NP * GF_B_PIECE];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -876,6 +1012,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
     a_row[1][i] = p.h_rows + ridx * p.ld_h + 8 * g;
   }
   const char* img[2] = {reinterpret_cast<const char*>(p.img0) + (int64_t)n0 * 64, reinterpret_cast<const char*>(p.img1) + (int64_t)n0 * 64};
+  // FMT 1: exponents of the image rows of this block, behind the tiles of each image
+  const int32_t* bexp[2] = {reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.img0) + (int64_t)T0 * NP * img_piece) + n0,
+                            reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.img1) + (int64_t)T1 * NP * img_piece) + n0};
   float4 a_raw[2][2];
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -889,9 +1028,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
 #pragma unroll
       for (int h = 0; h < 2; ++h)
         a_raw[i][h] = ld4<true>(a_row[src][i] + ts * BK + 4 * h, a_ok[i] ? Ks - (k + 4 * h) : 0, safe);
-    const char* tile = img[src] + (int64_t)ts * 3 * img_piece;
-    char* Bs = lds + buf * 3 * GF_B_PIECE;
-    bx_for<6>([&](auto uc) {                                   // 3 pieces x 512 units of 16 bytes = 6 rounds of 256 threads
+    const char* tile = img[src] + (int64_t)ts * NP * img_piece;
+    char* Bs = lds + buf * NP * GF_B_PIECE;
+    bx_for<2 * NP>([&](auto uc) {                              // NP pieces x 512 units of 16 bytes = 2 NP rounds of 256 threads
       constexpr int u = decltype(uc)::value;
       const int unit = tid + 256 * u;
       const int q = unit >> 9;                                 // 512 units per piece
@@ -899,45 +1038,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
                                        (lptr_t)(Bs + (64 * wave + 256 * u) * 16), 16, 0, 0);
     });
   };
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  bf16x8 a[2][3];
-  auto split_a = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      uint2 lo[3], hi[3];
-      bx_split4(a_raw[i][0], lo[0], lo[1], lo[2]);
-      bx_split4(a_raw[i][1], hi[0], hi[1], hi[2]);
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const u32x4 w = {lo[q].x, lo[q].y, hi[q].x, hi[q].y};
-        a[i][q] = __builtin_bit_cast(bf16x8, w);
-      }
-    }
-  };
+  u32x4 a[2][NP];
+  int rowE[2] = {HX_EMIN, HX_EMIN};
+  auto split_a = [&]() { bx_split_rows<FMT, GF_NJ>(a_raw, a, rowE, acc); };
   const int frag_off = r * 64 + ((g ^ bx_swz(r)) << 4);
   // tiles that take source SRC: the message part feeds r, z, n_i (tiles 0 1 2 | 4 5 6), the memory part r, z, n_h (0 1 3 | 4 5 7)
   auto compute_tile = [&](int buf, auto src_c) {
     constexpr int SRC = decltype(src_c)::value;
     constexpr int act[6] = {0, 1, SRC == 0 ? 2 : 3, 4, 5, SRC == 0 ? 6 : 7};
-    const char* Bs = lds + buf * 3 * GF_B_PIECE;
-    auto ldb = [&](bf16x8 (&b)[3], int j) {
+    const char* Bs = lds + buf * NP * GF_B_PIECE;
+    auto ldb = [&](u32x4 (&b)[NP], int j) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) b[q] = *reinterpret_cast<const bf16x8*>(Bs + q * GF_B_PIECE + (16 * j) * 64 + frag_off);
+      for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const u32x4*>(Bs + q * GF_B_PIECE + (16 * j) * 64 + frag_off);
     };
-    auto mma = [&](const bf16x8 (&b)[3], int j) {
+    auto mma = [&](const u32x4 (&b)[NP], int j) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        f32x4 c = acc[i][j];
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][2], c, 0, 0, 0);   // operands swapped, smallest terms first
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[2], a[i][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[i][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], a[i][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], a[i][0], c, 0, 0, 0);
-        acc[i][j] = c;
-      }
+      for (int i = 0; i < 2; ++i) acc[i][j] = bx_mma<FMT>(b, a[i], acc[i][j]);
     };
-    bf16x8 b0[3], b1[3];
+    u32x4 b0[NP], b1[NP];
     ldb(b0, act[0]);
 #pragma unroll
     for (int q = 0; q < 6; q += 2) {
@@ -954,6 +1072,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
   for (int t = 0; t < T; ++t) {
     const bool more = t + 1 < T;
     if (more) load_global(t + 1, (t + 1) & 1);
+    if constexpr (FMT == 1) {
+      if (t == T0) {                                // the memory part: the r and z tiles move from W_ih's row scales to W_hh's
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const int j = 4 * q + tt;
+            const int4 e1 = *reinterpret_cast<const int4*>(bexp[0] + 16 * j + 4 * g);
+            const int4 e2 = *reinterpret_cast<const int4*>(bexp[1] + 16 * j + 4 * g);
+            const int4 d = {e1.x - e2.x, e1.y - e2.y, e1.z - e2.z, e1.w - e2.w};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = hx_scale4(acc[i][j], d, 0);
+          }
+      }
+    }
     if (t < T0) compute_tile(t & 1, std::integral_constant<int, 0>{}); else compute_tile(t & 1, std::integral_constant<int, 1>{});
     if (more) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -969,6 +1102,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
     if (row >= Mlim) continue;
     const bool has = p.hm[row] != 0;
     const int64_t id = p.touched[row];
+    if constexpr (FMT == 1) {                         // back to plain fp32: r, z and n_h carry W_hh's row scales, n_i W_ih's
+#pragma unroll
+      for (int j = 0; j < GF_NJ; ++j)
+        acc[i][j] = hx_scale4(acc[i][j], *reinterpret_cast<const int4*>(bexp[(j & 3) == 2 ? 0 : 1] + 16 * j + 4 * g), rowE[i] - 2 * HX_TOP);
+    }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int u0 = 32 * (int)blockIdx.y + 16 * q + 4 * g;
@@ -1012,8 +1150,9 @@ int pfo_gru_fused_launch(const PfoGruFused& f, hipStream_t stream) {
   d.b_ih = f.b_ih; d.b_hh = f.b_hh; d.hm = f.hm; d.touched = f.touched; d.node_feat = f.node_feat;
   d.upd_mem = f.upd_mem; d.h0_tab = f.h0_tab; d.gates = f.gates; d.D = f.D; d.M = f.cap_rows; d.m_dev = f.n_rows;
   pfo_prof_begin(stream);
-  hipLaunchKernelGGL(gru_fused_kernel, dim3((unsigned)pfo_ceil_div(f.cap_rows, BM), (unsigned)pfo_ceil_div(f.D, 32), 1), dim3(GEMM_THREADS),
-                     0, stream, d);
+  const dim3 grid((unsigned)pfo_ceil_div(f.cap_rows, BM), (unsigned)pfo_ceil_div(f.D, 32), 1);
+  if (pfo_bx_fmt()) hipLaunchKernelGGL(gru_fused_kernel<1>, grid, dim3(GEMM_THREADS), 0, stream, d);
+  else hipLaunchKernelGGL(gru_fused_kernel<0>, grid, dim3(GEMM_THREADS), 0, stream, d);
   PFO_LAUNCH_CHECK();
   pfo_prof_end_dev(PFO_PROF_GEMM_BX, 2.0 * 3 * f.D * ((double)f.K_msg + f.D), f.n_rows, f.cap_rows, stream);   // per-row FLOPs of the two contractions
   return PFO_OK;
@@ -1028,11 +1167,12 @@ int pfo_gru_fused_launch(const PfoGruFused& f, hipStream_t stream) {
 // row tiles (layer 2 at C2: 80) put three times the workgroups on the chip, each staging a third of the image per k-tile.
 #define SK_ROWS 32
 #define SK_A_PIECE (SK_ROWS * 64)
-template <int NT>
+template <int NT, int FMT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const GemmDev p) {
+  constexpr int NP = BxFmt<FMT>::NP;
   constexpr int SK_B_PIECE = NT * 16 * 64;                     // bytes of one piece of the staged B slice
-  constexpr int SK_BUF_BYTES = 3 * SK_A_PIECE + 3 * SK_B_PIECE;
-  constexpr int NU = (3 * (SK_B_PIECE / 16) + 255) / 256;      // 16-byte units of the B slice per thread
+  constexpr int SK_BUF_BYTES = NP * SK_A_PIECE + NP * SK_B_PIECE + SK_ROWS * 4;   // + the row exponents of the A tile (FMT 1)
+  constexpr int NU = (NP * (SK_B_PIECE / 16) + 255) / 256;     // 16-byte units of the B slice per thread
   constexpr int NJW = (NT + 3) / 4;                            // column tiles per wavefront
   __shared__ __attribute__((aligned(16))) char lds[2 * SK_BUF_BYTES];
   const int tid = threadIdx.x;
@@ -1066,17 +1206,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const G
   const char* img1 = T1 > 0 ? reinterpret_cast<const char*>(p.b_img2) + (int64_t)n0 * 64 : img0;
   const int64_t img_piece = (int64_t)p.b_img_rows * 64;
   const int img_units_left = min(SK_B_PIECE / 16, (p.b_img_rows - n0) * 4);      // 16-byte units of this slice inside the image
+  // FMT 1: exponents of the image rows behind the tiles of each image; the A rows' running exponents travel with the tile
+  const int32_t* bexp0 = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.b_img) + (int64_t)T0 * NP * img_piece);
+  const int32_t* bexp1 = T1 > 0 ? reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.b_img2) + (int64_t)T1 * NP * img_piece) : bexp0;
+  int stE = HX_EMIN;                   // staging side: running exponent of row a_r (the same in its 8 staging lanes)
+  int accE[2] = {HX_EMIN, HX_EMIN};    // accumulator side: the exponent the sums of this lane's two rows are scaled with
   auto load_global = [&](int t, auto sc) {
     constexpr int st = decltype(sc)::value;
     const bool second = t >= T0;
     const int ts = second ? t - T0 : t;
     const int k = ts * BK + 4 * a_c4;
     a_st[st] = ld4<true>((second ? a_row1 : a_row0) + k, a_ok ? (second ? p.K[1] : p.K[0]) - k : 0, safe);
-    const char* tile = (second ? img1 : img0) + (int64_t)ts * 3 * img_piece;
+    const char* tile = (second ? img1 : img0) + (int64_t)ts * NP * img_piece;
     bx_for<NU>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
-      const int unit = min(tid + 256 * u, 3 * (SK_B_PIECE / 16) - 1);
-      const int q = (unit >= 2 * (SK_B_PIECE / 16)) ? 2 : (unit >= SK_B_PIECE / 16 ? 1 : 0);
+      const int unit = min(tid + 256 * u, NP * (SK_B_PIECE / 16) - 1);
+      const int q = unit / (SK_B_PIECE / 16);
       // the last 64-column slice of a 176-row image block is 48 rows: rows beyond the image are clamped (their columns are never stored)
       const int in_piece = min(unit - q * (SK_B_PIECE / 16), img_units_left - 1);
       i_st[st][u] = *reinterpret_cast<const f32x4*>(tile + q * img_piece + in_piece * 16);
@@ -1085,38 +1230,89 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const G
   auto store_lds = [&](int buf, auto sc) {
     constexpr int st = decltype(sc)::value;
     char* As = lds + buf * SK_BUF_BYTES;
-    char* Bs = As + 3 * SK_A_PIECE;
-    bx_split_store(As, SK_A_PIECE, a_r, a_c4, a_st[st]);
+    char* Bs = As + NP * SK_A_PIECE;
+    if constexpr (FMT == 0) bx_split_store(As, SK_A_PIECE, a_r, a_c4, a_st[st]);
+    else {
+      // the row's maximum over this k-tile sits in 8 neighbouring lanes (4 values each): quad swaps + half-row mirror
+      const float4 v = a_st[st];
+      uint32_t m = __float_as_uint(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+      m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+      m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, false));    // row_half_mirror
+      stE = max(stE, hx_exp_of_bits(m));
+      const int off = a_r * 64 + (((a_c4 >> 1) ^ bx_swz(a_r)) << 4) + ((a_c4 & 1) << 3);
+      uint2 oh, ol;
+      hx_split4(v, HX_TOP - stE, oh, ol);
+      *reinterpret_cast<uint2*>(As + off) = oh;
+      *reinterpret_cast<uint2*>(As + SK_A_PIECE + off) = ol;
+      if (a_c4 == 0) reinterpret_cast<int32_t*>(As + NP * SK_A_PIECE + NP * SK_B_PIECE)[a_r] = stE;
+    }
     bx_for<NU>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       const int unit = tid + 256 * u;
-      if (256 * (u + 1) <= 3 * (SK_B_PIECE / 16) || unit < 3 * (SK_B_PIECE / 16)) *reinterpret_cast<f32x4*>(Bs + unit * 16) = i_st[st][u];
+      if (256 * (u + 1) <= NP * (SK_B_PIECE / 16) || unit < NP * (SK_B_PIECE / 16)) *reinterpret_cast<f32x4*>(Bs + unit * 16) = i_st[st][u];
     });
   };
   const int frag_off = r * 64 + ((g ^ bx_swz(r)) << 4);
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, int t) {
     const char* As = lds + buf * SK_BUF_BYTES;
-    const char* Bs = As + 3 * SK_A_PIECE;
-    bf16x8 a[2][3], b[NJW][3];
+    const char* Bs = As + NP * SK_A_PIECE;
+    if constexpr (FMT == 1) {
+      const int32_t* Es = reinterpret_cast<const int32_t*>(Bs + NP * SK_B_PIECE);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int e = Es[16 * i + r];
+        if (e > accE[i]) {                                     // the row's scale moved with this tile: the sums follow
+#pragma unroll
+          for (int jj = 0; jj < NJW; ++jj)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[i][jj][c] = __builtin_amdgcn_ldexpf(acc[i][jj][c], accE[i] - e);
+          accE[i] = e;
+        }
+      }
+      if (T1 > 0 && t == T0) {                                 // second source: from the first image's row scales to the second's
+#pragma unroll
+        for (int jj = 0; jj < NJW; ++jj) {
+          const int col = min(n0 + 16 * min(wave + 4 * jj, NT - 1) + 4 * g, p.b_img_rows - 4);
+          const int4 e1 = *reinterpret_cast<const int4*>(bexp0 + col), e2 = *reinterpret_cast<const int4*>(bexp1 + col);
+          const int4 d = {e1.x - e2.x, e1.y - e2.y, e1.z - e2.z, e1.w - e2.w};
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][jj] = hx_scale4(acc[i][jj], d, 0);
+        }
+      }
+    }
+    u32x4 a[2][NP], b[NJW][NP];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(As + q * SK_A_PIECE + (16 * i) * 64 + frag_off);
+      for (int q = 0; q < NP; ++q) a[i][q] = *reinterpret_cast<const u32x4*>(As + q * SK_A_PIECE + (16 * i) * 64 + frag_off);
 #pragma unroll
     for (int jj = 0; jj < NJW; ++jj)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < NP; ++q) {
         const int j = min(wave + 4 * jj, NT - 1);             // NT = 11: wave 3 has no third tile, re-reads tile 10, result unused
-        b[jj][q] = *reinterpret_cast<const bf16x8*>(Bs + q * SK_B_PIECE + (16 * j) * 64 + frag_off);
+        b[jj][q] = *reinterpret_cast<const u32x4*>(Bs + q * SK_B_PIECE + (16 * j) * 64 + frag_off);
       }
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
+    if constexpr (FMT == 0) {
+      typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
 #pragma unroll
-    for (int t6 = 0; t6 < 6; ++t6)
+      for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
-      for (int jj = 0; jj < NJW; ++jj)
+        for (int jj = 0; jj < NJW; ++jj)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-          acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[jj][PB[t6]], a[i][PA[t6]], acc[i][jj], 0, 0, 0);
+          for (int i = 0; i < 2; ++i)
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8, b[jj][PB[t6]]), __builtin_bit_cast(v8, a[i][PA[t6]]), acc[i][jj], 0, 0, 0);
+    } else {
+      constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+      for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+        for (int jj = 0; jj < NJW; ++jj)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b[jj][PB[t3]]), __builtin_bit_cast(f16x8, a[i][PA[t3]]), acc[i][jj], 0, 0, 0);
+    }
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -1130,14 +1326,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const G
       store_lds(1, S1{});
       if (t + 3 < T) load_global(t + 3, S1{});
     }
-    compute(0);
+    compute(0, t);
     __syncthreads();
     if (t + 1 >= T) break;
     if (t + 2 < T) {                       // tile t+1 in buffer 1; stage 0 holds t+2, stage 1 has t+3 in flight
       store_lds(0, S0{});
       if (t + 4 < T) load_global(t + 4, S0{});
     }
-    compute(1);
+    compute(1, t + 1);
     __syncthreads();
   }
   float* Cb = p.C;
@@ -1154,7 +1350,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const G
     for (int jj = 0; jj < NJW; ++jj) {
       const int j = wave + 4 * jj;
       const int col = n0 + 16 * j + 4 * g;
-      if (j < NT && col < p.N) bx_store4(p, Cb, ldc, p.bias, rscale, zero, n4, row, col, acc[i][jj], addrow);
+      if (j < NT && col < p.N) {
+        f32x4 v = acc[i][jj];
+        if constexpr (FMT == 1) v = hx_scale4(v, *reinterpret_cast<const int4*>(bexp1 + col), accE[i] - 2 * HX_TOP);
+        bx_store4(p, Cb, ldc, p.bias, rscale, zero, n4, row, col, v, addrow);
+      }
     }
   }
 }
@@ -1420,6 +1620,107 @@ __global__ __launch_bounds__(256) void bimg_kernel(const BimgDev g) {
   }
 }
 
+
+// The fp16x2 image (FMT 1): [k-tile][piece h | l][row][64 B] in the same swizzled layout, then one int32 per image row: the
+// biased exponent E of the row's largest magnitude (clamped); the row is stored times 2^(HX_TOP - E).
+__device__ __forceinline__ int bimg_src_row(const BimgDev& g, int z, int n) {
+  if (g.gate[z]) return bimg_gate_row(n, g.gate[z], g.gate_D[z]);
+  return n < g.N[z] ? n : -1;
+}
+__device__ __forceinline__ int32_t* bimg_exps(const BimgDev& g, int z) {
+  const int T = (g.K[z] + 31) / 32;
+  return reinterpret_cast<int32_t*>(reinterpret_cast<char*>(g.dst[z]) + (int64_t)T * 2 * g.rows_total[z] * 64);
+}
+// Row-major operands (and the GRU's gate-ordered ones): one wavefront per image row, lanes along k with 16-byte loads; the
+// first pass finds the row maximum, the second (L1 / L2 hits) converts.  vec: every row start and K are multiples of 4 floats.
+__global__ __launch_bounds__(256) void bimg_h_rows_kernel(const BimgDev g) {
+  const int z = blockIdx.y;
+  const int K = g.K[z], rows = g.rows[z];
+  const int T = (K + 31) / 32;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int sr = bimg_src_row(g, z, n);
+  const float* __restrict__ row = g.src[z] + (int64_t)max(sr, 0) * g.ld[z];
+  const bool vec = ((g.ld[z] | K) & 3) == 0 && (((uintptr_t)g.src[z]) & 15) == 0;
+  auto ld4k = [&](int k) -> float4 {                            // k % 4 == 0
+    if (sr < 0 || k >= K) return float4{0.f, 0.f, 0.f, 0.f};
+    if (vec) return *reinterpret_cast<const float4*>(row + k);
+    return float4{row[k], k + 1 < K ? row[k + 1] : 0.f, k + 2 < K ? row[k + 2] : 0.f, k + 3 < K ? row[k + 3] : 0.f};
+  };
+  float m = 0.f;
+  for (int ci = lane; ci < 4 * T; ci += 64) m = fmaxf(m, hx_absmax8(ld4k(8 * ci), ld4k(8 * ci + 4)));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  const int E = hx_exp_of(m);
+  const int se = HX_TOP - E;
+  char* dst = reinterpret_cast<char*>(g.dst[z]);
+  const int ng = n + g.row0[z];
+  const int64_t piece = (int64_t)g.rows_total[z] * 64;
+  for (int ci = lane; ci < 4 * T; ci += 64) {
+    const int t = ci >> 2, c = ci & 3;
+    uint2 h0, l0, h1, l1;
+    hx_split4(ld4k(8 * ci), se, h0, l0);
+    hx_split4(ld4k(8 * ci + 4), se, h1, l1);
+    const int64_t off = (int64_t)ng * 64 + ((c ^ bx_swz(ng)) << 4);
+    *reinterpret_cast<uint4*>(dst + ((int64_t)t * 2 + 0) * piece + off) = uint4{h0.x, h0.y, h1.x, h1.y};
+    *reinterpret_cast<uint4*>(dst + ((int64_t)t * 2 + 1) * piece + off) = uint4{l0.x, l0.y, l1.x, l1.y};
+  }
+  if (lane == 0) bimg_exps(g, z)[ng] = E;
+}
+// Lists with k-major ("trans") operands take two launches: the row exponents (one wavefront per image row; a k-major row is
+// a strided column of the source, its 64-byte lines shared with the neighbouring rows' wavefronts), then the conversion in
+// bimg_kernel's thread order (coalesced along n for k-major sources).
+__global__ __launch_bounds__(256) void bimg_exp_kernel(const BimgDev g) {
+  const int z = blockIdx.y;
+  const int K = g.K[z], rows = g.rows[z];
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int sr = bimg_src_row(g, z, n);
+  const float* __restrict__ src = g.src[z];
+  const int64_t ld = g.ld[z];
+  float m = 0.f;
+  if (sr >= 0) {
+    if (g.trans[z]) for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(src[(int64_t)k * ld + sr]));
+    else for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(src[(int64_t)sr * ld + k]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) bimg_exps(g, z)[n + g.row0[z]] = hx_exp_of(m);
+}
+__global__ __launch_bounds__(256) void bimg_h_kernel(const BimgDev g) {
+  const int z = blockIdx.y;
+  const int N = g.N[z], K = g.K[z], rows = g.rows[z];
+  const int T = (K + 31) / 32;
+  const int64_t total = (int64_t)T * rows * 4;                 // one thread per (tile, row, 16-byte chunk)
+  const float* __restrict__ src = g.src[z];
+  const int64_t ld = g.ld[z];
+  char* dst = reinterpret_cast<char*>(g.dst[z]);
+  const int32_t* exps = bimg_exps(g, z);
+  const int64_t piece = (int64_t)g.rows_total[z] * 64;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int t, n, c;
+    if (g.trans[z]) { n = (int)(i % rows); c = (int)((i / rows) & 3); t = (int)(i / (4 * (int64_t)rows)); }
+    else            { c = (int)(i & 3); n = (int)((i >> 2) % rows); t = (int)((i >> 2) / rows); }
+    const int sr = bimg_src_row(g, z, n);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 32 * t + 8 * c + e;
+      x[e] = (sr >= 0 && k < K) ? (g.trans[z] ? src[(int64_t)k * ld + sr] : src[(int64_t)sr * ld + k]) : 0.f;
+    }
+    const int ng = n + g.row0[z];
+    const int se = HX_TOP - exps[ng];
+    uint2 h0, l0, h1, l1;
+    hx_split4(float4{x[0], x[1], x[2], x[3]}, se, h0, l0);
+    hx_split4(float4{x[4], x[5], x[6], x[7]}, se, h1, l1);
+    const int64_t off = (int64_t)ng * 64 + ((c ^ bx_swz(ng)) << 4);
+    *reinterpret_cast<uint4*>(dst + ((int64_t)t * 2 + 0) * piece + off) = uint4{h0.x, h0.y, h1.x, h1.y};
+    *reinterpret_cast<uint4*>(dst + ((int64_t)t * 2 + 1) * piece + off) = uint4{l0.x, l0.y, l1.x, l1.y};
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Several SMALL independent contractions in one launch (the composite-weight products of a layer and their
 // gradient chain: each is far too small to fill the chip or to amortise a launch).  32 x 64 tiles; the operand
@@ -1666,6 +1967,9 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
   static const int bx = getenv("PFO_GEMM_BF16X3") ? atoi(getenv("PFO_GEMM_BF16X3")) : PFO_DEFAULT_BF16X3;
   const bool use_bx = vec && bx >= 1;
   pfo_prof_begin(stream);
+  // (the weight-gradient tile stays bf16x3: its scales would belong to the COLUMNS of both operands - running maxima in LDS,
+  //  raised before the barrier between the MFMAs and the staging - and that version measured 2 % slower per step: the tile is
+  //  bound by its two-barrier staging, not by the matrix pipe.  profiles/r3_gemm_areg_experiments.txt)
   if (use_bx) hipLaunchKernelGGL(gemm_tn_group_bx_kernel, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   else if (vec) hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   else hipLaunchKernelGGL(gemm_tn_group_kernel<false>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
@@ -1723,7 +2027,17 @@ int pfo_bimg_launch(const PfoBimg* list, int n, hipStream_t stream) {
     PFO_REQUIRE(d.row0[i] >= 0 && d.rows[i] >= list[i].N && d.row0[i] + d.rows[i] <= d.rows_total[i], "bad stacked image rows");
     most = std::max<int64_t>(most, (int64_t)pfo_ceil_div(list[i].K, 32) * d.rows[i] * 4);
   }
-  hipLaunchKernelGGL(bimg_kernel, dim3((unsigned)pfo_ceil_div(most, 256), n), dim3(256), 0, stream, d);
+  if (pfo_bx_fmt()) {
+    int most_rows = 0;
+    bool any_trans = false;
+    for (int i = 0; i < n; ++i) { most_rows = std::max(most_rows, d.rows[i]); any_trans = any_trans || d.trans[i] != 0; }
+    if (!any_trans) hipLaunchKernelGGL(bimg_h_rows_kernel, dim3((unsigned)pfo_ceil_div(most_rows, 4), n), dim3(256), 0, stream, d);
+    else {
+      hipLaunchKernelGGL(bimg_exp_kernel, dim3((unsigned)pfo_ceil_div(most_rows, 4), n), dim3(256), 0, stream, d);
+      hipLaunchKernelGGL(bimg_h_kernel, dim3((unsigned)pfo_ceil_div(most, 256), n), dim3(256), 0, stream, d);
+    }
+  } else
+    hipLaunchKernelGGL(bimg_kernel, dim3((unsigned)pfo_ceil_div(most, 256), n), dim3(256), 0, stream, d);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -1801,20 +2115,28 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
       // few row tiles (< one per CU even with 176-column workgroups): 64-column workgroups fill the chip three times better
       static const int narrow = getenv("PFO_SKINNY_NARROW") ? atoi(getenv("PFO_SKINNY_NARROW")) : 512;        // A/B switch: workgroup threshold, 0 = never
       const int64_t sk_wgs = (int64_t)pfo_ceil_div(g.M, SK_ROWS) * tn;
-      if (sk_wgs < narrow)
-        hipLaunchKernelGGL(gemm_bx_skinny_kernel<4>, dim3((unsigned)pfo_ceil_div(g.M, SK_ROWS), (unsigned)pfo_ceil_div(g.N, 64), 1),
-                           dim3(GEMM_THREADS), 0, stream, d);
-      else
-        hipLaunchKernelGGL(gemm_bx_skinny_kernel<11>, dim3((unsigned)pfo_ceil_div(g.M, SK_ROWS), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
+      const dim3 g4((unsigned)pfo_ceil_div(g.M, SK_ROWS), (unsigned)pfo_ceil_div(g.N, 64), 1), g11((unsigned)pfo_ceil_div(g.M, SK_ROWS), tn, 1);
+      if (sk_wgs < narrow) {
+        if (pfo_bx_fmt()) hipLaunchKernelGGL((gemm_bx_skinny_kernel<4, 1>), g4, dim3(GEMM_THREADS), 0, stream, d);
+        else hipLaunchKernelGGL((gemm_bx_skinny_kernel<4, 0>), g4, dim3(GEMM_THREADS), 0, stream, d);
+      } else {
+        if (pfo_bx_fmt()) hipLaunchKernelGGL((gemm_bx_skinny_kernel<11, 1>), g11, dim3(GEMM_THREADS), 0, stream, d);
+        else hipLaunchKernelGGL((gemm_bx_skinny_kernel<11, 0>), g11, dim3(GEMM_THREADS), 0, stream, d);
+      }
     } else if (g.b_img && (g.K[1] == 0 || g.b_img2) && a_rowvec && (g.bx_force || (bx >= 1 && big_tiles >= bx_min_tiles && force < 0))) {
       d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN); d.b_img2 = g.b_img2;
       kind = PFO_PROF_GEMM_BX;
       static const int areg = getenv("PFO_GEMM_AREG") ? atoi(getenv("PFO_GEMM_AREG")) : PFO_DEFAULT_AREG;    // A/B switch
       if (areg && g.batch == 1)
-        hipLaunchKernelGGL(gemm_bx_areg_kernel, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
-      else
+      {
+        if (pfo_bx_fmt()) hipLaunchKernelGGL(gemm_bx_areg_kernel<1>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
+        else hipLaunchKernelGGL(gemm_bx_areg_kernel<0>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
+      }
+      else {
+        PFO_REQUIRE(!pfo_bx_fmt(), "the fp16x2 images are read by the row-major-A kernels only (batch 1)");
         hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0,
                            stream, d);
+      }
     } else if (g.K[1] > 0 && g.b_img2) {
       // the caller fused two sources whose float B operands may differ in layout: only the image kernels can take that
       pfo_set_error("pfo_gemm_launch: a two-source launch with weight images needs 16-byte aligned row-major A operands");

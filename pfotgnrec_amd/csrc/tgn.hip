@@ -12,6 +12,7 @@
 #include "attn.hpp"
 #include "memory.hpp"
 #include <algorithm>
+#include <functional>
 #include <math.h>
 #include <string.h>
 #include <stdlib.h>
@@ -718,6 +719,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   RUN(pfo_seg_build_launch(idx0, w.nodes[0], (int)n[1], capP, b->uniform ? nullptr : w.cnt1, w.seg_ptr, w.seg_cur,
                            w.seg_tmp, w.seg_mem, w.seg_scratch, ss));
   HIPOK(hipEventRecord(sd.seg_done, ss), "event record failed");
+  std::function<int()> deferred_chain;                       // a layer's chain-back launches, issued one layer later (below)
   for (int l = L; l >= 1; --l) {
     const int N = (int)n[l];
     const LayerWs& lw = w.layer[l];
@@ -823,6 +825,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     const int dqk_by_member = pfo_attn_bwd_uses_runs(a) ? 1 : 0;
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
     if (det) det_rows += n_parts;
+    if (deferred_chain) { RUN(deferred_chain()); deferred_chain = nullptr; }     // the layer above's chain-back (side streams)
     // merged query/key projection: dx += dqk' Wqk, dWqk = dqk'^T x, gqk = colsum(dqk')
     if (l == 1) {
       // Layer 1: x is a row of the touched-node table shared by all instances on that node, so everything that is linear
@@ -873,7 +876,12 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       //  gradients of a layer >= 2 - 36 us of launch-latency-bound work off the critical path at C2)
     }
 
-    // ---- chain the composite-weight gradients back to the parameters (tiny products, side streams).
+    // ---- chain the composite-weight gradients back to the parameters (tiny products, side streams).  ~15 launches that no
+    // launch of the caller's stream waits for: for a layer >= 2 the HOST issues them only after the next layer's data-gradient
+    // launches are queued (r3 timeline: the caller's stream sat idle for ~60 us behind them while the host was the slower side);
+    // the event that releases them on the device stays where it was.
+    if (folded) HIPOK(hipEventRecord(sd.layer[l], s), "event record failed");
+    auto chain_back = [=]() -> int {
     if (folded) {
       // First undo the fc2 fold (notation of pfo_tgn_forward: A, b = W2, b2 of layer l-1; Q = Wqk, V = W1ovT, per head):
       //   dT1_node = A dQ_f,node      dT1_edge|time = dQ_f,edge|time         dt likewise from gqk_f
@@ -887,7 +895,6 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       const float* A = P.l[l - 1].w2;
       const float* bv = P.l[l - 1].b2;
       const int64_t HCpD = (int64_t)HCp * D, CpD = (int64_t)Cp * D, DD = (int64_t)D * D;
-      HIPOK(hipEventRecord(sd.layer[l], s), "event record failed");
       // (on the second side stream: the first one must stay free for layer 1's weight gradients over the instances)
       hipStream_t sf = sd.s2;
       HIPOK(hipStreamWaitEvent(sf, sd.layer[l], 0), "event wait failed");
@@ -1016,7 +1023,13 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
         if (top_ready_event) HIPOK(hipEventRecord((hipEvent_t)top_ready_event, sb), "event record failed");
       }
     }
+      return PFO_OK;
+    };
+    static const int defer = getenv("PFO_DEFER_CHAIN") ? atoi(getenv("PFO_DEFER_CHAIN")) : 1;      // A/B switch
+    if (l > 1 && defer && !pfo_prof_on()) deferred_chain = chain_back;
+    else RUN(chain_back());
   }
+  if (deferred_chain) { RUN(deferred_chain()); deferred_chain = nullptr; }
 
   // ---- GRU parameters (messages and stored memory are constants: SURVEY App. A-6)
   if (c->use_memory) {
