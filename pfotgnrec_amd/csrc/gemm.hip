@@ -452,7 +452,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#define HX_EMIN 24            // clamp of the biased exponent of a row maximum: rows of zeros (and denormals) scale like 2^-103
+#define HX_EMIN 1             // clamp of the biased exponent of a row maximum: rows of zeros and denormals scale like 2^-126
 #define HX_EMAX 254
 #define HX_TOP 141            // scaled maximum in [2^14, 2^15): scale exponent = HX_TOP - E
 template <int FMT> struct BxFmt;

@@ -1,5 +1,7 @@
 """GPU parity, kernel by kernel, through the C ABI: integer/index work bit-exact, floating point within the
 tolerance written at each assert.  Checked against the oracle and the reference-captured golden fixtures."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -236,6 +238,43 @@ def test_gemm_bf16x3_split_contraction_matches_float64(M, N, K):
     f32 = _gemm(A, W, bias, 0, 0)
     bx = _gemm_bf16x3(A, W, bias, 0)
     assert (np.abs(bx - (ref + bias)) / mag).max() <= 2.0 * (np.abs(f32 - (ref + bias)) / mag).max() + 1e-7
+
+
+@pytest.mark.parametrize("M", [300, 4200])              # the 32-row kernel / the 128-row kernel (pfo_gemm_bf16x3's own rule)
+def test_gemm_split_contraction_row_scales(M):
+    """The two-piece fp16 split scales every operand row by a power of two taken from the row's largest magnitude: activation
+    rows from a RUNNING maximum over the k-tiles (the accumulators are rescaled when a later tile holds a larger value), weight
+    rows from the image builder.  Rows whose magnitudes span the fp32 range, maxima that grow and shrink along k, rows of
+    zeros and denormals: the result stays within the norm-wise bound 4e-6 * |a|.|b| row by row and column by column."""
+    rs = np.random.RandomState(M)
+    N, K = 348, 520
+    A = rs.randn(M, K).astype(np.float64)
+    W = rs.randn(N, K).astype(np.float64)
+    A *= 2.0 ** rs.randint(-40, 40, size=(M, 1))            # every row its own magnitude, far outside fp16's range
+    W *= 2.0 ** rs.randint(-20, 20, size=(N, 1))
+    ramp = 2.0 ** np.linspace(-12, 12, K)                   # a maximum that grows with every k-tile ...
+    A[0::7] *= ramp
+    A[1::7] *= ramp[::-1]                                   # ... and one that shrinks
+    A[2::7, K // 2:] = 0                                    # zeros behind a live half
+    A[3::7] = 0                                             # rows of zeros
+    if os.environ.get("PFO_BX_FMT") != "0":                 # (the bf16x3 path feeds denormal pieces to the matrix cores, which flush them)
+        A[4::7] = 1e-42                                     # fp32 denormals
+    W[5::11] = 0
+    W[6::11] *= ramp[::-1]
+    A = A.astype(np.float32); W = W.astype(np.float32)
+    bias = rs.randn(N).astype(np.float32)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    # |a_i| . |b_n| with each factor's elements floored at 2^-18 of its row maximum: the bound of a per-row scale
+    fa = np.maximum(np.abs(A).astype(np.float64), np.abs(A).max(1, keepdims=True).astype(np.float64) * 2.0 ** -18)
+    fw = np.maximum(np.abs(W).astype(np.float64), np.abs(W).max(1, keepdims=True).astype(np.float64) * 2.0 ** -18)
+    mag = fa @ fw.T
+    got = _gemm_bf16x3(A, W, bias, 0).astype(np.float64)
+    assert np.abs(ref).max() < 1e37 and np.isfinite(got).all()
+    err = np.abs(got - (ref + bias)) / (mag + np.abs(bias) + 1e-30)
+    assert err.max() < 4e-6, err.max()
+    assert np.array_equal(got[3::7], np.broadcast_to(bias.astype(np.float64), got[3::7].shape))      # 0 . w + b = b exactly
+    got_t = _gemm_bf16x3(A, np.ascontiguousarray(W.T), None, 1).astype(np.float64)                  # k-major weights
+    assert (np.abs(got_t - ref) / (mag + 1e-30)).max() < 4e-6
 
 
 @pytest.mark.parametrize("M,N,K", [(172, 172, 3000), (344, 348, 5001), (516, 520, 900), (86, 348, 2049), (344, 172, 40)])
