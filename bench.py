@@ -82,8 +82,8 @@ def parse():
     return ap.parse_args()
 
 
-PMC_KERNEL = {"gemm_bx": "gemm_bx_areg_kernel", "gemm_tn_bx": "gemm_tn_group_bx_kernel",
-              "gemm_bx_skinny": "gemm_bx_skinny_kernel",
+PMC_KERNEL = {"gemm_bx": "void gemm_bx_areg_kernel<1>", "gemm_tn_bx": "gemm_tn_group_bx_kernel",
+              "gemm_bx_skinny": "void gemm_bx_skinny_kernel<4, 1>",
               "gemm_nt": "void gemm_f32_kernel<false, false, 0, true>",
               "gemm_nn": "void gemm_f32_kernel<false, true, 0, true>",
               "gemm_tn": "void gemm_tn_group_kernel<true>",
@@ -406,7 +406,8 @@ class Workload:
 def roofline_of(prof, n_prof_steps, profiled_workload=True):
     """Dominant KERNEL by device time over the sampled steps: a family is all launches of one kernel (the library reads
     the device-side row counts of the touched-table launches back, so every launch carries its work).  Contractions on the
-    bf16x3 kernels are priced against the dense bf16 MFMA peak divided by the six piece products one fp32 product costs;
+    split kernels are priced against the dense 16-bit MFMA peak divided by the piece products one fp32 product costs (three
+    for the fp16 image kernels, six for the bf16x3 weight-gradient tile);
     the fp32-MFMA kernels against the fp32 MFMA peak; the attention / sampling kernels against HBM."""
     fam = {k: v for k, v in prof.items() if v["count"] > 0}
     if not fam:
@@ -415,13 +416,17 @@ def roofline_of(prof, n_prof_steps, profiled_workload=True):
     v = fam[dom]
     per_launch_s = v["ms"] / v["count"] * 1e-3
     if dom.startswith("gemm"):
-        peak = MFMA_BF16_PEAK_TF / 6.0 if dom in BX_FAMILIES else MFMA_F32_PEAK_TF
+        products = bx_products(dom)
+        peak = MFMA_BF16_PEAK_TF / products if products else MFMA_F32_PEAK_TF
         achieved = v["work"] / v["count"] / per_launch_s / 1e12
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": None}
-        if peak != MFMA_F32_PEAK_TF:
+        if products == 6:
             roof["arithmetic"] = ("fp32 contraction as a 3-way bf16 operand split: 6 v_mfma_f32_16x16x32_bf16 per fp32 "
                                   "product block; peak = dense bf16 MFMA peak / 6")
+        elif products == 3:
+            roof["arithmetic"] = ("fp32 contraction as a 2-way scaled fp16 operand split: 3 v_mfma_f32_16x16x32_f16 per fp32 "
+                                  "product block; peak = dense f16 MFMA peak / 3")
     else:
         achieved = v["work"] / v["count"] / per_launch_s / 1e9
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -444,6 +449,16 @@ def roofline_of(prof, n_prof_steps, profiled_workload=True):
 
 
 BX_FAMILIES = ("gemm_bx", "gemm_tn_bx", "gemm_bx_skinny")
+
+
+def bx_products(family):
+    """MFMA instructions per fp32 product block of a split-contraction family (0: not one).  The image kernels take the
+    two-piece fp16 format (3 products) unless PFO_BX_FMT=0 keeps them on bf16x3; the weight-gradient tile is bf16x3 (6)."""
+    if family not in BX_FAMILIES:
+        return 0
+    if family == "gemm_tn_bx" or os.environ.get("PFO_BX_FMT", "1") == "0":
+        return 6
+    return 3
 
 
 def emulate_ranks(args, dev):
