@@ -76,6 +76,11 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=512, help="interactions per oracle step in the CPU baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=4, help="timed oracle steps (one more runs first, untimed)")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event bracketing of kernel launches")
+    ap.add_argument("--prefetch", type=int, default=0, choices=[0, 1],
+                    help="1: the next batch's negatives / frontier / compaction / packed rows are issued on a second stream right "
+                         "after the current forward (TGN.prefetch); 0 (default): inside the step, as the reference's call order "
+                         "has it.  Measured on C2: 1.52 ms with, 1.50 without - the ~70 us of small launches cost as much beside "
+                         "the backward's first kernels as they do at the head of the step (DESIGN 4.2)")
     ap.add_argument("--prof-every", type=int, default=8,
                     help="bracket the kernel launches of every Nth timed step with HIP events (the brackets cost ~0.2 ms "
                          "per step at C2, so the roofline sample is taken on a subset of the timed steps)")
@@ -270,6 +275,8 @@ class Workload:
         self.port_idx_all, self.port_len_all = t(graph.portfolio_idx, np.int32), t(graph.portfolio_len, np.int32)
         self.sampler = DeviceNegativeSampler(item_availability(d.destinations, graph.upper_u, cfg.n_items), graph.upper_u, dev, seed=1)
         self.n_neg = 3
+        self._next = None
+        self.prefetch = bool(getattr(args, "prefetch", 0))
         self.mvs = None
         if self.ours:
             self.mvs = P.MVSampler(graph.prices, graph.upper_u, dev, gamma=2.0, lambda_mv=0.5, p_pos_num=1, p_neg_num=3)
@@ -326,10 +333,25 @@ class Workload:
             from pfotgnrec_amd import _lib as _l
             return (self.gstep.eager if _l.prof_is_on() else self.gstep)(*self._batch(sl))   # bracketed steps run kernel by kernel
         if self.mvs is None:
-            neg = self.sampler.sample(self.port_idx_all[sl], self.port_len_all[sl], n_neg, offset=i)            # utils.py:86-114
-            emb, b = tgn.embed_device(self.src_all[sl], self.dst_all[sl], [neg.reshape(-1)], [n_neg], self.ts_all[sl],
+            if self._next is not None and self._next[0] == i:
+                neg = self._next[1]                               # drawn (and its neighbourhood prepared) beside the previous backward
+            else:
+                neg = self.sampler.sample(self.port_idx_all[sl], self.port_len_all[sl], n_neg, offset=i).reshape(-1)   # utils.py:86-114
+            self._next = None
+            emb, b = tgn.embed_device(self.src_all[sl], self.dst_all[sl], [neg], [n_neg], self.ts_all[sl],
                                       self.eidx_all[sl], cfg.n_neighbors)                                     # tgn.py:219-327
             pos_block = 1                                                                                      # main.py:364-381
+            if self.prefetch:
+                # the next batch's negatives, frontier, compaction and packed memory rows on the model's second stream: the
+                # reference's loop does this between batches on the host (main.py:190-207 + the neighbour finder); here it
+                # runs beside this batch's backward.  Every step still does exactly one step's worth of it.
+                lo2 = self.start + ((i + 1) * B) % self.span
+                s2 = slice(lo2, lo2 + B)
+                with tgn.prefetching():
+                    neg2 = self.sampler.sample(self.port_idx_all[s2], self.port_len_all[s2], n_neg, offset=i + 1).reshape(-1)
+                    if tgn.prefetch(self.src_all[s2], self.dst_all[s2], [neg2], [n_neg], self.ts_all[s2], self.eidx_all[s2],
+                                    cfg.n_neighbors):
+                        self._next = (i + 1, neg2)
         else:
             cand_neg = self.sampler.sample(self.port_idx_all[sl], self.port_len_all[sl], 20, offset=i)          # main.py:194-195
             cand = torch.cat([self.dst_all[sl].unsqueeze(1), cand_neg], 1).contiguous()                        # main.py:207
@@ -528,6 +550,7 @@ def main():
                                          "median": round(float(np.median(wl.block_ms)), 4), "last": round(wl.block_ms[-1], 4)},
                    **({"block_ms_all": [round(x, 4) for x in wl.block_ms]} if os.environ.get("PFO_BENCH_BLOCKS") else {}),
                    "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4), "hip_graph": wl.graph_note, "deterministic_backward": bool(args.deterministic),
+                   "next_batch_prepared_beside_backward": bool(wl.prefetch and wl.gstep is None and wl.mvs is None),
                    "collective": ("%s all-reduce of the flat fp32 gradient, world %d"
                                   % ("rccl" if dist.get_backend() == "nccl" else dist.get_backend(), dist.get_world_size())) if world > 1 else None},
     }

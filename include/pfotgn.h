@@ -267,7 +267,18 @@ typedef struct pfo_tgn_batch {
                                  partial bins - become order-free: the rows are added as 2^-40 fixed-point int64 (integer addition
                                  is associative), the partials go to one slab row per workgroup and are folded in row order.
                                  Costs ~4 % of a C2 step (8-byte atomics); every other sum of the step is ordered already */
+  int32_t prepared;         /* != 0: pfo_tgn_prepare already ran for this batch on this workspace (and the caller's stream is
+                                 ordered behind it): pfo_tgn_forward skips the frontier sampling, the compaction and the row pack */
 } pfo_tgn_batch;
+
+/* The part of pfo_tgn_forward that depends on neither parameters nor gradients - frontier sampling (utils.py:163-219 per level,
+ * embedding_module.py:125), compaction of the touched nodes, the packed copies of their memory / message rows (tgn.py:251) - on
+ * ANY stream.  A training loop issues it for batch n+1 on a second stream as soon as batch n's forward (whose state update
+ * writes the tables the pack reads) is queued, into a second workspace: it then runs beside batch n's backward, and batch
+ * n+1's forward (batch.prepared = 1, its stream made to wait for this one) starts at the GRU.  The reference does the same
+ * work on the host between batches (main.py:190-207 + the neighbour finder inside the model call). */
+int pfo_tgn_prepare(const pfo_tgn_config* cfg, const pfo_tgn_state* st, const pfo_tgn_batch* batch, void* workspace,
+                    void* stream);
 
 /* Lazy memory update for touched nodes (tgn.py:251, memory_updater.py:35-53) + L-layer temporal graph
  * attention (embedding_module.py:76-175, temporal_attention.py:34-90).  emb_out f32[R,D]. */

@@ -40,7 +40,7 @@ class TgnBatch(C.Structure):
     _fields_ = [("roots", _VP), ("root_ts", _VP), ("R", C.c_int32), ("K", C.c_int32), ("uniform", C.c_int32),
                 ("draws", C.POINTER(_VP)), ("seed", C.c_uint64), ("offset", C.c_uint64), ("dropout_p", C.c_float),
                 ("training", C.c_int32), ("extra_nodes", _VP), ("n_extra", C.c_int32), ("offset_dev", _VP),
-                ("deterministic", C.c_int32)]
+                ("deterministic", C.c_int32), ("prepared", C.c_int32)]
 
 
 class TgnDebug(C.Structure):
@@ -87,6 +87,7 @@ PROTOTYPES = {
     "pfo_tgn_param_layout": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnLayout)]),
     "pfo_tgn_workspace_bytes": (C.c_int64, [C.POINTER(TgnConfig)]),
     "pfo_tgn_forward": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP]),
+    "pfo_tgn_prepare": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP]),
     "pfo_tgn_backward": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP, _VP]),
     "pfo_tgn_backward_ev": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP, C.c_int32,
                                       _VP, _VP, C.c_int64, _VP, _VP]),

@@ -373,6 +373,74 @@ static int level_sizes(const pfo_tgn_config* c, const pfo_tgn_batch* b, int64_t*
   return PFO_OK;
 }
 
+// ---- the part of a forward call that depends on neither parameters nor gradients, in two halves (pfo_tgn_forward runs the
+// GRU's weight-image launch between them; pfo_tgn_prepare runs them back to back on any stream, ahead of time)
+static int prepare_sample(const pfo_tgn_config* c, const pfo_tgn_state* st, const pfo_tgn_batch* b, const Ws& w, const int64_t* n,
+                          hipStream_t s) {
+  const int L = c->n_layers, K = b->K;
+  void* stream = (void*)s;
+  // The compaction's flags are cleared on THIS stream (4 us): a wait for a side-stream memset costs the waiting stream 5-17 us
+  // on this part (r3 timeline), more than the memset itself.  Same reasoning for the GRU's two weight images below.
+  HIPOK(hipMemsetAsync(w.mark, 0, w.mark_bytes, s), "memset failed");
+  // ---- frontier expansion: K1 per level (utils.py:163-219 called from embedding_module.py:125).  Enqueued before the
+  // side-stream work below: it depends on nothing else, and the GPU samples while the host is still enqueueing
+  for (int l = L; l >= 1; --l) {
+    const int64_t* dr = (b->uniform == 1) ? b->draws[L - l] : nullptr;
+    PFO_REQUIRE(b->uniform != 1 || dr, "missing draws for a level");
+    // level L reads the caller's roots directly; every level writes [its own nodes | their neighbours] as the next one
+    const int32_t* lvl_nodes = (l == L) ? b->roots : w.nodes[l];
+    const double* lvl_ts = (l == L) ? b->root_ts : w.ts[l];
+    // the last launch writes the whole level-0 list [S_1 ; neighbours(S_1)]: it also sets the touched-node flags, so the
+    // compaction needs no marking pass
+    RUN(pfo_tnbr_sample_dev(st->indptr, st->adj_nbr, st->adj_eidx, st->adj_ts, c->n_nodes, lvl_nodes, lvl_ts, n[l], K,
+                            b->uniform, dr, b->seed, b->offset + (uint64_t)l * 0x100000000ull, b->offset_dev, nullptr,
+                            w.eidx[l], nullptr, w.dt[l], w.nodes[l - 1], l > 1 ? w.ts[l - 1] : nullptr, l == 1 ? w.mark : nullptr,
+                            l == 1 ? w.cnt1 : nullptr, stream));
+  }
+
+  return PFO_OK;
+}
+static int prepare_compact_pack(const pfo_tgn_config* c, const pfo_tgn_state* st, const pfo_tgn_batch* b, const Ws& w, const Dims& d,
+                                const int64_t* n, hipStream_t s) {
+  const int D = d.D;
+  // slot[v] = row of v in the per-step tables, idx0[i] = row of the i-th level-0 reference (roots and every sampled neighbour,
+  // all levels; + the caller's extra nodes)
+  RUN(pfo_touch_compact_launch(nullptr, 0, b->extra_nodes, b->n_extra, c->n_nodes, w.mark, w.slot, w.touched, w.n_touched,
+                               w.scan, true, true, s));
+  const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
+  // ---- level-0 rows of the touched nodes: memory' + node features (embedding_module.py:93-98), memory' = the lazily
+  // updated memory (tgn.py:251; memory_updater.py:35-53).  One launch copies the rows the GRU reads (and the backward reads
+  // again after the state update has overwritten the tables) and translates the level-0 list into table rows.
+  if (c->use_memory)
+    RUN(pfo_pack_remap_launch(st->msg_table, d.M, st->memory, D, st->has_msg, w.touched, w.n_touched, capP, w.msg_rows,
+                              w.h_rows, w.hm, w.nodes[0], n[0], w.slot, w.idx0, s));
+  else
+    RUN(pfo_pack_remap_launch(nullptr, d.M, st->node_feat, D, nullptr, w.touched, w.n_touched, capP, nullptr, w.h0_tab, nullptr,
+                              w.nodes[0], n[0], w.slot, w.idx0, s));
+  return PFO_OK;
+}
+
+// =============================================================================================
+extern "C" int pfo_tgn_prepare(const pfo_tgn_config* c, const pfo_tgn_state* st, const pfo_tgn_batch* b, void* workspace,
+                               void* stream) {
+  if (int rc = check_cfg(c)) return rc;
+  PFO_REQUIRE(st && workspace && b, "null argument");
+  PFO_REQUIRE(st->indptr && st->adj_nbr && st->adj_eidx && st->adj_ts && st->node_feat, "null state");
+  PFO_REQUIRE(!c->use_memory || (st->memory && st->msg_table && st->has_msg), "null memory state");
+  int64_t n[PFO_MAX_LAYERS + 1];
+  RUN(level_sizes(c, b, n));
+  PFO_REQUIRE(b->roots && b->root_ts, "null batch arrays");
+  PFO_REQUIRE(b->uniform >= 0 && b->uniform <= 2, "bad sampling mode");
+  PFO_REQUIRE(b->uniform != 1 || b->draws, "mode 1 needs draws");
+  PFO_REQUIRE(b->n_extra >= 0 && b->n_extra <= 2 * c->max_batch, "n_extra exceeds 2 * max_batch");
+  PFO_REQUIRE(b->n_extra == 0 || b->extra_nodes, "null extra_nodes");
+  const Dims d = dims_of(c);
+  const Ws w = carve(c, workspace);
+  RUN(prepare_sample(c, st, b, w, n, (hipStream_t)stream));
+  RUN(prepare_compact_pack(c, st, b, w, d, n, (hipStream_t)stream));
+  return PFO_OK;
+}
+
 // =============================================================================================
 extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st, const pfo_tgn_batch* b, void* workspace,
                                float* emb_out, void* stream) {
@@ -405,24 +473,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   // stream did before this call); all layers share each launch.
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
-  // The compaction's flags are cleared on THIS stream (4 us): a wait for a side-stream memset costs the waiting stream 5-17 us
-  // on this part (r3 timeline), more than the memset itself.  Same reasoning for the GRU's two weight images below.
-  HIPOK(hipMemsetAsync(w.mark, 0, w.mark_bytes, s), "memset failed");
-  // ---- frontier expansion: K1 per level (utils.py:163-219 called from embedding_module.py:125).  Enqueued before the
-  // side-stream work below: it depends on nothing else, and the GPU samples while the host is still enqueueing
-  for (int l = L; l >= 1; --l) {
-    const int64_t* dr = (b->uniform == 1) ? b->draws[L - l] : nullptr;
-    PFO_REQUIRE(b->uniform != 1 || dr, "missing draws for a level");
-    // level L reads the caller's roots directly; every level writes [its own nodes | their neighbours] as the next one
-    const int32_t* lvl_nodes = (l == L) ? b->roots : w.nodes[l];
-    const double* lvl_ts = (l == L) ? b->root_ts : w.ts[l];
-    // the last launch writes the whole level-0 list [S_1 ; neighbours(S_1)]: it also sets the touched-node flags, so the
-    // compaction needs no marking pass
-    RUN(pfo_tnbr_sample_dev(st->indptr, st->adj_nbr, st->adj_eidx, st->adj_ts, c->n_nodes, lvl_nodes, lvl_ts, n[l], K,
-                            b->uniform, dr, b->seed, b->offset + (uint64_t)l * 0x100000000ull, b->offset_dev, nullptr,
-                            w.eidx[l], nullptr, w.dt[l], w.nodes[l - 1], l > 1 ? w.ts[l - 1] : nullptr, l == 1 ? w.mark : nullptr,
-                            l == 1 ? w.cnt1 : nullptr, stream));
-  }
+  if (!b->prepared) RUN(prepare_sample(c, st, b, w, n, s));
 
   if (c->use_memory) {
     // the GRU contractions come first on the main stream: their two weight images are made there too (one 4 us launch)
@@ -434,28 +485,18 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   }
   bool composites_awaited = false;
 
-  // ---- the nodes this step reads (roots and every sampled neighbour, all levels; + the caller's extra nodes), compacted:
-  // slot[v] = row of v in the per-step tables, idx0[i] = row of the i-th level-0 reference
+  // ---- the nodes this step reads, compacted, and their level-0 rows packed (prepare_compact_pack; a prepared batch has them)
   PFO_REQUIRE(b->n_extra >= 0 && b->n_extra <= 2 * c->max_batch, "n_extra exceeds 2 * max_batch");
   PFO_REQUIRE(b->n_extra == 0 || b->extra_nodes, "null extra_nodes");
-  RUN(pfo_touch_compact_launch(nullptr, 0, b->extra_nodes, b->n_extra, c->n_nodes, w.mark, w.slot, w.touched, w.n_touched,
-                               w.scan, true, true, s));
+  if (!b->prepared) RUN(prepare_compact_pack(c, st, b, w, d, n, s));
   const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
-  // ---- level-0 rows of the touched nodes: memory' + node features (embedding_module.py:93-98), memory' = the lazily
-  // updated memory (tgn.py:251; memory_updater.py:35-53).  One launch copies the rows the GRU reads (and the backward reads
-  // again after the state update has overwritten the tables) and translates the level-0 list into table rows.
   if (c->use_memory) {
-    RUN(pfo_pack_remap_launch(st->msg_table, d.M, st->memory, D, st->has_msg, w.touched, w.n_touched, capP, w.msg_rows,
-                              w.h_rows, w.hm, w.nodes[0], n[0], w.slot, w.idx0, s));
     // both GRU contractions and the gate math in ONE launch (gemm.hip gru_fused_kernel): gi / gh never exist in HBM
     PfoGruFused f;
     f.msg_rows = w.msg_rows; f.K_msg = d.M; f.h_rows = w.h_rows; f.img_ih = w.iWih; f.img_hh = w.iWhh;
     f.b_ih = P.b_ih; f.b_hh = P.b_hh; f.hm = w.hm; f.touched = w.touched; f.node_feat = st->node_feat;
     f.upd_mem = w.upd_mem; f.h0_tab = w.h0_tab; f.gates = w.gates; f.D = D; f.cap_rows = capP; f.n_rows = w.n_touched;
     RUN(pfo_gru_fused_launch(f, s));
-  } else {
-    RUN(pfo_pack_remap_launch(nullptr, d.M, st->node_feat, D, nullptr, w.touched, w.n_touched, capP, nullptr, w.h0_tab, nullptr,
-                              w.nodes[0], n[0], w.slot, w.idx0, s));
   }
   // ---- composite weights of every layer and their bf16x3 images: side stream.  Enqueued HERE, after the sampling / compaction /
   // GRU launches of the caller's stream (which need none of it): when the host is the slower side (small batches, profilers)
@@ -768,7 +809,8 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     const int n_tn_a = ntn;
     // The weight gradients over the INSTANCES (dW2 / db2 at the top, dW1ovT) need only d out, h1, ctx' and dh1: they go to the side
     // stream as soon as dh1 exists, beside the d ctx' contraction and the attention backward (measured: 15 us/step better than
-    // forking them next to the attention backward alone, whose single-wavefront workgroups starve a 74 KB-LDS kernel of slots)
+    // forking them next to the attention backward alone, whose single-wavefront workgroups starve a 74 KB-LDS kernel of slots;
+    // r3: issuing them BEHIND the attention backward, beside the serial tail, measured +2 % per step)
     static const int tna_mode = getenv("PFO_TNA_MODE") ? atoi(getenv("PFO_TNA_MODE")) : 2;   // A/B: 0 fork before the attention backward, 1 main stream
     auto tn_a_side = [&]() -> int {
       HIPOK(hipEventRecord(sd.tn_a, s), "event record failed");

@@ -34,6 +34,9 @@ class Memory(nn.Module):
         # host-side knowledge "some node holds a pending message": False = unknown (the TGN reads has_msg back once);
         # the native state update sets it.  Decides whether the GRU takes part in a step (TGN._attach_grads)
         self._any_msg = False
+        # counts the rewrites of the tables from outside the training step (a batch prepared ahead of time holds packed copies
+        # of memory rows: TGN.prefetch stamps them with this number)
+        self._state_version = 0
 
     def __init_memory__(self):
         """Zero the memory and drop every pending message (modules/memory.py:23-33); called per epoch (main.py:153).
@@ -47,6 +50,7 @@ class Memory(nn.Module):
             self.msg_time.zero_()
             self.has_msg.zero_()
         self._any_msg = False
+        self._state_version += 1
 
     def get_memory(self, node_idxs):
         return self.memory[torch.as_tensor(node_idxs, device=self.memory.device, dtype=torch.long), :]
@@ -54,6 +58,7 @@ class Memory(nn.Module):
     def set_memory(self, node_idxs, values):
         with torch.no_grad():
             self.memory[torch.as_tensor(node_idxs, device=self.memory.device, dtype=torch.long), :] = values
+        self._state_version += 1
 
     def get_last_update(self, node_idxs):
         return self.last_update[torch.as_tensor(node_idxs, device=self.memory.device, dtype=torch.long)]
@@ -72,6 +77,7 @@ class Memory(nn.Module):
             self.msg_time.copy_(t)
             self.has_msg.copy_(has)
         self._any_msg = False
+        self._state_version += 1
 
     def detach_memory(self):
         """modules/memory.py:62-71.  Stored messages and memory never carry an autograd graph here."""

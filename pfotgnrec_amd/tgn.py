@@ -38,7 +38,7 @@ def _normalise_edge_features(edge_features):
 class _Call:
     """Everything one forward/backward pair of native calls needs to agree on."""
     __slots__ = ("roots", "root_ts", "R", "K", "mode", "draws", "draw_ptrs", "seed", "offset", "dropout_p", "training",
-                 "extra", "batch_struct", "ws", "ws_caps", "cfg", "pool", "gru_applied", "__weakref__")
+                 "extra", "batch_struct", "ws", "ws_caps", "cfg", "pool", "gru_applied", "ready", "keep", "__weakref__")
 
     def release(self):
         """Hands the call's workspace back to its TGN's pool (after the backward, or when the graph is dropped)."""
@@ -131,6 +131,7 @@ class TGN(nn.Module):
         self._adj_cache = None
         self.dp_grad_scale = 1.0
         self._ws_pool = []        # free workspaces: [(caps, tensor)]
+        self._prefetched, self._pre_stream, self._pre_main = None, None, None
         self._ws_caps = (0, 0, 0)
         self._last_ws = None      # (config, workspace) of the newest forward (debug_touched)
         self._step = 0
@@ -257,6 +258,7 @@ class TGN(nn.Module):
             self.memory_updater.layer_norm._apply(fn)
         self.device = self._flat.device
         self._ws_pool, self._last_ws, self._adj_cache = [], None, None
+        self._prefetched = None
         return self
 
     # ------------------------------------------------------------------ neighbour finder plumbing
@@ -352,7 +354,7 @@ class TGN(nn.Module):
         self._adj_cache = (key, nf, (indptr, nbr, eidx, ts))
         return self._adj_cache[2]
 
-    def _make_call(self, roots, root_ts, K, draws, dropout_p, extra, B, offset_dev=None):
+    def _make_call(self, roots, root_ts, K, draws, dropout_p, extra, B, offset_dev=None, defer_step=False):
         c = _Call()
         c.roots, c.root_ts, c.R, c.K = roots, root_ts, int(roots.shape[0]), int(K)
         uniform = bool(getattr(self.neighbor_finder, "uniform", False))
@@ -363,11 +365,12 @@ class TGN(nn.Module):
             if len(draws) != self.n_layers:
                 raise ValueError("uniform mode with injected draws needs one index tensor per layer")
             c.draw_ptrs = (ctypes.c_void_p * self.n_layers)(*[d.data_ptr() for d in draws])
-        self._step += 1
+        if not defer_step:                # (a call prepared ahead of time takes its place in the sequence when it is used)
+            self._step += 1
         c.seed = self.seed + getattr(self.neighbor_finder, "seed", 0)
         # position in the Philox streams (dropout masks, uniform draws): the call counter - or, for a step captured into a HIP
         # graph (whose kernel arguments are frozen), a device word the graph itself advances
-        c.offset = (self._step << 36) if offset_dev is None else 0
+        c.offset = (self._step << 36) if (offset_dev is None and not defer_step) else 0
         c.dropout_p = float(dropout_p)
         c.training = int(dropout_p > 0.0)
         c.extra = extra
@@ -457,6 +460,106 @@ class TGN(nn.Module):
                   ts.data_ptr(), eidx.data_ptr(), int(src.shape[0]), call.ws.data_ptr(), _lib.stream_ptr())
 
     # ------------------------------------------------------------------ the step
+    def _assemble_roots(self, src, dst, edge_times, groups, lo, hi, R):
+        """roots = [src | dst | extra groups] of this rank's shard, root_ts = the interaction's edge time per root."""
+        b = hi - lo
+        if b == 0:
+            # empty shard (B < world): nothing to embed, but the state update still runs on every rank; one padding
+            # root keeps the native call well-formed (node 0 never has neighbours; its row is dropped below)
+            return (torch.zeros(1, dtype=torch.int32, device=self.device),
+                    torch.full((1,), -1.0, dtype=torch.float64, device=self.device))
+        roots = torch.empty(R, dtype=torch.int32, device=self.device)
+        root_ts = torch.empty(R, dtype=torch.float64, device=self.device)
+        ng = len(groups)
+        gptr = (ctypes.c_void_p * max(1, ng))(*[t.data_ptr() for t, _ in groups])
+        greps = (ctypes.c_int32 * max(1, ng))(*[r for _, r in groups])
+        _lib.call("pfo_roots_assemble", src.data_ptr(), dst.data_ptr(), edge_times.data_ptr(), lo, hi, gptr, greps, ng,
+                  roots.data_ptr(), root_ts.data_ptr(), _lib.stream_ptr())
+        return roots, root_ts
+
+    # ------------------------------------------------------------------ next batch's neighbourhood beside this batch's backward
+    def _batch_key(self, src, dst, groups, edge_times, K):
+        nf = self.neighbor_finder
+        return (src.data_ptr(), dst.data_ptr(), edge_times.data_ptr(), int(src.shape[0]), int(K),
+                tuple((t.data_ptr(), int(t.shape[0]), r) for t, r in groups),
+                self.memory._state_version if self.use_memory else 0, id(nf), getattr(nf, "_version", 0),
+                self.dp_rank, self.dp_world)
+
+    def prefetching(self):
+        """Context manager: work issued inside runs on this model's prefetch stream, ordered behind everything the caller's
+        stream holds at entry.  A training loop draws the NEXT batch's negatives and calls ``prefetch`` inside it, right after
+        the current batch's forward: the whole preparation then runs beside the current batch's backward."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            if self._pre_stream is None:
+                self._pre_stream = torch.cuda.Stream(device=self.device)
+            ev = torch.cuda.Event()
+            ev.record()                                           # after the caller's forward (whose state update the pack reads)
+            self._pre_main = torch.cuda.current_stream()
+            self._pre_stream.wait_event(ev)
+            with torch.cuda.stream(self._pre_stream):
+                yield
+        return ctx()
+
+    def prefetch(self, src, dst, extra_roots, extra_repeat, edge_times, edge_idxs, n_neighbors):
+        """Everything of the next training ``embed_device`` / ``compute_temporal_embeddings[_p]`` call (SAME tensors, passed
+        again there) that depends on neither parameters nor gradients: root assembly, frontier sampling (utils.py:163-219 per
+        level), compaction of the touched nodes, packed copies of their memory / message rows - the work the reference's loop
+        does on the host between batches.  Call inside ``with tgn.prefetching():``.  Most-recent sampling only (the random
+        modes draw from the step's stream position); a call that does not match is simply not used."""
+        _lib.require_gpu(self.device)
+        if bool(getattr(self.neighbor_finder, "uniform", False)) or not torch.is_grad_enabled():
+            return False
+        self._drop_prefetched()
+        B, K = int(src.shape[0]), int(n_neighbors)
+        lo, hi = 0, B
+        if self.dp_world > 1:
+            lo, hi = self.dp_rank * B // self.dp_world, (self.dp_rank + 1) * B // self.dp_world
+        b = hi - lo
+        if b == 0 or K <= 0:
+            return False
+        groups = [(t.contiguous(), int(r)) for t, r in zip(extra_roots, extra_repeat) if int(r) > 0]
+        R = b * (2 + sum(r for _, r in groups))
+        extra = torch.cat([src, dst]).contiguous() if (self.use_memory and self.dp_world > 1) else None
+        roots, root_ts = self._assemble_roots(src, dst, edge_times, groups, lo, hi, R)
+        dropout_p = self.dropout if self.training else 0.0
+        call = self._make_call(roots, root_ts, K, None, dropout_p, extra, B, defer_step=True)
+        call.batch_struct.prepared = 1
+        st = self._state_struct()
+        _lib.call("pfo_tgn_prepare", ctypes.byref(call.cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
+                  call.ws.data_ptr(), _lib.stream_ptr())
+        call.ready = torch.cuda.Event()
+        call.ready.record()
+        call.keep = (src, dst, edge_times, groups)                 # the key's addresses stay theirs until the call is used
+        main = self._pre_main if self._pre_main is not None else torch.cuda.default_stream(self.device)
+        for t in (roots, root_ts, extra) + tuple(g for g, _ in groups):
+            if t is not None:
+                t.record_stream(main)                             # allocated on the prefetch stream, read on the caller's
+        self._prefetched = (self._batch_key(src, dst, groups, edge_times, K), dropout_p, call)
+        return True
+
+    def _drop_prefetched(self):
+        if self._prefetched is not None:
+            self._prefetched[2].release()
+            self._prefetched = None
+
+    def _take_prefetched(self, src, dst, groups, edge_times, K, draws, offset_dev, grad_mode, dropout_p):
+        if self._prefetched is None:
+            return None
+        key, p_drop, call = self._prefetched
+        self._prefetched = None
+        if (grad_mode and draws is None and offset_dev is None and p_drop == dropout_p
+                and key == self._batch_key(src, dst, groups, edge_times, K)
+                and bool(self.deterministic) == bool(call.batch_struct.deterministic)):
+            self._step += 1                                       # its position in the random streams (dropout masks): now
+            call.offset = self._step << 36
+            call.batch_struct.offset = call.offset
+            return call
+        call.release()
+        return None
+
     def embed_device(self, src, dst, extra_roots, extra_repeat, edge_times, edge_idxs, n_neighbors, draws=None, offset_dev=None):
         """Device-resident core of both reference entry points.
 
@@ -494,20 +597,12 @@ class TGN(nn.Module):
         D = self.n_node_features
         grad_mode = torch.is_grad_enabled()
         dropout_p = self.dropout if self.training else 0.0       # dropout follows train()/eval(), not the autograd mode
-        extra = torch.cat([src, dst]).contiguous() if (self.use_memory and self.dp_world > 1) else None
-        if b == 0:
-            # empty shard (B < world): nothing to embed, but the state update still runs on every rank; one padding
-            # root keeps the native call well-formed (node 0 never has neighbours; its row is dropped below)
-            roots = torch.zeros(1, dtype=torch.int32, device=self.device)
-            root_ts = torch.full((1,), -1.0, dtype=torch.float64, device=self.device)
+        pre = self._take_prefetched(src, dst, groups, edge_times, K, draws, offset_dev, grad_mode, dropout_p)
+        if pre is not None:
+            roots, root_ts, extra = pre.roots, pre.root_ts, pre.extra
         else:
-            roots = torch.empty(R, dtype=torch.int32, device=self.device)
-            root_ts = torch.empty(R, dtype=torch.float64, device=self.device)
-            ng = len(groups)
-            gptr = (ctypes.c_void_p * max(1, ng))(*[t.data_ptr() for t, _ in groups])
-            greps = (ctypes.c_int32 * max(1, ng))(*[r for _, r in groups])
-            _lib.call("pfo_roots_assemble", src.data_ptr(), dst.data_ptr(), edge_times.data_ptr(), lo, hi, gptr, greps, ng,
-                      roots.data_ptr(), root_ts.data_ptr(), _lib.stream_ptr())
+            extra = torch.cat([src, dst]).contiguous() if (self.use_memory and self.dp_world > 1) else None
+            roots, root_ts = self._assemble_roots(src, dst, edge_times, groups, lo, hi, R)
         if K <= 0:                       # utils.py:175: a single all-padding column
             K, root_ts = 1, torch.full_like(root_ts, -1.0)
         post = None
@@ -525,7 +620,12 @@ class TGN(nn.Module):
             # a leaf that requires grad: the caller's loss.backward() is a no-op instead of an error
             return torch.zeros((0, D), dtype=torch.float32, device=self.device, requires_grad=grad_mode), 0
         if grad_mode:
-            call = self._make_call(roots, root_ts, K, draws, dropout_p, extra, B, offset_dev)
+            if pre is not None:
+                call = pre
+                call.gru_applied = self._gru_applied_now
+                torch.cuda.current_stream().wait_event(call.ready)    # the frontier, the compaction and the packed rows exist
+            else:
+                call = self._make_call(roots, root_ts, K, draws, dropout_p, extra, B, offset_dev)
             emb = _EmbedFn.apply(self, call, post, *self.hot_parameters())
             return emb, b
         # forward only (evaluation.py:94: R = B*(2+N_ITEMS) roots): walk the roots in chunks through the same

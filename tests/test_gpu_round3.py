@@ -179,3 +179,56 @@ def test_deterministic_backward_is_bitwise_reproducible(uniform):
     assert (g1[2 * D:] - g0[2 * D:]).abs().max().item() <= 2e-5 * den       # same sums, different rounding order
     assert (g1[:2 * D] - g0[:2 * D]).abs().max().item() <= 3e-3 * g0[:2 * D].abs().max().item()   # time encoder: cancellation-heavy
     tgn.deterministic = False
+
+
+# ------------------------------------------------------------------ next batch prepared beside this batch's backward
+@pytest.mark.parametrize("use_memory", [True, False])
+def test_prefetched_batches_give_the_same_steps(use_memory):
+    """``TGN.prefetch`` (pfo_tgn_prepare: root assembly, frontier sampling, compaction, packed memory rows of the NEXT batch on
+    a second stream, into a second workspace, issued right after the current forward) changes when that work runs, not what
+    it computes: embeddings, gradients (deterministic mode: bitwise), parameters after Adam and the memory tables of a 5-step
+    run are identical with and without it.  A prefetch whose batch does not come next is dropped."""
+    from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+    cfg = SyntheticConfig("pre", 300, 25, 6000, 64, 2, 8, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    B, q, K = 64, 3, 8
+    rs = np.random.RandomState(5)
+    starts = [3000 + 64 * i for i in range(5)]
+    negs = [rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * q) for _ in starts]
+
+    def run(prefetch):
+        torch.manual_seed(11)
+        tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=2, dropout=0.1,
+                    use_memory=use_memory, memory_dimension=64, message_function="identity", n_neighbors=K)
+        tgn.deterministic = True
+        tgn.train()
+        opt = torch.optim.Adam(tgn.parameters(), lr=1e-3)
+        dev = lambda a, t: tgn._to_dev(a, t)
+        batches = [(dev(d.sources[s:s + B], np.int32), dev(d.destinations[s:s + B], np.int32), dev(n, np.int32),
+                    dev(d.timestamps[s:s + B], np.float64), dev(d.edge_idxs[s:s + B], np.int32)) for s, n in zip(starts, negs)]
+        out = []
+        for i, (s_, d_, n_, t_, e_) in enumerate(batches):
+            emb, b = tgn.embed_device(s_, d_, [n_], [q], t_, e_, K)
+            if prefetch and i + 1 < len(batches):
+                s2, d2, n2, t2, e2 = batches[i + 1]
+                with tgn.prefetching():
+                    if i == 1:                                     # a batch that does NOT come next: dropped when the real one arrives
+                        assert tgn.prefetch(s2, d2, [batches[0][2]], [q], t2, e2, K)
+                    else:
+                        assert tgn.prefetch(s2, d2, [n2], [q], t2, e2, K)
+            P.bpr_step(tgn, emb, b, q)
+            grad = tgn.flat_grad.clone()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            out.append((emb.detach().clone(), grad, tgn._flat.detach().clone()))
+        mem = [t.clone() for t in (tgn.memory.memory.data, tgn.memory.msg_table, tgn.memory.msg_time)] if use_memory else []
+        torch.cuda.synchronize()
+        return out, mem
+
+    a, mem_a = run(False)
+    b_, mem_b = run(True)
+    for (e0, g0, p0), (e1, g1, p1) in zip(a, b_):
+        assert torch.equal(e0, e1) and torch.equal(g0, g1) and torch.equal(p0, p1)
+    for x, y in zip(mem_a, mem_b):
+        assert torch.equal(x, y)
