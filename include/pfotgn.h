@@ -105,11 +105,14 @@ int pfo_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, 
                  float* workspace, int64_t workspace_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * The same contraction for row-major A, computed on the BF16 matrix cores by a 3-way split of every fp32 operand
- * (x = x1 + x2 + x3, bf16 pieces with exact residuals; six piece products accumulated in fp32): fp32-level accuracy
- * (error <= ~2^-22 sum_k |a||b|, the same bound as an fp32 accumulation) at 2.7x the fp32 matrix rate.  This is the
- * kernel the large launches of pfo_tgn_forward / pfo_tgn_backward use for torch.nn.Linear (utils.py:7-17,
- * torch.nn.MultiheadAttention in temporal_attention.py:27-31); it is exported so that it can be checked alone.
+ * The same contraction for row-major A, computed on the 16-bit matrix cores by splitting every fp32 operand into pieces
+ * with exact residuals and accumulating the piece products in fp32: fp32-level accuracy (error <= ~2^-22 sum_k |a||b|,
+ * the bound of an fp32 accumulation).  Default: TWO fp16 pieces of the operand times a per-row power of two, x 2^s = h + l,
+ * three v_mfma_f32_16x16x32_f16 per block (weight rows scaled from their maximum, activation rows from a running maximum with
+ * exact accumulator rescaling; elements below 2^-18 of their row's maximum keep an absolute error <= 2^-40 of that maximum).
+ * With PFO_BX_FMT=0 in the environment: THREE bf16 pieces, x = x1 + x2 + x3, six v_mfma_f32_16x16x32_bf16 per block (the
+ * symbol's name).  This is the kernel the large launches of pfo_tgn_forward / pfo_tgn_backward use for torch.nn.Linear
+ * (utils.py:7-17, torch.nn.MultiheadAttention in temporal_attention.py:27-31); it is exported so that it can be checked alone.
  *   workspace: pfo_gemm_bf16x3_workspace_bytes(N, K) bytes, 16-byte aligned (receives the split image of B).
  *   A 16-byte aligned, lda % 4 == 0, K % 4 == 0.
  */
