@@ -109,7 +109,7 @@ int pfo_gemm_f32(const float* A, int64_t lda, int32_t a_kmajor, const float* B, 
  * with exact residuals and accumulating the piece products in fp32: fp32-level accuracy (error <= ~2^-22 sum_k |a||b|,
  * the bound of an fp32 accumulation).  Default: TWO fp16 pieces of the operand times a per-row power of two, x 2^s = h + l,
  * three v_mfma_f32_16x16x32_f16 per block (weight rows scaled from their maximum, activation rows from a running maximum with
- * exact accumulator rescaling; elements below 2^-18 of their row's maximum keep an absolute error <= 2^-40 of that maximum).
+ * exact accumulator rescaling; elements below 2^-16 of their row's maximum keep an absolute error <= 2^-38 of that maximum).
  * With PFO_BX_FMT=0 in the environment: THREE bf16 pieces, x = x1 + x2 + x3, six v_mfma_f32_16x16x32_bf16 per block (the
  * symbol's name).  This is the kernel the large launches of pfo_tgn_forward / pfo_tgn_backward use for torch.nn.Linear
  * (utils.py:7-17, torch.nn.MultiheadAttention in temporal_attention.py:27-31); it is exported so that it can be checked alone.

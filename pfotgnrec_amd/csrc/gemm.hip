@@ -442,7 +442,8 @@ __device__ __forceinline__ void bx_split_store(char* base, int piece_bytes, int 
 // v_mfma_f32_16x16x32_f16 (h.l + l.h + h.h) instead of the six bf16 products: half the matrix-pipe work and two thirds of the
 // staging traffic at the same accuracy on the fp64 test (tests/test_gpu_kernels.py).  fp16 has 5 exponent bits, so the power of
 // two is chosen per ROW of each operand, from the row's largest magnitude, so that the largest scaled value lies in
-// [2^14, 2^15): elements down to 2^-18 of their row's maximum keep all 22 bits, smaller ones an absolute error of 2^-40 of the
+// [2^12, 2^15) (weight rows at the top, activation rows with HX_GROW binades of headroom): elements down to 2^-16 of their
+// row's maximum keep all 22 bits, smaller ones an absolute error of 2^-38 of the
 // row maximum - far below the rounding of an fp32 accumulation, but a NORM-wise bound where bf16x3 (fp32's own exponent range)
 // gives a component-wise one.  Weight images carry the exponent of each image row behind the tiles (bimg_h_kernel); activation
 // rows are scaled by the consuming kernel from a RUNNING maximum over the k-tiles it has seen: when a later tile holds a larger
@@ -454,7 +455,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define HX_EMIN 1             // clamp of the biased exponent of a row maximum: rows of zeros and denormals scale like 2^-126
 #define HX_EMAX 254
-#define HX_TOP 141            // scaled maximum in [2^14, 2^15): scale exponent = HX_TOP - E
+#define HX_TOP 141            // a row whose exponent is E is scaled by 2^(HX_TOP - E): maximum in [2^14, 2^15)
+#define HX_GROW 2             // binades of headroom a row takes when its running maximum outgrows its scale (see bx_split_rows)
 template <int FMT> struct BxFmt;
 template <> struct BxFmt<0> { static constexpr int NP = 3; };
 template <> struct BxFmt<1> { static constexpr int NP = 2; };
@@ -517,7 +519,8 @@ __device__ __forceinline__ f32x4 hx_scale4(const f32x4 a, const int4 e, int base
 // The A fragments of one k-tile from the raw rows a lane holds ([strip][half]: 8 consecutive k of one row per strip).  FMT 1
 // keeps the running row scale (rowE) and moves the row's accumulators when a larger value arrives.
 template <int FMT, int NJ>
-__device__ __forceinline__ void bx_split_rows(const float4 (&a_raw)[2][2], u32x4 (&a)[2][BxFmt<FMT>::NP], int (&rowE)[2], f32x4 (&acc)[2][NJ]) {
+__device__ __forceinline__ void bx_split_rows(const float4 (&a_raw)[2][2], u32x4 (&a)[2][BxFmt<FMT>::NP], int (&rowE)[2], f32x4 (&acc)[2][NJ],
+                                              const bool first) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     if constexpr (FMT == 0) {
@@ -530,12 +533,17 @@ __device__ __forceinline__ void bx_split_rows(const float4 (&a_raw)[2][2], u32x4
       // the row's maximum over this k-tile: 8 values here, the other 24 in the lanes 16 / 32 / 48 further on
       const int e = hx_exp_of_bits(hx_max_over_g(__float_as_uint(hx_absmax8(a_raw[i][0], a_raw[i][1]))));
       if (e > rowE[i]) {                                     // a larger value than any before: the sums so far move to the new scale
-        const int d = rowE[i] - e;
+        // HX_GROW binades of headroom with every move (a maximum that creeps up does not move the row at every tile); on the
+        // first tile the sums are still zero and nothing has to move
+        const int en = min(e + HX_GROW, HX_EMAX);
+        if (!first) {
+          const int d = rowE[i] - en;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+          for (int j = 0; j < NJ; ++j)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) acc[i][j][c] = __builtin_amdgcn_ldexpf(acc[i][j][c], d);
-        rowE[i] = e;
+            for (int c = 0; c < 4; ++c) acc[i][j][c] = __builtin_amdgcn_ldexpf(acc[i][j][c], d);
+        }
+        rowE[i] = en;
       }
       const int se = HX_TOP - rowE[i];
       uint2 h0, l0, h1, l1;
@@ -857,7 +865,7 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
   };
   u32x4 a[2][NP];
   int rowE[2] = {HX_EMIN, HX_EMIN};    // FMT 1: biased exponent of the running maximum of this lane's two rows
-  auto split_a = [&](auto setc) { bx_split_rows<FMT, 11>(a_raw[decltype(setc)::value], a, rowE, acc); };
+  auto split_a = [&](auto setc, bool first) { bx_split_rows<FMT, 11>(a_raw[decltype(setc)::value], a, rowE, acc, first); };
   const int frag_off = r * 64 + ((g ^ bx_swz(r)) << 4);
   auto compute_tile = [&](int buf) {
     const char* Bs = lds + buf * NP * BX_B_PIECE;
@@ -904,7 +912,7 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
     if (more) {
       // the DMA is ordered only by the issuing wave's vmcnt + the barrier; the four row loads of tile t+2 were issued last
       if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      split_a(std::integral_constant<int, 1 - cur>{});         // this wavefront's own fragments for tile t+1
+      split_a(std::integral_constant<int, 1 - cur>{}, false);  // this wavefront's own fragments for tile t+1
     }
     __syncthreads();
   };
@@ -913,7 +921,7 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
     load_b(0, 0);
     if (T > 1) { load_a(1, C1{}); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    split_a(C0{});
+    split_a(C0{}, true);
     __syncthreads();
     for (int t = 0; t < T; t += 2) {
       step(t, C0{});
@@ -1040,7 +1048,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
   };
   u32x4 a[2][NP];
   int rowE[2] = {HX_EMIN, HX_EMIN};
-  auto split_a = [&]() { bx_split_rows<FMT, GF_NJ>(a_raw, a, rowE, acc); };
+  auto split_a = [&](bool first) { bx_split_rows<FMT, GF_NJ>(a_raw, a, rowE, acc, first); };
   const int frag_off = r * 64 + ((g ^ bx_swz(r)) << 4);
   // tiles that take source SRC: the message part feeds r, z, n_i (tiles 0 1 2 | 4 5 6), the memory part r, z, n_h (0 1 3 | 4 5 7)
   auto compute_tile = [&](int buf, auto src_c) {
@@ -1067,7 +1075,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
   };
   load_global(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  split_a();
+  split_a(true);
   __syncthreads();
   for (int t = 0; t < T; ++t) {
     const bool more = t + 1 < T;
@@ -1090,7 +1098,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
     if (t < T0) compute_tile(t & 1, std::integral_constant<int, 0>{}); else compute_tile(t & 1, std::integral_constant<int, 1>{});
     if (more) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      split_a();
+      split_a(false);
     }
     __syncthreads();
   }
@@ -1239,7 +1247,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const G
       m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
       m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
       m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, false));    // row_half_mirror
-      stE = max(stE, hx_exp_of_bits(m));
+      { const int e = hx_exp_of_bits(m); if (e > stE) stE = min(e + HX_GROW, HX_EMAX); }      // (headroom: see bx_split_rows)
       const int off = a_r * 64 + (((a_c4 >> 1) ^ bx_swz(a_r)) << 4) + ((a_c4 & 1) << 3);
       uint2 oh, ol;
       hx_split4(v, HX_TOP - stE, oh, ol);

@@ -264,9 +264,9 @@ def test_gemm_split_contraction_row_scales(M):
     A = A.astype(np.float32); W = W.astype(np.float32)
     bias = rs.randn(N).astype(np.float32)
     ref = A.astype(np.float64) @ W.astype(np.float64).T
-    # |a_i| . |b_n| with each factor's elements floored at 2^-18 of its row maximum: the bound of a per-row scale
-    fa = np.maximum(np.abs(A).astype(np.float64), np.abs(A).max(1, keepdims=True).astype(np.float64) * 2.0 ** -18)
-    fw = np.maximum(np.abs(W).astype(np.float64), np.abs(W).max(1, keepdims=True).astype(np.float64) * 2.0 ** -18)
+    # |a_i| . |b_n| with each factor's elements floored at 2^-16 of its row maximum: the bound of a per-row scale
+    fa = np.maximum(np.abs(A).astype(np.float64), np.abs(A).max(1, keepdims=True).astype(np.float64) * 2.0 ** -16)
+    fw = np.maximum(np.abs(W).astype(np.float64), np.abs(W).max(1, keepdims=True).astype(np.float64) * 2.0 ** -16)
     mag = fa @ fw.T
     got = _gemm_bf16x3(A, W, bias, 0).astype(np.float64)
     assert np.abs(ref).max() < 1e37 and np.isfinite(got).all()
