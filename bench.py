@@ -13,11 +13,11 @@ dim 172, batch 512, 3 negatives).
 N > 1: one process per GPU over RCCL.  When the ranks are not already there (no WORLD_SIZE in the
 environment, i.e. plain ``python bench.py --gpus N``) this process starts N child ranks itself - before
 touching any GPU - and relays rank 0's line; under ``python -m torch.distributed.run`` it IS a rank.
-Default workload for N > 1 is BASELINE.json configs[3] (C4: 500k users, 10M edges) at a FIXED global batch
-of 4096 interactions cut into N shards (strong scaling, SURVEY 8d/8e: TGN semantics are identical for every
-N), one all-reduce of the flat gradient buffer per step; the line also carries the same workload on ONE
-of those GPUs (``strong_scaling_reference``) and the weak-scaling figure on C2 (512 interactions per GPU).
-``--config`` / ``--scaling`` override.
+Default workload for N > 1 is the SAME headline graph (C2) with 512 interactions per GPU - a global batch of 512 N cut
+into N shards, one all-reduce of the flat gradient buffer per step (weak scaling: value(N) / (N value(1)) is the
+efficiency, on one workload); the line also carries, under ``secondary``, BASELINE.json configs[3] (C4: 500k users,
+10M edges) at a FIXED global batch of 4096 interactions (strong scaling) with the same batch on ONE of
+those GPUs.  ``--config`` / ``--scaling`` override (``--config C4`` makes the strong-scaling case the main line).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   "roofline":     live HIP-event timing of the dominant kernel family over the timed region
@@ -241,7 +241,7 @@ def launcher_selftest(args):
 class Workload:
     """One configuration resident on this rank's GPU: graph, model, optimizer, device-side batch sources."""
 
-    def __init__(self, args, cfg_name, dev, rank, world, scaling):
+    def __init__(self, args, cfg_name, dev, rank, world, scaling, emulate=False):
         import torch
         import pfotgnrec_amd as P
         from pfotgnrec_amd.distributed import broadcast_parameters
@@ -264,8 +264,9 @@ class Workload:
         tgn.set_data_parallel(rank, world)
         tgn.deterministic = bool(args.deterministic)
         tgn.dp_bucketed = world > 1 and args.allreduce == "buckets"
-        self.emulate = False                                  # --emulate-ranks: a rank's compute without the collective
-        broadcast_parameters(tgn.flat_parameters, world)
+        self.emulate = emulate                                # --emulate-ranks: a rank's compute without the collective
+        if not emulate:
+            broadcast_parameters(tgn.flat_parameters, world)
         if cfg.use_memory:
             steady_state_init(tgn, None)
         self.opt = P.FusedAdam(tgn, lr=args.lr)
@@ -488,9 +489,29 @@ def emulate_ranks(args, dev):
     sampler / forward / loss / backward for its B/N interactions, the state update and the lazy GRU rows of ALL B global
     positives, Adam - without the all-reduce.  Strong scaling (the config's batch is fixed), default C4 at 4096."""
     import torch
-    cfg_name = args.config or "C4"
     worlds = [int(x) for x in args.emulate_ranks.split(",")]
     args.graph = "off"
+    if args.scaling == "weak":
+        # the default N-GPU line: the per-GPU batch is fixed, the global batch (and with it the replicated state update and
+        # lazy GRU rows of every rank) grows with N
+        cfg_name = args.config or "C2"
+        rows = []
+        for n in worlds:
+            wl = Workload(args, cfg_name, dev, 0, n, "weak", emulate=True)
+            el, nt, _, _, _ = wl.timed(args.steps, args.warmup, min(args.min_seconds, 1.0), 0, first_step=1000 * n, collective=False)
+            ms = 1e3 * el / nt
+            rows.append({"world": n, "rank": 0, "local_batch": wl.per_gpu, "global_batch": wl.B, "ms_per_step": round(ms, 4),
+                         "interactions_per_s_if_all_ranks_like_this": round(wl.B / (ms * 1e-3), 1),
+                         "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4)})
+            desc = wl.describe()
+            del wl
+            torch.cuda.empty_cache()
+        for r in rows:
+            r["compute_scaling_efficiency_vs_first"] = round(rows[0]["ms_per_step"] / r["ms_per_step"], 4)
+        print(json.dumps({"emulated_ranks": True, "scaling": "weak", "workload": desc, "collective": "none (stubbed)",
+                          "device": torch.cuda.get_device_name(dev), "table": rows}), flush=True)
+        return
+    cfg_name = args.config or "C4"
     wl = Workload(args, cfg_name, dev, 0, 1, "strong")
     wl.emulate = True
     rows = []
@@ -530,7 +551,7 @@ def main():
 
     if args.emulate_ranks:
         return emulate_ranks(args, dev)
-    cfg_name = args.config or ("C2" if world == 1 else "C4")
+    cfg_name = args.config or "C2"       # the headline graph at every N (BASELINE.json: "1M-edge graph at 1/2/4/8 MI355X")
     scaling = args.scaling or ("strong" if (cfg_name == "C4" and world > 1) else "weak")
     wl = Workload(args, cfg_name, dev, rank, world, scaling)
     prof_every = 0 if args.no_prof else max(1, args.prof_every)
@@ -581,6 +602,22 @@ def main():
             sec["weak_scaling_C2"] = {"n_gpus": world, "value": round(n2 * w2.B / el, 1), "ms_per_step": round(1e3 * el / n2, 4),
                                       "workload": w2.describe(), "global_batch": w2.B}
             del w2
+        else:
+            # the SURVEY 8(d) strong-scaling case beside the headline: C4 (10 M edges) at a FIXED global batch of 4096 cut
+            # into N shards, and the same batch on one of these GPUs (rank 0 alone, the others wait)
+            del wl
+            torch.cuda.empty_cache()
+            w4 = Workload(args, "C4", dev, rank, world, "strong")
+            el, n4, _, _, _ = w4.timed(args.steps, args.warmup, min(args.min_seconds, 1.0), 0)
+            sec["strong_scaling_C4"] = {"n_gpus": world, "value": round(n4 * w4.B / el, 1), "ms_per_step": round(1e3 * el / n4, 4),
+                                        "workload": w4.describe(), "global_batch": w4.B}
+            dist.barrier()
+            if rank == 0:
+                w4.set_world(0, 1)
+                el, n1, _, _, _ = w4.timed(args.steps, 2, min(args.min_seconds, 1.0), 0, first_step=100000, collective=False)
+                sec["strong_scaling_C4"]["one_gpu_reference"] = {"value": round(n1 * w4.B / el, 1), "ms_per_step": round(1e3 * el / n1, 4)}
+            dist.barrier()
+            del w4
         out["secondary"] = sec
 
     if rank != 0:
