@@ -272,6 +272,11 @@ typedef struct pfo_tgn_batch {
                                  Costs ~4 % of a C2 step (8-byte atomics); every other sum of the step is ordered already */
   int32_t prepared;         /* != 0: pfo_tgn_prepare already ran for this batch on this workspace (and the caller's stream is
                                  ordered behind it): pfo_tgn_forward skips the frontier sampling, the compaction and the row pack */
+  /* optional: the interactions whose state update (pfo_tgn_update_state's arguments: the GLOBAL batch's src / dst / time /
+     edge index, upd_B of them) pfo_tgn_forward performs ITSELF - on its side stream, behind the lazy GRU, beside layer 1,
+     joined by the event the call's layer 2 waits for anyway: two small launches leave the critical path.  Taken with
+     use_memory and n_layers >= 2; otherwise (upd_src NULL, one layer, no memory) the caller calls pfo_tgn_update_state. */
+  const int32_t* upd_src; const int32_t* upd_dst; const double* upd_ts; const int32_t* upd_eidx; int32_t upd_B;
 } pfo_tgn_batch;
 
 /* The part of pfo_tgn_forward that depends on neither parameters nor gradients - frontier sampling (utils.py:163-219 per level,

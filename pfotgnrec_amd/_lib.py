@@ -40,7 +40,8 @@ class TgnBatch(C.Structure):
     _fields_ = [("roots", _VP), ("root_ts", _VP), ("R", C.c_int32), ("K", C.c_int32), ("uniform", C.c_int32),
                 ("draws", C.POINTER(_VP)), ("seed", C.c_uint64), ("offset", C.c_uint64), ("dropout_p", C.c_float),
                 ("training", C.c_int32), ("extra_nodes", _VP), ("n_extra", C.c_int32), ("offset_dev", _VP),
-                ("deterministic", C.c_int32), ("prepared", C.c_int32)]
+                ("deterministic", C.c_int32), ("prepared", C.c_int32),
+                ("upd_src", _VP), ("upd_dst", _VP), ("upd_ts", _VP), ("upd_eidx", _VP), ("upd_B", C.c_int32)]
 
 
 class TgnDebug(C.Structure):

@@ -278,7 +278,7 @@ PfoGemm g_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const int
 // dependent launches; they run beside the main stream's work and are joined by events where their results are needed.
 struct Side {
   hipStream_t s = nullptr, s2 = nullptr;
-  hipEvent_t tn_a_done = nullptr, done2 = nullptr;
+  hipEvent_t tn_a_done = nullptr, done2 = nullptr, gru_done = nullptr;
   hipEvent_t fork = nullptr, done = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr, fold_done = nullptr;
   hipEvent_t layer[PFO_MAX_LAYERS + 1] = {};
   bool ok = false;
@@ -300,6 +300,7 @@ Side& side() {
     good = good && hipEventCreateWithFlags(&sd.tn_a, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.tn_b, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.fold_done, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.gru_done, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; l <= PFO_MAX_LAYERS; ++l) good = good && hipEventCreateWithFlags(&sd.layer[l], hipEventDisableTiming) == hipSuccess;
     sd.ok = good;
   }
@@ -370,6 +371,21 @@ static int level_sizes(const pfo_tgn_config* c, const pfo_tgn_batch* b, int64_t*
   n[c->n_layers] = b->R;
   for (int l = c->n_layers; l >= 1; --l) n[l - 1] = n[l] * (1 + (int64_t)b->K);
   PFO_REQUIRE(n[0] < (int64_t)1 << 31, "too many level-0 references");
+  return PFO_OK;
+}
+
+// persist the lazily updated memory of the batch's positives + store their raw messages (tgn.py:290-317, 357-378)
+static int state_update(const pfo_tgn_config* c, const pfo_tgn_state* st, const Ws& w, const int32_t* src, const int32_t* dst,
+                        const double* ts, const int32_t* eidx, int32_t B, hipStream_t s) {
+  pfo_tgn_layout lay;
+  RUN(pfo_tgn_param_layout(c, &lay));
+  const float* tw = st->params + lay.time_w;
+  const float* tb = st->params + lay.time_b;
+  // (the last-message-wins test needs the per-node table only for very large batches: memory.hip MSG_INLINE_MAX)
+  int32_t* winner = pfo_msg_store_needs_winner(B) ? w.winner : nullptr;
+  RUN(pfo_persist_launch(src, dst, B, w.slot, w.upd_mem, st->has_msg, st->msg_time, st->memory, st->last_update, c->D, winner, s));
+  RUN(pfo_msg_store_launch(src, dst, ts, eidx, B, st->memory, st->last_update, st->edge_feat, tw, tb, c->D, c->Ef,
+                           st->msg_table, st->msg_time, st->has_msg, winner, s));
   return PFO_OK;
 }
 
@@ -474,6 +490,8 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
   if (!b->prepared) RUN(prepare_sample(c, st, b, w, n, s));
+  const bool fused_state = b->upd_src != nullptr && c->use_memory && L >= 2;
+  PFO_REQUIRE(!fused_state || (b->upd_dst && b->upd_ts && b->upd_eidx && b->upd_B >= 1), "bad state-update arguments");
 
   if (c->use_memory) {
     // the GRU contractions come first on the main stream: their two weight images are made there too (one 4 us launch)
@@ -497,6 +515,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     f.b_ih = P.b_ih; f.b_hh = P.b_hh; f.hm = w.hm; f.touched = w.touched; f.node_feat = st->node_feat;
     f.upd_mem = w.upd_mem; f.h0_tab = w.h0_tab; f.gates = w.gates; f.D = D; f.cap_rows = capP; f.n_rows = w.n_touched;
     RUN(pfo_gru_fused_launch(f, s));
+    if (fused_state) HIPOK(hipEventRecord(sd.gru_done, s), "event record failed");
   }
   // ---- composite weights of every layer and their bf16x3 images: side stream.  Enqueued HERE, after the sampling / compaction /
   // GRU launches of the caller's stream (which need none of it): when the host is the slower side (small batches, profilers)
@@ -601,6 +620,12 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
       }
       for (int i = 0; i < m2; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(f2 + i, std::min(PFO_GEMM_MULTI_MAX, m2 - i), ss));
       for (int i = 0; i < mi; i += PFO_BIMG_MAX) RUN(pfo_bimg_launch(fim + i, std::min(PFO_BIMG_MAX, mi - i), ss));
+      if (fused_state) {
+        // the batch's state update, here: behind the lazy GRU (whose rows it persists), beside layer 1, in front of the event
+        // layer 2 waits for - persist + message store leave the critical path and are joined at no extra wait
+        HIPOK(hipStreamWaitEvent(ss, sd.gru_done, 0), "event wait failed");
+        RUN(state_update(c, st, w, b->upd_src, b->upd_dst, b->upd_ts, b->upd_eidx, b->upd_B, ss));
+      }
       HIPOK(hipEventRecord(sd.fold_done, ss), "event record failed");
     }
   }
@@ -1126,15 +1151,5 @@ extern "C" int pfo_tgn_update_state(const pfo_tgn_config* c, const pfo_tgn_state
   if (!c->use_memory) return PFO_OK;
   PFO_REQUIRE(st && workspace && src && dst && ts && eidx && B >= 1, "bad arguments");
   const Ws w = carve(c, workspace);
-  hipStream_t s = (hipStream_t)stream;
-  pfo_tgn_layout lay;
-  RUN(pfo_tgn_param_layout(c, &lay));
-  const float* tw = st->params + lay.time_w;
-  const float* tb = st->params + lay.time_b;
-  // (the last-message-wins test needs the per-node table only for very large batches: memory.hip MSG_INLINE_MAX)
-  int32_t* winner = pfo_msg_store_needs_winner(B) ? w.winner : nullptr;
-  RUN(pfo_persist_launch(src, dst, B, w.slot, w.upd_mem, st->has_msg, st->msg_time, st->memory, st->last_update, c->D, winner, s));
-  RUN(pfo_msg_store_launch(src, dst, ts, eidx, B, st->memory, st->last_update, st->edge_feat, tw, tb, c->D, c->Ef,
-                           st->msg_table, st->msg_time, st->has_msg, winner, s));
-  return PFO_OK;
+  return state_update(c, st, w, src, dst, ts, eidx, B, (hipStream_t)stream);
 }

@@ -13,6 +13,7 @@ Supported (what the training path of main.py:106-121 selects): ``embedding_modul
 Other enum values raise ``ValueError`` like the reference's factories do for unknown names.
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -132,6 +133,7 @@ class TGN(nn.Module):
         self.dp_grad_scale = 1.0
         self._ws_pool = []        # free workspaces: [(caps, tensor)]
         self._prefetched, self._pre_stream, self._pre_main = None, None, None
+        self.fuse_state_update = os.environ.get("PFO_FUSE_STATE", "1") != "0"      # training calls: persist + message store inside the native forward, on its side stream
         self._ws_caps = (0, 0, 0)
         self._last_ws = None      # (config, workspace) of the newest forward (debug_touched)
         self._step = 0
@@ -608,6 +610,7 @@ class TGN(nn.Module):
         post = None
         if self.use_memory:
             post = lambda call: self._native_update_state(call, src, dst, edge_times, edge_idxs)
+        fuse_state = self.use_memory and self.n_layers >= 2 and b > 0 and grad_mode and self.fuse_state_update
         if b == 0:
             call = self._make_call(roots, root_ts, K, None, 0.0, extra, B)
             self._native_forward(call)
@@ -626,6 +629,14 @@ class TGN(nn.Module):
                 torch.cuda.current_stream().wait_event(call.ready)    # the frontier, the compaction and the packed rows exist
             else:
                 call = self._make_call(roots, root_ts, K, draws, dropout_p, extra, B, offset_dev)
+            if fuse_state:
+                # the native forward performs the state update itself (pfo_tgn_batch.upd_*): on its side stream, beside layer 1
+                bs = call.batch_struct
+                bs.upd_src, bs.upd_dst, bs.upd_ts, bs.upd_eidx, bs.upd_B = (src.data_ptr(), dst.data_ptr(), edge_times.data_ptr(),
+                                                                           edge_idxs.data_ptr(), B)
+                call.keep = (getattr(call, "keep", None), src, dst, edge_times, edge_idxs)
+                self.memory._any_msg = True
+                post = None
             emb = _EmbedFn.apply(self, call, post, *self.hot_parameters())
             return emb, b
         # forward only (evaluation.py:94: R = B*(2+N_ITEMS) roots): walk the roots in chunks through the same
