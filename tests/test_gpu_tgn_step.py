@@ -146,8 +146,15 @@ def test_step_against_reference_golden(tag):
                                                       (24, 4, 3, 3, True, False), (36, 2, 2, 4, True, False),
                                                       (52, 1, 1, 7, False, False),
                                                       (256, 4, 1, 12, True, False),      # widest rows the kernels take (NR = 4)
-                                                      (128, 2, 2, 20, True, False)])     # K = 20 through the run-merged backward
+                                                      (128, 2, 2, 20, True, False),      # K = 20 through the run-merged backward
+                                                      (172, 2, 2, 8, True, "scaled")])   # weight blocks binades apart (below)
 def test_step_against_oracle(D, H, L, K, use_mem, uniform):
+    # "scaled": most-recent sampling, with the weight blocks that meet in ONE contraction moved 2^9-2^10 apart (W_ih against
+    # W_hh in the fused GRU, fc1's attention half against its node half and the query weights against them in the two-source
+    # launches): the per-row power-of-two scales of the fp16 weight images then differ by ~10 binades between the sources of a
+    # launch, and the accumulators are moved from one image's scales to the other's in mid-contraction
+    scaled = uniform == "scaled"
+    uniform = bool(uniform) and not scaled
     torch.manual_seed(1234 + D + H)
     cfg = SyntheticConfig("t", 300, 25, 5000, D, L, K, H)
     g = make_graph(cfg, with_prices=False)
@@ -160,6 +167,15 @@ def test_step_against_oracle(D, H, L, K, use_mem, uniform):
         for att in tgn.embedding_module.attention_models:
             att.multi_head_target.in_proj_bias.normal_(0, 0.1)
             att.multi_head_target.out_proj.bias.normal_(0, 0.1)
+        if scaled:
+            gru = tgn.memory_updater.memory_updater
+            gru.weight_ih.mul_(2.0 ** 3); gru.weight_hh.mul_(2.0 ** -6)
+            for att in tgn.embedding_module.attention_models:
+                E_ = att.multi_head_target.out_proj.weight.shape[0]
+                att.merger.fc1.weight[:, :E_].mul_(2.0 ** 2)
+                att.merger.fc1.weight[:, E_:].mul_(2.0 ** -8)
+                att.merger.fc2.weight.mul_(2.0 ** -4)                 # (keeps the scores of the loss in range)
+                att.multi_head_target.q_proj_weight.mul_(2.0 ** 2)
     opt = P.FusedAdam(tgn, lr=1e-3)
     onf = OracleNeighborFinder(*build_adjacency(d.sources, d.destinations, d.edge_idxs, d.timestamps), uniform=uniform)
     names = [k for k in tgn.state_dict() if "layer_norm" not in k and not k.startswith("memory.")]
