@@ -320,10 +320,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
       dsb[h] = dc[h * Cp + C];          // d loss / d (Σ_j a'_jh): the gradient of the context's extra column
     }
     // delta_h = sum_j a_jh * da_jh = dctx_h . ctx_h + d(Σa')_h * (Σa')_h; interleaved butterflies
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-      for (int h = 0; h < H; ++h) t[h] += __shfl_xor(t[h], o, 64);
+    pfo_wave_sum_scalar_n<H>(t);
 #pragma unroll
     for (int h = 0; h < H; ++h) t[h] = fmaf(dsb[h], cx[h * Cp + C], t[h]);
 

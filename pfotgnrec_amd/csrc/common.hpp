@@ -128,8 +128,43 @@ __device__ __forceinline__ float pfo_wave_sum_scalar(float v) {
 }
 // N independent wave-wide sums with their DPP stages interleaved: a dependent DPP chain needs wait states between its
 // steps (the compiler pads them with s_nop); stage by stage over N values there is always an independent instruction
+// Halving form for N = 4 and N = 2 (gfx950 lane swaps): v_permlane32_swap exchanges the upper half of one register with the
+// lower half of another, so ONE swap + ONE add folds TWO values across lanes i / i + 32, each surviving in one half of the
+// wavefront; v_permlane16_swap does the same across rows of 16 - after two such steps every row holds the partials of one
+// sum, and four row-local DPP steps finish all four sums at once: 3 swaps + 7 adds instead of 24 DPP adds.
+__device__ __forceinline__ float pfo_swap_add32(float a, float b) {       // lanes 0-31: a[i] + a[i + 32], lanes 32-63: b[i - 32] + b[i]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float pfo_swap_add16(float a, float b) {       // rows 0, 2: a's row pair sums, rows 1, 3: b's
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float pfo_row_sum(float v) {                    // every lane: the sum over its row of 16
+  v = pfo_dpp_add<0xB1, 0xF>(v);
+  v = pfo_dpp_add<0x4E, 0xF>(v);
+  v = pfo_dpp_add<0x124, 0xF>(v);
+  return pfo_dpp_add<0x128, 0xF>(v);
+}
 template <int N>
 __device__ __forceinline__ void pfo_wave_sum_scalar_n(float (&v)[N]) {
+  if constexpr (N == 4) {
+    // after the two steps: row 0 holds sum 0, row 1 sum 2, row 2 sum 1, row 3 sum 3 (partials over 16 lanes each)
+    const float x = pfo_row_sum(pfo_swap_add16(pfo_swap_add32(v[0], v[1]), pfo_swap_add32(v[2], v[3])));
+    v[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
+    v[2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+    v[1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
+    v[3] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+    return;
+  }
+  if constexpr (N == 2) {
+    // rows 0-1: sum 0, rows 2-3: sum 1; the row pairs are folded by a second swap of the register with itself
+    const float y = pfo_swap_add32(v[0], v[1]);
+    const float x = pfo_row_sum(pfo_swap_add16(y, y));
+    v[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
+    v[1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < N; ++i) v[i] = pfo_dpp_add<0xB1, 0xF>(v[i]);
 #pragma unroll
@@ -149,14 +184,25 @@ __device__ __forceinline__ void pfo_wave_sum_scalar_n(float (&v)[N]) {
 // expf()'s full range reduction costs ~10 instructions per call, and the attention kernels make 4-8 calls per key pair.
 __device__ __forceinline__ float pfo_exp_neg(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
+// wave-wide sum / maximum, the result in EVERY lane: two lane swaps fold the halves and the row pairs, four row-local DPP
+// steps the rows - eight vector instructions, no trip through the LDS crossbar (six ds_bpermute round trips before)
+template <int CTRL>
+__device__ __forceinline__ float pfo_dpp_max(float v) {
+  return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false)));
+}
 __device__ __forceinline__ float pfo_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = pfo_swap_add32(v, v);
+  v = pfo_swap_add16(v, v);
+  return pfo_row_sum(v);
 }
 __device__ __forceinline__ float pfo_wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+  v = pfo_dpp_max<0xB1>(v);
+  v = pfo_dpp_max<0x4E>(v);
+  v = pfo_dpp_max<0x124>(v);
+  return pfo_dpp_max<0x128>(v);
 }
 #endif  // __HIPCC__
