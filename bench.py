@@ -430,7 +430,7 @@ def roofline_of(prof, n_prof_steps, profiled_workload=True):
     """Dominant KERNEL by device time over the sampled steps: a family is all launches of one kernel (the library reads
     the device-side row counts of the touched-table launches back, so every launch carries its work).  Contractions on the
     split kernels are priced against the dense 16-bit MFMA peak divided by the piece products one fp32 product costs (three
-    for the fp16 image kernels, six for the bf16x3 weight-gradient tile);
+    for the two-piece fp16 split, six for bf16x3);
     the fp32-MFMA kernels against the fp32 MFMA peak; the attention / sampling kernels against HBM."""
     fam = {k: v for k, v in prof.items() if v["count"] > 0}
     if not fam:
@@ -476,12 +476,12 @@ BX_FAMILIES = ("gemm_bx", "gemm_tn_bx", "gemm_bx_skinny")
 
 def bx_products(family):
     """MFMA instructions per fp32 product block of a split-contraction family (0: not one).  The image kernels take the
-    two-piece fp16 format (3 products) unless PFO_BX_FMT=0 keeps them on bf16x3; the weight-gradient tile is bf16x3 (6)."""
+    two-piece fp16 format (3 products) unless PFO_BX_FMT=0 keeps them on bf16x3; the weight-gradient tile likewise (PFO_TN_FMT)."""
     if family not in BX_FAMILIES:
         return 0
-    if family == "gemm_tn_bx" or os.environ.get("PFO_BX_FMT", "1") == "0":
-        return 6
-    return 3
+    if family == "gemm_tn_bx":
+        return 6 if os.environ.get("PFO_TN_FMT", "1") == "0" else 3
+    return 6 if os.environ.get("PFO_BX_FMT", "1") == "0" else 3
 
 
 def emulate_ranks(args, dev):

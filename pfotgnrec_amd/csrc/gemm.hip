@@ -462,6 +462,7 @@ template <> struct BxFmt<0> { static constexpr int NP = 3; };
 template <> struct BxFmt<1> { static constexpr int NP = 2; };
 // process-wide choice of the format of every pre-split image and of the kernels that read them (A/B switch: PFO_BX_FMT=0)
 #define PFO_DEFAULT_BX_FMT 1
+#define PFO_DEFAULT_TN_FMT 1     // the weight-gradient tile: 1 = two fp16 pieces with one scale per operand and K-slab, 0 = bf16x3
 #ifndef BX_AREG_OCC
 #define BX_AREG_OCC 2
 #endif
@@ -1408,9 +1409,30 @@ __device__ __forceinline__ bf16x8 tx_read(const char* piece, int row_bytes, int 
 }
 
 // one 128 x 176 tile of a split-K weight gradient into its slab (the grouped launch below); VEC operands only
+// FMT 1 (two fp16 pieces, three products): the contraction runs over the instance rows, so a per-row scale cannot be factored
+// out; each OPERAND of the workgroup's K-slab takes ONE power-of-two scale instead - a running maximum over the k-tiles seen so
+// far, with HX_GROW binades of headroom when it moves.  The maxima of the tile being staged are found while it waits in
+// registers (per-wavefront maxima through eight LDS words, in front of the barrier that already separates the MFMAs of tile t
+// from the staging of tile t+1); every thread derives the same two exponents from them, so the state lives in registers, the
+// conversion takes a wave-uniform exponent, and when a scale moves the accumulators are multiplied by one exact power of two.
+// Elements below 2^-16 of the slab's largest magnitude keep an absolute error of 2^-38 of it: norm-wise bound, as for the
+// image kernels, now per slab and operand rather than per row.
+__device__ __forceinline__ uint32_t tx_wave_max_u32(uint32_t u) {
+  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  u = max(a[0], a[1]);
+  const auto b = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = max(b[0], b[1]);
+  u = max(u, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xF, 0xF, false));
+  u = max(u, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x4E, 0xF, 0xF, false));
+  u = max(u, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x124, 0xF, 0xF, false));
+  return max(u, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x128, 0xF, 0xF, false));
+}
+template <int FMT>
 __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by, int split, char* lds) {
+  constexpr int NP = BxFmt<FMT>::NP;
   char* const As = lds;
-  char* const Bs = lds + 3 * TX_A_PIECE;
+  char* const Bs = lds + NP * TX_A_PIECE;
+  uint32_t* const wmax = reinterpret_cast<uint32_t*>(lds + NP * TX_A_PIECE + NP * TX_B_PIECE);     // [4 wavefronts: A | 4: B]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -1494,41 +1516,72 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
     }
     if (t + 1 < T) fetch_rows(t + 1);
   };
-  auto store_tile = [&]() {
+  int eA = HX_EMIN, eB = HX_EMIN;           // FMT 1: exponents of the two operands' scales (the same in every thread)
+  // maxima of the tile in the staging registers -> one word per wavefront and operand (called in front of a barrier)
+  auto publish_max = [&]() {
+    float ma = 0.f, mb = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tx_split_store(As, TX_A_PIECE, a_off[i], a_reg[i]);
+    for (int i = 0; i < 4; ++i) ma = fmaxf(fmaxf(ma, fmaxf(fabsf(a_reg[i].x), fabsf(a_reg[i].y))), fmaxf(fabsf(a_reg[i].z), fabsf(a_reg[i].w)));
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-      if (b_live[i]) tx_split_store(Bs, TX_B_PIECE, b_off[i], b_reg[i]);
+    for (int i = 0; i < 6; ++i) mb = fmaxf(fmaxf(mb, fmaxf(fabsf(b_reg[i].x), fabsf(b_reg[i].y))), fmaxf(fabsf(b_reg[i].z), fabsf(b_reg[i].w)));
+    const uint32_t ua = tx_wave_max_u32(__float_as_uint(ma)), ub = tx_wave_max_u32(__float_as_uint(mb));
+    if (lane == 0) { wmax[wave] = ua; wmax[4 + wave] = ub; }
+  };
+  auto hstore = [&](char* base, int piece_bytes, int off, const float4 v, const int se) {
+    uint2 oh, ol;
+    hx_split4(v, se, oh, ol);
+    *reinterpret_cast<uint2*>(base + off) = oh;
+    *reinterpret_cast<uint2*>(base + piece_bytes + off) = ol;
+  };
+  auto store_tile = [&](bool first) {
+    if constexpr (FMT == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tx_split_store(As, TX_A_PIECE, a_off[i], a_reg[i]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        if (b_live[i]) tx_split_store(Bs, TX_B_PIECE, b_off[i], b_reg[i]);
+    } else {
+      const uint4 wa = *reinterpret_cast<const uint4*>(wmax), wb = *reinterpret_cast<const uint4*>(wmax + 4);
+      const int ta = hx_exp_of_bits(max(max(wa.x, wa.y), max(wa.z, wa.w))), tb = hx_exp_of_bits(max(max(wb.x, wb.y), max(wb.z, wb.w)));
+      const int nA = ta > eA ? min(ta + HX_GROW, HX_EMAX) : eA, nB = tb > eB ? min(tb + HX_GROW, HX_EMAX) : eB;
+      if (nA != eA || nB != eB) {                              // a scale moves (the same decision in every thread): the sums follow
+        if (!first) {
+          const int d = (eA - nA) + (eB - nB);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 11; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[i][j][q] = __builtin_amdgcn_ldexpf(acc[i][j][q], d);
+        }
+        eA = nA; eB = nB;
+      }
+      const int sa = HX_TOP - eA, sb = HX_TOP - eB;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hstore(As, TX_A_PIECE, a_off[i], a_reg[i], sa);
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        if (b_live[i]) hstore(Bs, TX_B_PIECE, b_off[i], b_reg[i], sb);
+    }
   };
   const int strips = __builtin_amdgcn_readfirstlane((m0 + wrow + 16 < p.M) ? 2 : ((m0 + wrow < p.M) ? 1 : 0));
   auto compute_tile = [&]() {
-    bf16x8 a[2][3];
+    u32x4 a[2][NP];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) a[i][q] = tx_read(As + q * TX_A_PIECE, TX_A_ROW, 7, 2 * wave + i, g, r);
-    auto ldb = [&](bf16x8 (&b)[3], int j) {
+      for (int q = 0; q < NP; ++q) a[i][q] = __builtin_bit_cast(u32x4, tx_read(As + q * TX_A_PIECE, TX_A_ROW, 7, 2 * wave + i, g, r));
+    auto ldb = [&](u32x4 (&b)[NP], int j) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) b[q] = tx_read(Bs + q * TX_B_PIECE, TX_B_ROW, 15, j, g, r);
-    };
-    auto mma1 = [&](const bf16x8 (&b)[3], int i, int j) {
-      f32x4 c = acc[i][j];
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[2], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[0], c, 0, 0, 0);
-      acc[i][j] = c;
+      for (int q = 0; q < NP; ++q) b[q] = __builtin_bit_cast(u32x4, tx_read(Bs + q * TX_B_PIECE, TX_B_ROW, 15, j, g, r));
     };
     // a wavefront whose strips lie beyond M skips their MFMAs (172-row gradients): `strips` is wave-uniform (an SGPR
     // after readfirstlane), so these are scalar branches, not exec-mask sequences
-    auto mma = [&](const bf16x8 (&b)[3], int j) {
-      if (strips >= 1) mma1(b, 0, j);
-      if (strips >= 2) mma1(b, 1, j);
+    auto mma = [&](const u32x4 (&b)[NP], int j) {
+      if (strips >= 1) acc[0][j] = bx_mma<FMT>(a[0], b, acc[0][j]);
+      if (strips >= 2) acc[1][j] = bx_mma<FMT>(a[1], b, acc[1][j]);
     };
-    bf16x8 b0[3], b1[3];                      // double-buffered B fragments (see gemm_bf16x3_kernel)
+    u32x4 b0[NP], b1[NP];                     // double-buffered B fragments (see gemm_bf16x3_kernel)
     ldb(b0, 0);
 #pragma unroll
     for (int j = 0; j < 11; j += 2) {
@@ -1540,14 +1593,16 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
   };
   if (T > 0) {
     load_tile(0);
-    store_tile();
+    if constexpr (FMT == 1) { publish_max(); __syncthreads(); }
+    store_tile(true);
     __syncthreads();
     for (int t = 0; t < T; ++t) {
       const bool more = (BX_EXP == 1) ? false : (t + 1 < T);
       if (more) load_tile(t + 1);
       if (BX_EXP != 2) compute_tile();
+      if constexpr (FMT == 1) { if (more) publish_max(); }
       __syncthreads();
-      if (more && BX_EXP != 3) store_tile();
+      if (more && BX_EXP != 3) store_tile(false);
       __syncthreads();
     }
   }
@@ -1561,7 +1616,7 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
 #pragma unroll
       for (int j = 0; j < 11; ++j) {
         const int col = n0 + 16 * j + r;
-        if (col < p.N) Cb[(int64_t)row * p.N + col] = acc[i][j][reg];
+        if (col < p.N) Cb[(int64_t)row * p.N + col] = FMT == 1 ? __builtin_amdgcn_ldexpf(acc[i][j][reg], eA + eB - 2 * HX_TOP) : acc[i][j][reg];
       }
     }
 }
@@ -1886,8 +1941,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_group_kernel(const TnGro
 }
 
 // the same grouped launch on the bf16 matrix cores (3-way split, transposed LDS reads)
+template <int FMT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_group_bx_kernel(const TnGroupDev g) {
-  __shared__ __attribute__((aligned(16))) char lds[TX_LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) char lds[BxFmt<FMT>::NP * (TX_A_PIECE + TX_B_PIECE) + 32];
   int q = 0;
 #pragma unroll
   for (int i = 1; i < TN_MAX_PROBLEMS; ++i)
@@ -1902,7 +1958,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_group_bx_kernel(const
   d.slab_base = g.slabs + pr.slab_off;
   d.nsplit = g.nsplit;
   d.dyn_chunk = (g.k_dev != nullptr && g.nsplit > 1) ? 1 : 0;
-  gemm_tile_tn_bx(d, t / pr.tn, t % pr.tn, blockIdx.y, lds);
+  gemm_tile_tn_bx<FMT>(d, t / pr.tn, t % pr.tn, blockIdx.y, lds);
 }
 __global__ __launch_bounds__(256) void tn_group_reduce_kernel(const TnGroupDev g) {
   int K = g.K;
@@ -1975,10 +2031,9 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
   static const int bx = getenv("PFO_GEMM_BF16X3") ? atoi(getenv("PFO_GEMM_BF16X3")) : PFO_DEFAULT_BF16X3;
   const bool use_bx = vec && bx >= 1;
   pfo_prof_begin(stream);
-  // (the weight-gradient tile stays bf16x3: its scales would belong to the COLUMNS of both operands - running maxima in LDS,
-  //  raised before the barrier between the MFMAs and the staging - and that version measured 2 % slower per step: the tile is
-  //  bound by its two-barrier staging, not by the matrix pipe.  profiles/r3_gemm_areg_experiments.txt)
-  if (use_bx) hipLaunchKernelGGL(gemm_tn_group_bx_kernel, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
+  static const int tn_fmt = getenv("PFO_TN_FMT") ? atoi(getenv("PFO_TN_FMT")) : PFO_DEFAULT_TN_FMT;      // A/B switch
+  if (use_bx && tn_fmt) hipLaunchKernelGGL(gemm_tn_group_bx_kernel<1>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
+  else if (use_bx) hipLaunchKernelGGL(gemm_tn_group_bx_kernel<0>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   else if (vec) hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   else hipLaunchKernelGGL(gemm_tn_group_kernel<false>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   PFO_LAUNCH_CHECK();

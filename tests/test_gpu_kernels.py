@@ -289,6 +289,28 @@ def test_gemm_weight_gradient_form(M, N, K):
     assert np.array_equal(got, _gemm(A, B, None, 1, 1))                       # bitwise reproducible
 
 
+@pytest.mark.parametrize("grow", [True, False])
+def test_gemm_weight_gradient_form_operand_scales(grow):
+    """The weight-gradient tile's fp16 split keeps ONE power-of-two scale per operand and K-slab, a running maximum over the
+    k-tiles: rows whose magnitude grows by 2^24 along k make the scale move (the accumulators are multiplied by the power of
+    two in between) tile after tile; shrinking rows leave it where the first tile put it.  Columns a few binades apart, a
+    block of zero rows.  Norm-wise bound against fp64, and bitwise reproducible."""
+    rs = np.random.RandomState(7)
+    M, N, K = 344, 348, 4096
+    ramp = 2.0 ** np.linspace(-12, 12, K)
+    if not grow:
+        ramp = ramp[::-1]
+    A = rs.randn(K, M) * ramp[:, None] * 2.0 ** rs.randint(-3, 4, size=(1, M))
+    B = rs.randn(K, N) * ramp[::-1][:, None] * 2.0 ** rs.randint(-3, 4, size=(1, N))
+    A[1000:1100] = 0
+    A = A.astype(np.float32); B = B.astype(np.float32)
+    ref = A.astype(np.float64).T @ B.astype(np.float64)
+    mag = np.abs(A).astype(np.float64).T @ np.abs(B).astype(np.float64)
+    got = _gemm(A, B, None, 1, 1)
+    assert np.abs(got - ref).max() < 4e-6 * mag.max()
+    assert np.array_equal(got, _gemm(A, B, None, 1, 1))
+
+
 # ------------------------------------------------------------------ BPR + Adam
 def test_bpr_loss_and_gradient_vs_oracle():
     rs = np.random.RandomState(3)
