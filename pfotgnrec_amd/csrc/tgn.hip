@@ -833,10 +833,11 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     ++ntn;
     const int n_tn_a = ntn;
     // The weight gradients over the INSTANCES (dW2 / db2 at the top, dW1ovT) need only d out, h1, ctx' and dh1: they go to the side
-    // stream as soon as dh1 exists, beside the d ctx' contraction and the attention backward (measured: 15 us/step better than
-    // forking them next to the attention backward alone, whose single-wavefront workgroups starve a 74 KB-LDS kernel of slots;
-    // r3: issuing them BEHIND the attention backward, beside the serial tail, measured +2 % per step)
-    static const int tna_mode = getenv("PFO_TNA_MODE") ? atoi(getenv("PFO_TNA_MODE")) : 2;   // A/B: 0 fork before the attention backward, 1 main stream
+    // stream.  With the bf16x3 tile they were best started as soon as dh1 existed, beside the d ctx' contraction (15 us/step
+    // better than next to the attention backward alone, whose single-wavefront workgroups starved a 74 KB-LDS kernel of slots);
+    // the fp16 tile (49 KB, half the matrix work) does better behind d ctx', beside the attention backward: 1.4495 against
+    // 1.4532 ms over four interleaved pairs.  (Behind the attention backward, beside the serial tail: +2 % per step.)
+    static const int tna_mode = getenv("PFO_TNA_MODE") ? atoi(getenv("PFO_TNA_MODE")) : 0;   // A/B: 0 fork behind the d ctx' contraction (beside the attention backward), 2 beside d ctx', 1 main stream
     auto tn_a_side = [&]() -> int {
       HIPOK(hipEventRecord(sd.tn_a, s), "event record failed");
       HIPOK(hipStreamWaitEvent(ss, sd.tn_a, 0), "event wait failed");
