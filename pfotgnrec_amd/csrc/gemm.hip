@@ -981,6 +981,7 @@ struct GruFusedDev {
   const uint8_t* hm; const int32_t* touched; const float* node_feat;
   float* upd_mem; float* h0_tab; float* gates;
   int D, M; const int32_t* m_dev;
+  int gather;
 };
 int pfo_gru_img_rows(int D) { return (int)pfo_ceil_div(D, 32) * GF_BN; }
 int64_t pfo_gru_img_bytes(int D, int K) { return (int64_t)pfo_ceil_div(K, 32) * 3 * pfo_gru_img_rows(D) * 64; }
@@ -1016,7 +1017,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
   for (int i = 0; i < 2; ++i) {
     const int gm = m0 + wrow + 16 * i + r;
     a_ok[i] = gm < Mlim;
-    const int64_t ridx = a_ok[i] ? gm : 0;
+    int64_t ridx = a_ok[i] ? gm : 0;
+    if (p.gather) ridx = a_ok[i] ? p.touched[gm] : 0;          // straight from the per-node tables
     a_row[0][i] = p.msg_rows + ridx * p.ld_msg + 8 * g;
     a_row[1][i] = p.h_rows + ridx * p.ld_h + 8 * g;
   }
@@ -1109,8 +1111,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
   for (int i = 0; i < 2; ++i) {
     const int row = m0 + wrow + 16 * i + r;
     if (row >= Mlim) continue;
-    const bool has = p.hm[row] != 0;
     const int64_t id = p.touched[row];
+    const int64_t srow = p.gather ? id : row;                  // row of the state operands (tables or packed copies)
+    const bool has = p.hm[srow] != 0;
     if constexpr (FMT == 1) {                         // back to plain fp32: r, z and n_h carry W_hh's row scales, n_i W_ih's
 #pragma unroll
       for (int j = 0; j < GF_NJ; ++j)
@@ -1120,7 +1123,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
     for (int q = 0; q < 2; ++q) {
       const int u0 = 32 * (int)blockIdx.y + 16 * q + 4 * g;
       if (u0 >= D) continue;                                    // D % 4 == 0: a lane's four units are all inside or all outside
-      const float4 h4 = *reinterpret_cast<const float4*>(p.h_rows + (int64_t)row * p.ld_h + u0);
+      const float4 h4 = *reinterpret_cast<const float4*>(p.h_rows + srow * p.ld_h + u0);
       const float4 nf = *reinterpret_cast<const float4*>(p.node_feat + id * D + u0);
       const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
       float rr[4], zz[4], nn[4], gh[4], hn[4];
@@ -1158,6 +1161,7 @@ int pfo_gru_fused_launch(const PfoGruFused& f, hipStream_t stream) {
   d.img0 = f.img_ih; d.img1 = f.img_hh; d.img_rows = pfo_gru_img_rows(f.D);
   d.b_ih = f.b_ih; d.b_hh = f.b_hh; d.hm = f.hm; d.touched = f.touched; d.node_feat = f.node_feat;
   d.upd_mem = f.upd_mem; d.h0_tab = f.h0_tab; d.gates = f.gates; d.D = f.D; d.M = f.cap_rows; d.m_dev = f.n_rows;
+  d.gather = f.gather;
   pfo_prof_begin(stream);
   const dim3 grid((unsigned)pfo_ceil_div(f.cap_rows, BM), (unsigned)pfo_ceil_div(f.D, 32), 1);
   if (pfo_bx_fmt()) hipLaunchKernelGGL(gru_fused_kernel<1>, grid, dim3(GEMM_THREADS), 0, stream, d);

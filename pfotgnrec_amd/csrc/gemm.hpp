@@ -63,6 +63,9 @@ struct PfoGruFused {
   const uint8_t* hm = nullptr; const int32_t* touched = nullptr; const float* node_feat = nullptr;
   float* upd_mem = nullptr; float* h0_tab = nullptr; float* gates = nullptr;
   int D = 0, cap_rows = 0; const int32_t* n_rows = nullptr;
+  // gather = 1: msg_rows / h_rows / hm are the FULL per-node tables (message table, memory, has_msg) and row m of the launch is
+  // node touched[m] of them - the packed copies the backward needs are then made off the critical path
+  int gather = 0;
 };
 int pfo_gru_fused_launch(const PfoGruFused& f, hipStream_t stream);
 int64_t pfo_bimg_bytes(int N, int K);

@@ -278,7 +278,7 @@ PfoGemm g_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const int
 // dependent launches; they run beside the main stream's work and are joined by events where their results are needed.
 struct Side {
   hipStream_t s = nullptr, s2 = nullptr;
-  hipEvent_t tn_a_done = nullptr, done2 = nullptr, gru_done = nullptr;
+  hipEvent_t tn_a_done = nullptr, done2 = nullptr, gru_done = nullptr, comp_done = nullptr;
   hipEvent_t fork = nullptr, done = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr, fold_done = nullptr;
   hipEvent_t layer[PFO_MAX_LAYERS + 1] = {};
   bool ok = false;
@@ -301,6 +301,7 @@ Side& side() {
     good = good && hipEventCreateWithFlags(&sd.tn_b, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.fold_done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.gru_done, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.comp_done, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; l <= PFO_MAX_LAYERS; ++l) good = good && hipEventCreateWithFlags(&sd.layer[l], hipEventDisableTiming) == hipSuccess;
     sd.ok = good;
   }
@@ -416,17 +417,20 @@ static int prepare_sample(const pfo_tgn_config* c, const pfo_tgn_state* st, cons
 
   return PFO_OK;
 }
-static int prepare_compact_pack(const pfo_tgn_config* c, const pfo_tgn_state* st, const pfo_tgn_batch* b, const Ws& w, const Dims& d,
-                                const int64_t* n, hipStream_t s) {
-  const int D = d.D;
-  // slot[v] = row of v in the per-step tables, idx0[i] = row of the i-th level-0 reference (roots and every sampled neighbour,
-  // all levels; + the caller's extra nodes)
+static int prepare_compact(const pfo_tgn_config* c, const pfo_tgn_batch* b, const Ws& w, hipStream_t s) {
+  // slot[v] = row of v in the per-step tables (roots and every sampled neighbour, all levels; + the caller's extra nodes)
   RUN(pfo_touch_compact_launch(nullptr, 0, b->extra_nodes, b->n_extra, c->n_nodes, w.mark, w.slot, w.touched, w.n_touched,
                                w.scan, true, true, s));
+  return PFO_OK;
+}
+static int prepare_pack(const pfo_tgn_config* c, const pfo_tgn_state* st, const pfo_tgn_batch* b, const Ws& w, const Dims& d,
+                        const int64_t* n, hipStream_t s) {
+  const int D = d.D;
   const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
   // ---- level-0 rows of the touched nodes: memory' + node features (embedding_module.py:93-98), memory' = the lazily
   // updated memory (tgn.py:251; memory_updater.py:35-53).  One launch copies the rows the GRU reads (and the backward reads
-  // again after the state update has overwritten the tables) and translates the level-0 list into table rows.
+  // again after the state update has overwritten the tables) and translates the level-0 list into table rows
+  // (idx0[i] = row of the i-th level-0 reference).
   if (c->use_memory)
     RUN(pfo_pack_remap_launch(st->msg_table, d.M, st->memory, D, st->has_msg, w.touched, w.n_touched, capP, w.msg_rows,
                               w.h_rows, w.hm, w.nodes[0], n[0], w.slot, w.idx0, s));
@@ -434,6 +438,11 @@ static int prepare_compact_pack(const pfo_tgn_config* c, const pfo_tgn_state* st
     RUN(pfo_pack_remap_launch(nullptr, d.M, st->node_feat, D, nullptr, w.touched, w.n_touched, capP, nullptr, w.h0_tab, nullptr,
                               w.nodes[0], n[0], w.slot, w.idx0, s));
   return PFO_OK;
+}
+static int prepare_compact_pack(const pfo_tgn_config* c, const pfo_tgn_state* st, const pfo_tgn_batch* b, const Ws& w, const Dims& d,
+                                const int64_t* n, hipStream_t s) {
+  RUN(prepare_compact(c, b, w, s));
+  return prepare_pack(c, st, b, w, d, n, s);
 }
 
 // =============================================================================================
@@ -506,7 +515,19 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   // ---- the nodes this step reads, compacted, and their level-0 rows packed (prepare_compact_pack; a prepared batch has them)
   PFO_REQUIRE(b->n_extra >= 0 && b->n_extra <= 2 * c->max_batch, "n_extra exceeds 2 * max_batch");
   PFO_REQUIRE(b->n_extra == 0 || b->extra_nodes, "null extra_nodes");
-  if (!b->prepared) RUN(prepare_compact_pack(c, st, b, w, d, n, s));
+  // With memory the row pack leaves the caller's stream: the fused GRU gathers its rows straight from the per-node tables, and
+  // the packed copies (for the backward, which runs after the state update has overwritten the tables) + the level-0 remap
+  // (first used by layer 1's attention) are made on the side stream, in front of the event layer 1 waits for anyway.
+  static const int pack_side_env = getenv("PFO_PACK_SIDE") ? atoi(getenv("PFO_PACK_SIDE")) : 1;      // A/B switch
+  const bool pack_side = pack_side_env && c->use_memory && !b->prepared;
+  if (!b->prepared) {
+    if (pack_side) {
+      RUN(prepare_compact(c, b, w, s));
+      HIPOK(hipEventRecord(sd.comp_done, s), "event record failed");
+    } else {
+      RUN(prepare_compact_pack(c, st, b, w, d, n, s));
+    }
+  }
   const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
   if (c->use_memory) {
     // both GRU contractions and the gate math in ONE launch (gemm.hip gru_fused_kernel): gi / gh never exist in HBM
@@ -514,6 +535,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     f.msg_rows = w.msg_rows; f.K_msg = d.M; f.h_rows = w.h_rows; f.img_ih = w.iWih; f.img_hh = w.iWhh;
     f.b_ih = P.b_ih; f.b_hh = P.b_hh; f.hm = w.hm; f.touched = w.touched; f.node_feat = st->node_feat;
     f.upd_mem = w.upd_mem; f.h0_tab = w.h0_tab; f.gates = w.gates; f.D = D; f.cap_rows = capP; f.n_rows = w.n_touched;
+    if (pack_side) { f.gather = 1; f.msg_rows = st->msg_table; f.h_rows = st->memory; f.hm = st->has_msg; }
     RUN(pfo_gru_fused_launch(f, s));
     if (fused_state) HIPOK(hipEventRecord(sd.gru_done, s), "event record failed");
   }
@@ -565,6 +587,10 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     for (int i = 0; i < n1; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(st1 + i, std::min(PFO_GEMM_MULTI_MAX, n1 - i), ss));
     for (int i = 0; i < n2; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(st2 + i, std::min(PFO_GEMM_MULTI_MAX, n2 - i), ss));
     for (int i = 0; i < ni; i += PFO_BIMG_MAX) RUN(pfo_bimg_launch(im + i, std::min(PFO_BIMG_MAX, ni - i), ss));
+    if (pack_side) {
+      HIPOK(hipStreamWaitEvent(ss, sd.comp_done, 0), "event wait failed");
+      RUN(prepare_pack(c, st, b, w, d, n, ss));
+    }
     HIPOK(hipEventRecord(sd.layer[0], ss), "event record failed");      // layer 1 (and the top layer's fc2) can go
 
     // ---- fc2 fold.  A layer l >= 2 reads rows of the previous layer, out = A h + b (A = W2, b = b2 of layer l-1, h = that
