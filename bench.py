@@ -15,7 +15,7 @@ environment, i.e. plain ``python bench.py --gpus N``) this process starts N chil
 touching any GPU - and relays rank 0's line; under ``python -m torch.distributed.run`` it IS a rank.
 Default workload for N > 1 is the SAME headline graph (C2) with 512 interactions per GPU - a global batch of 512 N cut
 into N shards, one all-reduce of the flat gradient buffer per step (weak scaling: value(N) / (N value(1)) is the
-efficiency, on one workload); the line also carries, under ``secondary``, BASELINE.json configs[3] (C4: 500k users,
+efficiency, on one workload); with ``--secondary`` the line also carries BASELINE.json configs[3] (C4: 500k users,
 10M edges) at a FIXED global batch of 4096 interactions (strong scaling) with the same batch on ONE of
 those GPUs.  ``--config`` / ``--scaling`` override (``--config C4`` makes the strong-scaling case the main line).
 
@@ -53,7 +53,11 @@ def parse():
                     help="N > 1: weak = --batch interactions per GPU, strong = the config's batch cut into N shards "
                          "(default: strong for C4, weak otherwise)")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step timed block until this much time is covered")
-    ap.add_argument("--no-secondary", action="store_true", help="N > 1: skip the single-GPU reference and the weak-scaling C2 figure")
+    ap.add_argument("--no-secondary", action="store_true", help="(kept for old command lines: the secondary figures are off unless --secondary)")
+    ap.add_argument("--secondary", action="store_true",
+                    help="N > 1: also run the other scaling case (C4 at a fixed global batch of 4 096 with its one-GPU reference, or the "
+                         "weak-scaling C2 figure when the main line is C4) - a second 10 M-edge graph per rank; off by default so that "
+                         "nothing can come between the N-GPU run and its line")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a captured HIP graph (one launch per step instead of ~85).  auto (one GPU, per-GPU "
                          "batch <= 256): capture, time ten steps either way during set-up and keep the faster form - the graph "
@@ -581,7 +585,7 @@ def main():
         if roof:
             out["roofline"] = roof
 
-    if world > 1 and not args.no_secondary:
+    if world > 1 and args.secondary and not args.no_secondary:
         # (1) the same workload on ONE of these GPUs (rank 0 alone, the others wait): the denominator of the strong-scaling
         #     figure.  (2) weak scaling on C2, 512 interactions per GPU, what round 1 reported.
         sec = {}
