@@ -58,15 +58,26 @@ def allreduce_flat_grad_buckets(tgn, world, force=False):
     if g is None or (world <= 1 and not force):
         return g
     split = tgn.grad_split
-    if not (tgn.dp_bucketed and tgn._bucket_event_fresh and 0 < split < g.numel()):
-        dist.all_reduce(g, op=dist.ReduceOp.SUM)            # no event this step (empty shard, one layer): one piece
+    # The NUMBER and the SIZES of the collectives must be the same on every rank: the cut is chosen from rank-invariant
+    # state only (the model's layout and the dp_bucketed switch).  A rank whose backward did not run this step (empty
+    # shard: batch shorter than the world) has no fresh event - its zero gradient is final already, so it issues the same
+    # two collectives in the same order and only skips the wait.
+    if not (tgn.dp_bucketed and 0 < split < g.numel()):
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)            # one layer / bucketing off: one piece, on every rank
         return g
-    tgn._bucket_event_fresh = False
+    fresh, tgn._bucket_event_fresh = tgn._bucket_event_fresh, False
+    if g.device.type != "cuda":                             # host tensors (gloo rehearsal of the call pattern): no streams
+        dist.all_reduce(g[split:], op=dist.ReduceOp.SUM)
+        dist.all_reduce(g[:split], op=dist.ReduceOp.SUM)
+        return g
     main = torch.cuda.current_stream(g.device)
     side = _COMM_STREAMS.get(g.device)
     if side is None:
         side = _COMM_STREAMS[g.device] = torch.cuda.Stream(device=g.device)
-    side.wait_event(tgn._bucket_event)
+    if fresh:
+        side.wait_event(tgn._bucket_event)
+    else:
+        side.wait_stream(main)                              # whatever produced (or cleared) the buffer on the caller's stream
     with torch.cuda.stream(side):
         dist.all_reduce(g[split:], op=dist.ReduceOp.SUM)
     dist.all_reduce(g[:split], op=dist.ReduceOp.SUM)

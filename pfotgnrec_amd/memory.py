@@ -87,6 +87,7 @@ class Memory(nn.Module):
         with torch.no_grad():
             self.has_msg[torch.as_tensor(nodes, device=self.has_msg.device, dtype=torch.long)] = 0
         self._any_msg = False
+        self._state_version += 1          # a batch prepared ahead of time holds packed has_msg / message rows
 
     @property
     def messages(self):

@@ -259,6 +259,8 @@ class TGN(nn.Module):
             mem.device = self._flat.device
             self.memory_updater.layer_norm._apply(fn)
         self.device = self._flat.device
+        if self._prefetched is not None and self._prefetched[2].ws is not None and self._prefetched[2].ws.is_cuda:
+            torch.cuda.current_stream(self._prefetched[2].ws.device).wait_event(self._prefetched[2].ready)
         self._ws_pool, self._last_ws, self._adj_cache = [], None, None
         self._prefetched = None
         return self
@@ -527,7 +529,11 @@ class TGN(nn.Module):
         extra = torch.cat([src, dst]).contiguous() if (self.use_memory and self.dp_world > 1) else None
         roots, root_ts = self._assemble_roots(src, dst, edge_times, groups, lo, hi, R)
         dropout_p = self.dropout if self.training else 0.0
-        call = self._make_call(roots, root_ts, K, None, dropout_p, extra, B, defer_step=True)
+        main = self._pre_main if self._pre_main is not None else torch.cuda.default_stream(self.device)
+        with torch.cuda.stream(main):
+            # a NEW workspace (pool miss) must belong to the caller's stream's allocator pool: the forward / backward that use
+            # it run there, and a later pool purge must free it to that stream's allocator, not the prefetch stream's
+            call = self._make_call(roots, root_ts, K, None, dropout_p, extra, B, defer_step=True)
         call.batch_struct.prepared = 1
         st = self._state_struct()
         _lib.call("pfo_tgn_prepare", ctypes.byref(call.cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
@@ -535,16 +541,24 @@ class TGN(nn.Module):
         call.ready = torch.cuda.Event()
         call.ready.record()
         call.keep = (src, dst, edge_times, groups)                 # the key's addresses stay theirs until the call is used
-        main = self._pre_main if self._pre_main is not None else torch.cuda.default_stream(self.device)
         for t in (roots, root_ts, extra) + tuple(g for g, _ in groups):
             if t is not None:
                 t.record_stream(main)                             # allocated on the prefetch stream, read on the caller's
         self._prefetched = (self._batch_key(src, dst, groups, edge_times, K), dropout_p, call)
         return True
 
+    def _discard_call(self, call):
+        """Hands a prepared-but-unused call's workspace back.  ``pfo_tgn_prepare`` may still be running on the prefetch
+        stream: whoever pops that workspace from the pool next works on the CALLER's stream, so that stream is made to
+        wait for the preparation first (stream-ordered, no host sync)."""
+        ready = getattr(call, "ready", None)
+        if ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(ready)
+        call.release()
+
     def _drop_prefetched(self):
         if self._prefetched is not None:
-            self._prefetched[2].release()
+            self._discard_call(self._prefetched[2])
             self._prefetched = None
 
     def _take_prefetched(self, src, dst, groups, edge_times, K, draws, offset_dev, grad_mode, dropout_p):
@@ -559,7 +573,7 @@ class TGN(nn.Module):
             call.offset = self._step << 36
             call.batch_struct.offset = call.offset
             return call
-        call.release()
+        self._discard_call(call)
         return None
 
     def embed_device(self, src, dst, extra_roots, extra_repeat, edge_times, edge_idxs, n_neighbors, draws=None, offset_dev=None):
@@ -605,7 +619,8 @@ class TGN(nn.Module):
         else:
             extra = torch.cat([src, dst]).contiguous() if (self.use_memory and self.dp_world > 1) else None
             roots, root_ts = self._assemble_roots(src, dst, edge_times, groups, lo, hi, R)
-        if K <= 0:                       # utils.py:175: a single all-padding column
+        no_neighbours = K <= 0
+        if no_neighbours:                # utils.py:175: a single all-padding column
             K, root_ts = 1, torch.full_like(root_ts, -1.0)
         post = None
         if self.use_memory:
@@ -619,7 +634,10 @@ class TGN(nn.Module):
             call.release()
             if grad_mode:
                 self._attach_grads(self._gru_applied_now)         # this rank still joins the all-reduce: with a zero gradient
-                self._bucket_event_fresh = False                  # ... in one piece (no backward ran to record the event)
+                if self._zero_next:                               # request_zero_grad(): no backward will run to honour it
+                    self._flat_grad.zero_()
+                    self._zero_next = False
+                self._bucket_event_fresh = False                  # no backward ran to record the event (the collectives stay the same)
             # a leaf that requires grad: the caller's loss.backward() is a no-op instead of an error
             return torch.zeros((0, D), dtype=torch.float32, device=self.device, requires_grad=grad_mode), 0
         if grad_mode:
@@ -645,7 +663,8 @@ class TGN(nn.Module):
         # items (evaluation.py:88-89): interactions that share a timestamp (day-granular data) repeat whole blocks of
         # roots.  Those are embedded once and gathered back.
         inverse = None
-        if self.eval_dedup and draws is None and R >= 4096:
+        if self.eval_dedup and draws is None and R >= 4096 and not no_neighbours:   # (the grid is rebuilt from the real edge
+            # times: with the K <= 0 override every root's time is -1 and the list is embedded as it stands)
             roots, root_ts, inverse = self._dedup_roots(src[lo:hi], dst[lo:hi], edge_times[lo:hi], groups, lo, hi, B, roots, root_ts)
             R = int(roots.shape[0])
         cap = int(self.eval_chunk_roots)

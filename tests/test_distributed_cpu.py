@@ -67,6 +67,45 @@ def test_two_rank_gloo_gradient_equals_single_rank():
         assert ret[r] < 1e-5, ret[r]        # fp32 summation-order tolerance
 
 
+def _bucket_worker(rank, world, port, ret):
+    """Rank 1 plays the empty shard (batch shorter than the world): no backward ran, so no fresh event."""
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from pfotgnrec_amd.distributed import init_from_env, allreduce_flat_grad_buckets
+    init_from_env(backend="gloo")
+    sizes = []
+    real = dist.all_reduce
+
+    def counting(t, op=dist.ReduceOp.SUM, **kw):
+        sizes.append(int(t.numel()))
+        return real(t, op=op, **kw)
+    dist.all_reduce = counting
+
+    class Stub:                                      # the attributes of TGN the function reads
+        flat_grad = torch.full((100,), float(rank + 1)) if rank == 0 else torch.zeros(100)
+        grad_split = 60
+        dp_bucketed = True
+        _bucket_event_fresh = rank == 0
+        _bucket_event = None
+    allreduce_flat_grad_buckets(Stub, world)
+    ret[rank] = (sizes, Stub.flat_grad.tolist(), Stub._bucket_event_fresh)
+    dist.all_reduce = real
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_issues_the_same_collectives_on_a_rank_with_an_empty_shard():
+    """the number and sizes of the collectives must not depend on per-rank state.  Rank 1 has no fresh "top
+    layer final" event (its shard was empty, no backward ran); it must still issue the two pieces rank 0 issues."""
+    port = 29400 + (os.getpid() % 150)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bucket_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret[0][0] == ret[1][0] == [40, 60]
+    assert ret[0][1] == ret[1][1] == [1.0] * 100
+    assert ret[0][2] is False and ret[1][2] is False
+
+
 def test_shard_bounds_cover_batch_exactly():
     from pfotgnrec_amd.distributed import shard_bounds
     for B in (1, 7, 512, 4096):

@@ -130,3 +130,20 @@ def test_two_bucket_allreduce_equals_the_single_one(tmp_path):
         one, two = np.load(tmp_path / ("w2_r%d_B48.npz" % r)), np.load(tmp_path / ("w2_r%d_B48_buckets.npz" % r))
         for k in one.files:
             assert np.array_equal(one[k], two[k]), (r, k)
+
+
+def test_bucketed_allreduce_with_an_empty_shard(tmp_path):
+    """world 2, global batch 1, two-bucket all-reduce.  Rank 1's shard is empty (no backward, no event): it must
+    join BOTH pieces rank 0 issues, with a zero gradient - one whole-buffer collective against two pieces hangs or sums
+    wrongly.  Result equals the single all-reduce bit for bit, replicas stay identical."""
+    port = 29890 + (os.getpid() % 40)
+    _spawn(2, port, tmp_path, 2, 1, det=True)
+    _spawn(2, port + 1, tmp_path, 2, 1, buckets=True, det=True)
+    for r in (0, 1):
+        one, two = np.load(tmp_path / ("w2_r%d_B1.npz" % r)), np.load(tmp_path / ("w2_r%d_B1_buckets.npz" % r))
+        for k in one.files:
+            assert np.array_equal(one[k], two[k]), (r, k)
+    a, b = np.load(tmp_path / "w2_r0_B1_buckets.npz"), np.load(tmp_path / "w2_r1_B1_buckets.npz")
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), "replicas diverged: " + k
+    assert np.abs(a["grad0"]).max() > 0
