@@ -15,9 +15,12 @@ environment, i.e. plain ``python bench.py --gpus N``) this process starts N chil
 touching any GPU - and relays rank 0's line; under ``python -m torch.distributed.run`` it IS a rank.
 Default workload for N > 1 is the SAME headline graph (C2) with 512 interactions per GPU - a global batch of 512 N cut
 into N shards, one all-reduce of the flat gradient buffer per step (weak scaling: value(N) / (N value(1)) is the
-efficiency, on one workload); with ``--secondary`` the line also carries BASELINE.json configs[3] (C4: 500k users,
-10M edges) at a FIXED global batch of 4096 interactions (strong scaling) with the same batch on ONE of
-those GPUs.  ``--config`` / ``--scaling`` override (``--config C4`` makes the strong-scaling case the main line).
+efficiency, on one workload).  Every N > 1 line reports the collective's own time (``config.collective_ms_per_step``,
+event-bracketed on the caller's stream) and carries, under ``secondary``, a 1 s run of the same workload with the other
+all-reduce form (one piece / two buckets); at N = 8 (or with ``--secondary``) also BASELINE.json configs[3] (C4: 500k
+users, 10M edges) at a FIXED global batch of 4096 interactions (strong scaling) with the same batch on ONE of
+those GPUs.  ``--no-secondary`` drops all of that; ``--config`` / ``--scaling`` override (``--config C4`` makes the
+strong-scaling case the main line).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   "roofline":     live HIP-event timing of the dominant kernel family over the timed region
@@ -53,11 +56,12 @@ def parse():
                     help="N > 1: weak = --batch interactions per GPU, strong = the config's batch cut into N shards "
                          "(default: strong for C4, weak otherwise)")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step timed block until this much time is covered")
-    ap.add_argument("--no-secondary", action="store_true", help="(kept for old command lines: the secondary figures are off unless --secondary)")
+    ap.add_argument("--no-secondary", action="store_true", help="N > 1: no secondary figures at all (only the main line's workload runs)")
     ap.add_argument("--secondary", action="store_true",
                     help="N > 1: also run the other scaling case (C4 at a fixed global batch of 4 096 with its one-GPU reference, or the "
-                         "weak-scaling C2 figure when the main line is C4) - a second 10 M-edge graph per rank; off by default so that "
-                         "nothing can come between the N-GPU run and its line")
+                         "weak-scaling C2 figure when the main line is C4) - a second 10 M-edge graph per rank.  ON by default at N = 8 "
+                         "(BASELINE.json configs[3] names exactly that machine), 1 s budget; every N > 1 line also carries a 1 s run of "
+                         "the main workload with the other all-reduce form (secondary.allreduce_buckets / _single)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a captured HIP graph (one launch per step instead of ~85).  auto (one GPU, per-GPU "
                          "batch <= 256): capture, time ten steps either way during set-up and keep the faster form - the graph "
@@ -91,7 +95,11 @@ def parse():
     return ap.parse_args()
 
 
-PMC_KERNEL = {"gemm_bx": "void gemm_bx_areg_kernel<1>", "gemm_tn_bx": "gemm_tn_group_bx_kernel",
+VALU_ISSUE_PEAK_GINST = 1024 * 2.4 / 4   # 256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles at 2.4 GHz: 614.4 G wave-instructions/s
+
+# family (one PFO_PROF_* kind = one kernel, every launch of it) -> the kernel's name in the rocprofv3 summaries of profiles/
+PMC_KERNEL = {"gemm_bx": "void gemm_bx_areg_kernel<1>", "gemm_tn_bx": "void gemm_tn_group_bx_kernel<1>",
+              "gru_fused": "void gru_fused_kernel<1>",
               "gemm_bx_skinny": "void gemm_bx_skinny_kernel<4, 1>",
               "gemm_nt": "void gemm_f32_kernel<false, false, 0, true>",
               "gemm_nn": "void gemm_f32_kernel<false, true, 0, true>",
@@ -100,18 +108,25 @@ PMC_KERNEL = {"gemm_bx": "void gemm_bx_areg_kernel<1>", "gemm_tn_bx": "gemm_tn_g
               "attn_bwd_runs": "void attn_bwd_runs_kernel<3, 2, false>"}
 
 
-def pmc_traffic(family):
-    """HBM bytes per launch of the family's kernel from the newest committed PMC pass (profiles/r*_summary.json:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs, (2*FETCH + WRITE)*1024 on gfx950); None if not profiled."""
+def pmc_counters(family):
+    """Counters per launch of the family's kernel from the newest committed PMC passes (profiles/r*_summary.json: separate
+    --pmc runs; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950; ``sq`` = the SQ instruction counts of the same
+    kernel).  (bytes or None, {counter: value} or {}, file name)."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_summary.json")))
     if not files:
-        return None
+        return None, {}, None
     try:
         k = json.load(open(files[-1]))["pmc"]["kernels"].get(PMC_KERNEL.get(family, ""))
-        return int(k["hbm_bytes_per_launch_corrected"]) if k else None
+        if not k:
+            return None, {}, os.path.basename(files[-1])
+        return int(k["hbm_bytes_per_launch_corrected"]), dict(k.get("sq", {})), os.path.basename(files[-1])
     except Exception:
-        return None
+        return None, {}, None
+
+
+def pmc_traffic(family):
+    return pmc_counters(family)[0]
 
 
 def steady_state_init(tgn, rs):
@@ -267,8 +282,13 @@ class Workload:
                                message_function="identity", n_neighbors=cfg.n_neighbors)
         tgn.set_data_parallel(rank, world)
         tgn.deterministic = bool(args.deterministic)
-        tgn.dp_bucketed = world > 1 and args.allreduce == "buckets"
+        tgn.dp_bucketed = (world > 1 or os.environ.get("PFO_DIST_FORCE") == "1") and args.allreduce == "buckets"
         self.emulate = emulate                                # --emulate-ranks: a rank's compute without the collective
+        import torch.distributed as _dist
+        self.dist_on = (not emulate) and _dist.is_available() and _dist.is_initialized()   # world 1 with PFO_DIST_FORCE=1: the rank path on one GPU
+        self.force_dist = os.environ.get("PFO_DIST_FORCE") == "1"
+        self.allreduce_mode = args.allreduce
+        self.coll_events, self.time_collective = [], False
         if not emulate:
             broadcast_parameters(tgn.flat_parameters, world)
         if cfg.use_memory:
@@ -367,28 +387,45 @@ class Workload:
         # loss + loss.backward() (main.py:337,388) as two native calls: the loss kernel hands its gradient rows straight to
         # the TGN backward (P.bpr_loss(...).backward() is the autograd spelling of the same thing, tests/test_gpu_round2.py)
         loss = P.bpr_step(tgn, emb, b, n_neg, pos_block=pos_block)
-        if not self.emulate:
-            if self.args.allreduce == "buckets":
-                allreduce_flat_grad_buckets(tgn, self.world)
+        if self.dist_on and (self.world > 1 or self.force_dist):     # (set_world(0, 1): rank 0 alone, no collective)
+            ev = None
+            if self.time_collective:                          # sampled steps: the collective bracketed by events on the caller's stream
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            if self.allreduce_mode == "buckets":
+                allreduce_flat_grad_buckets(tgn, self.world, force=True)
             else:
-                allreduce_flat_grad(tgn.flat_grad, self.world)
+                allreduce_flat_grad(tgn.flat_grad, self.world, force=True)
+            if ev is not None:
+                ev[1].record()
+                self.coll_events.append(ev)
         self.opt.step()                                                                                        # main.py:389
         self.opt.zero_grad(set_to_none=True)
         return loss
 
-    def timed(self, steps, warmup, min_seconds, prof_every=0, first_step=0, collective=True):
+    def collective_ms(self):
+        """Mean device time of the bracketed all-reduce calls (ms), number of samples: from the first event - queued behind
+        the backward's last kernel on the caller's stream - to the point where the reduced buffer is usable there.  It
+        includes waiting for the slowest rank's backward; with the two-bucket form only the exposed remainder."""
+        if not self.coll_events:
+            return None, 0
+        self.torch.cuda.synchronize()
+        t = [a.elapsed_time(b) for a, b in self.coll_events]
+        return float(np.mean(t)), len(t)
+
+    def timed(self, steps, warmup, min_seconds, prof_every=0, first_step=0, collective=True, coll_every=4):
         """W warm-up steps, then blocks of exactly K steps, each bracketed by barrier + synchronize on both sides, until
         min_seconds are covered; per block the MAX over ranks is taken.  Returns (seconds, timed steps, blocks, loss, sampled)."""
         import torch.distributed as dist
         from pfotgnrec_amd import _lib
         torch = self.torch
-        multi = collective and self.world > 1
+        multi = collective and self.dist_on and (self.world > 1 or self.force_dist)
         i = first_step
         for _ in range(warmup):
             self.step(i)
             i += 1
         total, n_steps, blocks, n_prof = 0.0, 0, 0, 0
-        self.block_ms, self.host_ms = [], []
+        self.block_ms, self.host_ms, self.coll_events = [], [], []
         loss = None
         while True:
             if multi:
@@ -400,6 +437,8 @@ class Workload:
                 if sampled:
                     _lib.prof_enable(True)
                     n_prof += 1
+                # the collective's own time: bracketed on every 4th step of every block (two event records, no kernel brackets)
+                self.time_collective = self.dist_on and coll_every > 0 and (k % coll_every == 1 % coll_every) and not sampled
                 loss = self.step(i)
                 i += 1
                 if sampled:
@@ -430,52 +469,87 @@ class Workload:
                    "%d/GPU" % self.per_gpu if self.scaling == "weak" else "%d global (fixed), %d shards" % (self.B, self.world)))
 
 
-def roofline_of(prof, n_prof_steps, profiled_workload=True):
-    """Dominant KERNEL by device time over the sampled steps: a family is all launches of one kernel (the library reads
-    the device-side row counts of the touched-table launches back, so every launch carries its work).  Contractions on the
-    split kernels are priced against the dense 16-bit MFMA peak divided by the piece products one fp32 product costs (three
-    for the two-piece fp16 split, six for bf16x3);
-    the fp32-MFMA kernels against the fp32 MFMA peak; the attention / sampling kernels against HBM."""
-    fam = {k: v for k, v in prof.items() if v["count"] > 0}
-    if not fam:
-        return None
-    dom = max(fam, key=lambda k: fam[k]["ms"])
-    v = fam[dom]
+def family_roofline(fam, v, profiled_workload=True):
+    """Roofline record of ONE kernel family (= one kernel, every launch of it over the sampled steps).
+    Split contractions: MFMA, against the dense 16-bit peak / the piece products one fp32 product costs (three for the
+    two-piece fp16 split, six for bf16x3); fp32-MFMA kernels against the fp32 MFMA peak.  The attention kernels gather rows
+    that sit in L2 / Infinity Cache and are bound by their vector instruction stream: ``bound: "valu"`` - achieved = vector
+    wave-instructions per launch (SQ_INSTS_VALU of the committed counter pass) / the live launch time, peak = 1024 SIMDs x
+    2.4 GHz / 4 cycles; the HBM view (counter bytes / time) and the no-reuse algorithmic bytes of SURVEY 8(d) ride along.  The
+    sampler is priced against HBM."""
     per_launch_s = v["ms"] / v["count"] * 1e-3
-    if dom.startswith("gemm"):
-        products = bx_products(dom)
+    traffic, sq, src = pmc_counters(fam) if profiled_workload else (None, {}, None)
+    if fam.startswith("gemm") or fam == "gru_fused":
+        products = bx_products(fam)
         peak = MFMA_BF16_PEAK_TF / products if products else MFMA_F32_PEAK_TF
         achieved = v["work"] / v["count"] / per_launch_s / 1e12
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None}
+                "frac": round(achieved / peak, 4), "traffic": traffic}
         if products == 6:
             roof["arithmetic"] = ("fp32 contraction as a 3-way bf16 operand split: 6 v_mfma_f32_16x16x32_bf16 per fp32 "
                                   "product block; peak = dense bf16 MFMA peak / 6")
         elif products == 3:
             roof["arithmetic"] = ("fp32 contraction as a 2-way scaled fp16 operand split: 3 v_mfma_f32_16x16x32_f16 per fp32 "
                                   "product block; peak = dense f16 MFMA peak / 3")
+    elif fam.startswith("attn") and sq.get("SQ_INSTS_VALU"):
+        ginst = sq["SQ_INSTS_VALU"] / per_launch_s / 1e9
+        roof = {"bound": "valu", "achieved": round(ginst, 1), "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave-inst/s",
+                "frac": round(ginst / VALU_ISSUE_PEAK_GINST, 4), "traffic": traffic,
+                "valu_insts_per_launch": sq["SQ_INSTS_VALU"], "salu_insts_per_launch": sq.get("SQ_INSTS_SALU"),
+                "algorithmic_gbs_no_reuse": round(v["work"] / v["count"] / per_launch_s / 1e9, 1)}
     else:
         achieved = v["work"] / v["count"] / per_launch_s / 1e9
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}
-    # the committed counter pass was taken on the default workload (C2, 512 interactions per launch): other shapes get null
-    roof["traffic"] = pmc_traffic(dom) if profiled_workload else None
-    roof["kernel"] = dom
-    roof["kernel_name"] = PMC_KERNEL.get(dom, dom)
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic}
+        if fam.startswith("attn"):
+            roof["note"] = "no committed SQ pass for this kernel: no-reuse algorithmic bytes (SURVEY 8d) over 8 TB/s, not a tight bound"
+    if traffic:
+        roof["hbm_gbs_from_traffic"] = round(traffic / per_launch_s / 1e9, 1)
+        roof["hbm_frac_from_traffic"] = round(traffic / per_launch_s / 1e9 / HBM_PEAK_GBS, 4)
+    roof["counters_from"] = src
+    roof["kernel"] = fam
+    roof["kernel_name"] = PMC_KERNEL.get(fam, fam)
     roof["avg_launch_us"] = round(per_launch_s * 1e6, 2)
     roof["launches"] = int(v["count"])
+    return roof
+
+
+def roofline_of(prof, n_prof_steps, profiled_workload=True):
+    """Dominant KERNEL by summed device time over the sampled steps (a family is ONE kernel name, every launch of it; the
+    library reads the device-side row counts of the touched-table launches back, so every launch carries its work), priced
+    by ``family_roofline``; the runner-up rides along in full so that a near-tie between two kernels cannot hide either."""
+    fam = {k: v for k, v in prof.items() if v["count"] > 0}
+    if not fam:
+        return None
+    order = sorted(fam, key=lambda k: -fam[k]["ms"])
+    dom = order[0]
+    roof = family_roofline(dom, fam[dom], profiled_workload)
+    v = fam[dom]
     roof["launches_per_step"] = round(v["count"] / max(1, n_prof_steps), 2)
+    roof["ms_per_step"] = round(v["ms"] / max(1, n_prof_steps), 4)
     roof["sampled_steps"] = n_prof_steps
+    if len(order) > 1:
+        ru = family_roofline(order[1], fam[order[1]], profiled_workload)
+        ru["launches_per_step"] = round(fam[order[1]]["count"] / max(1, n_prof_steps), 2)
+        ru["ms_per_step"] = round(fam[order[1]]["ms"] / max(1, n_prof_steps), 4)
+        roof["runner_up"] = ru
     roof["families_ms_per_step"] = {k: round(x["ms"] / max(1, n_prof_steps), 4) for k, x in prof.items() if x["count"] > 0}
+    roof["families_launches_per_step"] = {k: round(x["count"] / max(1, n_prof_steps), 2) for k, x in prof.items() if x["count"] > 0}
+    is_flop = lambda k: k.startswith("gemm") or k == "gru_fused"
     rate = lambda x, unit: round(x["work"] / max(1e-12, x["ms"] * 1e-3) / unit, 2)
-    roof["families_rate"] = {k: rate(x, 1e12 if k.startswith("gemm") else 1e9) for k, x in prof.items() if x["count"] > 0}
+    roof["families_rate"] = {k: rate(x, 1e12 if is_flop(k) else 1e9) for k, x in prof.items() if x["count"] > 0}
     tot = lambda ks: (sum(prof[k]["work"] for k in ks if k in prof) / max(1e-9, sum(prof[k]["ms"] for k in ks if k in prof) * 1e-3))
-    roof["gemm_all_tflops"] = round(tot([k for k in prof if k.startswith("gemm")]) / 1e12, 2)
+    roof["gemm_all_tflops"] = round(tot([k for k in prof if is_flop(k)]) / 1e12, 2)
     roof["attn_all_gbs"] = round(tot([k for k in prof if k.startswith("attn")]) / 1e9, 1)
     return roof
 
 
-BX_FAMILIES = ("gemm_bx", "gemm_tn_bx", "gemm_bx_skinny")
+def cfg_layers(cfg_name):
+    from pfotgnrec_amd.synthetic import CONFIGS
+    return CONFIGS[cfg_name].n_layers
+
+
+BX_FAMILIES = ("gemm_bx", "gemm_tn_bx", "gemm_bx_skinny", "gru_fused")
 
 
 def bx_products(family):
@@ -577,7 +651,7 @@ def main():
                    "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4), "hip_graph": wl.graph_note, "deterministic_backward": bool(args.deterministic),
                    "next_batch_prepared_beside_backward": bool(wl.prefetch and wl.gstep is None and wl.mvs is None),
                    "collective": ("%s all-reduce of the flat fp32 gradient, world %d"
-                                  % ("rccl" if dist.get_backend() == "nccl" else dist.get_backend(), dist.get_world_size())) if world > 1 else None},
+                                  % ("rccl" if dist.get_backend() == "nccl" else dist.get_backend(), dist.get_world_size())) if dist.is_initialized() else None},
     }
     if prof is not None:
         roof = roofline_of(prof, n_prof_steps, profiled_workload=(cfg_name == "C2" and wl.mvs is None and
@@ -585,47 +659,81 @@ def main():
         if roof:
             out["roofline"] = roof
 
-    if world > 1 and args.secondary and not args.no_secondary:
-        # (1) the same workload on ONE of these GPUs (rank 0 alone, the others wait): the denominator of the strong-scaling
-        #     figure.  (2) weak scaling on C2, 512 interactions per GPU, what round 1 reported.
+    coll_ms, coll_n = wl.collective_ms()
+    if coll_ms is not None:
+        out["config"]["collective_ms_per_step"] = round(coll_ms, 4)
+        out["config"]["compute_ms_per_step"] = round(1e3 * elapsed / n_timed - coll_ms, 4)
+        out["config"]["collective_samples"] = coll_n
+        out["config"]["allreduce"] = wl.allreduce_mode
+        out["config"]["predicted_scaling_efficiency"] = {"weak_C2_512_per_gpu": {"2": 0.90, "4": 0.87, "8": 0.86},
+                                                         "strong_C4_4096_global": {"2": 0.89, "4": 0.76, "8": 0.54},
+                                                         "source": "DESIGN.md 6: emulated-rank compute table + ring all-reduce estimate"}
+
+    if (world > 1 or wl.force_dist) and not args.no_secondary:
+        # Secondary figures ride in the same line.  Nothing here may cost the main line: every part is bounded (1 s of timed
+        # steps) and an exception is recorded instead of raised.
         sec = {}
-        if scaling == "strong":
-            dist.barrier()
-            if rank == 0:
-                wl.set_world(0, 1)
-                el, n1, _, _, _ = wl.timed(args.steps, 2, min(args.min_seconds, 1.0), 0, first_step=100000, collective=False)
-                sec["strong_scaling_reference"] = {"n_gpus": 1, "value": round(n1 * B / el, 1), "ms_per_step": round(1e3 * el / n1, 4),
-                                                   "workload": "the same global batch on one GPU"}
-                wl.set_world(0, world)
-            dist.barrier()
-        if not (cfg_name == "C2" and scaling == "weak"):
-            del wl
-            torch.cuda.empty_cache()
-            w2 = Workload(args, "C2", dev, rank, world, "weak")
-            el, n2, _, _, _ = w2.timed(args.steps, args.warmup, min(args.min_seconds, 1.0), 0)
-            sec["weak_scaling_C2"] = {"n_gpus": world, "value": round(n2 * w2.B / el, 1), "ms_per_step": round(1e3 * el / n2, 4),
-                                      "workload": w2.describe(), "global_batch": w2.B}
-            del w2
-        else:
-            # the SURVEY 8(d) strong-scaling case beside the headline: C4 (10 M edges) at a FIXED global batch of 4096 cut
-            # into N shards, and the same batch on one of these GPUs (rank 0 alone, the others wait)
-            del wl
-            torch.cuda.empty_cache()
-            w4 = Workload(args, "C4", dev, rank, world, "strong")
-            el, n4, _, _, _ = w4.timed(args.steps, args.warmup, min(args.min_seconds, 1.0), 0)
-            sec["strong_scaling_C4"] = {"n_gpus": world, "value": round(n4 * w4.B / el, 1), "ms_per_step": round(1e3 * el / n4, 4),
-                                        "workload": w4.describe(), "global_batch": w4.B}
-            dist.barrier()
-            if rank == 0:
-                w4.set_world(0, 1)
-                el, n1, _, _, _ = w4.timed(args.steps, 2, min(args.min_seconds, 1.0), 0, first_step=100000, collective=False)
-                sec["strong_scaling_C4"]["one_gpu_reference"] = {"value": round(n1 * w4.B / el, 1), "ms_per_step": round(1e3 * el / n1, 4)}
-            dist.barrier()
-            del w4
+        try:
+            # (0) the same workload with the OTHER all-reduce form (one piece after the backward / two pieces, the top layer's
+            #     block on a communication stream beside the backward): single vs. bucketed decided by data
+            other = "buckets" if wl.allreduce_mode == "single" else "single"
+            if cfg_layers(cfg_name) >= 2:
+                wl.allreduce_mode, wl.tgn.dp_bucketed = other, other == "buckets"
+                el, nb, _, _, _ = wl.timed(args.steps, 5, min(args.min_seconds, 1.0), 0, first_step=50000)
+                cms, cn = wl.collective_ms()
+                sec["allreduce_" + other] = {"n_gpus": world, "value": round(nb * B / el, 1), "ms_per_step": round(1e3 * el / nb, 4),
+                                            "collective_ms_per_step": None if cms is None else round(cms, 4),
+                                            "workload": "the main line's workload, all-reduce form '%s'" % other}
+                wl.allreduce_mode, wl.tgn.dp_bucketed = args.allreduce, args.allreduce == "buckets"
+            want_other_case = world > 1 and (args.secondary or world == 8)
+            # (1) the same workload on ONE of these GPUs (rank 0 alone, the others wait): the denominator of the strong-scaling
+            #     figure.  (2) the other scaling case.
+            if want_other_case and scaling == "strong":
+                dist.barrier()
+                if rank == 0:
+                    wl.set_world(0, 1)
+                    el, n1, _, _, _ = wl.timed(args.steps, 2, min(args.min_seconds, 1.0), 0, first_step=100000, collective=False)
+                    sec["strong_scaling_reference"] = {"n_gpus": 1, "value": round(n1 * B / el, 1), "ms_per_step": round(1e3 * el / n1, 4),
+                                                       "workload": "the same global batch on one GPU"}
+                    wl.set_world(0, world)
+                dist.barrier()
+            if want_other_case and not (cfg_name == "C2" and scaling == "weak"):
+                del wl
+                torch.cuda.empty_cache()
+                w2 = Workload(args, "C2", dev, rank, world, "weak")
+                el, n2, _, _, _ = w2.timed(args.steps, args.warmup, min(args.min_seconds, 1.0), 0)
+                cms, _ = w2.collective_ms()
+                sec["weak_scaling_C2"] = {"n_gpus": world, "value": round(n2 * w2.B / el, 1), "ms_per_step": round(1e3 * el / n2, 4),
+                                          "collective_ms_per_step": None if cms is None else round(cms, 4),
+                                          "workload": w2.describe(), "global_batch": w2.B}
+                del w2
+            elif want_other_case:
+                # BASELINE.json configs[3] - the SURVEY 8(d) strong-scaling case - beside the headline: C4 (10 M edges) at a
+                # FIXED global batch of 4096 cut into N shards, and the same batch on one of these GPUs (rank 0 alone, the
+                # others wait)
+                del wl
+                torch.cuda.empty_cache()
+                w4 = Workload(args, "C4", dev, rank, world, "strong")
+                el, n4, _, _, _ = w4.timed(args.steps, args.warmup, min(args.min_seconds, 1.0), 0)
+                cms, _ = w4.collective_ms()
+                sec["strong_scaling_C4"] = {"n_gpus": world, "value": round(n4 * w4.B / el, 1), "ms_per_step": round(1e3 * el / n4, 4),
+                                            "collective_ms_per_step": None if cms is None else round(cms, 4),
+                                            "workload": w4.describe(), "global_batch": w4.B, "scaling": "strong"}
+                dist.barrier()
+                if rank == 0:
+                    w4.set_world(0, 1)
+                    el, n1, _, _, _ = w4.timed(args.steps, 2, min(args.min_seconds, 1.0), 0, first_step=100000, collective=False)
+                    sec["strong_scaling_C4"]["one_gpu_reference"] = {"value": round(n1 * w4.B / el, 1), "ms_per_step": round(1e3 * el / n1, 4)}
+                    sec["strong_scaling_C4"]["efficiency_vs_one_gpu"] = round(sec["strong_scaling_C4"]["value"] /
+                                                                               (world * sec["strong_scaling_C4"]["one_gpu_reference"]["value"]), 4)
+                dist.barrier()
+                del w4
+        except Exception as e:                                  # the secondary figures never cost the main line
+            sec["error"] = repr(e)[:300]
         out["secondary"] = sec
 
     if rank != 0:
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -652,7 +760,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "interactions/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": "failed: %r" % (e,)}
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -338,11 +338,12 @@ int pfo_tgn_debug_views(const pfo_tgn_config* cfg, void* workspace, pfo_tgn_debu
 #define PFO_PROF_ATTN_FWD 4
 #define PFO_PROF_ATTN_BWD 5
 #define PFO_PROF_SAMPLER 6
-#define PFO_PROF_GEMM_BX 7   /* gemm_bx_areg_kernel: every row-major bf16x3 launch, device-side row counts included (flops = 2MNK, M read back) */
+#define PFO_PROF_GEMM_BX 7   /* gemm_bx_areg_kernel and nothing else: every row-major split-contraction launch, device-side row counts included (flops = 2MNK, M read back) */
 #define PFO_PROF_GEMM_TN_BX 8 /* grouped weight gradients on the bf16x3 kernel (GEMM kernel only)  */
 #define PFO_PROF_GEMM_BX_SKINNY 9 /* the 32-row bf16x3 kernel of the short (layer-2) launches           */
 #define PFO_PROF_ATTN_BWD_RUNS 10 /* layer-1 attention backward, run-merged kernel (attn_bwd_runs_kernel)  */
-#define PFO_PROF_KINDS 11
+#define PFO_PROF_GRU_FUSED 11 /* gru_fused_kernel: both GRUCell contractions + gates (flops = per-row FLOPs x touched rows read back) */
+#define PFO_PROF_KINDS 12
 int pfo_prof_enable(int32_t on);
 int pfo_prof_collect(double* ms, double* work, int64_t* count); /* HOST arrays of PFO_PROF_KINDS entries */
 

@@ -34,6 +34,18 @@ void pfo_prof_end(int kind, double work, hipStream_t s);
 // work = work_per_unit * min(*units_dev, units_cap): launches whose extent is a device-side count (read back at collect time)
 void pfo_prof_end_dev(int kind, double work_per_unit, const int32_t* units_dev, int units_cap, hipStream_t s);
 
+// Named ranges for `rocprofv3 --marker-trace` (tracing hooks): roctxRangePushA / roctxRangePop are looked up in
+// the process at first use (the profiler preloads librocprofiler-sdk-roctx.so; an application may link libroctx64 itself) -
+// no link dependency, and a no-op pointer test when no tracer is present.
+void pfo_range_push(const char* name);
+void pfo_range_pop();
+struct PfoRange {
+  explicit PfoRange(const char* name) { pfo_range_push(name); }
+  ~PfoRange() { pfo_range_pop(); }
+  PfoRange(const PfoRange&) = delete;
+  PfoRange& operator=(const PfoRange&) = delete;
+};
+
 static inline int64_t pfo_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t pfo_align_up(int64_t a, int64_t b) { return pfo_ceil_div(a, b) * b; }
 

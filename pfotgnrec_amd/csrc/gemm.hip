@@ -1167,7 +1167,7 @@ int pfo_gru_fused_launch(const PfoGruFused& f, hipStream_t stream) {
   if (pfo_bx_fmt()) hipLaunchKernelGGL(gru_fused_kernel<1>, grid, dim3(GEMM_THREADS), 0, stream, d);
   else hipLaunchKernelGGL(gru_fused_kernel<0>, grid, dim3(GEMM_THREADS), 0, stream, d);
   PFO_LAUNCH_CHECK();
-  pfo_prof_end_dev(PFO_PROF_GEMM_BX, 2.0 * 3 * f.D * ((double)f.K_msg + f.D), f.n_rows, f.cap_rows, stream);   // per-row FLOPs of the two contractions
+  pfo_prof_end_dev(PFO_PROF_GRU_FUSED, 2.0 * 3 * f.D * ((double)f.K_msg + f.D), f.n_rows, f.cap_rows, stream);   // per-row FLOPs of the two contractions
   return PFO_OK;
 }
 

@@ -96,6 +96,41 @@ extern "C" int pfo_prof_collect(double* ms, double* work, int64_t* count) {
 extern "C" int pfo_abi_version(void) { return 2; }
 
 // ---------------------------------------------------------------------------------------------
+// roctx ranges (common.hpp)
+#include <dlfcn.h>
+namespace {
+typedef int (*roctx_push_t)(const char*);
+typedef int (*roctx_pop_t)(void);
+roctx_push_t g_roctx_push = nullptr;
+roctx_pop_t g_roctx_pop = nullptr;
+bool g_roctx_looked = false;
+void roctx_lookup() {
+  g_roctx_looked = true;
+  const char* off = getenv("PFO_ROCTX");
+  if (off && off[0] == '0') return;
+  void* push = dlsym(RTLD_DEFAULT, "roctxRangePushA");
+  void* pop = dlsym(RTLD_DEFAULT, "roctxRangePop");
+  if (!push || !pop) {
+    // PFO_ROCTX=1: load the marker library even when no profiler preloaded it (a tool attached later sees the ranges)
+    if (!(off && off[0] == '1')) return;
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = dlsym(h, "roctxRangePushA");
+    pop = dlsym(h, "roctxRangePop");
+  }
+  if (push && pop) { g_roctx_push = (roctx_push_t)push; g_roctx_pop = (roctx_pop_t)pop; }
+}
+}  // namespace
+void pfo_range_push(const char* name) {
+  if (!g_roctx_looked) roctx_lookup();
+  if (g_roctx_push) (void)g_roctx_push(name);
+}
+void pfo_range_pop() {
+  if (g_roctx_pop) (void)g_roctx_pop();
+}
+
+// ---------------------------------------------------------------------------------------------
 __global__ void time_encode_kernel(const float* __restrict__ t, int64_t n, const float* __restrict__ w,
                                    const float* __restrict__ b, int D, float* __restrict__ out) {
   const int64_t total = n * D;

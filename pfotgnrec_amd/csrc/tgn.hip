@@ -461,6 +461,7 @@ extern "C" int pfo_tgn_prepare(const pfo_tgn_config* c, const pfo_tgn_state* st,
   PFO_REQUIRE(b->n_extra == 0 || b->extra_nodes, "null extra_nodes");
   const Dims d = dims_of(c);
   const Ws w = carve(c, workspace);
+  PfoRange range("pfo_tgn_prepare");
   RUN(prepare_sample(c, st, b, w, n, (hipStream_t)stream));
   RUN(prepare_compact_pack(c, st, b, w, d, n, (hipStream_t)stream));
   return PFO_OK;
@@ -489,6 +490,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   bind(lay, st->params, P, d.L, c->use_memory != 0);
   const int L = d.L, D = d.D, Ef = d.Ef, H = d.H, E = d.E, C = d.C, dh = d.dh, K = b->K;
 
+  PfoRange range_call(b->training ? "pfo_tgn_forward (training)" : "pfo_tgn_forward");
   // ---- composite weights of every layer: on the side stream, beside the sampling / memory phase
   Side& sd = side();
   PFO_REQUIRE(sd.ok, "could not create the side stream");
@@ -530,6 +532,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   }
   const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
   if (c->use_memory) {
+    PfoRange range_gru("forward lazy GRU");
     // both GRU contractions and the gate math in ONE launch (gemm.hip gru_fused_kernel): gi / gh never exist in HBM
     PfoGruFused f;
     f.msg_rows = w.msg_rows; f.K_msg = d.M; f.h_rows = w.h_rows; f.img_ih = w.iWih; f.img_hh = w.iWhh;
@@ -671,7 +674,9 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   //   out    = W2 h1 + b2
   // 0.60 MFLOP per instance instead of 1.13 (and 10.3 un-folded); Q, O and attn_out are never formed.
   const float scale = 1.0f / sqrtf((float)dh);
+  static const char* const fwd_names[PFO_MAX_LAYERS + 1] = {"", "forward layer 1", "forward layer 2", "forward layer 3", "forward layer 4"};
   for (int l = 1; l <= L; ++l) {
+    PfoRange range_layer(fwd_names[l]);
     const int N = (int)n[l];
     const LayerWs& lw = w.layer[l];
     const auto& p = P.l[l];
@@ -795,6 +800,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   int64_t det_rows = 0;                                        // slab rows written so far (deterministic mode)
 
   const int Cp = d.Cp, HCp = H * d.Cp, WQ = HCp + D;
+  PfoRange range_call("pfo_tgn_backward");
   Side& sd = side();
   PFO_REQUIRE(sd.ok, "could not create the side stream");
   hipStream_t ss = sd.s;
@@ -812,7 +818,9 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
                            w.seg_tmp, w.seg_mem, w.seg_scratch, ss));
   HIPOK(hipEventRecord(sd.seg_done, ss), "event record failed");
   std::function<int()> deferred_chain;                       // a layer's chain-back launches, issued one layer later (below)
+  static const char* const bwd_names[PFO_MAX_LAYERS + 1] = {"", "backward layer 1", "backward layer 2", "backward layer 3", "backward layer 4"};
   for (int l = L; l >= 1; --l) {
+    PfoRange range_layer(bwd_names[l]);
     const int N = (int)n[l];
     const LayerWs& lw = w.layer[l];
     const auto& p = P.l[l];
@@ -1127,6 +1135,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
 
   // ---- GRU parameters (messages and stored memory are constants: SURVEY App. A-6)
   if (c->use_memory) {
+    PfoRange range_gru("backward GRU");
     // (the GRU's backward covers the rows the layers read: rows only the extra list names carry no gradient)
     RUN(pfo_gru_gates_bwd_launch(w.gates, w.gi, w.gh, w.h_rows, w.hm, w.n_core, capP, D, w.d_h0, n_rep, rep_stride,
                                  w.dx_tab, det, s));
@@ -1178,5 +1187,6 @@ extern "C" int pfo_tgn_update_state(const pfo_tgn_config* c, const pfo_tgn_state
   if (!c->use_memory) return PFO_OK;
   PFO_REQUIRE(st && workspace && src && dst && ts && eidx && B >= 1, "bad arguments");
   const Ws w = carve(c, workspace);
+  PfoRange range("pfo_tgn_update_state");
   return state_update(c, st, w, src, dst, ts, eidx, B, (hipStream_t)stream);
 }

@@ -14,20 +14,34 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract).  Returns (rank, world, local_rank)."""
+def init_from_env(backend=None, force=None, timeout_s=None):
+    """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract).  Returns (rank, world, local_rank).
+
+    ``force`` (default: PFO_DIST_FORCE=1 in the environment): initialise the process group at world 1 too, so that the
+    rank path - RCCL communicator, the all-reduce of the flat gradient - runs end to end on a single GPU.
+    The group gets an explicit timeout (default 180 s, PFO_DIST_TIMEOUT_S): a rank that never arrives at the rendezvous or
+    at a collective fails the job quickly instead of holding it for the backend's 10-30 minute default.  With RCCL the
+    communicator is bound to this rank's device at once (``device_id``): no lazy initialisation inside the first timed step."""
+    import datetime
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if force is None:
+        force = os.environ.get("PFO_DIST_FORCE", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             # PFO_DIST_BACKEND is a test hook (2 ranks sharing one GPU over gloo); production = nccl (RCCL)
             backend = os.environ.get("PFO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("PFO_DIST_TIMEOUT_S", "180"))
+        kw = dict(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
         if backend == "nccl":
-            torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dev = int(os.environ["PFO_FORCE_DEVICE"]) if os.environ.get("PFO_FORCE_DEVICE") is not None else local
+            torch.cuda.set_device(dev)
+            kw["device_id"] = torch.device("cuda", dev)
+        dist.init_process_group(**kw)
     return rank, world, local
 
 
@@ -37,9 +51,9 @@ def shard_bounds(batch, rank, world):
     return rank * batch // world, (rank + 1) * batch // world
 
 
-def allreduce_flat_grad(flat_grad, world):
-    """The step's single collective: sum of the flat gradient buffer over all ranks."""
-    if world > 1:
+def allreduce_flat_grad(flat_grad, world, force=False):
+    """The step's single collective: sum of the flat gradient buffer over all ranks (``force``: also at world 1)."""
+    if world > 1 or force:
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return flat_grad
 

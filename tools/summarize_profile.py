@@ -52,13 +52,20 @@ for k in fetch:
     f, w = fetch[k], write.get(k, 0.0)
     pmc[k] = {"FETCH_SIZE_per_launch": round(f, 1), "WRITE_SIZE_per_launch": round(w, 1),
               "hbm_bytes_per_launch_corrected": int((2 * f + w) * 1024)}
+for sub, names in (("pmc_sq1", ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")),
+                   ("pmc_sq2", ("SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES"))):
+    for name in names:
+        for k, v in counter(sub, name).items():
+            if k in pmc:
+                pmc[k].setdefault("sq", {})[name] = round(v, 1)
 bench_line = None
 try:
     bench_line = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 except Exception:
     pass
 out = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 "
-                  "--no-cpu-baseline --no-prof --min-seconds 0   (+ separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes)",
+                  "--no-cpu-baseline --no-prof --min-seconds 0   (+ separate --pmc passes: FETCH_SIZE; WRITE_SIZE; "
+                  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS; SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES)",
        "steps_in_trace": steps, "kernels": kern,
        "pmc": {"correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes (gfx950, MI355X_MICROARCH.md)", "kernels": pmc},
        "bench_line_same_build": bench_line}
