@@ -94,6 +94,15 @@ int pfo_mv_select(const double* returns, int32_t n_days, int32_t n_items, int32_
  */
 int pfo_time_encode(const float* t, int64_t n, const float* w, const float* b, int32_t D, float* out, void* stream);
 
+/* The train-mode dropout multipliers of one attention layer, exactly as the step's kernels draw them
+ * (nn.MultiheadAttention(dropout=p) on the softmax weights, temporal_attention.py:28,70): out[n, h, j] = 1/(1-p) where the
+ * weight of key slot j / head h of instance n is kept, 0 where it is dropped.  Philox4x32 keyed by `seed`, counter
+ * (n * 64 + j, offset): the step uses offset = pfo_tgn_batch.offset + 0x51ED0000 + layer (1-based), n = the instance's index
+ * in the layer's level list.  Test / parity infrastructure: lets an oracle replay a dropout-0.1 step with the SAME masks
+ * (the RNG stream itself is not part of the reference's contract). */
+int pfo_attn_dropout_mask(uint64_t seed, uint64_t offset, int64_t N, int32_t K, int32_t H, float p, float* out /* [N,H,K] */,
+                          void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Dense fp32 contraction on the matrix cores (v_mfma_f32_16x16x4_f32), exposed for tests.
  *   C[M,N] = A[M,K] * op(B) + bias,  op(B) = B[N,K]^T (b_kmajor = 0, the nn.Linear weight layout)
@@ -277,6 +286,11 @@ typedef struct pfo_tgn_batch {
      joined by the event the call's layer 2 waits for anyway: two small launches leave the critical path.  Taken with
      use_memory and n_layers >= 2; otherwise (upd_src NULL, one layer, no memory) the caller calls pfo_tgn_update_state. */
   const int32_t* upd_src; const int32_t* upd_dst; const double* upd_ts; const int32_t* upd_eidx; int32_t upd_B;
+  /* Optional INJECTED dropout decisions (parity tests against masks captured from the reference, like `draws` for the uniform
+     sampler): dropout_keep[L - l] for layer l (same order as `draws`: the roots' level first) is a device array u8 [n_l, K],
+     bit h of entry (n, j) = the attention weight of key slot j / head h of instance n is KEPT; null = the step's own Philox
+     draws.  Only read when dropout_p > 0 and training != 0. */
+  const uint8_t* const* dropout_keep;
 } pfo_tgn_batch;
 
 /* The part of pfo_tgn_forward that depends on neither parameters nor gradients - frontier sampling (utils.py:163-219 per level,
@@ -322,6 +336,15 @@ typedef struct pfo_tgn_debug {
   const int32_t* touched_ids;/* [n_touched] */
   const float* h0_table;     /* [n_touched,D] layer-0 features memory'+node_feat (embedding_module.py:98) */
   const int32_t* slot;       /* [n_nodes] */
+  /* operands and results of the two largest weight-gradient contractions of the last backward (valid until the workspace's
+     next forward): parity tests re-contract the SAME fp32 operands in fp64 (per-element evidence for the split contraction) */
+  const int32_t* n_core;     /* [1] table rows the step's levels reference (the GRU backward's row count) */
+  const float* l1_ctx;       /* [n_1, H*Cp]   layer-1 context rows ctx' (a operand of dW1ov)                     */
+  const float* l1_dh1;       /* [n_1, D]      d loss / d (layer-1 fc1 pre-activation) (b operand)               */
+  const float* l1_dW1ovT;    /* [H*Cp, D]     = ctx'^T dh1                                                      */
+  const float* gru_dgi;      /* [n_core, 3D]  d loss / d (GRU input-side pre-activations) (a operand of dW_ih)  */
+  const float* gru_msg_rows; /* [n_core, 3D+Ef] packed message rows (b operand); dW_ih lands in the gradient buffer */
+  int32_t Cp;                /* per-head row stride of ctx' */
 } pfo_tgn_debug;
 int pfo_tgn_debug_views(const pfo_tgn_config* cfg, void* workspace, pfo_tgn_debug* out);
 

@@ -128,11 +128,15 @@ def gru_cell_backward(cache, d_hn, W_ih, W_hh):
 
 
 # ----------------------------------------------------------------------------- temporal attention layer
-def attention_forward(p, x, tq, nbr_feat, ef, te, mask, n_head):
-    """TemporalAttentionLayer.forward (temporal_attention.py:34-90) at dropout 0.
+def attention_forward(p, x, tq, nbr_feat, ef, te, mask, n_head, drop=None):
+    """TemporalAttentionLayer.forward (temporal_attention.py:34-90).
 
     p: dict with Wq [E,E], Wk [E,C], Wv [E,C], b_in [3E], Wo [E,E], bo [E], W1 [D,E+D], b1, W2 [D,D], b2
     x [N,D]; tq [N,D]; nbr_feat [N,K,D]; ef [N,K,Ef]; te [N,K,D]; mask bool [N,K] (True = padding).
+    drop: None (dropout 0 / eval mode) or f32 [N,H,K], the multiplier nn.MultiheadAttention's train-mode dropout puts on the
+    softmax weights (temporal_attention.py:28,70: ``dropout=dropout`` -> F.dropout(attn_output_weights, p) before the
+    product with V): 1/(1-p) where the weight is kept, 0 where it is dropped.  The mask itself is INJECTED (the RNG stream
+    that draws it is not part of the contract).
     """
     N, K = mask.shape
     q_in = np.concatenate([x, tq], 1)                                  # :51
@@ -156,14 +160,15 @@ def attention_forward(p, x, tq, nbr_feat, ef, te, mask, n_head):
     m = scores.max(-1, keepdims=True)
     e = np.exp(scores - m)
     a = (e / e.sum(-1, keepdims=True)).astype(f32)                     # [N,H,K]
-    Oh = np.matmul(a[:, :, None, :], Vh.transpose(0, 2, 1, 3))[:, :, 0, :].reshape(N, E)
+    ad = a if drop is None else (a * drop).astype(f32)                 # F.dropout on the attention weights (train mode)
+    Oh = np.matmul(ad[:, :, None, :], Vh.transpose(0, 2, 1, 3))[:, :, 0, :].reshape(N, E)
     attn = Oh @ p["Wo"].T + p["bo"]
     attn[inv] = 0                                                      # :84
     cat = np.concatenate([attn, x], 1)                                 # :88 / utils.py:15
     z1 = cat @ p["W1"].T + p["b1"]
     h1 = np.maximum(z1, 0)
     out = (h1 @ p["W2"].T + p["b2"]).astype(f32)
-    cache = dict(q_in=q_in, key=key, inv=inv, Qh=Qh, Kh=Kh, Vh=Vh, a=a, Oh=Oh, cat=cat, z1=z1, h1=h1, scale=scale)
+    cache = dict(q_in=q_in, key=key, inv=inv, Qh=Qh, Kh=Kh, Vh=Vh, a=a, ad=ad, drop=drop, Oh=Oh, cat=cat, z1=z1, h1=h1, scale=scale)
     return out, cache
 
 
@@ -182,8 +187,10 @@ def attention_backward(p, c, d_out, n_head, D):
     dattn[c["inv"]] = 0
     g["Wo"] = dattn.T @ c["Oh"]; g["bo"] = dattn.sum(0)
     dOh = (dattn @ p["Wo"]).reshape(N, n_head, E // n_head)
-    da = np.matmul(c["Vh"].transpose(0, 2, 1, 3), dOh[:, :, :, None])[..., 0]
-    dVh = (c["a"].transpose(0, 2, 1)[:, :, :, None] * dOh[:, None, :, :])
+    da = np.matmul(c["Vh"].transpose(0, 2, 1, 3), dOh[:, :, :, None])[..., 0]      # d loss / d (post-dropout weight)
+    dVh = (c["ad"].transpose(0, 2, 1)[:, :, :, None] * dOh[:, None, :, :])
+    if c["drop"] is not None:
+        da = da * c["drop"]                                             # through the dropout multiplier
     a = c["a"]
     ds = a * (da - (a * da).sum(-1, keepdims=True))                     # softmax backward; masked a == 0
     dQh = np.matmul(ds[:, :, None, :], c["Kh"].transpose(0, 2, 1, 3))[:, :, 0, :]
@@ -242,14 +249,15 @@ class _one_blas_thread:
             self._ctx.__exit__(*a)
 
 
-def attention_forward_mt(p, x, tq, nbr_feat, ef, te, mask, n_head):
+def attention_forward_mt(p, x, tq, nbr_feat, ef, te, mask, n_head, drop=None):
     N = mask.shape[0]
     if N < MT_MIN_ROWS:
-        return attention_forward(p, x, tq, nbr_feat, ef, te, mask, n_head)
+        return attention_forward(p, x, tq, nbr_feat, ef, te, mask, n_head, drop)
     bounds = [(i, min(N, i + MT_CHUNK)) for i in range(0, N, MT_CHUNK)]
     with _one_blas_thread():
         res = list(_pool().map(lambda b: attention_forward(p, x[b[0]:b[1]], tq[b[0]:b[1]], nbr_feat[b[0]:b[1]], ef[b[0]:b[1]],
-                                                           te[b[0]:b[1]], mask[b[0]:b[1]], n_head), bounds))
+                                                           te[b[0]:b[1]], mask[b[0]:b[1]], n_head,
+                                                           None if drop is None else drop[b[0]:b[1]]), bounds))
     out = np.concatenate([r[0] for r in res])
     cache = dict(chunks=[r[1] for r in res], bounds=bounds, z1=np.concatenate([r[1]["z1"] for r in res]))
     return out, cache
@@ -338,6 +346,10 @@ class OracleTGN:
         self.P = {k: np.asarray(v, f32) for k, v in params.items()}
         self.n_layers, self.n_heads, self.use_memory = n_layers, n_heads, use_memory
         self.n_nodes, self.D = self.node_features.shape
+        # train-mode attention dropout, injected: {layer l (1-based): f32 [n_l, H, K]} multipliers for the n_l instances of
+        # layer l in LEVEL ORDER (S_L = roots, S_{l-1} = [S_l ; neighbours(S_l) flattened]: instance i of S_l keeps index i
+        # in S_{l-1}, its j-th neighbour sits at |S_l| + i K + j), or None = dropout 0 / eval mode
+        self.dropout_masks = None
         self.init_memory()
 
     # -- modules/memory.py:23-33
@@ -397,28 +409,37 @@ class OracleTGN:
             self.messages[int(src[i])].append((msg[i], et[i]))                      # :375-376 (store_raw_messages extends)
 
     # -- embedding_module.py:76-175 (recursive)
-    def _embed(self, memory, nodes, ts, l, K, draws):
+    def _embed(self, memory, nodes, ts, l, K, draws, base=0, n_l=None):
+        """``base`` / ``n_l``: position of nodes[0] in the level list S_l and |S_l| (only used to address injected dropout
+        masks: the recursion itself is the reference's)."""
         nodes = np.asarray(nodes, np.int64)
+        if n_l is None:
+            n_l = len(nodes)
         if l == 0:
             feat = self.node_features[nodes]
             if self.use_memory:
                 feat = memory[nodes] + feat                                         # :98
             return feat.astype(f32), ("leaf", nodes)
         w, b = self._w()
-        x, c_x = self._embed(memory, nodes, ts, l - 1, K, draws)                    # :115
+        Kc = K if K > 0 else 1
+        n_below = n_l * (1 + Kc)
+        x, c_x = self._embed(memory, nodes, ts, l - 1, K, draws, base, n_below)     # :115
         if draws is not None and self.neighbor_finder.uniform:
             nbr, eidx, et = self.neighbor_finder.gather_uniform(nodes, ts, draws.pop(0), K)
         else:
             nbr, eidx, et = self.neighbor_finder.get_temporal_neighbor(nodes, ts, K)   # :125
         deltas = (ts[:, None] - et).astype(f32)                                     # :133-135 (f64 - f32 -> f32)
-        nb, c_nb = self._embed(memory, nbr.flatten(), np.repeat(ts, K), l - 1, K, draws)   # :141
-        Kc = K if K > 0 else 1
+        nb, c_nb = self._embed(memory, nbr.flatten(), np.repeat(ts, K), l - 1, K, draws, n_l + base * Kc, n_below)   # :141
         nb = nb.reshape(len(nodes), Kc, -1)
         te = time_encode(deltas, w, b)                                              # :150
         tq = np.broadcast_to(time_encode(np.zeros(1, f32), w, b), (len(nodes), self.D)).astype(f32)   # :92
         ef = self.edge_features[eidx]                                               # :152
         mask = nbr == 0                                                             # :154
-        out, c = attention_forward_mt(layer_params(self.P, l - 1), x, tq, nb, ef, te, mask, self.n_heads)
+        drop = None
+        if self.dropout_masks is not None:
+            drop = self.dropout_masks[l][base:base + len(nodes)]
+            assert drop.shape == (len(nodes), self.n_heads, Kc), (drop.shape, len(nodes), self.n_heads, Kc)
+        out, c = attention_forward_mt(layer_params(self.P, l - 1), x, tq, nb, ef, te, mask, self.n_heads, drop)
         return out, ("layer", l, c_x, c_nb, c, deltas, (nbr, eidx, et))
 
     def _embed_backward(self, ctx, d_out, grads, d_mem):

@@ -41,11 +41,13 @@ class TgnBatch(C.Structure):
                 ("draws", C.POINTER(_VP)), ("seed", C.c_uint64), ("offset", C.c_uint64), ("dropout_p", C.c_float),
                 ("training", C.c_int32), ("extra_nodes", _VP), ("n_extra", C.c_int32), ("offset_dev", _VP),
                 ("deterministic", C.c_int32), ("prepared", C.c_int32),
-                ("upd_src", _VP), ("upd_dst", _VP), ("upd_ts", _VP), ("upd_eidx", _VP), ("upd_B", C.c_int32)]
+                ("upd_src", _VP), ("upd_dst", _VP), ("upd_ts", _VP), ("upd_eidx", _VP), ("upd_B", C.c_int32),
+                ("dropout_keep", C.POINTER(_VP))]
 
 
 class TgnDebug(C.Structure):
-    _fields_ = [(n, _VP) for n in ("n_touched", "touched_ids", "h0_table", "slot")]
+    _fields_ = [(n, _VP) for n in ("n_touched", "touched_ids", "h0_table", "slot", "n_core", "l1_ctx", "l1_dh1", "l1_dW1ovT",
+                                   "gru_dgi", "gru_msg_rows")] + [("Cp", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol of include/pfotgn.h
@@ -62,6 +64,7 @@ PROTOTYPES = {
                                 C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, _VP, _VP, _VP,
                                 _VP, _VP]),
     "pfo_time_encode": (C.c_int, [_VP, C.c_int64, _VP, _VP, C.c_int32, _VP, _VP]),
+    "pfo_attn_dropout_mask": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_float, _VP, _VP]),
     "pfo_gemm_f32": (C.c_int, [_VP, C.c_int64, C.c_int32, _VP, C.c_int64, C.c_int32, _VP, C.c_int64, _VP, C.c_int32,
                                C.c_int32, C.c_int32, C.c_int32, _VP, C.c_int64, _VP]),
     "pfo_gemm_bf16x3_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),

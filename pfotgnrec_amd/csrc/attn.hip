@@ -15,7 +15,7 @@ struct AttnDev {
   int N, K, D, Ef, H, Cp;
   const float* QK; const int32_t* qk_row; int64_t qk_ld; const float* nbr_tab; int64_t nbr_ld; const int32_t* nbr_row; int64_t nbr_row_base; int nbr_relu;
   const int32_t* nbr_ids; const float* edge_feat; const int32_t* eidx; const float* dt; const float* tw; const float* tb;
-  float scale, dropout_p; uint64_t seed, offset; const uint64_t* offset_dev;
+  float scale, dropout_p; uint64_t seed, offset; const uint64_t* offset_dev; const uint8_t* keep_inject;
   float* ctx; float* attw; uint8_t* inv;
   const float* dctx; float* dQK; float* d_nbr; int64_t d_nbr_ld; double* dtime_part;
   int64_t d_nbr_rep;  // DMODE 1: floats between the per-XCD replicas of the gradient table (0: one table)
@@ -38,6 +38,12 @@ __device__ __forceinline__ unsigned attn_keep_bits(uint64_t seed, uint64_t offse
   const pfo_u4 r = pfo_philox(seed, (uint64_t)n * 64ull + (uint64_t)lane, offset);
   const uint32_t thr = (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f);
   return (r.x >= thr ? 1u : 0u) | (r.y >= thr ? 2u : 0u) | (r.z >= thr ? 4u : 0u) | (r.w >= thr ? 8u : 0u);
+}
+
+// ... or the caller's injected decisions (parity tests): one wave-uniform test per instance
+__device__ __forceinline__ unsigned attn_keep_for(const AttnDev& a, uint64_t rng_off, int64_t n, int lane) {
+  if (a.keep_inject && a.dropout_p > 0.f) return lane < a.K ? (unsigned)a.keep_inject[n * a.K + lane] : 0xFu;
+  return attn_keep_bits(a.seed, rng_off, n, lane, a.dropout_p);
 }
 
 // Keys are processed in chunks of KC: all gathers of a chunk are issued back to back (one memory latency per
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD_WAVES(N
   }
   if (lane == 0) a.inv[n] = 0;
 
-  const unsigned keep = attn_keep_bits(a.seed, a.offset + (a.offset_dev ? *a.offset_dev : 0ull), n, lane, a.dropout_p);
+  const unsigned keep = attn_keep_for(a, a.offset + (a.offset_dev ? *a.offset_dev : 0ull), n, lane);
   const float keep_scale = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
 
   float m[H], l[H], ld[H], my_s[H];
@@ -324,7 +330,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
 #pragma unroll
     for (int h = 0; h < H; ++h) t[h] = fmaf(dsb[h], cx[h * Cp + C], t[h]);
 
-    const unsigned keep = attn_keep_bits(a.seed, a.offset + (a.offset_dev ? *a.offset_dev : 0ull), n, lane, a.dropout_p);
+    const unsigned keep = attn_keep_for(a, a.offset + (a.offset_dev ? *a.offset_dev : 0ull), n, lane);
     float my_a[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) my_a[h] = inK ? a.attw[(n * H + h) * K + lane] : 0.f;
@@ -688,7 +694,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         dsb[h] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(dc[h * Cp + C])));
         t[h] = fmaf(dsb[h], __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cx[h * Cp + C]))), tds[h]);
       }
-      const unsigned keep = attn_keep_bits(a.seed, rng_off, n, lane, a.dropout_p);
+      const unsigned keep = attn_keep_for(a, rng_off, n, lane);
       float my_a[H];
 #pragma unroll
       for (int h = 0; h < H; ++h) my_a[h] = inK ? a.attw[(n * H + h) * K + lane] : 0.f;
@@ -819,7 +825,7 @@ static void to_dev(const PfoAttn& a, AttnDev& d) {
   d.N = a.N; d.K = a.K; d.D = a.D; d.Ef = a.Ef; d.H = a.H; d.Cp = a.Cp;
   d.QK = a.QK; d.qk_row = a.qk_row; d.qk_ld = a.qk_ld > 0 ? a.qk_ld : (int64_t)a.H * a.Cp; d.nbr_tab = a.nbr_tab; d.nbr_ld = a.nbr_ld; d.nbr_row = a.nbr_row; d.nbr_row_base = a.nbr_row_base; d.nbr_relu = a.nbr_relu;
   d.nbr_ids = a.nbr_ids; d.edge_feat = a.edge_feat; d.eidx = a.eidx; d.dt = a.dt; d.tw = a.tw; d.tb = a.tb;
-  d.scale = a.scale; d.dropout_p = a.dropout_p; d.seed = a.seed; d.offset = a.offset; d.offset_dev = a.offset_dev;
+  d.scale = a.scale; d.dropout_p = a.dropout_p; d.seed = a.seed; d.offset = a.offset; d.offset_dev = a.offset_dev; d.keep_inject = a.keep_inject;
   static const int abl = getenv("PFO_ATTN_ABL") ? atoi(getenv("PFO_ATTN_ABL")) : 0;
   d.abl = abl;
   d.ctx = a.ctx; d.attw = a.attw; d.inv = a.inv;
@@ -884,6 +890,31 @@ int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream) {
   ATTN_DISPATCH(attn_fwd_kernel, pfo_ceil_div(a.N, 4));
   PFO_LAUNCH_CHECK();
   pfo_prof_end(PFO_PROF_ATTN_FWD, bytes, stream);
+  return PFO_OK;
+}
+
+// the step's dropout multipliers, written out (include/pfotgn.h pfo_attn_dropout_mask): same function, same counters
+__global__ void attn_dropout_mask_kernel(uint64_t seed, uint64_t offset, int64_t N, int K, int H, float p, float* __restrict__ out) {
+  const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const int64_t total = N * K;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = e / K;
+    const int j = (int)(e - n * K);
+    const unsigned keep = attn_keep_bits(seed, offset, n, j, p);
+    for (int h = 0; h < H; ++h) out[(n * H + h) * K + j] = ((keep >> h) & 1u) ? keep_scale : 0.f;
+  }
+}
+extern "C" int pfo_attn_dropout_mask(uint64_t seed, uint64_t offset, int64_t N, int32_t K, int32_t H, float p, float* out,
+                                     void* stream) {
+  PFO_REQUIRE(out != nullptr && N >= 0, "bad arguments");
+  PFO_REQUIRE(K >= 1 && K <= 64, "K must be in [1, 64] (one keep word per lane of a wavefront)");
+  PFO_REQUIRE(H == 1 || H == 2 || H == 4, "n_heads must be 1, 2 or 4");
+  PFO_REQUIRE(p >= 0.f && p < 1.f, "dropout must be in [0, 1)");
+  if (N == 0) return PFO_OK;
+  const int64_t total = N * K;
+  const unsigned grid = (unsigned)std::min<int64_t>(4096, pfo_ceil_div(total, 256));
+  hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, seed, offset, N, (int)K, (int)H, p, out);
+  PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
 

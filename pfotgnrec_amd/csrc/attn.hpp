@@ -38,6 +38,7 @@ struct PfoAttn {
   float dropout_p = 0.f;
   uint64_t seed = 0, offset = 0;
   const uint64_t* offset_dev = nullptr;   // optional device word added to offset (graph-captured steps)
+  const uint8_t* keep_inject = nullptr;   // optional [N, K] injected dropout decisions (bit h = head h kept) instead of the Philox draws
   // forward outputs / backward inputs
   float* ctx = nullptr;             // [N, H*Cp] sum_j a'_jh key_j (+ the two extra columns)
   float* attw = nullptr;            // [N, H, K] softmax probabilities before dropout (0 on padding)

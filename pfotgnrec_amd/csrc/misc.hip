@@ -93,7 +93,7 @@ extern "C" int pfo_prof_collect(double* ms, double* work, int64_t* count) {
   g_pin_next = 0;
   return PFO_OK;
 }
-extern "C" int pfo_abi_version(void) { return 2; }
+extern "C" int pfo_abi_version(void) { return 3; }   // 3: pfo_tgn_batch.dropout_keep, pfo_attn_dropout_mask, PFO_PROF_GRU_FUSED
 
 // ---------------------------------------------------------------------------------------------
 // roctx ranges (common.hpp)

@@ -362,6 +362,14 @@ extern "C" int pfo_tgn_debug_views(const pfo_tgn_config* c, void* workspace, pfo
   PFO_REQUIRE(workspace && out, "null argument");
   const Ws w = carve(c, workspace);
   out->n_touched = w.n_touched; out->touched_ids = w.touched; out->h0_table = w.h0_tab; out->slot = w.slot;
+  const Dims d = dims_of(c);
+  out->n_core = w.n_core;
+  out->l1_ctx = w.layer[1].ctx;
+  out->l1_dh1 = d.L == 1 ? w.dh1 : w.dH[1];       // the top layer writes dh1 itself, below it the layer above does
+  out->l1_dW1ovT = w.layer[1].dW1ovT;
+  out->gru_dgi = c->use_memory ? w.gi : nullptr;
+  out->gru_msg_rows = c->use_memory ? w.msg_rows : nullptr;
+  out->Cp = d.Cp;
   return PFO_OK;
 }
 
@@ -719,6 +727,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     a.nbr_ids = w.nodes[l - 1] + N;
     a.edge_feat = st->edge_feat; a.eidx = w.eidx[l]; a.dt = w.dt[l]; a.tw = P.tw; a.tb = P.tb;
     a.scale = scale; a.dropout_p = b->dropout_p; a.seed = b->seed; a.offset = b->offset + 0x51ED0000ull + (uint64_t)l; a.offset_dev = b->offset_dev;
+    a.keep_inject = (b->dropout_keep && b->training) ? b->dropout_keep[L - l] : nullptr;
     a.ctx = lw.ctx; a.attw = lw.attw; a.inv = lw.inv;
     RUN(pfo_attn_fwd_launch(a, s));
     // ---- h1 = relu(ctx' W1ovT + x W1[:, E:]^T + b1)   (MergeLayer fc1 with out_proj and the value projection folded in)
@@ -911,6 +920,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     a.nbr_ids = w.nodes[l - 1] + N;
     a.edge_feat = st->edge_feat; a.eidx = w.eidx[l]; a.dt = w.dt[l]; a.tw = P.tw; a.tb = P.tb;
     a.scale = scale; a.dropout_p = b->dropout_p; a.seed = b->seed; a.offset = b->offset + 0x51ED0000ull + (uint64_t)l; a.offset_dev = b->offset_dev;
+    a.keep_inject = (b->dropout_keep && b->training) ? b->dropout_keep[L - l] : nullptr;
     a.ctx = lw.ctx; a.attw = lw.attw; a.inv = lw.inv;
     float* const dqk_l = (l == 1) ? w.dQK : lw.dQK;
     a.dctx = w.dctx; a.dQK = dqk_l;

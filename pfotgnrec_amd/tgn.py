@@ -38,7 +38,7 @@ def _normalise_edge_features(edge_features):
 
 class _Call:
     """Everything one forward/backward pair of native calls needs to agree on."""
-    __slots__ = ("roots", "root_ts", "R", "K", "mode", "draws", "draw_ptrs", "seed", "offset", "dropout_p", "training",
+    __slots__ = ("roots", "root_ts", "R", "K", "mode", "draws", "draw_ptrs", "keep_ptrs", "seed", "offset", "dropout_p", "training",
                  "extra", "batch_struct", "ws", "ws_caps", "cfg", "pool", "gru_applied", "ready", "keep", "__weakref__")
 
     def release(self):
@@ -358,7 +358,7 @@ class TGN(nn.Module):
         self._adj_cache = (key, nf, (indptr, nbr, eidx, ts))
         return self._adj_cache[2]
 
-    def _make_call(self, roots, root_ts, K, draws, dropout_p, extra, B, offset_dev=None, defer_step=False):
+    def _make_call(self, roots, root_ts, K, draws, dropout_p, extra, B, offset_dev=None, defer_step=False, dropout_keep=None):
         c = _Call()
         c.roots, c.root_ts, c.R, c.K = roots, root_ts, int(roots.shape[0]), int(K)
         uniform = bool(getattr(self.neighbor_finder, "uniform", False))
@@ -385,6 +385,19 @@ class TGN(nn.Module):
                                        int(extra.shape[0]) if extra is not None else 0,
                                        offset_dev.data_ptr() if offset_dev is not None else None,
                                        1 if self.deterministic else 0)
+        c.keep_ptrs = None
+        if dropout_keep is not None:
+            # injected dropout decisions (parity tests): one u8 [n_l, K] tensor per layer, the roots' level first (like draws)
+            if len(dropout_keep) != self.n_layers:
+                raise ValueError("injected dropout decisions need one uint8 tensor per layer")
+            n = c.R
+            for t in dropout_keep:
+                if t.dtype != torch.uint8 or tuple(t.shape) != (n, c.K) or not t.is_contiguous():
+                    raise ValueError("dropout_keep tensors must be contiguous uint8 [n_l, K] in level order (roots first)")
+                n *= 1 + c.K
+            c.keep = (getattr(c, "keep", None), dropout_keep)
+            c.keep_ptrs = (ctypes.c_void_p * self.n_layers)(*[t.data_ptr() for t in dropout_keep])
+            c.batch_struct.dropout_keep = ctypes.cast(c.keep_ptrs, ctypes.POINTER(ctypes.c_void_p))
         c.pool = self._ws_pool
         c.ws_caps, c.cfg, c.ws = self._acquire_workspace(c.R, c.K, B)
         c.gru_applied = self._gru_applied_now
@@ -397,6 +410,8 @@ class TGN(nn.Module):
         _lib.call("pfo_tgn_forward", ctypes.byref(call.cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
                   call.ws.data_ptr(), emb.data_ptr(), _lib.stream_ptr())
         self._last_ws = (call.cfg, call.ws)
+        self._last_call = (int(call.seed), int(call.batch_struct.offset), int(call.R), int(call.K), float(call.dropout_p),
+                           call.batch_struct.offset_dev is not None)
         return emb
 
     def _attach_grads(self, gru_applied=True, defer_zero=False):
@@ -576,7 +591,8 @@ class TGN(nn.Module):
         self._discard_call(call)
         return None
 
-    def embed_device(self, src, dst, extra_roots, extra_repeat, edge_times, edge_idxs, n_neighbors, draws=None, offset_dev=None):
+    def embed_device(self, src, dst, extra_roots, extra_repeat, edge_times, edge_idxs, n_neighbors, draws=None, offset_dev=None,
+                     dropout_keep=None):
         """Device-resident core of both reference entry points.
 
         src/dst i32[B], edge_times f64[B], edge_idxs i32[B], extra_roots: list of i32 tensors [B*r_k] (negatives /
@@ -613,6 +629,8 @@ class TGN(nn.Module):
         D = self.n_node_features
         grad_mode = torch.is_grad_enabled()
         dropout_p = self.dropout if self.training else 0.0       # dropout follows train()/eval(), not the autograd mode
+        if dropout_keep is not None:
+            self._drop_prefetched()
         pre = self._take_prefetched(src, dst, groups, edge_times, K, draws, offset_dev, grad_mode, dropout_p)
         if pre is not None:
             roots, root_ts, extra = pre.roots, pre.root_ts, pre.extra
@@ -646,7 +664,7 @@ class TGN(nn.Module):
                 call.gru_applied = self._gru_applied_now
                 torch.cuda.current_stream().wait_event(call.ready)    # the frontier, the compaction and the packed rows exist
             else:
-                call = self._make_call(roots, root_ts, K, draws, dropout_p, extra, B, offset_dev)
+                call = self._make_call(roots, root_ts, K, draws, dropout_p, extra, B, offset_dev, dropout_keep=dropout_keep)
             if fuse_state:
                 # the native forward performs the state update itself (pfo_tgn_batch.upd_*): on its side stream, beside layer 1
                 bs = call.batch_struct
@@ -668,8 +686,10 @@ class TGN(nn.Module):
             roots, root_ts, inverse = self._dedup_roots(src[lo:hi], dst[lo:hi], edge_times[lo:hi], groups, lo, hi, B, roots, root_ts)
             R = int(roots.shape[0])
         cap = int(self.eval_chunk_roots)
+        if dropout_keep is not None and (inverse is not None or R > int(self.eval_chunk_roots)):
+            raise ValueError("injected dropout decisions address the roots as given: not with the forward-only dedup / chunk walk")
         if R <= cap or draws is not None:
-            call = self._make_call(roots, root_ts, K, draws, dropout_p, extra, B)
+            call = self._make_call(roots, root_ts, K, draws, dropout_p, extra, B, dropout_keep=dropout_keep)
             emb = self._native_forward(call)
         else:
             emb = torch.empty((R, D), dtype=torch.float32, device=self.device)
@@ -739,7 +759,7 @@ class TGN(nn.Module):
         return self._to_dev(a, np.int32)
 
     def compute_temporal_embeddings(self, source_nodes, destination_nodes, p_neg_nodes, edge_times, edge_idxs,
-                                    n_neighbors=20, draws=None):
+                                    n_neighbors=20, draws=None, dropout_keep=None):
         """tgn.py:219-327.  numpy in (i64, i64, i64 flat row-major, f64, i64), device tensors out:
         (src_emb [B,D], dst_emb [B,D], neg_emb [B*size,D])."""
         B = len(source_nodes)
@@ -747,7 +767,8 @@ class TGN(nn.Module):
         src, dst = self._nodes_to_dev(source_nodes, "source_nodes"), self._nodes_to_dev(destination_nodes, "destination_nodes")
         neg = self._nodes_to_dev(p_neg_nodes, "p_neg_nodes")
         ts, eidx = self._to_dev(edge_times, np.float64), self._edges_to_dev(edge_idxs)
-        emb, b = self.embed_device(src, dst, [neg], [size], ts, eidx, n_neighbors, self._dev_draws(draws))
+        emb, b = self.embed_device(src, dst, [neg], [size], ts, eidx, n_neighbors, self._dev_draws(draws),
+                                   dropout_keep=self._dev_keep(dropout_keep))
         return emb[:b], emb[b:2 * b], emb[2 * b:]
 
     def compute_temporal_embeddings_p(self, source_nodes, destination_nodes, p_pos_nodes, p_neg_nodes, edge_times,
@@ -761,12 +782,70 @@ class TGN(nn.Module):
         emb, b = self.embed_device(src, dst, [pp, pn], [n_pos, n_neg], ts, eidx, n_neighbors, self._dev_draws(draws))
         return emb[:b], emb[b:2 * b], emb[2 * b:(2 + n_pos) * b], emb[(2 + n_pos) * b:]
 
+    def _dev_keep(self, masks):
+        """Injected dropout decisions for a parity test: ``{l: multipliers or booleans [n_l, H, K]}`` (level order, the layout
+        of ``debug_dropout_masks`` and of the oracle's ``dropout_masks``) -> per layer, roots' level first, u8 [n_l, K] with bit
+        h = head h kept."""
+        if masks is None:
+            return None
+        out = []
+        for l in range(self.n_layers, 0, -1):
+            m = np.asarray(masks[l]) != 0                                   # [n_l, H, K]
+            bits = np.zeros((m.shape[0], m.shape[2]), np.uint8)
+            for h in range(m.shape[1]):
+                bits |= (m[:, h, :].astype(np.uint8) << h)
+            out.append(torch.from_numpy(np.ascontiguousarray(bits)).to(self.device))
+        return out
+
     def _dev_draws(self, draws):
         if draws is None:
             return None
         return [self._to_dev(d, np.int64) for d in draws]
 
     # ------------------------------------------------------------------ introspection for tests
+    def debug_dropout_masks(self):
+        """The train-mode dropout multipliers the LAST forward applied to its attention weights, per layer:
+        ``{l: f32 ndarray [n_l, H, K]}`` in level order (n_L = R roots, n_{l-1} = n_l (1 + K)); 1/(1-p) = kept, 0 = dropped.
+        Regenerated through the C ABI from the call's seed and stream position (``pfo_attn_dropout_mask``): what an oracle
+        needs to replay the step with the same masks.  None when the call ran without dropout."""
+        seed, offset, R, K, p, dev_offset = self._last_call
+        if p <= 0.0:
+            return None
+        if dev_offset:
+            raise RuntimeError("the stream position of a graph-captured step lives on the device")
+        out, n = {}, R
+        for l in range(self.n_layers, 0, -1):
+            m = torch.empty((n, self.n_heads, K), dtype=torch.float32, device=self.device)
+            _lib.call("pfo_attn_dropout_mask", seed, offset + 0x51ED0000 + l, n, K, self.n_heads, p, m.data_ptr(), _lib.stream_ptr())
+            out[l] = m.cpu().numpy()
+            n *= 1 + K
+        return out
+
+    def debug_weight_gradient_operands(self):
+        """fp32 operands and results of the two largest weight-gradient contractions of the LAST backward (before the next
+        forward reuses the workspace): ``dict(ctx [n_1, H*Cp], dh1 [n_1, D], dW1ovT [H*Cp, D], dgi [n_core, 3D],
+        msg_rows [n_core, 3D+Ef])`` as numpy arrays (tests re-contract them in fp64)."""
+        cfg, ws = self._last_ws
+        seed, offset, R, K, p, _ = self._last_call
+        dbg = _lib.TgnDebug()
+        _lib.call("pfo_tgn_debug_views", ctypes.byref(cfg), ws.data_ptr(), ctypes.byref(dbg))
+        base = ws.data_ptr()
+
+        def view(ptr, count, dtype=torch.float32):
+            off = ptr - base
+            return ws[off:off + count * torch.empty((), dtype=dtype).element_size()].view(dtype)
+        D, H, Cp = self.n_node_features, self.n_heads, int(dbg.Cp)
+        n1 = R * (1 + K) ** (self.n_layers - 1)
+        out = dict(ctx=view(dbg.l1_ctx, n1 * H * Cp).view(n1, H * Cp).cpu().numpy(),
+                   dh1=view(dbg.l1_dh1, n1 * D).view(n1, D).cpu().numpy(),
+                   dW1ovT=view(dbg.l1_dW1ovT, H * Cp * D).view(H * Cp, D).cpu().numpy())
+        if self.use_memory:
+            nc = int(view(dbg.n_core, 1, torch.int32).item())
+            M = 3 * D + self.n_edge_features
+            out.update(dgi=view(dbg.gru_dgi, nc * 3 * D).view(nc, 3 * D).cpu().numpy(),
+                       msg_rows=view(dbg.gru_msg_rows, nc * M).view(nc, M).cpu().numpy())
+        return out
+
     def debug_touched(self):
         """(touched node ids, layer-0 feature table rows) of the last forward (use_memory only)."""
         cfg, ws = self._last_ws

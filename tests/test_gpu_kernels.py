@@ -286,6 +286,10 @@ def test_gemm_weight_gradient_form(M, N, K):
     ref = A.astype(np.float64).T @ B.astype(np.float64)
     got = _gemm(A, B, None, 1, 1)
     assert np.abs(got - ref).max() < 3e-5 * np.abs(ref).max()
+    # ... and PER ELEMENT against that element's own sum of magnitudes (Adam divides every gradient element by its own
+    # sqrt(v): main.py:123,389 - a norm-wise bound would let small elements be all noise)
+    mag = np.abs(A).astype(np.float64).T @ np.abs(B).astype(np.float64)
+    assert (np.abs(got - ref) / mag).max() < 4e-6
     assert np.array_equal(got, _gemm(A, B, None, 1, 1))                       # bitwise reproducible
 
 
@@ -309,6 +313,53 @@ def test_gemm_weight_gradient_form_operand_scales(grow):
     got = _gemm(A, B, None, 1, 1)
     assert np.abs(got - ref).max() < 4e-6 * mag.max()
     assert np.array_equal(got, _gemm(A, B, None, 1, 1))
+
+
+def _tn_scale_floor(X, col_block, k_tile=32, floor=2.0 ** -14):
+    """max(|x_kc|, floor * S(k, block(c))) with S = the largest magnitude of the operand's column block over every row up to
+    the end of k's tile: an upper bound of the ONE running scale the weight-gradient tile keeps per operand, workgroup tile
+    (128 columns of A, 176 of B: gemm.hip BM / BN) and K-slab (a slab starts later than row 0, so its running maximum is at
+    most this one).  ``floor``: 2^-16 of the scaled top, which sits up to HX_GROW = 2 binades above the maximum."""
+    K, C = X.shape
+    out = np.abs(X).astype(np.float64)
+    for c0 in range(0, C, col_block):
+        blk = out[:, c0:c0 + col_block]
+        per_tile = blk.reshape(-1, k_tile, blk.shape[1]).max((1, 2)) if K % k_tile == 0 else None
+        assert per_tile is not None, "K must be a multiple of the k-tile in this test"
+        run = np.maximum.accumulate(per_tile)                         # [tiles]
+        out[:, c0:c0 + col_block] = np.maximum(blk, floor * np.repeat(run, k_tile)[:, None])
+    return out
+
+
+@pytest.mark.parametrize("shape", ["ramp_up", "ramp_down", "flat"])
+def test_gemm_weight_gradient_form_per_element_bound(shape):
+    """VERDICT r3 item 2b.  The weight-gradient tile's two-piece fp16 split keeps ONE power-of-two scale per operand, workgroup
+    tile and K-slab, so an element far below its tile's largest magnitude loses RELATIVE precision; what the design claims is
+      |dW_mn - exact| <= c * sum_k max(|a_km|, 2^-16 top_a) * max(|b_kn|, 2^-16 top_b)        PER ELEMENT (m, n),
+    top = the (headroom-adjusted) running maximum of the operand's tile.  Operand columns 2^+-12 apart inside one tile, one
+    column of A all tiny (2^-30 of its neighbours), magnitudes that grow / shrink by 2^24 along k: every element of the
+    result is held to that bound - not the largest one only."""
+    rs = np.random.RandomState(17)
+    M, N, K = 344, 348, 4096
+    ramp = {"ramp_up": 2.0 ** np.linspace(-12, 12, K), "ramp_down": 2.0 ** np.linspace(12, -12, K), "flat": np.ones(K)}[shape]
+    A = rs.randn(K, M) * ramp[:, None] * 2.0 ** rs.randint(-12, 13, size=(1, M))
+    B = rs.randn(K, N) * ramp[::-1][:, None] * 2.0 ** rs.randint(-12, 13, size=(1, N))
+    A[:, 5] *= 2.0 ** -30                                            # a column that is tiny everywhere
+    B[:, 200] *= 2.0 ** -30
+    A[1000:1100] = 0
+    A = A.astype(np.float32); B = B.astype(np.float32)
+    ref = A.astype(np.float64).T @ B.astype(np.float64)
+    bound = _tn_scale_floor(A, 128).T @ _tn_scale_floor(B, 176)
+    got = _gemm(A, B, None, 1, 1).astype(np.float64)
+    ratio = np.abs(got - ref) / bound
+    assert ratio.max() < 4e-6, (ratio.max(), np.unravel_index(ratio.argmax(), ratio.shape))
+    # columns that sit within 2^-12 of their tile's maximum are above the floor almost everywhere: for them the bound IS the
+    # component-wise one, sum_k |a||b| - checked explicitly on the largest-magnitude columns of each operand
+    big_a = np.abs(A).max(0) >= 2.0 ** -4 * np.abs(A).max()
+    big_b = np.abs(B).max(0) >= 2.0 ** -4 * np.abs(B).max()
+    mag = np.abs(A).astype(np.float64).T @ np.abs(B).astype(np.float64)
+    if shape == "flat":
+        assert (np.abs(got - ref) / mag)[np.ix_(big_a, big_b)].max() < 4e-6
 
 
 # ------------------------------------------------------------------ BPR + Adam

@@ -46,3 +46,182 @@ def test_bench_rank_path_on_rccl_world1(allreduce):
     sec = rec["secondary"]
     assert "error" not in sec, sec
     assert sec["allreduce_" + other]["value"] > 0 and sec["allreduce_" + other]["collective_ms_per_step"] > 0
+
+
+# ------------------------------------------------------------------ oracle parity at the benched dropout
+from test_gpu_tgn_step import _masked_bpr_backward, _legal_draws, relerr  # noqa: E402
+
+RTOL_EMB = 1e-4            # north_star: embeddings within 1e-4 relative
+RTOL_GRAD_L2 = 5e-3        # small shapes: relative L2 with near-kink roots left out on both sides (test_gpu_tgn_step.py)
+RTOL_GRAD_TIME = 3e-3
+
+
+def _oracle_for(tgn, g, d, L, H, use_mem, uniform):
+    from oracle import tgn_oracle as T
+    from oracle.neighbor_finder import OracleNeighborFinder, build_adjacency
+    onf = OracleNeighborFinder(*build_adjacency(d.sources, d.destinations, d.edge_idxs, d.timestamps), uniform=uniform)
+    names = [k for k in tgn.state_dict() if "layer_norm" not in k and not k.startswith("memory.")]
+    ref = T.OracleTGN(onf, g.node_features, g.edge_features, {k: tgn.state_dict()[k].cpu().numpy() for k in names}, L, H, use_mem)
+    return onf, names, ref
+
+
+def test_dropout_mask_export_statistics_and_determinism():
+    """pfo_attn_dropout_mask: multipliers are 0 or 1/(1-p), the drop rate is p (binomial bound), masks differ between layers,
+    heads and steps and are reproduced exactly by a second export."""
+    from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+    cfg = SyntheticConfig("dm", 200, 20, 3000, 32, 2, 10, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=2, dropout=0.25,
+                use_memory=True, memory_dimension=32, message_function="identity", n_neighbors=10)
+    tgn.train()
+    B = 64
+    s = 1500
+    neg = np.random.RandomState(0).randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * 3)
+    tgn.compute_temporal_embeddings(d.sources[s:s + B], d.destinations[s:s + B], neg, d.timestamps[s:s + B], d.edge_idxs[s:s + B], 10)
+    m1 = tgn.debug_dropout_masks()
+    m1b = tgn.debug_dropout_masks()
+    assert m1[2].shape == (5 * B, 2, 10) and m1[1].shape == (5 * B * 11, 2, 10)
+    for l in (1, 2):
+        assert np.array_equal(m1[l], m1b[l])
+        vals = np.unique(m1[l])
+        assert len(vals) == 2 and vals[0] == 0 and abs(vals[1] - 1 / 0.75) < 1e-6
+        n = m1[l].size
+        assert abs((m1[l] == 0).mean() - 0.25) < 5 * np.sqrt(0.25 * 0.75 / n)
+        assert not np.array_equal(m1[l][:, 0], m1[l][:, 1])                     # heads draw independently
+    assert not np.array_equal(m1[1][:5 * B], m1[2])                             # layers draw independently
+    tgn.compute_temporal_embeddings(d.sources[s:s + B], d.destinations[s:s + B], neg, d.timestamps[s:s + B], d.edge_idxs[s:s + B], 10)
+    assert not np.array_equal(tgn.debug_dropout_masks()[2], m1[2])              # a new step, a new position in the stream
+    tgn.eval()
+    with torch.no_grad():
+        tgn.compute_temporal_embeddings(d.sources[s:s + B], d.destinations[s:s + B], neg, d.timestamps[s:s + B], d.edge_idxs[s:s + B], 10)
+    assert tgn.debug_dropout_masks() is None
+
+
+@pytest.mark.parametrize("D,H,L,K,use_mem,uniform,pdrop", [(32, 2, 1, 10, True, False, 0.1), (172, 2, 2, 8, True, False, 0.1),
+                                                            (172, 4, 2, 6, False, True, 0.1), (64, 1, 2, 5, True, False, 0.5),
+                                                            (128, 2, 2, 20, True, False, 0.3),   # K = 20: run-merged layer-1 backward
+                                                            (256, 4, 1, 12, True, False, 0.1)])
+def test_step_with_dropout_against_oracle(D, H, L, K, use_mem, uniform, pdrop):
+    """Training steps in TRAIN mode with attention dropout (the setting bench.py times; temporal_attention.py:28,70) against
+    the oracle replaying the step with the SAME masks (exported through the C ABI; the oracle's dropout algebra is pinned to
+    the reference by the g8 fixture).  Embeddings 1e-4, loss, kink-masked gradients, the memory state machine; four steps
+    with Adam in between, the oracle re-injected with the product's parameters every step."""
+    from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+    torch.manual_seed(4321 + D + H)
+    cfg = SyntheticConfig("t", 300, 25, 5000, D, L, K, H)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    nf = P.get_neighbor_finder(d, uniform=uniform)
+    tgn = P.TGN(nf, g.node_features, g.edge_features, DEV, n_layers=L, n_heads=H, dropout=pdrop, use_memory=use_mem,
+                memory_dimension=D, message_function="identity", n_neighbors=K)
+    with torch.no_grad():
+        tgn.time_encoder.w.bias.normal_(0, 0.3)
+        for att in tgn.embedding_module.attention_models:
+            att.multi_head_target.in_proj_bias.normal_(0, 0.1)
+            att.multi_head_target.out_proj.bias.normal_(0, 0.1)
+    opt = P.FusedAdam(tgn, lr=1e-3)
+    onf, names, ref = _oracle_for(tgn, g, d, L, H, use_mem, uniform)
+    rs = np.random.RandomState(6)
+    B = 40
+    for step in range(4):
+        s = 2500 + step * B
+        sb, db, tb, eb = d.sources[s:s + B], d.destinations[s:s + B], d.timestamps[s:s + B], d.edge_idxs[s:s + B]
+        neg = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * 3)
+        ref.P = {k: tgn.state_dict()[k].detach().cpu().numpy().copy() for k in names}
+        draws, odraws = None, None
+        if uniform:
+            R = 5 * B
+            raw = [rs.randint(0, 1 << 30, size=(R * (1 + K) ** i, K)).astype(np.int64) for i in range(L)]
+            draws, odraws = _legal_draws(onf, np.concatenate([sb, db, neg]), np.concatenate([tb, tb, np.repeat(tb, 3)]), K, L, raw)
+        tgn.train(); opt.zero_grad()
+        se, de, ne = tgn.compute_temporal_embeddings(sb, db, neg, tb, eb, K, draws=draws)
+        ref.dropout_masks = tgn.debug_dropout_masks()
+        assert ref.dropout_masks is not None and (ref.dropout_masks[L] == 0).any()
+        rse, rde, rne = ref.compute_temporal_embeddings(sb, db, neg, tb, eb, K, draws=None if odraws is None else list(odraws))
+        emb = torch.cat([se, de, ne])
+        remb = np.concatenate([rse, rde, rne])
+        e = relerr(emb.detach().cpu().numpy(), remb)
+        assert e < RTOL_EMB, (step, e)
+        rgrads = _masked_bpr_backward(tgn, ref, emb, rse, rde, rne, B, K)
+        for name, p in tgn.named_parameters():
+            if name not in rgrads:
+                continue
+            r = rgrads[name].reshape(p.shape)
+            if np.abs(r).max() < 1e-7:
+                assert p.grad is None or p.grad.abs().max().item() < 1e-6, name
+                continue
+            got = p.grad.cpu().numpy().astype(np.float64)
+            err = np.linalg.norm(got - r) / (np.linalg.norm(r) + 1e-30)
+            assert err < (RTOL_GRAD_TIME if name.startswith("time_encoder") else RTOL_GRAD_L2), (step, name, err)
+        if use_mem:
+            assert relerr(tgn.memory.memory.cpu().numpy(), ref.memory) < RTOL_EMB
+            assert np.array_equal(tgn.memory.last_update.cpu().numpy(), ref.last_update)
+            tab, mt, has = ref.pending_table()
+            assert np.array_equal(tgn.memory.has_msg.cpu().numpy() > 0, has)
+            assert relerr(tgn.memory.msg_table.cpu().numpy()[has], tab[has]) < RTOL_EMB
+        opt.step()
+    # the masks matter: the same step replayed WITHOUT them is far outside the bar (the test would notice a no-op dropout)
+    ref.dropout_masks = None
+    ref.P = {k: tgn.state_dict()[k].detach().cpu().numpy().copy() for k in names}
+    tgn.train()
+    se, de, ne = tgn.compute_temporal_embeddings(sb, db, neg, tb, eb, K, draws=draws)
+    rse, _, _ = ref.compute_temporal_embeddings(sb, db, neg, tb, eb, K, draws=None if odraws is None else list(odraws))
+    assert relerr(se.detach().cpu().numpy(), rse) > 10 * RTOL_EMB
+
+
+def test_step_against_reference_golden_at_dropout_01():
+    """g8: one training step of the REFERENCE itself in train mode at dropout 0.1 (main.py's default), with the multipliers
+    its own F.dropout applied captured per attention call.  The product takes them as injected decisions
+    (pfo_tgn_batch.dropout_keep, the dropout counterpart of the uniform sampler's injected draws) and must land on the
+    reference's embeddings (1e-4), loss, every parameter gradient (5e-4; time encoder 3e-3) and memory state."""
+    from conftest import load_golden
+    from test_gpu_tgn_step import inject
+    g = load_golden("g8_dropout")
+    L, H, K = int(g["step_L"]), int(g["step_H"]), int(g["step_K"])
+    nf = P.NeighborFinder.from_arrays(g["src_all"], g["dst_all"], g["eidx_all"], g["ts_all"], uniform=False)
+    D = g["node_features"].shape[1]
+    tgn = P.TGN(nf, g["node_features"], g["edge_features"], DEV, n_layers=L, n_heads=H, dropout=float(g["step_p"]), use_memory=True,
+                memory_dimension=D, message_function="identity", n_neighbors=K)
+    inject(tgn, g, "s_")
+    sb, db, tb, eb, neg = g["s_src"], g["s_dst"], g["s_ts"], g["s_eidx"], g["s_neg"]
+    B = len(sb)
+    masks = {1: g["s_drop_l1"], 2: g["s_drop_l2"]}
+    tgn.train()
+    se, de, ne = tgn.compute_temporal_embeddings(sb, db, neg.flatten(), tb, eb, K, dropout_keep=masks)
+    for got, key in ((se, "emb_src"), (de, "emb_dst"), (ne, "emb_neg")):
+        e = relerr(got.detach().cpu().numpy(), g["s_" + key])
+        assert e < RTOL_EMB, (key, e)
+    emb = torch.cat([se, de, ne])
+    loss = P.bpr_loss(emb, B, 3)
+    assert abs(float(loss) - float(g["s_loss"])) < 1e-5 * max(1.0, abs(float(g["s_loss"])))
+    loss.backward()
+    n_checked = 0
+    params = dict(tgn.named_parameters())
+    for k in g.files:
+        if not k.startswith("s_grad_"):
+            continue
+        name = k[len("s_grad_"):]
+        if "layer_norm" in name or name.startswith("memory."):
+            continue
+        ref = g[k]
+        got = params[name].grad.cpu().numpy()
+        if np.abs(ref).max() < 1e-7:
+            assert np.abs(got).max() < 1e-6, name
+            continue
+        e = relerr(got, ref)
+        assert e < (3e-3 if name.startswith("time_encoder") else 5e-4), (name, e)
+        n_checked += 1
+    assert n_checked >= 20
+    assert relerr(tgn.memory.memory.cpu().numpy(), g["s_after_memory"]) < RTOL_EMB
+    assert np.array_equal(tgn.memory.last_update.cpu().numpy(), g["s_after_last_update"])
+    has = g["s_after_msg_cnt"] > 0
+    assert np.array_equal(tgn.memory.has_msg.cpu().numpy() > 0, has)
+    assert relerr(tgn.memory.msg_table.cpu().numpy()[has], g["s_after_msg_tab"][has]) < RTOL_EMB
+    # the injected decisions are what ran: without them (the step's own Philox masks) the embeddings are far off
+    inject(tgn, g, "s_")
+    with torch.no_grad():
+        m = tgn.memory
+        m.memory.copy_(torch.from_numpy(g["s_sd_memory.memory"])); m.last_update.copy_(torch.from_numpy(g["s_sd_memory.last_update"]))
+    se2, _, _ = tgn.compute_temporal_embeddings(sb, db, neg.flatten(), tb, eb, K)
+    assert relerr(se2.detach().cpu().numpy(), g["s_emb_src"]) > 10 * RTOL_EMB

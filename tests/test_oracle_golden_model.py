@@ -149,3 +149,75 @@ def test_g5_full_step(tag):
             cnt = np.array([len(tgn.messages.get(i, [])) for i in range(tgn.n_nodes)])
             touched = np.zeros(tgn.n_nodes, bool); touched[np.concatenate([sb, db])] = True
             assert np.array_equal(cnt[touched], g[pre + "after_msg_cnt"][touched])
+
+
+# ------------------------------------------------------------------ g8: train-mode attention dropout (the benched setting, round 4)
+def _att_params_pre(g, pre):
+    p = pre + "p_"
+    return dict(Wq=g[p + "multi_head_target.q_proj_weight"], Wk=g[p + "multi_head_target.k_proj_weight"],
+                Wv=g[p + "multi_head_target.v_proj_weight"], b_in=g[p + "multi_head_target.in_proj_bias"],
+                Wo=g[p + "multi_head_target.out_proj.weight"], bo=g[p + "multi_head_target.out_proj.bias"],
+                W1=g[p + "merger.fc1.weight"], b1=g[p + "merger.fc1.bias"], W2=g[p + "merger.fc2.weight"], b2=g[p + "merger.fc2.bias"])
+
+
+@pytest.mark.parametrize("tag", ["p10", "p50"])
+def test_g8_attention_layer_with_dropout(tag):
+    """TemporalAttentionLayer in train mode (nn.MultiheadAttention dropout on the softmax weights, temporal_attention.py:28,70)
+    with the reference's own dropout multipliers injected: forward, input gradients and every parameter gradient."""
+    g = load_golden("g8_dropout")
+    pre = "att_%s_" % tag
+    p = _att_params_pre(g, pre)
+    H, D = int(g["H"]), int(g["D"])
+    drop = g[pre + "drop"]
+    pd = float(g[pre + "p"])
+    assert all(min(abs(float(v)), abs(float(v) - 1 / (1 - pd))) < 1e-5 for v in np.unique(drop)) and (drop == 0).any()
+    out, c = T.attention_forward(p, g[pre + "x"], g[pre + "tq"], g[pre + "nb"], g[pre + "ef"], g[pre + "tn"], g[pre + "mask"], H, drop)
+    assert relerr(out, g[pre + "out"]) < 1e-5
+    out0, _ = T.attention_forward(p, g[pre + "x"], g[pre + "tq"], g[pre + "nb"], g[pre + "ef"], g[pre + "tn"], g[pre + "mask"], H)
+    assert relerr(out0, g[pre + "out"]) > 1e-3                 # the mask matters: without it the outputs differ
+    grads, dx, dtq, dnb, dte = T.attention_backward(p, c, g[pre + "go"], H, D)
+    assert relerr(dx, g[pre + "gx"]) < 1e-5 and relerr(dnb, g[pre + "gnb"]) < 1e-5
+    assert relerr(dte, g[pre + "gtn"]) < 1e-5 and relerr(dtq, g[pre + "gtq"]) < 1e-5
+    for k, name in T._LAYER_KEYS.items():
+        assert relerr(grads[k], g[pre + "g_" + name]) < 1e-5, name
+
+
+def test_g8_full_step_with_dropout():
+    """One training step of the 2-layer TGN with memory at dropout 0.1 (main.py --drop_out default), the reference's three
+    dropout masks injected in level order: embeddings, loss, every parameter gradient, memory state machine."""
+    g = load_golden("g8_dropout")
+    L, H, K = int(g["step_L"]), int(g["step_H"]), int(g["step_K"])
+    nf = OracleNeighborFinder(*build_adjacency(g["src_all"], g["dst_all"], g["eidx_all"], g["ts_all"]), uniform=False)
+    tgn = T.OracleTGN(nf, g["node_features"], g["edge_features"], {}, L, H, use_memory=True)
+    _load_state(g, "s_", tgn, True)
+    tgn.dropout_masks = {1: g["s_drop_l1"], 2: g["s_drop_l2"]}
+    sb, db, tb, eb, neg = g["s_src"], g["s_dst"], g["s_ts"], g["s_eidx"], g["s_neg"]
+    B = len(sb)
+    se, de, ne = tgn.compute_temporal_embeddings(sb, db, neg.flatten(), tb, eb, K)
+    for got, key in ((se, "emb_src"), (de, "emb_dst"), (ne, "emb_neg")):
+        assert relerr(got, g["s_" + key]) < RTOL, (key, relerr(got, g["s_" + key]))
+    loss, cache = T.bpr_loss(se, de.reshape(B, 1, -1), ne.reshape(B, 3, -1))
+    assert abs(loss - g["s_loss"]) < 1e-5 * max(1.0, abs(g["s_loss"]))
+    d_src, d_pos, d_neg = T.bpr_loss_backward(cache)
+    grads = tgn.backward(np.concatenate([d_src, d_pos.reshape(B, -1), d_neg.reshape(3 * B, -1)]))
+    n_checked = 0
+    for k in g.files:
+        if k.startswith("s_grad_"):
+            name = k[len("s_grad_"):]
+            if "layer_norm" in name or name.startswith("memory."):
+                continue
+            ref = g[k]
+            if np.abs(ref).max() == 0:
+                continue
+            assert relerr(grads[name].reshape(ref.shape), ref) < 5e-4, (name, relerr(grads[name].reshape(ref.shape), ref))
+            n_checked += 1
+    assert n_checked >= 20
+    assert relerr(tgn.memory, g["s_after_memory"]) < RTOL
+    assert np.array_equal(tgn.last_update, g["s_after_last_update"])
+    tab, mt, has = tgn.pending_table()
+    assert np.array_equal(has, g["s_after_msg_cnt"] > 0) and relerr(tab, g["s_after_msg_tab"]) < RTOL
+    # without the masks the embeddings are off by far more than the bar: the fixture does pin the dropout algebra
+    _load_state(g, "s_", tgn, True)
+    tgn.dropout_masks = None
+    se0, _, _ = tgn.compute_temporal_embeddings(sb, db, neg.flatten(), tb, eb, K)
+    assert relerr(se0, g["s_emb_src"]) > 1e-3

@@ -7,7 +7,7 @@ reference's outputs.  The fixtures are data only - no reference source text is
 stored.  The inline MV block of main.py (not importable: wandb/CUDA/data files)
 is executed in place from the reference tree, as SURVEY.md App. E describes.
 
-Usage:  python tools/make_golden.py [g1 g2 g3 g4 g5 g6 g7]      (default: all)
+Usage:  python tools/make_golden.py [g1 g2 g3 g4 g5 g6 g7 g8]      (default: all)
 Library versions used are recorded in each fixture (``versions``).
 """
 import os
@@ -456,9 +456,129 @@ def g7():
          cand_len=np.array(shapes), features=np.concatenate(feats), mus=np.concatenate(mus))
 
 
+# ------------------------------------------------------------------ G8: train-mode attention dropout (the benched setting)
+class DropoutLog:
+    """Runs the reference with torch.nn.functional.dropout wrapped: the REAL dropout is called and the multiplier it applied
+    is read off its result (1/(1-p) where the weight survived, 0 where it was dropped; entries whose input is 0 - masked
+    keys - are recorded as kept: they contribute nothing either way).  nn.MultiheadAttention's explicit path
+    (need_weights=True, temporal_attention.py:70) calls it on the softmax weights [N*H, 1, K], row n*H + h."""
+
+    def __init__(self):
+        import torch.nn.functional as F
+        self.F, self.real, self.masks = F, F.dropout, []
+
+    def __enter__(self):
+        def rec(input, p=0.5, training=True, inplace=False):
+            out = self.real(input, p, training, False)
+            if training and p > 0:
+                kept = (out != 0) | (input == 0)
+                self.masks.append((kept.float() / (1.0 - p)).numpy().copy())
+            return out
+        self.F.dropout = rec
+        return self
+
+    def __exit__(self, *a):
+        self.F.dropout = self.real
+
+
+def g8():
+    R = ref_modules()
+    out = {}
+    # (a) the layer alone, two rates, all-padding rows and partial masks as in g4
+    for tag, pdrop in (("p10", 0.1), ("p50", 0.5)):
+        torch.manual_seed(3); rs = np.random.RandomState(3)
+        D, Ef, K, N, H = 12, 4, 6, 40, 2
+        att = R.TemporalAttentionLayer(D, D, Ef, D, output_dimension=D, n_head=H, dropout=pdrop)
+        att.train()
+        with torch.no_grad():
+            att.multi_head_target.in_proj_bias.normal_(0, 0.2); att.multi_head_target.out_proj.bias.normal_(0, 0.2)
+        xs = torch.randn(N, D, requires_grad=True); tq = torch.randn(N, 1, D, requires_grad=True)
+        nb = torch.randn(N, K, D, requires_grad=True); tn = torch.randn(N, K, D, requires_grad=True); ef = torch.randn(N, K, Ef)
+        mask = torch.zeros(N, K, dtype=torch.bool)
+        mask[:8] = True
+        for i in range(8, 24):
+            mask[i, :rs.randint(1, K)] = True
+        with DropoutLog() as log:
+            o, wts = att(xs, tq, nb, tn, ef, mask.clone())
+        assert len(log.masks) == 1 and log.masks[0].shape == (N * H, 1, K)
+        go = torch.randn(N, D)
+        o.backward(go)
+        pre = "att_%s_" % tag
+        out.update({pre + "p": np.array(pdrop), pre + "drop": log.masks[0].reshape(N, H, K),
+                    pre + "x": xs.detach().numpy(), pre + "tq": tq.detach().numpy()[:, 0], pre + "nb": nb.detach().numpy(),
+                    pre + "tn": tn.detach().numpy(), pre + "ef": ef.numpy(), pre + "mask": mask.numpy(),
+                    pre + "out": o.detach().numpy(), pre + "go": go.numpy(),
+                    pre + "gx": xs.grad.numpy(), pre + "gtq": tq.grad.numpy()[:, 0], pre + "gnb": nb.grad.numpy(), pre + "gtn": tn.grad.numpy(),
+                    **{pre + "p_" + k: v.detach().numpy() for k, v in att.named_parameters()},
+                    **{pre + "g_" + k: v.grad.numpy() for k, v in att.named_parameters()}})
+    out.update(D=np.array(12), Ef=np.array(4), K=np.array(6), H=np.array(2))
+    # (b) one full training step of a 2-layer TGN with memory at dropout 0.1 (main.py:33 default --drop_out 0.1), state
+    # injected like g5; the masks of the three attention calls in call order (layer 1 on the roots, layer 1 on their
+    # neighbours, layer 2 on the roots: embedding_module.py:115,141,159)
+    torch.manual_seed(2); np.random.seed(2)
+    cfg = SyntheticConfig("g8", 120, 20, 1500, 16, 2, 5, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    D, Ef, K, B, n, L, H = cfg.dim, cfg.edge_dim, cfg.n_neighbors, 24, g.n_nodes, 2, 2
+    M = 3 * D + Ef
+    rdata = R.Data(d.sources, d.destinations, d.timestamps, d.edge_idxs, d.labels, d.portfolios)
+    nf = R.get_neighbor_finder(rdata, uniform=False)
+    tgn = R.TGN(neighbor_finder=nf, node_features=g.node_features, edge_features=g.edge_features.copy(), device=torch.device("cpu"),
+                n_layers=L, n_heads=H, dropout=0.1, use_memory=True, message_dimension=100, memory_dimension=D,
+                memory_update_at_start=True, embedding_module_type="graph_attention", message_function="identity",
+                aggregator_type="last", memory_updater_type="gru", n_neighbors=K)
+    with torch.no_grad():
+        tgn.time_encoder.w.bias.copy_(torch.randn(D) * 0.3)
+    opt = torch.optim.Adam(tgn.parameters(), lr=1e-3)
+    rs = np.random.RandomState(4)
+    out.update(step_L=np.array(L), step_H=np.array(H), step_K=np.array(K), step_p=np.array(0.1),
+               src_all=d.sources, dst_all=d.destinations, ts_all=d.timestamps, eidx_all=d.edge_idxs,
+               node_features=g.node_features, edge_features=g.edge_features)
+    for step in range(3):
+        s = 700 + step * B
+        sb, db, tb, eb = d.sources[s:s + B], d.destinations[s:s + B], d.timestamps[s:s + B], d.edge_idxs[s:s + B]
+        neg = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=(B, 3))
+        record = step == 2
+        if record:
+            for k, v in tgn.state_dict().items():
+                if not (k.startswith("memory_updater.memory.") or k.startswith("embedding_module.memory.")
+                        or k.startswith("embedding_module.time_encoder.")):
+                    out["s_sd_" + k] = v.detach().numpy().copy()
+            tab, mt, cnt = dense_messages(tgn, n, M)
+            out.update(s_msg_tab=tab, s_msg_t=mt, s_msg_cnt=cnt)
+        tgn.train(); opt.zero_grad()
+        with DropoutLog() as log:
+            se, de, ne = tgn.compute_temporal_embeddings(sb, db, neg.flatten(), tb, eb, K)
+        bs = se.shape[0]
+        pos_scores = torch.sum(se.view(bs, 1, -1) * de.view(bs, 1, -1), dim=2)
+        neg_scores = torch.matmul(se.view(bs, 1, -1), ne.view(bs, 3, -1).transpose(1, 2)).squeeze()
+        loss = -torch.mean(torch.log(torch.sigmoid(torch.mean(pos_scores - neg_scores, dim=1))))
+        loss.backward()
+        if record:
+            Rr = 5 * B
+            assert [m.shape[0] for m in log.masks] == [Rr * H, Rr * K * H, Rr * H], [m.shape for m in log.masks]
+            out.update(s_src=sb, s_dst=db, s_ts=tb, s_eidx=eb, s_neg=neg,
+                       s_drop_l1=np.concatenate([log.masks[0].reshape(Rr, H, K), log.masks[1].reshape(Rr * K, H, K)]),
+                       s_drop_l2=log.masks[2].reshape(Rr, H, K),
+                       s_emb_src=se.detach().numpy(), s_emb_dst=de.detach().numpy(), s_emb_neg=ne.detach().numpy(),
+                       s_loss=np.array(loss.item(), np.float32))
+            for k, v in tgn.named_parameters():
+                if v.requires_grad:
+                    out["s_grad_" + k] = (v.grad.numpy().copy() if v.grad is not None else np.zeros(v.shape, np.float32))
+        opt.step()
+        tgn.memory.detach_memory()
+        if record:
+            tab, mt, cnt = dense_messages(tgn, n, M)
+            out.update(s_after_memory=tgn.memory.memory.detach().numpy().copy(),
+                       s_after_last_update=tgn.memory.last_update.detach().numpy().copy(),
+                       s_after_msg_tab=tab, s_after_msg_t=mt, s_after_msg_cnt=cnt)
+    save("g8_dropout", **out)
+
+
+
 if __name__ == "__main__":
     import warnings
     warnings.filterwarnings("ignore")
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for w in which:
         globals()[w]()
