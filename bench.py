@@ -89,6 +89,10 @@ def parse():
                          "after the current forward (TGN.prefetch); 0 (default): inside the step, as the reference's call order "
                          "has it.  Measured on C2: 1.52 ms with, 1.50 without - the ~70 us of small launches cost as much beside "
                          "the backward's first kernels as they do at the head of the step (DESIGN 4.2)")
+    ap.add_argument("--marks", type=int, default=0,
+                    help="after the timed region run this many extra steps with the library's milestones on (timing events on the "
+                         "caller's stream at named points of the step: the critical path as the GPU ran it, no tracer) and print the "
+                         "per-segment means to stderr")
     ap.add_argument("--prof-every", type=int, default=8,
                     help="bracket the kernel launches of every Nth timed step with HIP events (the brackets cost ~0.2 ms "
                          "per step at C2, so the roofline sample is taken on a subset of the timed steps)")
@@ -354,6 +358,8 @@ class Workload:
         P, torch, tgn, cfg, B, n_neg = self.P, self.torch, self.tgn, self.cfg, self.B, self.n_neg
         lo = self.start + (i * B) % self.span
         sl = slice(lo, lo + B)
+        from pfotgnrec_amd import _lib as _lm
+        _lm.mark("step.begin")
         if self.gstep is not None:
             from pfotgnrec_amd import _lib as _l
             return (self.gstep.eager if _l.prof_is_on() else self.gstep)(*self._batch(sl))   # bracketed steps run kernel by kernel
@@ -386,7 +392,9 @@ class Workload:
             pos_block = 2                                                                                      # main.py:321-337
         # loss + loss.backward() (main.py:337,388) as two native calls: the loss kernel hands its gradient rows straight to
         # the TGN backward (P.bpr_loss(...).backward() is the autograd spelling of the same thing, tests/test_gpu_round2.py)
+        _lm.mark("step.embedded")
         loss = P.bpr_step(tgn, emb, b, n_neg, pos_block=pos_block)
+        _lm.mark("step.backward_done")
         if self.dist_on and (self.world > 1 or self.force_dist):     # (set_world(0, 1): rank 0 alone, no collective)
             ev = None
             if self.time_collective:                          # sampled steps: the collective bracketed by events on the caller's stream
@@ -400,6 +408,7 @@ class Workload:
                 ev[1].record()
                 self.coll_events.append(ev)
         self.opt.step()                                                                                        # main.py:389
+        _lm.mark("step.adam")
         self.opt.zero_grad(set_to_none=True)
         return loss
 
@@ -636,6 +645,17 @@ def main():
     elapsed, n_timed, blocks, final_loss, n_prof_steps = wl.timed(args.steps, args.warmup, args.min_seconds, prof_every)
     prof = _lib.prof_collect() if not args.no_prof else None
     _lib.prof_enable(False)
+    if args.marks > 0:
+        for k in range(5):
+            wl.step(900000 + k)
+        torch.cuda.synchronize()
+        _lib.marks_enable(True)
+        for k in range(args.marks):
+            wl.step(900005 + k)
+        torch.cuda.synchronize()
+        _lib.marks_enable(False)
+        if rank == 0:
+            sys.stderr.write("milestones (mean over %d steps, caller's stream):\n%s" % (args.marks, _lib.marks_dump()))
     B = wl.B
     value = n_timed * B / elapsed
     out = {

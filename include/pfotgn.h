@@ -256,6 +256,17 @@ typedef struct pfo_tgn_state {
   float* msg_time;          /* [n_nodes] */
   uint8_t* has_msg;         /* [n_nodes] */
   const float* params;      /* flat, pfo_tgn_layout */
+  /* Parameter cache (optional, abi 3): a caller-owned device buffer of pfo_tgn_pcache_bytes(cfg) bytes that holds
+     everything the step derives from the PARAMETERS alone - the composite weights of every layer (Wqk, cqk, W1ov^T, the
+     fc2-folded forms), cos(b) and the fp16 weight images of all contractions incl. the GRU's.  The reference re-reads
+     nn.Linear weights per batch and recomputes nothing (tgn.py:219-327); here that work is ~15 small dependent launches,
+     so it is done once per parameter VERSION: with pcache_valid == 0 pfo_tgn_forward builds the cache (side stream, as it
+     did per step before), with pcache_valid != 0 it launches none of it.  The caller owns the validity: it must pass 0
+     after anything wrote `params` (optimizer step, load_state_dict ...) unless pfo_tgn_refresh ran since.  pfo_tgn_backward
+     reads the composites from the same buffer: parameters must not change between a forward and its backward.
+     NULL: the composites live in the workspace and are rebuilt by every forward. */
+  void* pcache;
+  int32_t pcache_valid;
 } pfo_tgn_state;
 
 typedef struct pfo_tgn_batch {
@@ -348,6 +359,14 @@ typedef struct pfo_tgn_debug {
 } pfo_tgn_debug;
 int pfo_tgn_debug_views(const pfo_tgn_config* cfg, void* workspace, pfo_tgn_debug* out);
 
+/* Parameter cache (pfo_tgn_state.pcache): its size, and the call that (re)builds it from state->params on the library's
+ * side stream, forked from `stream` and NOT joined back - the next pfo_tgn_forward with pcache_valid = 1 queues its own
+ * side-stream work behind it, so the caller's stream never waits for the build itself.  Meant to be called right behind the
+ * optimizer's kernel: the build then runs beside the next batch's sampling phase.  Not capturable into a HIP graph
+ * (unjoined fork): a captured step passes pcache_valid = 0 instead. */
+int64_t pfo_tgn_pcache_bytes(const pfo_tgn_config* cfg);
+int pfo_tgn_refresh(const pfo_tgn_config* cfg, const pfo_tgn_state* state, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Live per-kernel timing with HIP events on the launch stream (bench.py roofline numbers).
  * While enabled every launch of the kinds below is bracketed by an event pair; pfo_prof_collect
@@ -367,6 +386,14 @@ int pfo_tgn_debug_views(const pfo_tgn_config* cfg, void* workspace, pfo_tgn_debu
 #define PFO_PROF_ATTN_BWD_RUNS 10 /* layer-1 attention backward, run-merged kernel (attn_bwd_runs_kernel)  */
 #define PFO_PROF_GRU_FUSED 11 /* gru_fused_kernel: both GRUCell contractions + gates (flops = per-row FLOPs x touched rows read back) */
 #define PFO_PROF_KINDS 12
+/* Milestones: while enabled (pfo_marks_enable(1)) the step's native calls record a timing event on the CALLER's stream at
+ * named points of the critical path (sampling done, lazy GRU done, every large launch of every layer ...; callers may add
+ * their own with pfo_mark).  pfo_marks_dump waits for them and writes one line per consecutive pair "from -> to  mean_us  n"
+ * in first-seen order: the segments of the caller's stream as the GPU ran them, WITHOUT a tracer slowing the host down.
+ * ~1 us per mark; off by default. */
+int pfo_marks_enable(int32_t on);
+int pfo_mark(const char* name /* static string */, void* stream);
+int64_t pfo_marks_dump(char* out, int64_t cap); /* HOST buffer; returns the bytes written (0-terminated), clears the records */
 int pfo_prof_enable(int32_t on);
 int pfo_prof_collect(double* ms, double* work, int64_t* count); /* HOST arrays of PFO_PROF_KINDS entries */
 

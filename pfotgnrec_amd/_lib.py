@@ -33,7 +33,7 @@ class TgnLayout(C.Structure):
 
 class TgnState(C.Structure):
     _fields_ = [(n, _VP) for n in ("indptr", "adj_nbr", "adj_eidx", "adj_ts", "node_feat", "edge_feat", "memory",
-                                   "last_update", "msg_table", "msg_time", "has_msg", "params")]
+                                   "last_update", "msg_table", "msg_time", "has_msg", "params", "pcache")] + [("pcache_valid", C.c_int32)]
 
 
 class TgnBatch(C.Structure):
@@ -90,6 +90,8 @@ PROTOTYPES = {
                                            C.POINTER(C.c_int32), _VP, C.c_float, C.c_float, C.c_float, C.c_float, _VP]),
     "pfo_tgn_param_layout": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnLayout)]),
     "pfo_tgn_workspace_bytes": (C.c_int64, [C.POINTER(TgnConfig)]),
+    "pfo_tgn_pcache_bytes": (C.c_int64, [C.POINTER(TgnConfig)]),
+    "pfo_tgn_refresh": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), _VP]),
     "pfo_tgn_forward": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP]),
     "pfo_tgn_prepare": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP]),
     "pfo_tgn_backward": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP, _VP]),
@@ -100,11 +102,36 @@ PROTOTYPES = {
                                        _VP]),
     "pfo_tgn_debug_views": (C.c_int, [C.POINTER(TgnConfig), _VP, C.POINTER(TgnDebug)]),
     "pfo_prof_enable": (C.c_int, [C.c_int32]),
+    "pfo_marks_enable": (C.c_int, [C.c_int32]),
+    "pfo_mark": (C.c_int, [C.c_char_p, _VP]),
+    "pfo_marks_dump": (C.c_int64, [C.c_char_p, C.c_int64]),
     "pfo_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 PROF_KINDS = ["gemm_nt", "gemm_nn", "gemm_tn", "gemm_devm", "attn_fwd", "attn_bwd", "sampler", "gemm_bx", "gemm_tn_bx", "gemm_bx_skinny",
               "attn_bwd_runs", "gru_fused"]
+
+
+_MARK_NAMES = {}
+
+
+def mark(name):
+    """A milestone on the current stream (no-op unless ``marks_enable(True)``); the C side keeps the pointer, so the bytes
+    object of every name is kept alive here."""
+    b = _MARK_NAMES.get(name)
+    if b is None:
+        b = _MARK_NAMES[name] = C.c_char_p(name.encode())
+    load().pfo_mark(b, stream_ptr())
+
+
+def marks_enable(on):
+    call("pfo_marks_enable", 1 if on else 0)
+
+
+def marks_dump():
+    buf = C.create_string_buffer(1 << 16)
+    load().pfo_marks_dump(buf, len(buf))
+    return buf.value.decode()
 
 
 _PROF_ON = [False]

@@ -34,6 +34,11 @@ void pfo_prof_end(int kind, double work, hipStream_t s);
 // work = work_per_unit * min(*units_dev, units_cap): launches whose extent is a device-side count (read back at collect time)
 void pfo_prof_end_dev(int kind, double work_per_unit, const int32_t* units_dev, int units_cap, hipStream_t s);
 
+// milestones on the caller's stream (include/pfotgn.h pfo_marks_*): no-op unless enabled
+bool pfo_marks_on();
+void pfo_mark_at(const char* name, hipStream_t s);
+#define PFO_MARK(name, s) do { if (pfo_marks_on()) pfo_mark_at(name, s); } while (0)
+
 // Named ranges for `rocprofv3 --marker-trace` (tracing hooks): roctxRangePushA / roctxRangePop are looked up in
 // the process at first use (the profiler preloads librocprofiler-sdk-roctx.so; an application may link libroctx64 itself) -
 // no link dependency, and a no-op pointer test when no tracer is present.

@@ -93,6 +93,55 @@ extern "C" int pfo_prof_collect(double* ms, double* work, int64_t* count) {
   g_pin_next = 0;
   return PFO_OK;
 }
+// ---------------------------------------------------------------------------------------------
+// milestones (include/pfotgn.h)
+#include <map>
+#include <string>
+namespace {
+struct MarkRec { const char* name; hipEvent_t ev; };
+bool g_marks_on = false;
+std::vector<MarkRec> g_marks;
+std::vector<hipEvent_t> g_mark_pool;
+}  // namespace
+bool pfo_marks_on() { return g_marks_on; }
+void pfo_mark_at(const char* name, hipStream_t s) {
+  if (!g_marks_on || g_marks.size() >= 200000) return;
+  hipEvent_t e = nullptr;
+  if (!g_mark_pool.empty()) { e = g_mark_pool.back(); g_mark_pool.pop_back(); }
+  else if (hipEventCreate(&e) != hipSuccess) return;
+  if (hipEventRecord(e, s) != hipSuccess) { g_mark_pool.push_back(e); return; }
+  g_marks.push_back(MarkRec{name, e});
+}
+extern "C" int pfo_marks_enable(int32_t on) { g_marks_on = on != 0; return PFO_OK; }
+extern "C" int pfo_mark(const char* name, void* stream) { pfo_mark_at(name, (hipStream_t)stream); return PFO_OK; }
+extern "C" int64_t pfo_marks_dump(char* out, int64_t cap) {
+  if (!out || cap <= 0) return 0;
+  (void)hipDeviceSynchronize();
+  std::vector<std::string> order;
+  std::map<std::string, std::pair<double, int64_t>> acc;
+  for (size_t i = 1; i < g_marks.size(); ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_marks[i - 1].ev, g_marks[i].ev) != hipSuccess) continue;
+    std::string key = std::string(g_marks[i - 1].name) + " -> " + g_marks[i].name;
+    auto it = acc.find(key);
+    if (it == acc.end()) { order.push_back(key); acc[key] = {ms, 1}; }
+    else { it->second.first += ms; it->second.second += 1; }
+  }
+  for (auto& m : g_marks) g_mark_pool.push_back(m.ev);
+  g_marks.clear();
+  int64_t n = 0;
+  for (auto& k : order) {
+    char line[256];
+    const int len = snprintf(line, sizeof(line), "%-44s %9.2f us  n=%lld\n", k.c_str(), 1e3 * acc[k].first / (double)acc[k].second,
+                             (long long)acc[k].second);
+    if (len <= 0 || n + len >= cap) break;
+    memcpy(out + n, line, (size_t)len);
+    n += len;
+  }
+  out[n] = 0;
+  return n;
+}
+
 extern "C" int pfo_abi_version(void) { return 3; }   // 3: pfo_tgn_batch.dropout_keep, pfo_attn_dropout_mask, PFO_PROF_GRU_FUSED
 
 // ---------------------------------------------------------------------------------------------

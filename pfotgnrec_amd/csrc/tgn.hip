@@ -61,7 +61,10 @@ struct Ws {
   double *dtime, *fold_scratch, *dtime_slab;
   int32_t* tickets;
   int64_t slab_floats;
+  // cleared per step: [zero | tickets | dtime] (zero_bytes); cleared per composite build: pz = [64 zero floats | Wqk, W1ovT, cqk
+  // of every layer] (pz_bytes) - in the workspace right behind the per-step region, or in the parameter cache
   size_t zero_bytes, mark_bytes;
+  float* pz; size_t pz_bytes;
   int64_t bytes;
 };
 
@@ -105,9 +108,13 @@ Ws carve(const pfo_tgn_config* c, void* base) {
       w.dt[l] = take<float>(p, d.ncap[l] * Km);
     }
   }
-  // one memset per step clears [zero | tickets | Wqk, W1ovT, cqk of every layer] (the composites are accumulated into)
+  // one memset per step clears [zero | tickets | dtime]; a composite build clears pz = [64 floats | Wqk, W1ovT, cqk of every
+  // layer] (padding rows / columns of the composites must be zero; with a parameter cache pz lives there: pcache_bind)
   w.zero = take<float>(p, 64);
   w.tickets = take<int32_t>(p, 64);
+  w.dtime = take<double>(p, (int64_t)pfo_attn_bwd_max_parts() * 2 * d.D);      // time-encoder gradient bins, also cleared per step
+  w.zero_bytes = (size_t)(p - reinterpret_cast<char*>(w.zero));
+  w.pz = take<float>(p, 64);
   for (int l = 1; l <= d.L; ++l) {
     LayerWs& lw = w.layer[l];
     lw.Wqk = take<float>(p, (int64_t)d.H * d.Cp * d.D);
@@ -116,8 +123,7 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     lw.cqk = take<float>(p, (int64_t)d.H * d.Cp + (l == 1 ? d.D : 0));
   }
   w.l1_bias = w.layer[1].cqk;
-  w.dtime = take<double>(p, (int64_t)pfo_attn_bwd_max_parts() * 2 * d.D);      // time-encoder gradient bins, also cleared per step
-  w.zero_bytes = (size_t)(p - reinterpret_cast<char*>(w.zero));
+  w.pz_bytes = (size_t)(p - reinterpret_cast<char*>(w.pz));
   w.cosb = take<float>(p, d.D);
   w.tb_part = take<float>(p, d.D);
   {
@@ -212,6 +218,45 @@ Ws carve(const pfo_tgn_config* c, void* base) {
   return w;
 }
 
+// The parameter cache (pfo_tgn_state.pcache): every buffer of `w` that depends on the parameters alone is re-pointed into
+// `base` (same sizes as in the workspace, which keeps its own - then unused - copies).  Returns the cache's size.
+int64_t pcache_bind(const pfo_tgn_config* c, void* base, Ws& w) {
+  const Dims d = dims_of(c);
+  char* p = reinterpret_cast<char*>(base);
+  const int HCp = d.H * d.Cp, WQ = HCp + d.D;
+  const int64_t HCpD = (int64_t)HCp * d.D, DD = (int64_t)d.D * d.D;
+  w.pz = take<float>(p, 64);
+  for (int l = 1; l <= d.L; ++l) {
+    LayerWs& lw = w.layer[l];
+    lw.Wqk = take<float>(p, HCpD);
+    lw.W1ovT = take<float>(p, HCpD);
+    lw.cqk = take<float>(p, (int64_t)HCp + (l == 1 ? d.D : 0));
+  }
+  w.l1_bias = w.layer[1].cqk;
+  w.pz_bytes = (size_t)(p - reinterpret_cast<char*>(w.pz));
+  w.cosb = take<float>(p, d.D);
+  w.iQX = take<char>(p, pfo_bimg_bytes(WQ, d.D));
+  if (c->use_memory) {
+    w.iWih = take<char>(p, pfo_gru_img_bytes(d.D, d.M));
+    w.iWhh = take<char>(p, pfo_gru_img_bytes(d.D, d.D));
+  }
+  for (int l = 1; l <= d.L; ++l) {
+    LayerWs& lw = w.layer[l];
+    lw.cq = take<float>(p, d.E);
+    lw.W1oT = take<float>(p, (int64_t)d.E * d.D);
+    lw.iWqk = take<char>(p, pfo_bimg_bytes(HCp, d.D));   lw.iWqkT = take<char>(p, pfo_bimg_bytes(d.D, HCp));
+    lw.iW1ovT = take<char>(p, pfo_bimg_bytes(HCp, d.D)); lw.iW1ov = take<char>(p, pfo_bimg_bytes(d.D, HCp));
+    lw.iW1b = take<char>(p, pfo_bimg_bytes(d.D, d.D));   lw.iW1bT = take<char>(p, pfo_bimg_bytes(d.D, d.D));
+    lw.iW2 = take<char>(p, pfo_bimg_bytes(d.D, d.D));    lw.iW2T = take<char>(p, pfo_bimg_bytes(d.D, d.D));
+    if (l >= 2) {
+      lw.T1 = take<float>(p, HCpD);      lw.tq = take<float>(p, HCp);
+      lw.Wqk_f = take<float>(p, HCpD);   lw.cqk_f = take<float>(p, HCp);
+      lw.W1ovT_f = take<float>(p, HCpD); lw.W1b_f = take<float>(p, DD);   lw.b1_f = take<float>(p, d.D);
+    }
+  }
+  return (int64_t)(p - reinterpret_cast<char*>(base));
+}
+
 int check_cfg(const pfo_tgn_config* c) {
   PFO_REQUIRE(c != nullptr, "null config");
   PFO_REQUIRE(c->n_layers >= 1 && c->n_layers <= PFO_MAX_LAYERS, "n_layers must be in [1, 4]");
@@ -278,7 +323,7 @@ PfoGemm g_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const int
 // dependent launches; they run beside the main stream's work and are joined by events where their results are needed.
 struct Side {
   hipStream_t s = nullptr, s2 = nullptr;
-  hipEvent_t tn_a_done = nullptr, done2 = nullptr, gru_done = nullptr, comp_done = nullptr;
+  hipEvent_t tn_a_done = nullptr, done2 = nullptr, gru_done = nullptr, comp_done = nullptr, pc_a = nullptr, pc_b = nullptr;
   hipEvent_t fork = nullptr, done = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr, fold_done = nullptr;
   hipEvent_t layer[PFO_MAX_LAYERS + 1] = {};
   bool ok = false;
@@ -302,6 +347,8 @@ Side& side() {
     good = good && hipEventCreateWithFlags(&sd.fold_done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.gru_done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.comp_done, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.pc_a, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.pc_b, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; l <= PFO_MAX_LAYERS; ++l) good = good && hipEventCreateWithFlags(&sd.layer[l], hipEventDisableTiming) == hipSuccess;
     sd.ok = good;
   }
@@ -453,6 +500,167 @@ static int prepare_compact_pack(const pfo_tgn_config* c, const pfo_tgn_state* st
   return prepare_pack(c, st, b, w, d, n, s);
 }
 
+// ---- Everything the step derives from the PARAMETERS alone, in two stages of small dependent launches on one stream
+// (pfo_tgn_forward runs them on its side stream when the parameter cache is absent or stale; pfo_tgn_refresh right behind the
+// optimizer).  Stage A: cos(b), the composite weights of every layer and the weight images layer 1 and the top layer's fc2
+// need.  Stage B ("fc2 fold"): the composites of the layers >= 2 with the fc2 of the layer below folded in, and their images.
+static int build_gru_images(const pfo_tgn_config* c, const Dims& d, const Ws& w, const Params& P, hipStream_t s) {
+  // gate-ordered rows: r | z | n_i | n_h per 16 hidden units (gemm.hip gru_fused_kernel)
+  const int D = d.D;
+  PfoBimg im[2];
+  im[0].src = P.w_ih; im[0].ld = d.M; im[0].N = 3 * D; im[0].K = d.M; im[0].trans = 0; im[0].dst = w.iWih;
+  im[1].src = P.w_hh; im[1].ld = D; im[1].N = 3 * D; im[1].K = D; im[1].trans = 0; im[1].dst = w.iWhh;
+  im[0].gate = 1; im[0].gate_D = D; im[1].gate = 2; im[1].gate_D = D;
+  (void)c;
+  return pfo_bimg_launch(im, 2, s);
+}
+static int build_stage_a(const Dims& d, const Ws& w, const Params& P, hipStream_t ss) {
+  const int L = d.L, D = d.D, H = d.H, E = d.E, C = d.C, dh = d.dh, Cp = d.Cp, HCp = d.H * d.Cp;
+  HIPOK(hipMemsetAsync(w.pz, 0, w.pz_bytes, ss), "memset failed");              // 64 zero floats | Wqk / W1ovT / cqk of every layer
+  RUN(pfo_time_encode(w.pz, 1, P.tw, P.tb, D, w.cosb, ss));                     // cos(fma(0, w, b)) (embedding_module.py:92)
+  PfoGemm st1[3 * PFO_MAX_LAYERS], st2[4 * PFO_MAX_LAYERS];
+  PfoBimg im[8 * PFO_MAX_LAYERS + 2];
+  int n1 = 0, n2 = 0, ni = 0;
+  auto img = [&](const float* src, int64_t ld, int N_, int K_, int trans, void* dst) {
+    im[ni].src = src; im[ni].ld = ld; im[ni].N = N_; im[ni].K = K_; im[ni].trans = trans; im[ni].dst = dst; ++ni;
+  };
+  for (int l = 1; l <= L; ++l) {
+    const LayerWs& lw = w.layer[l];
+    const auto& p = P.l[l];
+    PfoGemm* a1 = st1 + n1;
+    a1[0] = g_nt(w.cosb, D, nullptr, p.wq + D, E, lw.cq, E, 1, E, D, p.b_in);            // cq = Wq[:, D:] cos(b) + bq
+    a1[1] = g_nt(p.wo, E, nullptr, p.w1, E + D, lw.W1oT, D, E, D, E, nullptr);           // W1oT = Wo^T W1[:, :E]^T
+    a1[1].a_kmajor = 1;
+    a1[2] = g_nt(p.wk, C, nullptr, p.wq, E, lw.Wqk, D, C, D, dh, nullptr);               // Wqk_h = Wk_h^T Wq_h[:, :D]
+    a1[2].a_kmajor = 1; a1[2].b_kmajor = 1; a1[2].batch = H;
+    a1[2].a_bs[0] = (int64_t)dh * C; a1[2].b_bs[0] = (int64_t)dh * E; a1[2].c_bs = (int64_t)Cp * D;
+    n1 += 3;
+    PfoGemm* a2 = st2 + n2;
+    a2[0] = g_nn(lw.cq, E, p.wk, C, lw.cqk, HCp, 1, C, dh);                               // cqk_h = Wk_h^T cq_h
+    a2[0].batch = H; a2[0].a_bs[0] = dh; a2[0].b_bs[0] = (int64_t)dh * C; a2[0].c_bs = Cp;
+    a2[1] = g_nt(p.wv, C, nullptr, lw.W1oT, D, lw.W1ovT, D, C, D, dh, nullptr);           // W1ovT_h = Wv_h^T W1oT_h
+    a2[1].a_kmajor = 1; a2[1].b_kmajor = 1; a2[1].batch = H;
+    a2[1].a_bs[0] = (int64_t)dh * C; a2[1].b_bs[0] = (int64_t)dh * D; a2[1].c_bs = (int64_t)Cp * D;
+    a2[2] = g_nn(p.b_in + 2 * E, dh, lw.W1oT, D, lw.W1ovT + (int64_t)C * D, D, 1, D, dh); // row C: (W1 Wo_h bv_h)^T
+    a2[2].batch = H; a2[2].a_bs[0] = dh; a2[2].b_bs[0] = (int64_t)dh * D; a2[2].c_bs = (int64_t)Cp * D;
+    a2[3] = g_nt(p.bo, E, nullptr, p.w1, E + D, lw.W1ovT + (int64_t)(C + 1) * D, D, 1, D, E, nullptr);   // row C+1 of head 0: (W1 bo)^T
+    n2 += 4;
+    // fp16 images of this layer's weight operands, in both orientations (forward and data-gradient launches).
+    // Layers >= 2 take theirs from the fc2-folded composites (stage B).
+    if (l == 1) {
+      // layer 1 projects the touched-node table once: [Wqk ; W1[:, E:]] stacked along the output dimension
+      img(lw.Wqk, D, HCp, D, 0, w.iQX);        im[ni - 1].row0 = 0;   im[ni - 1].rows_total = HCp + D;
+      img(p.w1 + E, E + D, D, D, 0, w.iQX);    im[ni - 1].row0 = HCp; im[ni - 1].rows_total = HCp + D; im[ni - 1].last = 1;
+      img(lw.Wqk, D, D, HCp, 1, lw.iWqkT);
+      img(lw.W1ovT, D, HCp, D, 0, lw.iW1ovT);  img(lw.W1ovT, D, D, HCp, 1, lw.iW1ov);
+      img(p.w1 + E, E + D, D, D, 1, lw.iW1bT);
+    }
+    if (l == L) { img(p.w2, D, D, D, 0, lw.iW2); img(p.w2, D, D, D, 1, lw.iW2T); }   // only the top layer applies its fc2
+  }
+  for (int i = 0; i < n1; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(st1 + i, std::min(PFO_GEMM_MULTI_MAX, n1 - i), ss));
+  for (int i = 0; i < n2; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(st2 + i, std::min(PFO_GEMM_MULTI_MAX, n2 - i), ss));
+  for (int i = 0; i < ni; i += PFO_BIMG_MAX) RUN(pfo_bimg_launch(im + i, std::min(PFO_BIMG_MAX, ni - i), ss));
+  return PFO_OK;
+}
+// fc2 fold.  A layer l >= 2 reads rows of the previous layer, out = A h + b (A = W2, b = b2 of layer l-1, h = that
+// layer's h1 row).  Every use of such a row is linear, so A and b move into THIS layer's composites and the previous
+// layer's fc2 contraction over all its instances (and, backward, d h1 = d out W2 and dW2 = d out^T h1) disappears:
+//   query side   qk'_h = Q_h x + cqk_h,  x = A s + b        ->  T1_h = Q_h A,  t_h = Q_h b + cqk_h
+//   scores       qk'_h,node . (A k + b) = (A^T qk'_h,node) . k + const(j)   (the constant drops out of the softmax)
+//                                                         ->  Q_f,h = [A^T T1_h,node ; T1_h,edge|time],  c_f,h likewise from t_h
+//   context      sum_j a'_j (A k_j + b) = A c + b sum_j a'_j  ->  V_f,h,node = A^T V_h,node,  V_f,h[C] = V_h[C] + b^T V_h,node
+//   x term       W1b (A s + b)                              ->  W1b_f = W1b A,  b1_f = b1 + W1b b
+// (Q_h = Wqk_h, V_h = W1ovT_h; tiny products, two more dependent stages.)
+static int build_stage_b(const Dims& d, const Ws& w, const Params& P, hipStream_t ss) {
+  const int L = d.L, D = d.D, H = d.H, E = d.E, C = d.C, Cp = d.Cp, HCp = d.H * d.Cp;
+  if (L < 2) return PFO_OK;
+  PfoGemm f1[4 * PFO_MAX_LAYERS], f2[4 * PFO_MAX_LAYERS];
+  PfoBimg fim[6 * PFO_MAX_LAYERS];
+  int m1 = 0, m2 = 0, mi = 0;
+  const int64_t HCpD = (int64_t)HCp * D;
+  for (int l = 2; l <= L; ++l) {
+    const LayerWs& lw = w.layer[l];
+    const auto& p = P.l[l];
+    const float* A = P.l[l - 1].w2;
+    const float* bv = P.l[l - 1].b2;
+    HIPOK(hipMemcpyAsync(lw.W1ovT_f, lw.W1ovT, HCpD * sizeof(float), hipMemcpyDeviceToDevice, ss), "copy failed");
+    PfoGemm* a = f1 + m1;
+    a[0] = g_nn(lw.Wqk, D, A, D, lw.T1, D, HCp, D, D);                                    // T1 = Q A (all heads' rows)
+    a[1] = g_nt(bv, D, nullptr, lw.Wqk, D, lw.tq, HCp, 1, HCp, D, lw.cqk);               // t = Q b + cqk
+    a[2] = g_nn(p.w1 + E, E + D, A, D, lw.W1b_f, D, D, D, D);                            // W1b_f = W1b A
+    a[3] = g_nt(bv, D, nullptr, p.w1 + E, E + D, lw.b1_f, D, 1, D, D, p.b1);             // b1_f = b1 + W1b b
+    m1 += 4;
+  }
+  for (int i = 0; i < m1; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(f1 + i, std::min(PFO_GEMM_MULTI_MAX, m1 - i), ss));
+  for (int l = 2; l <= L; ++l) {
+    const LayerWs& lw = w.layer[l];
+    const float* A = P.l[l - 1].w2;
+    const float* bv = P.l[l - 1].b2;
+    HIPOK(hipMemcpyAsync(lw.Wqk_f, lw.T1, HCpD * sizeof(float), hipMemcpyDeviceToDevice, ss), "copy failed");   // edge | time rows stay
+    HIPOK(hipMemcpyAsync(lw.cqk_f, lw.tq, (size_t)HCp * sizeof(float), hipMemcpyDeviceToDevice, ss), "copy failed");
+    PfoGemm* a = f2 + m2;
+    a[0] = g_nn(A, D, lw.T1, D, lw.Wqk_f, D, D, D, D);        a[0].a_kmajor = 1;          // Q_f,node = A^T T1_node
+    a[0].batch = H; a[0].b_bs[0] = (int64_t)Cp * D; a[0].c_bs = (int64_t)Cp * D;
+    a[1] = g_nn(lw.tq, D, A, D, lw.cqk_f, D, 1, D, D);                                    // c_f,node = A^T t_node
+    a[1].batch = H; a[1].a_bs[0] = Cp; a[1].c_bs = Cp;
+    a[2] = g_nn(A, D, lw.W1ovT, D, lw.W1ovT_f, D, D, D, D);   a[2].a_kmajor = 1;          // V_f,node = A^T V_node
+    a[2].batch = H; a[2].b_bs[0] = (int64_t)Cp * D; a[2].c_bs = (int64_t)Cp * D;
+    a[3] = g_nn(bv, D, lw.W1ovT, D, lw.W1ovT_f + (int64_t)C * D, D, 1, D, D);             // V_f[C] = V[C] + b^T V_node
+    a[3].batch = H; a[3].b_bs[0] = (int64_t)Cp * D; a[3].c_bs = (int64_t)Cp * D; a[3].accumulate = 1;
+    m2 += 4;
+    auto fimg = [&](const float* src, int64_t ld, int N_, int K_, int trans, void* dst) {
+      fim[mi].src = src; fim[mi].ld = ld; fim[mi].N = N_; fim[mi].K = K_; fim[mi].trans = trans; fim[mi].dst = dst; ++mi;
+    };
+    fimg(lw.Wqk_f, D, HCp, D, 0, lw.iWqk);      fimg(lw.W1b_f, D, D, D, 0, lw.iW1b);
+    fimg(lw.Wqk_f, D, D, HCp, 1, lw.iWqkT);     fimg(lw.W1b_f, D, D, D, 1, lw.iW1bT);
+    fimg(lw.W1ovT_f, D, HCp, D, 0, lw.iW1ovT);  fimg(lw.W1ovT_f, D, D, HCp, 1, lw.iW1ov);
+  }
+  for (int i = 0; i < m2; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(f2 + i, std::min(PFO_GEMM_MULTI_MAX, m2 - i), ss));
+  for (int i = 0; i < mi; i += PFO_BIMG_MAX) RUN(pfo_bimg_launch(fim + i, std::min(PFO_BIMG_MAX, mi - i), ss));
+  return PFO_OK;
+}
+
+// =============================================================================================
+extern "C" int64_t pfo_tgn_pcache_bytes(const pfo_tgn_config* c) {
+  if (check_cfg(c) != PFO_OK) return -1;
+  Ws w;
+  memset(&w, 0, sizeof(w));
+  return pcache_bind(c, nullptr, w) + 256;
+}
+
+extern "C" int pfo_tgn_refresh(const pfo_tgn_config* c, const pfo_tgn_state* st, void* stream) {
+  if (int rc = check_cfg(c)) return rc;
+  PFO_REQUIRE(st && st->params && st->pcache, "pfo_tgn_refresh needs parameters and a parameter cache");
+  const Dims d = dims_of(c);
+  Ws w;
+  memset(&w, 0, sizeof(w));
+  pcache_bind(c, st->pcache, w);
+  pfo_tgn_layout lay;
+  RUN(pfo_tgn_param_layout(c, &lay));
+  Params P;
+  bind(lay, st->params, P, d.L, c->use_memory != 0);
+  Side& sd = side();
+  PFO_REQUIRE(sd.ok, "could not create the side stream");
+  hipStream_t s = (hipStream_t)stream, sr = sd.s2;
+  PfoRange range("pfo_tgn_refresh");
+  // Forked from the caller's stream (behind the kernel that wrote the parameters, and behind every reader of the old
+  // composites: the previous backward joined its side streams into that stream) onto the SECOND side stream, not joined.
+  // The next forward's first side stream - which packs the touched rows as soon as the compaction is done - waits for pc_a
+  // only in front of the event layer 1 waits for anyway, and for pc_b in front of the one layer 2 waits for: the caller's
+  // stream itself never waits for this chain, and the row pack does not queue behind it (on one stream the ~15 dependent
+  // launches of both stages sat in front of the pack: +45 us per step, measured).
+  // (the GRU's two images stay on the caller's stream - one 4 us launch, as in the forward: the fused GRU launch reads them
+  //  on that stream BEFORE the forward's wait for the side stream)
+  if (c->use_memory) RUN(build_gru_images(c, d, w, P, s));
+  HIPOK(hipEventRecord(sd.fork, s), "event record failed");
+  HIPOK(hipStreamWaitEvent(sr, sd.fork, 0), "event wait failed");
+  RUN(build_stage_a(d, w, P, sr));
+  HIPOK(hipEventRecord(sd.pc_a, sr), "event record failed");
+  RUN(build_stage_b(d, w, P, sr));
+  HIPOK(hipEventRecord(sd.pc_b, sr), "event record failed");
+  return PFO_OK;
+}
+
 // =============================================================================================
 extern "C" int pfo_tgn_prepare(const pfo_tgn_config* c, const pfo_tgn_state* st, const pfo_tgn_batch* b, void* workspace,
                                void* stream) {
@@ -490,13 +698,17 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   PFO_REQUIRE(b->uniform >= 0 && b->uniform <= 2, "bad sampling mode");
   PFO_REQUIRE(b->uniform != 1 || b->draws, "mode 1 needs draws");
   const Dims d = dims_of(c);
-  const Ws w = carve(c, workspace);
+  Ws w_ = carve(c, workspace);
+  if (st->pcache) pcache_bind(c, st->pcache, w_);       // parameter-only buffers live in the caller's cache
+  const Ws& w = w_;
+  const bool build = !st->pcache || !st->pcache_valid;  // composites / images (re)built by this call
   hipStream_t s = (hipStream_t)stream;
   pfo_tgn_layout lay;
   RUN(pfo_tgn_param_layout(c, &lay));
   Params P;
   bind(lay, st->params, P, d.L, c->use_memory != 0);
   const int L = d.L, D = d.D, Ef = d.Ef, H = d.H, E = d.E, C = d.C, dh = d.dh, K = b->K;
+  (void)C; (void)dh; (void)E;
 
   PfoRange range_call(b->training ? "pfo_tgn_forward (training)" : "pfo_tgn_forward");
   // ---- composite weights of every layer: on the side stream, beside the sampling / memory phase
@@ -506,20 +718,16 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   const int Cp = d.Cp, HCp = H * d.Cp;
   // Everything on the side stream depends on the parameters only, so it may start at once (after whatever the main
   // stream did before this call); all layers share each launch.
+  PFO_MARK("fwd.begin", s);
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
   if (!b->prepared) RUN(prepare_sample(c, st, b, w, n, s));
+  PFO_MARK("fwd.sampled", s);
   const bool fused_state = b->upd_src != nullptr && c->use_memory && L >= 2;
   PFO_REQUIRE(!fused_state || (b->upd_dst && b->upd_ts && b->upd_eidx && b->upd_B >= 1), "bad state-update arguments");
 
-  if (c->use_memory) {
-    // the GRU contractions come first on the main stream: their two weight images are made there too (one 4 us launch)
-    PfoBimg im[2];
-    im[0].src = P.w_ih; im[0].ld = d.M; im[0].N = 3 * D; im[0].K = d.M; im[0].trans = 0; im[0].dst = w.iWih;
-    im[1].src = P.w_hh; im[1].ld = D; im[1].N = 3 * D; im[1].K = D; im[1].trans = 0; im[1].dst = w.iWhh;
-    im[0].gate = 1; im[0].gate_D = D; im[1].gate = 2; im[1].gate_D = D;      // gate-ordered rows: r | z | n_i | n_h per 16 hidden units
-    RUN(pfo_bimg_launch(im, 2, s));
-  }
+  // the GRU contractions come first on the main stream: their two weight images are made there too (one 4 us launch)
+  if (c->use_memory && build) RUN(build_gru_images(c, d, w, P, s));
   bool composites_awaited = false;
 
   // ---- the nodes this step reads, compacted, and their level-0 rows packed (prepare_compact_pack; a prepared batch has them)
@@ -538,6 +746,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
       RUN(prepare_compact_pack(c, st, b, w, d, n, s));
     }
   }
+  PFO_MARK("fwd.compacted", s);
   const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
   if (c->use_memory) {
     PfoRange range_gru("forward lazy GRU");
@@ -549,114 +758,33 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     if (pack_side) { f.gather = 1; f.msg_rows = st->msg_table; f.h_rows = st->memory; f.hm = st->has_msg; }
     RUN(pfo_gru_fused_launch(f, s));
     if (fused_state) HIPOK(hipEventRecord(sd.gru_done, s), "event record failed");
+    PFO_MARK("fwd.gru", s);
   }
-  // ---- composite weights of every layer and their bf16x3 images: side stream.  Enqueued HERE, after the sampling / compaction /
-  // GRU launches of the caller's stream (which need none of it): when the host is the slower side (small batches, profilers)
-  // the critical chain is already queued while these ~14 launches are being issued; layer 1 waits for them below.
-  PFO_REQUIRE(hipMemsetAsync(w.zero, 0, w.zero_bytes, ss) == hipSuccess, "memset failed");   // w.zero, w.tickets, Wqk / W1ovT / cqk of every layer
-  RUN(pfo_time_encode(w.zero, 1, P.tw, P.tb, D, w.cosb, ss));                  // cos(fma(0, w, b)) (embedding_module.py:92)
+  // ---- composite weights of every layer and their fp16 images (build_stage_a / _b): side stream.  Enqueued HERE, after the
+  // sampling / compaction / GRU launches of the caller's stream (which need none of it): when the host is the slower side
+  // (small batches, profilers) the critical chain is already queued while these ~14 launches are being issued; layer 1 waits
+  // for them below.  With a valid parameter cache (pfo_tgn_state.pcache_valid) NONE of it is launched: the side stream only
+  // clears the step's accumulators, packs the rows and runs the state update.
+  PFO_REQUIRE(hipMemsetAsync(w.zero, 0, w.zero_bytes, ss) == hipSuccess, "memset failed");   // w.zero, w.tickets, time-gradient bins
   {
-    PfoGemm st1[3 * PFO_MAX_LAYERS], st2[4 * PFO_MAX_LAYERS];
-    PfoBimg im[8 * PFO_MAX_LAYERS + 2];
-    int n1 = 0, n2 = 0, ni = 0;
-    auto img = [&](const float* src, int64_t ld, int N_, int K_, int trans, void* dst) {
-      im[ni].src = src; im[ni].ld = ld; im[ni].N = N_; im[ni].K = K_; im[ni].trans = trans; im[ni].dst = dst; ++ni;
-    };
-    for (int l = 1; l <= L; ++l) {
-      const LayerWs& lw = w.layer[l];
-      const auto& p = P.l[l];
-      PfoGemm* a1 = st1 + n1;
-      a1[0] = g_nt(w.cosb, D, nullptr, p.wq + D, E, lw.cq, E, 1, E, D, p.b_in);            // cq = Wq[:, D:] cos(b) + bq
-      a1[1] = g_nt(p.wo, E, nullptr, p.w1, E + D, lw.W1oT, D, E, D, E, nullptr);           // W1oT = Wo^T W1[:, :E]^T
-      a1[1].a_kmajor = 1;
-      a1[2] = g_nt(p.wk, C, nullptr, p.wq, E, lw.Wqk, D, C, D, dh, nullptr);               // Wqk_h = Wk_h^T Wq_h[:, :D]
-      a1[2].a_kmajor = 1; a1[2].b_kmajor = 1; a1[2].batch = H;
-      a1[2].a_bs[0] = (int64_t)dh * C; a1[2].b_bs[0] = (int64_t)dh * E; a1[2].c_bs = (int64_t)Cp * D;
-      n1 += 3;
-      PfoGemm* a2 = st2 + n2;
-      a2[0] = g_nn(lw.cq, E, p.wk, C, lw.cqk, HCp, 1, C, dh);                               // cqk_h = Wk_h^T cq_h
-      a2[0].batch = H; a2[0].a_bs[0] = dh; a2[0].b_bs[0] = (int64_t)dh * C; a2[0].c_bs = Cp;
-      a2[1] = g_nt(p.wv, C, nullptr, lw.W1oT, D, lw.W1ovT, D, C, D, dh, nullptr);           // W1ovT_h = Wv_h^T W1oT_h
-      a2[1].a_kmajor = 1; a2[1].b_kmajor = 1; a2[1].batch = H;
-      a2[1].a_bs[0] = (int64_t)dh * C; a2[1].b_bs[0] = (int64_t)dh * D; a2[1].c_bs = (int64_t)Cp * D;
-      a2[2] = g_nn(p.b_in + 2 * E, dh, lw.W1oT, D, lw.W1ovT + (int64_t)C * D, D, 1, D, dh); // row C: (W1 Wo_h bv_h)^T
-      a2[2].batch = H; a2[2].a_bs[0] = dh; a2[2].b_bs[0] = (int64_t)dh * D; a2[2].c_bs = (int64_t)Cp * D;
-      a2[3] = g_nt(p.bo, E, nullptr, p.w1, E + D, lw.W1ovT + (int64_t)(C + 1) * D, D, 1, D, E, nullptr);   // row C+1 of head 0: (W1 bo)^T
-      n2 += 4;
-      // bf16x3 images of this layer's weight operands, in both orientations (forward and data-gradient launches).
-      // Layers >= 2 take theirs from the fc2-folded composites below.
-      if (l == 1) {
-        // layer 1 projects the touched-node table once: [Wqk ; W1[:, E:]] stacked along the output dimension
-        img(lw.Wqk, D, HCp, D, 0, w.iQX);        im[ni - 1].row0 = 0;   im[ni - 1].rows_total = HCp + D;
-        img(p.w1 + E, E + D, D, D, 0, w.iQX);    im[ni - 1].row0 = HCp; im[ni - 1].rows_total = HCp + D; im[ni - 1].last = 1;
-        img(lw.Wqk, D, D, HCp, 1, lw.iWqkT);
-        img(lw.W1ovT, D, HCp, D, 0, lw.iW1ovT);  img(lw.W1ovT, D, D, HCp, 1, lw.iW1ov);
-        img(p.w1 + E, E + D, D, D, 1, lw.iW1bT);
-      }
-      if (l == L) { img(p.w2, D, D, D, 0, lw.iW2); img(p.w2, D, D, D, 1, lw.iW2T); }   // only the top layer applies its fc2
-    }
-    for (int i = 0; i < n1; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(st1 + i, std::min(PFO_GEMM_MULTI_MAX, n1 - i), ss));
-    for (int i = 0; i < n2; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(st2 + i, std::min(PFO_GEMM_MULTI_MAX, n2 - i), ss));
-    for (int i = 0; i < ni; i += PFO_BIMG_MAX) RUN(pfo_bimg_launch(im + i, std::min(PFO_BIMG_MAX, ni - i), ss));
+    // (a pfo_tgn_refresh chain may still be running on the second side stream: a rebuild waits for all of it, a call that uses
+    //  the cache waits for its two stages where their results are first needed - no-ops when no refresh is outstanding)
+    hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap_st) != hipSuccess) cap_st = hipStreamCaptureStatusActive;
+    const bool capturing = cap_st != hipStreamCaptureStatusNone;         // (events recorded outside a capture are not waited for inside one)
+    if (build && st->pcache && !capturing) HIPOK(hipStreamWaitEvent(ss, sd.pc_b, 0), "event wait failed");
+    if (build) RUN(build_stage_a(d, w, P, ss));
+    // (in front of the pack, not behind it: a cross-stream wait costs the waiting stream 5-17 us even when the event fired long
+    //  ago, and the record below is what layer 1 waits for - stage A of a refresh is done ~80 us after the optimizer's kernel)
+    if (!build && !capturing) HIPOK(hipStreamWaitEvent(ss, sd.pc_a, 0), "event wait failed");
     if (pack_side) {
       HIPOK(hipStreamWaitEvent(ss, sd.comp_done, 0), "event wait failed");
       RUN(prepare_pack(c, st, b, w, d, n, ss));
     }
     HIPOK(hipEventRecord(sd.layer[0], ss), "event record failed");      // layer 1 (and the top layer's fc2) can go
-
-    // ---- fc2 fold.  A layer l >= 2 reads rows of the previous layer, out = A h + b (A = W2, b = b2 of layer l-1, h = that
-    // layer's h1 row).  Every use of such a row is linear, so A and b move into THIS layer's composites and the previous
-    // layer's fc2 contraction over all its instances (and, backward, d h1 = d out W2 and dW2 = d out^T h1) disappears:
-    //   query side   qk'_h = Q_h x + cqk_h,  x = A s + b        ->  T1_h = Q_h A,  t_h = Q_h b + cqk_h
-    //   scores       qk'_h,node . (A k + b) = (A^T qk'_h,node) . k + const(j)   (the constant drops out of the softmax)
-    //                                                         ->  Q_f,h = [A^T T1_h,node ; T1_h,edge|time],  c_f,h likewise from t_h
-    //   context      sum_j a'_j (A k_j + b) = A c + b sum_j a'_j  ->  V_f,h,node = A^T V_h,node,  V_f,h[C] = V_h[C] + b^T V_h,node
-    //   x term       W1b (A s + b)                              ->  W1b_f = W1b A,  b1_f = b1 + W1b b
-    // (Q_h = Wqk_h, V_h = W1ovT_h; tiny products, two more dependent stages on this stream.)
     if (L >= 2) {
-      PfoGemm f1[4 * PFO_MAX_LAYERS], f2[4 * PFO_MAX_LAYERS];
-      PfoBimg fim[6 * PFO_MAX_LAYERS];
-      int m1 = 0, m2 = 0, mi = 0;
-      const int64_t HCpD = (int64_t)HCp * D;
-      for (int l = 2; l <= L; ++l) {
-        const LayerWs& lw = w.layer[l];
-        const auto& p = P.l[l];
-        const float* A = P.l[l - 1].w2;
-        const float* bv = P.l[l - 1].b2;
-        HIPOK(hipMemcpyAsync(lw.W1ovT_f, lw.W1ovT, HCpD * sizeof(float), hipMemcpyDeviceToDevice, ss), "copy failed");
-        PfoGemm* a = f1 + m1;
-        a[0] = g_nn(lw.Wqk, D, A, D, lw.T1, D, HCp, D, D);                                    // T1 = Q A (all heads' rows)
-        a[1] = g_nt(bv, D, nullptr, lw.Wqk, D, lw.tq, HCp, 1, HCp, D, lw.cqk);               // t = Q b + cqk
-        a[2] = g_nn(p.w1 + E, E + D, A, D, lw.W1b_f, D, D, D, D);                            // W1b_f = W1b A
-        a[3] = g_nt(bv, D, nullptr, p.w1 + E, E + D, lw.b1_f, D, 1, D, D, p.b1);             // b1_f = b1 + W1b b
-        m1 += 4;
-      }
-      for (int i = 0; i < m1; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(f1 + i, std::min(PFO_GEMM_MULTI_MAX, m1 - i), ss));
-      for (int l = 2; l <= L; ++l) {
-        const LayerWs& lw = w.layer[l];
-        const float* A = P.l[l - 1].w2;
-        const float* bv = P.l[l - 1].b2;
-        HIPOK(hipMemcpyAsync(lw.Wqk_f, lw.T1, HCpD * sizeof(float), hipMemcpyDeviceToDevice, ss), "copy failed");   // edge | time rows stay
-        HIPOK(hipMemcpyAsync(lw.cqk_f, lw.tq, (size_t)HCp * sizeof(float), hipMemcpyDeviceToDevice, ss), "copy failed");
-        PfoGemm* a = f2 + m2;
-        a[0] = g_nn(A, D, lw.T1, D, lw.Wqk_f, D, D, D, D);        a[0].a_kmajor = 1;          // Q_f,node = A^T T1_node
-        a[0].batch = H; a[0].b_bs[0] = (int64_t)Cp * D; a[0].c_bs = (int64_t)Cp * D;
-        a[1] = g_nn(lw.tq, D, A, D, lw.cqk_f, D, 1, D, D);                                    // c_f,node = A^T t_node
-        a[1].batch = H; a[1].a_bs[0] = Cp; a[1].c_bs = Cp;
-        a[2] = g_nn(A, D, lw.W1ovT, D, lw.W1ovT_f, D, D, D, D);   a[2].a_kmajor = 1;          // V_f,node = A^T V_node
-        a[2].batch = H; a[2].b_bs[0] = (int64_t)Cp * D; a[2].c_bs = (int64_t)Cp * D;
-        a[3] = g_nn(bv, D, lw.W1ovT, D, lw.W1ovT_f + (int64_t)C * D, D, 1, D, D);             // V_f[C] = V[C] + b^T V_node
-        a[3].batch = H; a[3].b_bs[0] = (int64_t)Cp * D; a[3].c_bs = (int64_t)Cp * D; a[3].accumulate = 1;
-        m2 += 4;
-        auto fimg = [&](const float* src, int64_t ld, int N_, int K_, int trans, void* dst) {
-          fim[mi].src = src; fim[mi].ld = ld; fim[mi].N = N_; fim[mi].K = K_; fim[mi].trans = trans; fim[mi].dst = dst; ++mi;
-        };
-        fimg(lw.Wqk_f, D, HCp, D, 0, lw.iWqk);      fimg(lw.W1b_f, D, D, D, 0, lw.iW1b);
-        fimg(lw.Wqk_f, D, D, HCp, 1, lw.iWqkT);     fimg(lw.W1b_f, D, D, D, 1, lw.iW1bT);
-        fimg(lw.W1ovT_f, D, HCp, D, 0, lw.iW1ovT);  fimg(lw.W1ovT_f, D, D, HCp, 1, lw.iW1ov);
-      }
-      for (int i = 0; i < m2; i += PFO_GEMM_MULTI_MAX) RUN(pfo_gemm_multi_launch(f2 + i, std::min(PFO_GEMM_MULTI_MAX, m2 - i), ss));
-      for (int i = 0; i < mi; i += PFO_BIMG_MAX) RUN(pfo_bimg_launch(fim + i, std::min(PFO_BIMG_MAX, mi - i), ss));
+      if (build) RUN(build_stage_b(d, w, P, ss));
+      else if (!capturing) HIPOK(hipStreamWaitEvent(ss, sd.pc_b, 0), "event wait failed");
       if (fused_state) {
         // the batch's state update, here: behind the lazy GRU (whose rows it persists), beside layer 1, in front of the event
         // layer 2 waits for - persist + message store leave the critical path and are joined at no extra wait
@@ -683,6 +811,9 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   // 0.60 MFLOP per instance instead of 1.13 (and 10.3 un-folded); Q, O and attn_out are never formed.
   const float scale = 1.0f / sqrtf((float)dh);
   static const char* const fwd_names[PFO_MAX_LAYERS + 1] = {"", "forward layer 1", "forward layer 2", "forward layer 3", "forward layer 4"};
+  static const char* const mk_qk[PFO_MAX_LAYERS + 1] = {"", "fwd.L1.qk", "fwd.L2.qk", "fwd.L3.qk", "fwd.L4.qk"};
+  static const char* const mk_at[PFO_MAX_LAYERS + 1] = {"", "fwd.L1.attn", "fwd.L2.attn", "fwd.L3.attn", "fwd.L4.attn"};
+  static const char* const mk_h1[PFO_MAX_LAYERS + 1] = {"", "fwd.L1.h1", "fwd.L2.h1", "fwd.L3.h1", "fwd.L4.h1"};
   for (int l = 1; l <= L; ++l) {
     PfoRange range_layer(fwd_names[l]);
     const int N = (int)n[l];
@@ -729,7 +860,9 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     a.scale = scale; a.dropout_p = b->dropout_p; a.seed = b->seed; a.offset = b->offset + 0x51ED0000ull + (uint64_t)l; a.offset_dev = b->offset_dev;
     a.keep_inject = (b->dropout_keep && b->training) ? b->dropout_keep[L - l] : nullptr;
     a.ctx = lw.ctx; a.attw = lw.attw; a.inv = lw.inv;
+    PFO_MARK(mk_qk[l], s);
     RUN(pfo_attn_fwd_launch(a, s));
+    PFO_MARK(mk_at[l], s);
     // ---- h1 = relu(ctx' W1ovT + x W1[:, E:]^T + b1)   (MergeLayer fc1 with out_proj and the value projection folded in)
     if (l == 1) {
       // the x term was projected with the table: it arrives as a row-gathered addend of the epilogue
@@ -752,6 +885,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
       g.accumulate = 1; g.relu = 1; g.b_img = lw.iW1b;
       RUN(pfo_gemm_launch(g, s));
     }
+    PFO_MARK(mk_h1[l], s);
     if (l == L) {
       // out = W2 h1 + b2: only the top layer's rows ARE embeddings (N == R; written in place, no copy) - below it the
       // contraction is folded into the next layer's composites
@@ -760,6 +894,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
       RUN(pfo_gemm_launch(g, s));
     }
   }
+  PFO_MARK("fwd.end", s);
   return PFO_OK;
 }
 
@@ -787,7 +922,9 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   int64_t n[PFO_MAX_LAYERS + 1];
   RUN(level_sizes(c, b, n));
   const Dims d = dims_of(c);
-  const Ws w = carve(c, workspace);
+  Ws w_ = carve(c, workspace);
+  if (st->pcache) pcache_bind(c, st->pcache, w_);       // the composites and images the forward used
+  const Ws& w = w_;
   hipStream_t s = (hipStream_t)stream;
   pfo_tgn_layout lay;
   RUN(pfo_tgn_param_layout(c, &lay));
@@ -817,6 +954,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   // per row, late in this call): built on the side stream, beside the layer-L .. 2 work.  The same stream first clears what
   // this call accumulates into: the level-0 gradient rows (layer 1's attention backward waits for seg_done)
   // (the gradient buffer is cleared on the caller's stream, before the fork: every writer on any stream comes after it)
+  PFO_MARK("bwd.begin", s);
   if (zero_grad_first) HIPOK(hipMemsetAsync(grad, 0, (size_t)lay.total * sizeof(float), s), "memset failed");
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
@@ -828,6 +966,10 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   HIPOK(hipEventRecord(sd.seg_done, ss), "event record failed");
   std::function<int()> deferred_chain;                       // a layer's chain-back launches, issued one layer later (below)
   static const char* const bwd_names[PFO_MAX_LAYERS + 1] = {"", "backward layer 1", "backward layer 2", "backward layer 3", "backward layer 4"};
+  static const char* const mk_dh1[PFO_MAX_LAYERS + 1] = {"", "bwd.L1.dh1", "bwd.L2.dh1", "bwd.L3.dh1", "bwd.L4.dh1"};
+  static const char* const mk_dctx[PFO_MAX_LAYERS + 1] = {"", "bwd.L1.dctx", "bwd.L2.dctx", "bwd.L3.dctx", "bwd.L4.dctx"};
+  static const char* const mk_battn[PFO_MAX_LAYERS + 1] = {"", "bwd.L1.attn", "bwd.L2.attn", "bwd.L3.attn", "bwd.L4.attn"};
+  static const char* const mk_dx[PFO_MAX_LAYERS + 1] = {"", "bwd.L1.dx_tab", "bwd.L2.dx", "bwd.L3.dx", "bwd.L4.dx"};
   for (int l = L; l >= 1; --l) {
     PfoRange range_layer(bwd_names[l]);
     const int N = (int)n[l];
@@ -865,6 +1007,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       q.relu_src = lw.h1; q.relu_ld = D;                     // ReLU backward
       q.b_img = lw.iW2T;
       RUN(pfo_gemm_launch(q, s));
+      PFO_MARK(mk_dh1[l], s);
       dh1 = w.dh1;
     } else {
       // below the top the layer above wrote d h1 directly, ReLU mask applied by its producers (attention backward's key
@@ -894,6 +1037,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       PfoGemm q = g_nt(dh1, D, nullptr, W1ovT_l, D, w.dctx, HCp, N, HCp, D, nullptr);
       q.b_img = lw.iW1ovT;
       RUN(pfo_gemm_launch(q, s));
+      PFO_MARK(mk_dctx[l], s);
     }
     if (l > 1) {
       set_tn(tn[ntn], dh1, D, xA, D, x_idx, D, D, lw.dW1b_f, D, lw.db1_f);              // d (W1[:, E:] A), d (b1 + W1[:, E:] b)
@@ -936,6 +1080,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     }
     const int dqk_by_member = pfo_attn_bwd_uses_runs(a) ? 1 : 0;
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
+    PFO_MARK(mk_battn[l], s);
     if (det) det_rows += n_parts;
     if (deferred_chain) { RUN(deferred_chain()); deferred_chain = nullptr; }     // the layer above's chain-back (side streams)
     // merged query/key projection: dx += dqk' Wqk, dWqk = dqk'^T x, gqk = colsum(dqk')
@@ -947,6 +1092,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       if (!c->use_memory) HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");   // (with memory: awaited before the attention backward)
       RUN(pfo_segsum_launch(dqk_l, HCp, dh1, D, w.seg_ptr, w.seg_mem, w.n_core, capP, dqk_by_member,
                             dqk_by_member ? w.dqk_live : nullptr, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
+      PFO_MARK("bwd.L1.segsum", s);
       // the weight gradients over the table rows go to the side stream too (beside d h0 / the GRU backward on this one)
       HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
       HIPOK(hipStreamWaitEvent(ss, sd.tn_b, 0), "event wait failed");
@@ -962,6 +1108,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
         q.A[1] = w.Dq + HCp; q.lda[1] = WQ; q.B[1] = p.w1 + E; q.ldb[1] = E + D; q.K[1] = D;
         q.b_img = lw.iWqkT; q.b_img2 = lw.iW1bT; q.m_dev = w.n_core;
         RUN(pfo_gemm_launch(q, s));
+        PFO_MARK(mk_dx[l], s);
       }
     } else {
       // d h1 of the layer below, self rows [0, N): [dqk' | dh1] [Q_f ; W1b_f], masked by that layer's ReLU
@@ -981,6 +1128,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
         q.relu_src = xA; q.relu_ld = D;
         RUN(pfo_gemm_launch(q, s));
       }
+      PFO_MARK(mk_dx[l], s);
       set_tn(tn[ntn], dqk_l, HCp, xA, D, x_idx, HCp, D, dWqk_l, D, gqk_l);
       tn[ntn].c_accumulate = 0; tn[ntn].bias_accumulate = 0;
       ++ntn;
@@ -1149,6 +1297,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     // (the GRU's backward covers the rows the layers read: rows only the extra list names carry no gradient)
     RUN(pfo_gru_gates_bwd_launch(w.gates, w.gi, w.gh, w.h_rows, w.hm, w.n_core, capP, D, w.d_h0, n_rep, rep_stride,
                                  w.dx_tab, det, s));
+    PFO_MARK("bwd.gru.gates", s);
     {
       PfoTnProblem gp[2];
       gp[0].A = w.gi; gp[0].lda = 3 * D; gp[0].B = w.msg_rows; gp[0].ldb = d.M; gp[0].M = 3 * D; gp[0].N = d.M;
@@ -1156,6 +1305,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       gp[1].A = w.gh; gp[1].lda = 3 * D; gp[1].B = w.h_rows; gp[1].ldb = D; gp[1].M = 3 * D; gp[1].N = D;
       gp[1].C = G.w_hh; gp[1].ldc = D; gp[1].bias_out = G.b_hh;
       RUN(pfo_gemm_tn_group_launch(gp, 2, capP, w.n_core, w.slabs, w.slab_floats, s));
+      PFO_MARK("bwd.gru.tn", s);
     }
   }
   // ---- the last small launches go to the first side stream, beside the GRU's weight gradients on the caller's stream:
@@ -1186,6 +1336,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   }
   HIPOK(hipEventRecord(sd.done, ss), "event record failed");
   HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
+  PFO_MARK("bwd.end", s);
   return PFO_OK;
 }
 

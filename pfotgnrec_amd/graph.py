@@ -94,7 +94,7 @@ class GraphedTrainStep:
         # and a replay is refused once the model would no longer run the same step on the same buffers.
         nf = tgn.neighbor_finder
         mem = tgn.memory
-        self._keep = (tgn._last_ws, tgn._adj_cache, tgn.flat_parameters, tgn.flat_grad, self.opt._m, self.opt._v,
+        self._keep = (tgn._last_ws, tgn._adj_cache, tgn._pcache, tgn.flat_parameters, tgn.flat_grad, self.opt._m, self.opt._v,
                       tgn.node_raw_features, tgn.edge_raw_features,
                       None if mem is None else (mem.memory, mem.last_update, mem.msg_table, mem.msg_time, mem.has_msg))
         self._guard = (nf, getattr(nf, "_version", 0), tgn._ws_caps, tgn.flat_parameters.data_ptr(), tgn.flat_grad.data_ptr())
@@ -117,6 +117,7 @@ class GraphedTrainStep:
         self._load(src, dst, ts, eidx, port_idx, port_len, day)
         self.graph.replay()
         self.replays += 1
+        self.tgn.parameters_changed()      # (the replayed Adam kernel wrote them; the replayed forward rebuilt its own composites)
         return self.loss
 
     def eager(self, src, dst, ts, eidx, port_idx, port_len, day=None):

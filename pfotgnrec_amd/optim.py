@@ -79,4 +79,9 @@ class FusedAdam(torch.optim.Optimizer):
                       self._v.data_ptr(), k, (ctypes.c_int64 * k)(*lo[i:i + k]), (ctypes.c_int64 * k)(*hi[i:i + k]),
                       (ctypes.c_int32 * k)(*st[i:i + k]), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
                       float(g["eps"]), _lib.stream_ptr())
+        if lo:
+            # the kernel above wrote the parameters behind torch's back: the model's parameter cache (composite weights, weight
+            # images) is rebuilt right here, on the library's side stream behind this kernel - beside the next batch's sampling
+            # phase - so that the next forward launches none of it.  (A step being captured rebuilds inside its own forward.)
+            tgn.parameters_changed(refresh=tgn.refresh_after_step and step_dev is None)
         return None

@@ -39,7 +39,7 @@ def _normalise_edge_features(edge_features):
 class _Call:
     """Everything one forward/backward pair of native calls needs to agree on."""
     __slots__ = ("roots", "root_ts", "R", "K", "mode", "draws", "draw_ptrs", "keep_ptrs", "seed", "offset", "dropout_p", "training",
-                 "extra", "batch_struct", "ws", "ws_caps", "cfg", "pool", "gru_applied", "ready", "keep", "__weakref__")
+                 "extra", "batch_struct", "ws", "ws_caps", "cfg", "pool", "gru_applied", "ready", "keep", "pkey", "__weakref__")
 
     def release(self):
         """Hands the call's workspace back to its TGN's pool (after the backward, or when the graph is dropped)."""
@@ -135,6 +135,13 @@ class TGN(nn.Module):
         self._prefetched, self._pre_stream, self._pre_main = None, None, None
         self.fuse_state_update = os.environ.get("PFO_FUSE_STATE", "1") != "0"      # training calls: persist + message store inside the native forward, on its side stream
         self._ws_caps = (0, 0, 0)
+        # Parameter cache (pfo_tgn_state.pcache): composite weights + fp16 weight images, rebuilt only when the parameters
+        # changed.  "Changed" = the torch version counter of the flat buffer (shared by every nn.Parameter view: in-place ops
+        # of any torch optimizer, load_state_dict, copy_ ... bump it) or ``parameters_changed()`` (native writers: FusedAdam,
+        # graph replays).  Writes through ``p.data`` bypass the counter: call ``parameters_changed()`` after them.
+        self.param_cache = os.environ.get("PFO_PCACHE", "1") != "0"
+        self.refresh_after_step = os.environ.get("PFO_PCACHE_REFRESH", "1") != "0"   # FusedAdam rebuilds the cache right behind its kernel
+        self._pcache, self._pcache_key, self._param_epoch = None, None, 0
         self._last_ws = None      # (config, workspace) of the newest forward (debug_touched)
         self._step = 0
         self.seed = 0
@@ -263,6 +270,7 @@ class TGN(nn.Module):
             torch.cuda.current_stream(self._prefetched[2].ws.device).wait_event(self._prefetched[2].ready)
         self._ws_pool, self._last_ws, self._adj_cache = [], None, None
         self._prefetched = None
+        self._pcache, self._pcache_key = None, None
         return self
 
     # ------------------------------------------------------------------ neighbour finder plumbing
@@ -314,17 +322,46 @@ class TGN(nn.Module):
         c = self._cfg
         return _lib.TgnConfig(c.n_nodes, c.n_edges_p1, c.D, c.Ef, c.n_layers, c.n_heads, c.use_memory, caps[0], caps[1], caps[2])
 
-    def _state_struct(self):
-        indptr, nbr, eidx, ts = self._adjacency()
-        self._keepalive = (indptr, nbr, eidx, ts)
+    def _param_key(self):
+        return (self._flat._version, self._param_epoch, self._flat.data_ptr())
+
+    def parameters_changed(self, refresh=False):
+        """Tells the model that something outside torch's view wrote the parameters (a native optimizer kernel, a graph replay,
+        a write through ``p.data``): the parameter cache is rebuilt by the next forward - or, with ``refresh``, right now on
+        the library's side stream (``pfo_tgn_refresh``), so that the next forward launches none of it."""
+        self._param_epoch += 1
+        self._pcache_key = None
+        if (refresh and self.param_cache and self._pcache is not None and self._flat.is_cuda
+                and not torch.cuda.is_current_stream_capturing()):
+            st = self._state_struct(adjacency=False)
+            _lib.call("pfo_tgn_refresh", ctypes.byref(self._cfg), ctypes.byref(st), _lib.stream_ptr())
+            self._pcache_key = self._param_key()
+
+    def _state_struct(self, adjacency=True):
+        if adjacency:
+            indptr, nbr, eidx, ts = self._adjacency()
+            self._keepalive = (indptr, nbr, eidx, ts)
+            adj = (indptr.data_ptr(), nbr.data_ptr(), eidx.data_ptr(), ts.data_ptr())
+        else:
+            adj = (None, None, None, None)
         mem = self.memory
-        return _lib.TgnState(indptr.data_ptr(), nbr.data_ptr(), eidx.data_ptr(), ts.data_ptr(),
-                             self.node_raw_features.data_ptr(), self.edge_raw_features.data_ptr(),
+        pc, valid = None, 0
+        if self.param_cache and self._flat.is_cuda:
+            if self._pcache is None:
+                nbytes = _lib.load().pfo_tgn_pcache_bytes(ctypes.byref(self._cfg))
+                if nbytes < 0:
+                    raise _lib.PfoError("pfo_tgn_pcache_bytes: %s" % _lib.load().pfo_last_error().decode())
+                self._pcache, self._pcache_key = torch.empty(nbytes, dtype=torch.uint8, device=self.device), None
+            pc = self._pcache.data_ptr()
+            # (a step being captured into a HIP graph always builds: its replays run with whatever the parameters are then)
+            valid = int(self._pcache_key is not None and self._pcache_key == self._param_key()
+                        and not torch.cuda.is_current_stream_capturing())
+        return _lib.TgnState(*adj, self.node_raw_features.data_ptr(), self.edge_raw_features.data_ptr(),
                              mem.memory.data_ptr() if mem is not None else None,
                              mem.last_update.data_ptr() if mem is not None else None,
                              mem.msg_table.data_ptr() if mem is not None else None,
                              mem.msg_time.data_ptr() if mem is not None else None,
-                             mem.has_msg.data_ptr() if mem is not None else None, self._flat.data_ptr())
+                             mem.has_msg.data_ptr() if mem is not None else None, self._flat.data_ptr(), pc, valid)
 
     def _adjacency(self):
         """Device CSR of the current neighbour finder, checked against this model's node table.
@@ -409,6 +446,14 @@ class TGN(nn.Module):
         emb = out if out is not None else torch.empty((call.R, self.n_node_features), dtype=torch.float32, device=self.device)
         _lib.call("pfo_tgn_forward", ctypes.byref(call.cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
                   call.ws.data_ptr(), emb.data_ptr(), _lib.stream_ptr())
+        if st.pcache:
+            if torch.cuda.is_current_stream_capturing():
+                self._pcache_key = None                            # (nothing ran: the capture's replays will build it)
+            elif not st.pcache_valid:
+                self._pcache_key = self._param_key()               # this call built the cache for the current parameters
+            call.pkey = self._param_key()
+        else:
+            call.pkey = None
         self._last_ws = (call.cfg, call.ws)
         self._last_call = (int(call.seed), int(call.batch_struct.offset), int(call.R), int(call.K), float(call.dropout_p),
                            call.batch_struct.offset_dev is not None)
@@ -445,6 +490,11 @@ class TGN(nn.Module):
         zero_first = self._attach_grads(call.gru_applied, defer_zero=True) or self._zero_next
         self._zero_next = False
         st = self._state_struct()
+        pkey = getattr(call, "pkey", None)
+        if pkey is not None and not torch.cuda.is_current_stream_capturing() and pkey != self._param_key():
+            # the composites the backward reads (parameter cache) belong to the parameters of the forward
+            raise RuntimeError("the parameters were modified between a TGN forward and its backward "
+                               "(optimizer step / load_state_dict in between): run the backward first")
         ev = None
         if self.dp_bucketed and self.grad_split < self._layout.total:
             # the top layer's gradient block is final when this event fires (distributed.allreduce_flat_grad_buckets)
