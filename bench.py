@@ -84,7 +84,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=512, help="interactions per oracle step in the CPU baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=4, help="timed oracle steps (one more runs first, untimed)")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event bracketing of kernel launches")
-    ap.add_argument("--prefetch", type=int, default=0, choices=[0, 1],
+    ap.add_argument("--prefetch", type=int, default=0, choices=[0, 1, 2],
                     help="1: the next batch's negatives / frontier / compaction / packed rows are issued on a second stream right "
                          "after the current forward (TGN.prefetch); 0 (default): inside the step, as the reference's call order "
                          "has it.  Measured on C2: 1.52 ms with, 1.50 without - the ~70 us of small launches cost as much beside "
@@ -305,7 +305,7 @@ class Workload:
         self.sampler = DeviceNegativeSampler(item_availability(d.destinations, graph.upper_u, cfg.n_items), graph.upper_u, dev, seed=1)
         self.n_neg = 3
         self._next = None
-        self.prefetch = bool(getattr(args, "prefetch", 0))
+        self.prefetch = int(getattr(args, "prefetch", 0))
         self.mvs = None
         if self.ours:
             self.mvs = P.MVSampler(graph.prices, graph.upper_u, dev, gamma=2.0, lambda_mv=0.5, p_pos_num=1, p_neg_num=3)
@@ -372,7 +372,7 @@ class Workload:
             emb, b = tgn.embed_device(self.src_all[sl], self.dst_all[sl], [neg], [n_neg], self.ts_all[sl],
                                       self.eidx_all[sl], cfg.n_neighbors)                                     # tgn.py:219-327
             pos_block = 1                                                                                      # main.py:364-381
-            if self.prefetch:
+            if self.prefetch == 1:
                 # the next batch's negatives, frontier, compaction and packed memory rows on the model's second stream: the
                 # reference's loop does this between batches on the host (main.py:190-207 + the neighbour finder); here it
                 # runs beside this batch's backward.  Every step still does exactly one step's worth of it.
@@ -395,6 +395,18 @@ class Workload:
         _lm.mark("step.embedded")
         loss = P.bpr_step(tgn, emb, b, n_neg, pos_block=pos_block)
         _lm.mark("step.backward_done")
+        if self.prefetch == 2 and self.mvs is None:
+            # the next batch's negatives, frontier, compaction and packed rows: queued behind the backward's "attention backward
+            # is next" event on the model's second stream - beside the longest kernel of the step.  The reference's loop does
+            # this work on the host between batches (main.py:190-207 + the neighbour finder); every step still does exactly one
+            # step's worth of it.
+            lo2 = self.start + ((i + 1) * B) % self.span
+            s2 = slice(lo2, lo2 + B)
+            with tgn.prefetching(beside_attention_backward=True):
+                neg2 = self.sampler.sample(self.port_idx_all[s2], self.port_len_all[s2], n_neg, offset=i + 1).reshape(-1)
+                if tgn.prefetch(self.src_all[s2], self.dst_all[s2], [neg2], [n_neg], self.ts_all[s2], self.eidx_all[s2],
+                                cfg.n_neighbors):
+                    self._next = (i + 1, neg2)
         if self.dist_on and (self.world > 1 or self.force_dist):     # (set_world(0, 1): rank 0 alone, no collective)
             ev = None
             if self.time_collective:                          # sampled steps: the collective bracketed by events on the caller's stream

@@ -302,6 +302,11 @@ typedef struct pfo_tgn_batch {
      bit h of entry (n, j) = the attention weight of key slot j / head h of instance n is KEPT; null = the step's own Philox
      draws.  Only read when dropout_p > 0 and training != 0. */
   const uint8_t* const* dropout_keep;
+  /* Optional hipEvent_t pfo_tgn_backward records on the caller's stream right behind layer 1's d ctx' contraction, i.e. when
+     the layer-1 attention backward - the longest kernel of the step, ~1/3 of it - is about to start.  A caller that prepares
+     the NEXT batch (pfo_tgn_prepare on another stream: sampling, compaction, row pack - small latency-bound launches) makes
+     that stream wait for this event, so the preparation runs beside the one phase of the step that hides it. */
+  void* mid_event;
 } pfo_tgn_batch;
 
 /* The part of pfo_tgn_forward that depends on neither parameters nor gradients - frontier sampling (utils.py:163-219 per level,

@@ -1038,6 +1038,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       q.b_img = lw.iW1ovT;
       RUN(pfo_gemm_launch(q, s));
       PFO_MARK(mk_dctx[l], s);
+      if (l == 1 && b->mid_event) HIPOK(hipEventRecord((hipEvent_t)b->mid_event, s), "event record failed");
     }
     if (l > 1) {
       set_tn(tn[ntn], dh1, D, xA, D, x_idx, D, D, lw.dW1b_f, D, lw.db1_f);              // d (W1[:, E:] A), d (b1 + W1[:, E:] b)

@@ -149,6 +149,7 @@ class TGN(nn.Module):
         self.deterministic = False        # bitwise run-to-run reproducible backward (pfo_tgn_batch.deterministic), ~4 % slower
         self.dp_bucketed = False          # ask the backward for the "top layer's gradients are final" event (two-bucket all-reduce)
         self._bucket_event, self._bucket_event_fresh, self._grad_split = None, False, None
+        self._mid_event, self._mid_event_fresh = None, False   # recorded by the native backward in front of layer 1's attention backward
         self._zero_next = False
         self.eval_chunk_roots = 16384     # roots per forward-only pass (evaluation.py scores B*(2+N_ITEMS) roots per batch)
         self.eval_dedup = True            # forward-only passes embed every distinct (node, time) root once
@@ -503,6 +504,12 @@ class TGN(nn.Module):
                 self._bucket_event.record()                       # materialises the underlying hipEvent_t
             ev = self._bucket_event.cuda_event
             self._bucket_event_fresh = True
+        if not torch.cuda.is_current_stream_capturing():
+            if self._mid_event is None:
+                self._mid_event = torch.cuda.Event()
+                self._mid_event.record()                          # materialises the underlying hipEvent_t
+            call.batch_struct.mid_event = self._mid_event.cuda_event
+            self._mid_event_fresh = True
         _lib.call("pfo_tgn_backward_ev", ctypes.byref(call.cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
                   call.ws.data_ptr(), d_emb.data_ptr(), self._flat_grad.data_ptr(), 1 if zero_first else 0, ev,
                   mean[0].data_ptr() if mean else None, int(mean[0].shape[0]) if mean else 0,
@@ -554,18 +561,27 @@ class TGN(nn.Module):
                 self.memory._state_version if self.use_memory else 0, id(nf), getattr(nf, "_version", 0),
                 self.dp_rank, self.dp_world)
 
-    def prefetching(self):
+    def prefetching(self, beside_attention_backward=False):
         """Context manager: work issued inside runs on this model's prefetch stream, ordered behind everything the caller's
         stream holds at entry.  A training loop draws the NEXT batch's negatives and calls ``prefetch`` inside it, right after
-        the current batch's forward: the whole preparation then runs beside the current batch's backward."""
+        the current batch's forward: the whole preparation then runs beside the current batch's backward.
+
+        ``beside_attention_backward``: enter AFTER the current batch's backward was queued; the prefetch stream then waits for
+        the event that backward recorded in front of its layer-1 attention kernel (``pfo_tgn_batch.mid_event``) instead of for
+        the whole backward: the preparation's small latency-bound launches run beside the longest kernel of the step, the one
+        phase that hides them (beside the layer-2 backward - equally small launches - they cost as much as they save)."""
         import contextlib
 
         @contextlib.contextmanager
         def ctx():
             if self._pre_stream is None:
                 self._pre_stream = torch.cuda.Stream(device=self.device)
-            ev = torch.cuda.Event()
-            ev.record()                                           # after the caller's forward (whose state update the pack reads)
+            if beside_attention_backward and self._mid_event_fresh:
+                ev = self._mid_event                              # (behind the forward's state update too: same stream, earlier)
+                self._mid_event_fresh = False
+            else:
+                ev = torch.cuda.Event()
+                ev.record()                                       # after the caller's forward (whose state update the pack reads)
             self._pre_main = torch.cuda.current_stream()
             self._pre_stream.wait_event(ev)
             with torch.cuda.stream(self._pre_stream):

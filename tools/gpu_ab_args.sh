@@ -1,13 +1,12 @@
 #!/bin/bash
-# A/B on ONE box between bench.py argument sets: ARGS_A="..." ARGS_B="..." (interleaved, 3 rounds)
+# A/B on ONE box between bench.py argument sets: tools/gpu_ab_args.sh "<args A>" "<args B>" ...   (each run twice, interleaved)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/ab_args; mkdir -p $out
-for rep in 1 2 3; do
-for v in A B; do
-  if [ $v = A ]; then a="$ARGS_A"; else a="$ARGS_B"; fi
-  echo "== $v: $a"
-  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-prof --min-seconds 1.0 $a 2>$out/err.txt | python -c "
+for rep in 1 2; do
+for v in "$@"; do
+  echo "== $v"
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-prof --min-seconds 1.0 $v 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(d['ms_per_step'], d['config']['block_ms_per_step'], d['config'].get('final_loss'))" || tail -5 $out/err.txt
+print(d['ms_per_step'], d['config']['block_ms_per_step'])"
 done; done 2>&1 | tee $out/ab.txt
