@@ -918,12 +918,15 @@ extern "C" int pfo_attn_dropout_mask(uint64_t seed, uint64_t offset, int64_t N, 
   return PFO_OK;
 }
 
-bool pfo_attn_bwd_runs_possible(int K) {
+bool pfo_attn_bwd_runs_possible(int K, int D, int H) {
   static const int runs_on = getenv("PFO_ATTN_RUNS") ? atoi(getenv("PFO_ATTN_RUNS")) : 1;                    // A/B switch
-  return runs_on && K <= 64;
+  // D > 192 with four heads (NR = 4, H = 4) needs more than the 256 registers a lane can have: the run-merged kernel would spill
+  // 160-176 B per lane to scratch there - that shape takes the per-instance kernel (no spill), like uniform sampling does
+  const bool fits = !(D > 192 && H == 4);
+  return runs_on && K <= 64 && fits;
 }
 bool pfo_attn_bwd_uses_runs(const PfoAttn& a) {
-  return a.d_nbr && a.nbr_row && pfo_attn_bwd_runs_possible(a.K) && a.members && a.seg_ptr && a.n_rows && a.qk_row && a.run_cnt &&
+  return a.d_nbr && a.nbr_row && pfo_attn_bwd_runs_possible(a.K, a.D, a.H) && a.members && a.seg_ptr && a.n_rows && a.qk_row && a.run_cnt &&
          a.dqk_live;
 }
 
@@ -959,7 +962,7 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
     break;
     switch (NRv * 8 + a.H) {
       RUNS_GO(1, 1) RUNS_GO(1, 2) RUNS_GO(1, 4) RUNS_GO(2, 1) RUNS_GO(2, 2) RUNS_GO(2, 4)
-      RUNS_GO(3, 1) RUNS_GO(3, 2) RUNS_GO(3, 4) RUNS_GO(4, 1) RUNS_GO(4, 2) RUNS_GO(4, 4)
+      RUNS_GO(3, 1) RUNS_GO(3, 2) RUNS_GO(3, 4) RUNS_GO(4, 1) RUNS_GO(4, 2)      // (4, 4): pfo_attn_bwd_runs_possible says no
       default: done = false;
     }
 #undef RUNS_GO

@@ -78,4 +78,4 @@ int64_t pfo_attn_bwd_det_parts(int64_t N);   // slab rows a deterministic backwa
 // true when pfo_attn_bwd_launch will take the run-merged kernel for `a`: dQK row m then belongs to the m-th MEMBER
 // (a.members[m]), not to instance m
 bool pfo_attn_bwd_uses_runs(const PfoAttn& a);
-bool pfo_attn_bwd_runs_possible(int K);   // the switch and the shape limit alone (known before the launch is described)
+bool pfo_attn_bwd_runs_possible(int K, int D, int H);   // the switch and the shape limits alone (known before the launch is described)

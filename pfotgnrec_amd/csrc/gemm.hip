@@ -42,6 +42,8 @@ struct GemmDev {
   int dyn_chunk;                   // split-K chunk = f(device-side K) instead of split_chunk
   const void* b_img; int b_img_rows;   // pre-split bf16x3 image of B (source 0) and its padded row count
   const void* b_img2;                  // ... of the second K-concatenated source (same padded row count)
+  // GRU gate backward epilogue of the 32-row kernel (gemm.hpp PfoGemm::gg_*)
+  const float* gg_gates; const float* gg_h; const uint8_t* gg_hm; const float* gg_dh0; float* gg_dgi; float* gg_dgh;
 };
 
 static bool aligned4(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -557,6 +559,39 @@ __device__ __forceinline__ void bx_split_rows(const float4 (&a_raw)[2][2], u32x4
 }
 
 // epilogue of the operand-swapped bf16x3 kernels: four consecutive columns col..col+3 of one output row
+// GRU gate backward for hidden units col .. col+3 of table row `row` (PfoGemm::gg_*): v = the row's query-side gradient
+__device__ __forceinline__ void bx_gru_gates4(const GemmDev& p, int row, int col, const f32x4 v) {
+  const int D = p.N;
+  float o[4][4] = {};                                  // [dpr | dpz | dpn | dpn r][unit]
+  if (p.gg_hm[row]) {
+    const int64_t e = (int64_t)row * D + col;
+    const float* gs = p.gg_gates + (int64_t)row * 4 * D + col;
+    const float4 h4 = *reinterpret_cast<const float4*>(p.gg_h + e), k4 = *reinterpret_cast<const float4*>(p.gg_dh0 + e);
+    const float4 r4 = *reinterpret_cast<const float4*>(gs), z4 = *reinterpret_cast<const float4*>(gs + D);
+    const float4 n4 = *reinterpret_cast<const float4*>(gs + 2 * D), g4 = *reinterpret_cast<const float4*>(gs + 3 * D);
+    const float dh[4] = {k4.x + v[0], k4.y + v[1], k4.z + v[2], k4.w + v[3]};      // key side (scattered by the attention backward) + query side
+    const float hh[4] = {h4.x, h4.y, h4.z, h4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
+    const float nn[4] = {n4.x, n4.y, n4.z, n4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float dn = dh[u] * (1.f - zz[u]);
+      const float dz = dh[u] * (hh[u] - nn[u]);
+      const float dpn = dn * (1.f - nn[u] * nn[u]);
+      const float dr = dpn * gg[u];
+      o[0][u] = dr * rr[u] * (1.f - rr[u]);
+      o[1][u] = dz * zz[u] * (1.f - zz[u]);
+      o[2][u] = dpn;
+      o[3][u] = dpn * rr[u];
+    }
+  }
+  float* gis = p.gg_dgi + (int64_t)row * 3 * D + col;
+  float* ghs = p.gg_dgh + (int64_t)row * 3 * D + col;
+  const float4 a = {o[0][0], o[0][1], o[0][2], o[0][3]}, b = {o[1][0], o[1][1], o[1][2], o[1][3]};
+  const float4 c = {o[2][0], o[2][1], o[2][2], o[2][3]}, c2 = {o[3][0], o[3][1], o[3][2], o[3][3]};
+  *reinterpret_cast<float4*>(gis) = a; *reinterpret_cast<float4*>(gis + D) = b; *reinterpret_cast<float4*>(gis + 2 * D) = c;
+  *reinterpret_cast<float4*>(ghs) = a; *reinterpret_cast<float4*>(ghs + D) = b; *reinterpret_cast<float4*>(ghs + 2 * D) = c2;
+}
+
 __device__ __forceinline__ void bx_store4(const GemmDev& p, float* Cb, int64_t ldc, const float* bias, float rscale, bool zero,
                                           bool n4, int row, int col, const f32x4 a, const float* addrow = nullptr) {
   float v[4] = {a[0], a[1], a[2], a[3]};
@@ -1366,7 +1401,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const G
       if (j < NT && col < p.N) {
         f32x4 v = acc[i][jj];
         if constexpr (FMT == 1) v = hx_scale4(v, *reinterpret_cast<const int4*>(bexp1 + col), accE[i] - 2 * HX_TOP);
-        bx_store4(p, Cb, ldc, p.bias, rscale, zero, n4, row, col, v, addrow);
+        if (p.gg_gates) bx_gru_gates4(p, row, col, v);           // (wave-uniform: a kernel argument)
+        else bx_store4(p, Cb, ldc, p.bias, rscale, zero, n4, row, col, v, addrow);
       }
     }
   }
@@ -2065,6 +2101,7 @@ static void to_dev(const PfoGemm& g, GemmDev& d) {
   d.c_bs = g.c_bs; d.bias_bs = g.bias_bs; d.rs_bs = g.rs_bs;
   d.n_real = g.N; d.slab_base = g.slabs; d.dyn_chunk = 0;
   d.b_img = nullptr; d.b_img_rows = 0; d.b_img2 = nullptr;
+  d.gg_gates = g.gg_gates; d.gg_h = g.gg_h; d.gg_hm = g.gg_hm; d.gg_dh0 = g.gg_dh0; d.gg_dgi = g.gg_dgi; d.gg_dgh = g.gg_dgh;
 }
 
 
@@ -2109,6 +2146,14 @@ int pfo_bimg_launch(const PfoBimg* list, int n, hipStream_t stream) {
   return PFO_OK;
 }
 
+bool pfo_gemm_takes_skinny(int M, int N) {
+  static const int bx = getenv("PFO_GEMM_BF16X3") ? atoi(getenv("PFO_GEMM_BF16X3")) : PFO_DEFAULT_BF16X3;
+  static const int bx_min_tiles = getenv("PFO_BX_MIN_TILES") ? atoi(getenv("PFO_BX_MIN_TILES")) : PFO_BX_MIN_TILES;
+  static const bool forced = getenv("PFO_GEMM_TILE") != nullptr;
+  static const int sk = getenv("PFO_GEMM_SKINNY") ? atoi(getenv("PFO_GEMM_SKINNY")) : 1;
+  if (bx < 1 || forced || !sk) return false;
+  return (int64_t)pfo_ceil_div(M, BM) * pfo_ceil_div(N, BN) < bx_min_tiles;
+}
 bool pfo_gemm_takes_bx(int M, int N) {
   static const int bx = getenv("PFO_GEMM_BF16X3") ? atoi(getenv("PFO_GEMM_BF16X3")) : PFO_DEFAULT_BF16X3;
   static const int bx_min_tiles = getenv("PFO_BX_MIN_TILES") ? atoi(getenv("PFO_BX_MIN_TILES")) : PFO_BX_MIN_TILES;
@@ -2193,6 +2238,7 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
     } else if (g.b_img && (g.K[1] == 0 || g.b_img2) && a_rowvec && (g.bx_force || (bx >= 1 && big_tiles >= bx_min_tiles && force < 0))) {
       d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN); d.b_img2 = g.b_img2;
       kind = PFO_PROF_GEMM_BX;
+      PFO_REQUIRE(!g.gg_gates, "the GRU gate epilogue exists in the 32-row image kernel only (pfo_gemm_takes_skinny)");
       static const int areg = getenv("PFO_GEMM_AREG") ? atoi(getenv("PFO_GEMM_AREG")) : PFO_DEFAULT_AREG;    // A/B switch
       if (areg && g.batch == 1)
       {

@@ -35,7 +35,16 @@ struct PfoGemm {
   const void* b_img = nullptr;
   const void* b_img2 = nullptr;     // image of the second source's B (two K-concatenated sources in one bf16x3 launch)
   int bx_force = 0;                 // tests: 1 = the 128-row bf16x3 kernel, 2 = the 32-row one, whatever the heuristic says
+  // GRU gate backward as the EPILOGUE (32-row image kernel only, pfo_gemm_takes_skinny): the contraction's result is the
+  // query-side gradient of the touched rows' level-0 features (dx_tab); instead of storing it, row m / hidden unit d gets
+  //   dh = C[m][d] + gg_dh0[m][d];  the GRUCell gate derivatives of memory_updater.py:18-61 via autograd (memory.hip
+  //   gru_gates_bwd_vec_kernel has the same arithmetic)  ->  gg_dgi[m][3N], gg_dgh[m][3N]     (N = the hidden size)
+  // C is not written.  gg_gates [M, 4N] = r | z | n | gh_n kept by the forward, gg_h [M, N] the packed memory rows,
+  // gg_hm u8[M] "the row had a pending message" (0: zero gradients).
+  const float* gg_gates = nullptr; const float* gg_h = nullptr; const uint8_t* gg_hm = nullptr; const float* gg_dh0 = nullptr;
+  float* gg_dgi = nullptr; float* gg_dgh = nullptr;
 };
+bool pfo_gemm_takes_skinny(int M, int N);   // a launch of this shape with weight images takes the 32-row kernel
 
 // Pre-split ("bf16x3") image of a weight operand W(n, k) = src[n*ld + k] (trans = 0) or src[k*ld + n] (trans = 1):
 // three bf16 pieces per element in the LDS layout of the split contraction kernel.  dst needs pfo_bimg_bytes(N, K).

@@ -941,7 +941,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   // Per-XCD replicas of the level-0 gradient table pay off only for the per-instance atomics (uniform sampling: 4 replicas
   // 0.537 -> 0.506 ms); the run-merged kernel issues 2-3x fewer and measures best on ONE table (1.656 vs 1.665 ms/step)
   const int det = b->deterministic ? 1 : 0;
-  const int n_rep = (det || (c->use_memory && !b->uniform && pfo_attn_bwd_runs_possible(K))) ? 1 : PFO_GRAD_REPLICAS;
+  const int n_rep = (det || (c->use_memory && !b->uniform && pfo_attn_bwd_runs_possible(K, D, H))) ? 1 : PFO_GRAD_REPLICAS;
   static_assert(PFO_GRAD_REPLICAS >= 2, "the deterministic int64 gradient table needs the room of two float replicas");
   int64_t det_rows = 0;                                        // slab rows written so far (deterministic mode)
 
@@ -965,6 +965,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
                            w.seg_tmp, w.seg_mem, w.seg_scratch, ss));
   HIPOK(hipEventRecord(sd.seg_done, ss), "event record failed");
   std::function<int()> deferred_chain;                       // a layer's chain-back launches, issued one layer later (below)
+  bool gates_fused = false;                                  // the GRU gate backward ran as the epilogue of layer 1's dx_tab launch
   static const char* const bwd_names[PFO_MAX_LAYERS + 1] = {"", "backward layer 1", "backward layer 2", "backward layer 3", "backward layer 4"};
   static const char* const mk_dh1[PFO_MAX_LAYERS + 1] = {"", "bwd.L1.dh1", "bwd.L2.dh1", "bwd.L3.dh1", "bwd.L4.dh1"};
   static const char* const mk_dctx[PFO_MAX_LAYERS + 1] = {"", "bwd.L1.dctx", "bwd.L2.dctx", "bwd.L3.dctx", "bwd.L4.dctx"};
@@ -1108,6 +1109,14 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
         PfoGemm q = g_nn(w.Dq, WQ, lw.Wqk, D, w.dx_tab, D, capP, D, HCp);
         q.A[1] = w.Dq + HCp; q.lda[1] = WQ; q.B[1] = p.w1 + E; q.ldb[1] = E + D; q.K[1] = D;
         q.b_img = lw.iWqkT; q.b_img2 = lw.iW1bT; q.m_dev = w.n_core;
+        // The GRU's gate backward rides in this launch's epilogue when it takes the 32-row kernel (one table, float rows):
+        // d h0 = key side (scattered by the attention backward) + this contraction's query side never goes to HBM as dx_tab,
+        // and the separate gate launch (26 us + a launch gap on the serial tail at C2) disappears
+        static const int fuse_env = getenv("PFO_FUSE_GATES") ? atoi(getenv("PFO_FUSE_GATES")) : 1;         // A/B switch
+        if (fuse_env && n_rep == 1 && !det && pfo_gemm_takes_skinny(capP, D) && (D % 4) == 0) {
+          q.gg_gates = w.gates; q.gg_h = w.h_rows; q.gg_hm = w.hm; q.gg_dh0 = w.d_h0; q.gg_dgi = w.gi; q.gg_dgh = w.gh;
+          gates_fused = true;
+        }
         RUN(pfo_gemm_launch(q, s));
         PFO_MARK(mk_dx[l], s);
       }
@@ -1296,8 +1305,9 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   if (c->use_memory) {
     PfoRange range_gru("backward GRU");
     // (the GRU's backward covers the rows the layers read: rows only the extra list names carry no gradient)
-    RUN(pfo_gru_gates_bwd_launch(w.gates, w.gi, w.gh, w.h_rows, w.hm, w.n_core, capP, D, w.d_h0, n_rep, rep_stride,
-                                 w.dx_tab, det, s));
+    if (!gates_fused)
+      RUN(pfo_gru_gates_bwd_launch(w.gates, w.gi, w.gh, w.h_rows, w.hm, w.n_core, capP, D, w.d_h0, n_rep, rep_stride,
+                                   w.dx_tab, det, s));
     PFO_MARK("bwd.gru.gates", s);
     {
       PfoTnProblem gp[2];
