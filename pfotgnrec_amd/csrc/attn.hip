@@ -485,6 +485,14 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
 #ifndef RUNS_WAVES
 #define RUNS_WAVES(NR, H) ((NR) * (H) <= 6 ? 3 : 2)
 #endif
+// RUNS_PREFETCH (round 4): a member's d ctx' and ctx' rows (2 x 2.8 KB at C2) are streamed from HBM exactly once, by this
+// kernel, and the member's setup needs them before its first key can be scored: with three wavefronts per SIMD that round trip
+// was exposed once per member (~4 us of work each).  While member m is processed one LDS-DMA instruction touches every
+// 128-byte line of member m+1's two rows (lanes 0-31: d ctx', 32-63: ctx'; one dword per line into a landing pad nobody
+// reads - no registers, no wait): the rows are in L2 when m+1's setup asks for them.
+#ifndef RUNS_PREFETCH
+#define RUNS_PREFETCH 1
+#endif
 // How a wavefront spends its cycles (round 3; measured against the round-2 loop, 357 vs 363 us at equal atomics - the atomic
 // rate, not the issue rate, bounds this kernel):
 //  * the gathers of key chunk c+1 are issued before chunk c is scored (two register sets used alternately, as in the forward);
@@ -500,6 +508,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
   __shared__ float s_tw[NR * 64], s_tb[NR * 64];
   __shared__ float s_cA[RUN_CHUNK][H][64];     // [instance of the group][head][slot]: cA of that key; zero where the slot is empty
   __shared__ int s_delta[RUN_CHUNK];            // [instance of the group]: its shift (count - the group's first count)
+#if RUNS_PREFETCH
+  __shared__ float s_pf[64];                    // landing pad of the next member's row prefetch (never read)
+#endif
   const int lane = threadIdx.x;
   const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef, Cp = a.Cp;
   float wmax = 0.f, bmax = 0.f;
@@ -633,8 +644,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
     };
 
     const int m_end = min(M, (chunk + 1) * RUN_CHUNK);
+#if RUNS_PREFETCH
+    // the chunk's member ids in lanes 0 .. RUN_CHUNK-1 (one load per chunk instead of a dependent scalar load per member)
+    const int mem_ids = (lane < RUN_CHUNK && chunk * RUN_CHUNK + lane < m_end) ? a.members[chunk * RUN_CHUNK + lane] : 0;
+    const uint32_t row_bytes = (uint32_t)(H * Cp) * 4u;
+    const uint32_t pf_off = min((uint32_t)(lane & 31) * 128u, row_bytes - 4u);
+#endif
     for (int m = chunk * RUN_CHUNK; m < m_end; ++m) {
+#if RUNS_PREFETCH
+      const int64_t n = rl_i(mem_ids, m - chunk * RUN_CHUNK);
+      if (m + 1 < m_end) {
+        typedef __attribute__((address_space(1))) const void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int64_t n2 = rl_i(mem_ids, m + 1 - chunk * RUN_CHUNK);
+        const char* src = reinterpret_cast<const char*>(lane < 32 ? a.dctx : a.ctx) + n2 * (int64_t)row_bytes + pf_off;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)s_pf, 4, 0, 0);
+      }
+#else
       const int64_t n = a.members[m];
+#endif
       const int64_t slot0 = n * K;
       const bool inK = lane < K;
       const int my_id = inK ? a.nbr_ids[slot0 + lane] : 0;
