@@ -489,9 +489,11 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
 // kernel, and the member's setup needs them before its first key can be scored: with three wavefronts per SIMD that round trip
 // was exposed once per member (~4 us of work each).  While member m is processed one LDS-DMA instruction touches every
 // 128-byte line of member m+1's two rows (lanes 0-31: d ctx', 32-63: ctx'; one dword per line into a landing pad nobody
-// reads - no registers, no wait): the rows are in L2 when m+1's setup asks for them.
+// reads - no registers, no wait): the rows are on their way when m+1's setup asks for them.  Measured: the kernel 322-324 ->
+// 315-318 us (-2 %), but the counter pass shows FETCH_SIZE +36 % (the touched 64-byte sectors are fetched again by the real
+// loads: the pad warms the Infinity Cache, not the L2) - 6 us for 224 MB of extra fabric reads.  OFF by default.
 #ifndef RUNS_PREFETCH
-#define RUNS_PREFETCH 1
+#define RUNS_PREFETCH 0
 #endif
 // How a wavefront spends its cycles (round 3; measured against the round-2 loop, 357 vs 363 us at equal atomics - the atomic
 // rate, not the issue rate, bounds this kernel):
