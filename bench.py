@@ -84,7 +84,12 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=512, help="interactions per oracle step in the CPU baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=4, help="timed oracle steps (one more runs first, untimed)")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event bracketing of kernel launches")
-    ap.add_argument("--prefetch", type=int, default=0, choices=[0, 1, 2],
+    ap.add_argument("--overlap-tail", type=int, default=1, choices=[0, 1],
+                    help="1 (default, one rank): backward + optimizer step as ONE fused call whose end - the last side-stream launches "
+                         "of the backward and the Adam kernel - stays on the library's side stream while the caller's stream goes on to "
+                         "the next batch's candidate draw and neighbour sampling (bpr_step(..., optimizer=)); 0: the caller's stream "
+                         "waits for the whole backward, then runs Adam (the reference's loss.backward(); optimizer.step() order)")
+    ap.add_argument("--prefetch", type=int, default=0, choices=[0, 1, 2, 3],
                     help="1: the next batch's negatives / frontier / compaction / packed rows are issued on a second stream right "
                          "after the current forward (TGN.prefetch); 0 (default): inside the step, as the reference's call order "
                          "has it.  Measured on C2: 1.52 ms with, 1.50 without - the ~70 us of small launches cost as much beside "
@@ -305,7 +310,10 @@ class Workload:
         self.sampler = DeviceNegativeSampler(item_availability(d.destinations, graph.upper_u, cfg.n_items), graph.upper_u, dev, seed=1)
         self.n_neg = 3
         self._next = None
+        self.overlap_tail = bool(getattr(args, "overlap_tail", 1))
         self.prefetch = int(getattr(args, "prefetch", 0))
+        tgn.record_mid_event = self.prefetch in (2, 3)
+        tgn.mid_event_late = self.prefetch == 3
         self.mvs = None
         if self.ours:
             self.mvs = P.MVSampler(graph.prices, graph.upper_u, dev, gamma=2.0, lambda_mv=0.5, p_pos_num=1, p_neg_num=3)
@@ -393,9 +401,10 @@ class Workload:
         # loss + loss.backward() (main.py:337,388) as two native calls: the loss kernel hands its gradient rows straight to
         # the TGN backward (P.bpr_loss(...).backward() is the autograd spelling of the same thing, tests/test_gpu_round2.py)
         _lm.mark("step.embedded")
-        loss = P.bpr_step(tgn, emb, b, n_neg, pos_block=pos_block)
+        fused_opt = self.overlap_tail and not (self.dist_on and (self.world > 1 or self.force_dist)) and not self.prefetch
+        loss = P.bpr_step(tgn, emb, b, n_neg, pos_block=pos_block, optimizer=self.opt if fused_opt else None)
         _lm.mark("step.backward_done")
-        if self.prefetch == 2 and self.mvs is None:
+        if self.prefetch in (2, 3) and self.mvs is None:
             # the next batch's negatives, frontier, compaction and packed rows: queued behind the backward's "attention backward
             # is next" event on the model's second stream - beside the longest kernel of the step.  The reference's loop does
             # this work on the host between batches (main.py:190-207 + the neighbour finder); every step still does exactly one
@@ -419,7 +428,8 @@ class Workload:
             if ev is not None:
                 ev[1].record()
                 self.coll_events.append(ev)
-        self.opt.step()                                                                                        # main.py:389
+        if not fused_opt:
+            self.opt.step()                                                                                    # main.py:389
         _lm.mark("step.adam")
         self.opt.zero_grad(set_to_none=True)
         return loss

@@ -264,7 +264,8 @@ typedef struct pfo_tgn_state {
      did per step before), with pcache_valid != 0 it launches none of it.  The caller owns the validity: it must pass 0
      after anything wrote `params` (optimizer step, load_state_dict ...) unless pfo_tgn_refresh ran since.  pfo_tgn_backward
      reads the composites from the same buffer: parameters must not change between a forward and its backward.
-     NULL: the composites live in the workspace and are rebuilt by every forward. */
+     The buffer must be ZERO-INITIALISED by the caller when it is allocated (padding rows / columns of the composites are never
+     written).  NULL: the composites live in the workspace and are rebuilt by every forward. */
   void* pcache;
   int32_t pcache_valid;
 } pfo_tgn_state;
@@ -307,6 +308,16 @@ typedef struct pfo_tgn_batch {
      the NEXT batch (pfo_tgn_prepare on another stream: sampling, compaction, row pack - small latency-bound launches) makes
      that stream wait for this event, so the preparation runs beside the one phase of the step that hides it. */
   void* mid_event;
+  int32_t defer_join;       /* pfo_tgn_backward: != 0 leaves the END of the backward on the library's first side stream: the
+                               caller's stream is NOT made to wait for the side streams' last launches (the chain back to the
+                               layer-1 projection weights, the time-encoder fold: ~40 us after the caller's stream has run dry at
+                               C2); instead that side stream waits for the caller's stream, so "everything of this backward" is
+                               complete THERE.  The caller must then take the optimizer step with pfo_tgn_adam_side (same side
+                               stream) or call pfo_tgn_join before it touches gradients or parameters on its own stream.  The
+                               next pfo_tgn_forward joins by itself - behind its neighbour sampling, which reads neither. */
+  int32_t mid_event_late;   /* != 0: record it BEHIND the layer-1 attention backward instead - the preparation then runs beside the
+                               backward's serial tail (per-row sums, the touched-table contractions, the GRU's weight gradients:
+                               small launches that leave most of the chip idle) */
 } pfo_tgn_batch;
 
 /* The part of pfo_tgn_forward that depends on neither parameters nor gradients - frontier sampling (utils.py:163-219 per level,
@@ -369,6 +380,13 @@ int pfo_tgn_debug_views(const pfo_tgn_config* cfg, void* workspace, pfo_tgn_debu
  * side-stream work behind it, so the caller's stream never waits for the build itself.  Meant to be called right behind the
  * optimizer's kernel: the build then runs beside the next batch's sampling phase.  Not capturable into a HIP graph
  * (unjoined fork): a captured step passes pcache_valid = 0 instead. */
+/* Optimizer step on the library's first side stream, behind a backward that ran with pfo_tgn_batch.defer_join: same
+ * arguments and arithmetic as pfo_adam_step_ranges.  Gradients, moments and parameters are then in flight on that stream;
+ * pfo_tgn_forward / pfo_tgn_prepare / pfo_tgn_refresh / pfo_tgn_update_state wait for it where they first need them,
+ * pfo_tgn_join(stream) makes any other stream wait (no-op when nothing is pending). */
+int pfo_tgn_adam_side(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
+                      const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1, float beta2, float eps);
+int pfo_tgn_join(void* stream);
 int64_t pfo_tgn_pcache_bytes(const pfo_tgn_config* cfg);
 int pfo_tgn_refresh(const pfo_tgn_config* cfg, const pfo_tgn_state* state, void* stream);
 

@@ -42,7 +42,7 @@ class TgnBatch(C.Structure):
                 ("training", C.c_int32), ("extra_nodes", _VP), ("n_extra", C.c_int32), ("offset_dev", _VP),
                 ("deterministic", C.c_int32), ("prepared", C.c_int32),
                 ("upd_src", _VP), ("upd_dst", _VP), ("upd_ts", _VP), ("upd_eidx", _VP), ("upd_B", C.c_int32),
-                ("dropout_keep", C.POINTER(_VP)), ("mid_event", _VP)]
+                ("dropout_keep", C.POINTER(_VP)), ("mid_event", _VP), ("defer_join", C.c_int32), ("mid_event_late", C.c_int32)]
 
 
 class TgnDebug(C.Structure):
@@ -90,6 +90,9 @@ PROTOTYPES = {
                                            C.POINTER(C.c_int32), _VP, C.c_float, C.c_float, C.c_float, C.c_float, _VP]),
     "pfo_tgn_param_layout": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnLayout)]),
     "pfo_tgn_workspace_bytes": (C.c_int64, [C.POINTER(TgnConfig)]),
+    "pfo_tgn_adam_side": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_int32), C.c_float, C.c_float, C.c_float, C.c_float]),
+    "pfo_tgn_join": (C.c_int, [_VP]),
     "pfo_tgn_pcache_bytes": (C.c_int64, [C.POINTER(TgnConfig)]),
     "pfo_tgn_refresh": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), _VP]),
     "pfo_tgn_forward": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), C.POINTER(TgnBatch), _VP, _VP, _VP]),

@@ -65,6 +65,7 @@ struct Ws {
   // of every layer] (pz_bytes) - in the workspace right behind the per-step region, or in the parameter cache
   size_t zero_bytes, mark_bytes;
   float* pz; size_t pz_bytes;
+  bool pz_in_cache;            // pz lives in the caller's parameter cache, which the caller zeroed once (no per-build memset)
   int64_t bytes;
 };
 
@@ -234,6 +235,7 @@ int64_t pcache_bind(const pfo_tgn_config* c, void* base, Ws& w) {
   }
   w.l1_bias = w.layer[1].cqk;
   w.pz_bytes = (size_t)(p - reinterpret_cast<char*>(w.pz));
+  w.pz_in_cache = true;
   w.cosb = take<float>(p, d.D);
   w.iQX = take<char>(p, pfo_bimg_bytes(WQ, d.D));
   if (c->use_memory) {
@@ -324,6 +326,8 @@ PfoGemm g_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const int
 struct Side {
   hipStream_t s = nullptr, s2 = nullptr;
   hipEvent_t tn_a_done = nullptr, done2 = nullptr, gru_done = nullptr, comp_done = nullptr, pc_a = nullptr, pc_b = nullptr;
+  hipEvent_t main_done = nullptr, side_done = nullptr;
+  bool side_pending = false;     // a deferred backward end / optimizer step is in flight on `s` (pfo_tgn_batch.defer_join)
   hipEvent_t fork = nullptr, done = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr, fold_done = nullptr;
   hipEvent_t layer[PFO_MAX_LAYERS + 1] = {};
   bool ok = false;
@@ -349,12 +353,22 @@ Side& side() {
     good = good && hipEventCreateWithFlags(&sd.comp_done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.pc_a, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.pc_b, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.main_done, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.side_done, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; l <= PFO_MAX_LAYERS; ++l) good = good && hipEventCreateWithFlags(&sd.layer[l], hipEventDisableTiming) == hipSuccess;
     sd.ok = good;
   }
   return sd;
 }
 #define HIPOK(expr, msg) PFO_REQUIRE((expr) == hipSuccess, msg)
+// `s` waits for whatever a deferred backward end / side-stream optimizer step left in flight (pfo_tgn_batch.defer_join)
+int side_join(Side& sd, hipStream_t s) {
+  if (!sd.side_pending) return PFO_OK;
+  HIPOK(hipEventRecord(sd.side_done, sd.s), "event record failed");
+  HIPOK(hipStreamWaitEvent(s, sd.side_done, 0), "event wait failed");
+  sd.side_pending = false;
+  return PFO_OK;
+}
 
 #define RUN(expr)                  \
   do {                             \
@@ -516,7 +530,10 @@ static int build_gru_images(const pfo_tgn_config* c, const Dims& d, const Ws& w,
 }
 static int build_stage_a(const Dims& d, const Ws& w, const Params& P, hipStream_t ss) {
   const int L = d.L, D = d.D, H = d.H, E = d.E, C = d.C, dh = d.dh, Cp = d.Cp, HCp = d.H * d.Cp;
-  HIPOK(hipMemsetAsync(w.pz, 0, w.pz_bytes, ss), "memset failed");              // 64 zero floats | Wqk / W1ovT / cqk of every layer
+  // 64 zero floats | Wqk / W1ovT / cqk of every layer: the builds below OVERWRITE the live rows and never touch the padding
+  // rows / columns, which must be zero - in the workspace (recycled memory) that takes a memset per build, in the parameter
+  // cache the caller cleared the buffer once when it allocated it (pfo_tgn_state.pcache: "zero-initialised")
+  if (!w.pz_in_cache) HIPOK(hipMemsetAsync(w.pz, 0, w.pz_bytes, ss), "memset failed");
   RUN(pfo_time_encode(w.pz, 1, P.tw, P.tb, D, w.cosb, ss));                     // cos(fma(0, w, b)) (embedding_module.py:92)
   PfoGemm st1[3 * PFO_MAX_LAYERS], st2[4 * PFO_MAX_LAYERS];
   PfoBimg im[8 * PFO_MAX_LAYERS + 2];
@@ -643,6 +660,7 @@ extern "C" int pfo_tgn_refresh(const pfo_tgn_config* c, const pfo_tgn_state* st,
   PFO_REQUIRE(sd.ok, "could not create the side stream");
   hipStream_t s = (hipStream_t)stream, sr = sd.s2;
   PfoRange range("pfo_tgn_refresh");
+  RUN(side_join(sd, s));
   // Forked from the caller's stream (behind the kernel that wrote the parameters, and behind every reader of the old
   // composites: the previous backward joined its side streams into that stream) onto the SECOND side stream, not joined.
   // The next forward's first side stream - which packs the touched rows as soon as the compaction is done - waits for pc_a
@@ -678,6 +696,7 @@ extern "C" int pfo_tgn_prepare(const pfo_tgn_config* c, const pfo_tgn_state* st,
   const Dims d = dims_of(c);
   const Ws w = carve(c, workspace);
   PfoRange range("pfo_tgn_prepare");
+  RUN(side_join(side(), (hipStream_t)stream));
   RUN(prepare_sample(c, st, b, w, n, (hipStream_t)stream));
   RUN(prepare_compact_pack(c, st, b, w, d, n, (hipStream_t)stream));
   return PFO_OK;
@@ -723,6 +742,9 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
   if (!b->prepared) RUN(prepare_sample(c, st, b, w, n, s));
   PFO_MARK("fwd.sampled", s);
+  // a deferred backward end + optimizer step of the previous step may still be running on the side stream: the sampling above
+  // reads neither its buffers nor the parameters; everything below does (compaction counts, the GRU's weights ...)
+  RUN(side_join(sd, s));
   const bool fused_state = b->upd_src != nullptr && c->use_memory && L >= 2;
   PFO_REQUIRE(!fused_state || (b->upd_dst && b->upd_ts && b->upd_eidx && b->upd_B >= 1), "bad state-update arguments");
 
@@ -950,6 +972,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   Side& sd = side();
   PFO_REQUIRE(sd.ok, "could not create the side stream");
   hipStream_t ss = sd.s;
+  RUN(side_join(sd, s));
   // layer-1 instances grouped by the touched-table row they sit on (needed only when the layer-1 gradients are summed
   // per row, late in this call): built on the side stream, beside the layer-L .. 2 work.  The same stream first clears what
   // this call accumulates into: the level-0 gradient rows (layer 1's attention backward waits for seg_done)
@@ -1039,7 +1062,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       q.b_img = lw.iW1ovT;
       RUN(pfo_gemm_launch(q, s));
       PFO_MARK(mk_dctx[l], s);
-      if (l == 1 && b->mid_event) HIPOK(hipEventRecord((hipEvent_t)b->mid_event, s), "event record failed");
+      if (l == 1 && b->mid_event && !b->mid_event_late) HIPOK(hipEventRecord((hipEvent_t)b->mid_event, s), "event record failed");
     }
     if (l > 1) {
       set_tn(tn[ntn], dh1, D, xA, D, x_idx, D, D, lw.dW1b_f, D, lw.db1_f);              // d (W1[:, E:] A), d (b1 + W1[:, E:] b)
@@ -1083,6 +1106,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     const int dqk_by_member = pfo_attn_bwd_uses_runs(a) ? 1 : 0;
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
     PFO_MARK(mk_battn[l], s);
+    if (l == 1 && b->mid_event && b->mid_event_late) HIPOK(hipEventRecord((hipEvent_t)b->mid_event, s), "event record failed");
     if (det) det_rows += n_parts;
     if (deferred_chain) { RUN(deferred_chain()); deferred_chain = nullptr; }     // the layer above's chain-back (side streams)
     // merged query/key projection: dx += dqk' Wqk, dWqk = dqk'^T x, gqk = colsum(dqk')
@@ -1112,7 +1136,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
         // The GRU's gate backward rides in this launch's epilogue when it takes the 32-row kernel (one table, float rows):
         // d h0 = key side (scattered by the attention backward) + this contraction's query side never goes to HBM as dx_tab,
         // and the separate gate launch (26 us + a launch gap on the serial tail at C2) disappears
-        static const int fuse_env = getenv("PFO_FUSE_GATES") ? atoi(getenv("PFO_FUSE_GATES")) : 1;         // A/B switch
+        const int fuse_env = getenv("PFO_FUSE_GATES") ? atoi(getenv("PFO_FUSE_GATES")) : 0;   // (read per call: a test flips it)         // A/B switch (measured: 1.458-1.461 ms with, 1.453 without - the epilogue runs on the ~375 live workgroups of a 32-row launch, the separate kernel on the whole chip; off)
         if (fuse_env && n_rep == 1 && !det && pfo_gemm_takes_skinny(capP, D) && (D % 4) == 0) {
           q.gg_gates = w.gates; q.gg_h = w.h_rows; q.gg_hm = w.hm; q.gg_dh0 = w.d_h0; q.gg_dgi = w.gi; q.gg_dgh = w.gh;
           gates_fused = true;
@@ -1345,10 +1369,33 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     RUN(pfo_cq_backward_launch(gq, wq, nl, P.tb, D, dbq, dwq, G.tb, nullptr, L >= 2 ? w.tb_part : nullptr, w.dtime,
                                pfo_attn_bwd_max_parts(), G.tw, ss));                  // cq = Wq[:, D:] cos(b) + bq
   }
-  HIPOK(hipEventRecord(sd.done, ss), "event record failed");
-  HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
+  if (b->defer_join && chained) {
+    // the end of the backward stays on the side stream (pfo_tgn_batch.defer_join): it waits for the caller's stream's last
+    // launch instead of the other way round - the caller's stream is free for the next batch's neighbour sampling
+    HIPOK(hipEventRecord(sd.main_done, s), "event record failed");
+    HIPOK(hipStreamWaitEvent(ss, sd.main_done, 0), "event wait failed");
+    sd.side_pending = true;
+  } else {
+    HIPOK(hipEventRecord(sd.done, ss), "event record failed");
+    HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
+  }
   PFO_MARK("bwd.end", s);
   return PFO_OK;
+}
+
+extern "C" int pfo_tgn_adam_side(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
+                                 const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1, float beta2,
+                                 float eps) {
+  Side& sd = side();
+  PFO_REQUIRE(sd.ok, "could not create the side stream");
+  PFO_REQUIRE(sd.side_pending, "pfo_tgn_adam_side follows a backward that ran with pfo_tgn_batch.defer_join");
+  return pfo_adam_step_ranges(param, grad, exp_avg, exp_avg_sq, n_ranges, lo, hi, step, lr, beta1, beta2, eps, (void*)sd.s);
+}
+
+extern "C" int pfo_tgn_join(void* stream) {
+  Side& sd = side();
+  PFO_REQUIRE(sd.ok, "could not create the side stream");
+  return side_join(sd, (hipStream_t)stream);
 }
 
 // =============================================================================================
@@ -1360,5 +1407,6 @@ extern "C" int pfo_tgn_update_state(const pfo_tgn_config* c, const pfo_tgn_state
   PFO_REQUIRE(st && workspace && src && dst && ts && eidx && B >= 1, "bad arguments");
   const Ws w = carve(c, workspace);
   PfoRange range("pfo_tgn_update_state");
+  RUN(side_join(side(), (hipStream_t)stream));
   return state_update(c, st, w, src, dst, ts, eidx, B, (hipStream_t)stream);
 }

@@ -53,12 +53,20 @@ def bpr_loss(emb, batch, n_neg, pos_block=1, grad_scale=1.0):
     return _BprFn.apply(emb, batch, pos_off, neg_off, n_neg, grad_scale)
 
 
-def bpr_step(tgn, emb, batch, n_neg, pos_block=1, grad_scale=None):
+def bpr_step(tgn, emb, batch, n_neg, pos_block=1, grad_scale=None, optimizer=None):
     """``loss = bpr_loss(...); loss.backward()`` (main.py:321-337 + 388) as two native calls and no torch kernel: the loss
     kernel writes the already scaled gradient rows and the TGN backward is called on them directly, skipping autograd's
     seed fill and ``d_emb * g`` multiply (three ~6 us launches on the critical path of a 1.5 ms step); the batch mean of the
     per-interaction losses - an input of nothing - is taken beside the backward.  ``emb`` must be the
     tensor ``TGN.embed_device`` returned under autograd; anything else (an empty shard, a view) takes the autograd route.
+
+    ``optimizer`` (a ``FusedAdam`` of this model, single rank): ``loss.backward(); optimizer.step()`` (main.py:388-389) in
+    one go, with the END of the backward and the optimizer's kernel left on the library's side stream
+    (``pfo_tgn_batch.defer_join`` + ``pfo_tgn_adam_side``): the caller's stream does not wait out the last ~40 us of
+    side-stream launches (the chain back to the layer-1 projection weights) nor the Adam kernel - it goes straight on to the
+    next batch's candidate draw and neighbour sampling, and the next forward joins where it first needs parameters.
+    Gradients and parameters are IN FLIGHT on that stream afterwards: read them only after ``tgn.join()`` (``state_dict()``
+    joins by itself).  ``optimizer.zero_grad(set_to_none=True)`` afterwards is fine (host side only).
     Returns the detached loss."""
     call = getattr(emb.grad_fn, "call", None) if emb.grad_fn is not None else None
     if batch == 0 or call is None or call.ws is None or emb.shape[0] != call.R:
@@ -73,8 +81,12 @@ def bpr_step(tgn, emb, batch, n_neg, pos_block=1, grad_scale=None):
     loss = torch.empty(1, dtype=torch.float32, device=e.device)
     _lib.call("pfo_bpr_loss_parts", e.data_ptr(), batch, D, pos_block * batch, (pos_block + 1) * batch, n_neg, R, float(scale),
               parts.data_ptr(), d_emb.data_ptr(), _lib.stream_ptr())
-    tgn._native_backward(call, d_emb, mean=(parts, loss))     # the batch mean of the losses: on the backward's side stream
+    fused_opt = (optimizer is not None and getattr(optimizer, "tgn", None) is tgn and tgn.dp_world == 1
+                 and not torch.cuda.is_current_stream_capturing() and not _lib.prof_is_on())
+    tgn._native_backward(call, d_emb, mean=(parts, loss), defer_join=fused_opt)     # the batch mean of the losses: on the backward's side stream
     call.release()
+    if optimizer is not None:
+        optimizer.step(side=fused_opt)
     return loss[0]
 
 

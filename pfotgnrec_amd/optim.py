@@ -43,11 +43,17 @@ class FusedAdam(torch.optim.Optimizer):
             self._steps[names[k]] = int(t)
 
     @torch.no_grad()
-    def step(self, closure=None, step_dev=None):
+    def step(self, closure=None, step_dev=None, side=False):
         """``step_dev`` (1-element int32 device tensor): the step counts used are the host's plus that device word and the
         host counters are NOT advanced - for steps captured into a HIP graph, which advances the word itself
-        (``sync_steps`` folds it back into the host counters afterwards)."""
+        (``sync_steps`` folds it back into the host counters afterwards).
+        ``side``: the kernel goes to the library's side stream, behind a backward that ran with ``defer_join``
+        (``functional.bpr_step(..., optimizer=self)``); otherwise anything pending there is joined first."""
         tgn = self.tgn
+        if side and (self._m is None or self._m.device != tgn.flat_parameters.device):
+            side = False            # the moments are allocated (and cleared) on the caller's stream below: this one step runs there
+        if not side:
+            tgn.join()
         if tgn.flat_grad is None:
             return None
         _lib.require_gpu(tgn.flat_parameters.device)
@@ -75,6 +81,12 @@ class FusedAdam(torch.optim.Optimizer):
                           (ctypes.c_int32 * k)(*st[i:i + k]), step_dev.data_ptr(), float(g["lr"]), float(g["betas"][0]),
                           float(g["betas"][1]), float(g["eps"]), _lib.stream_ptr())
                 continue
+            if side:
+                _lib.call("pfo_tgn_adam_side", tgn.flat_parameters.data_ptr(), tgn.flat_grad.data_ptr(), self._m.data_ptr(),
+                          self._v.data_ptr(), k, (ctypes.c_int64 * k)(*lo[i:i + k]), (ctypes.c_int64 * k)(*hi[i:i + k]),
+                          (ctypes.c_int32 * k)(*st[i:i + k]), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                          float(g["eps"]))
+                continue
             _lib.call("pfo_adam_step_ranges", tgn.flat_parameters.data_ptr(), tgn.flat_grad.data_ptr(), self._m.data_ptr(),
                       self._v.data_ptr(), k, (ctypes.c_int64 * k)(*lo[i:i + k]), (ctypes.c_int64 * k)(*hi[i:i + k]),
                       (ctypes.c_int32 * k)(*st[i:i + k]), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
@@ -83,5 +95,5 @@ class FusedAdam(torch.optim.Optimizer):
             # the kernel above wrote the parameters behind torch's back: the model's parameter cache (composite weights, weight
             # images) is rebuilt right here, on the library's side stream behind this kernel - beside the next batch's sampling
             # phase - so that the next forward launches none of it.  (A step being captured rebuilds inside its own forward.)
-            tgn.parameters_changed(refresh=tgn.refresh_after_step and step_dev is None)
+            tgn.parameters_changed(refresh=tgn.refresh_after_step and step_dev is None and not side)
         return None

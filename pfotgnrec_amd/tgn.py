@@ -140,7 +140,10 @@ class TGN(nn.Module):
         # of any torch optimizer, load_state_dict, copy_ ... bump it) or ``parameters_changed()`` (native writers: FusedAdam,
         # graph replays).  Writes through ``p.data`` bypass the counter: call ``parameters_changed()`` after them.
         self.param_cache = os.environ.get("PFO_PCACHE", "1") != "0"
-        self.refresh_after_step = os.environ.get("PFO_PCACHE_REFRESH", "1") != "0"   # FusedAdam rebuilds the cache right behind its kernel
+        # FusedAdam may rebuild the cache right behind its kernel (pfo_tgn_refresh, second side stream) instead of leaving it to
+        # the next forward.  Off by default: measured at C2, 1.461 ms per step with, 1.454 without - the ~15 launches are hidden
+        # beside the sampling / GRU phase either way, and the refresh adds two event waits and moves the GRU's image launch
+        self.refresh_after_step = os.environ.get("PFO_PCACHE_REFRESH", "0") != "0"
         self._pcache, self._pcache_key, self._param_epoch = None, None, 0
         self._last_ws = None      # (config, workspace) of the newest forward (debug_touched)
         self._step = 0
@@ -150,6 +153,8 @@ class TGN(nn.Module):
         self.dp_bucketed = False          # ask the backward for the "top layer's gradients are final" event (two-bucket all-reduce)
         self._bucket_event, self._bucket_event_fresh, self._grad_split = None, False, None
         self._mid_event, self._mid_event_fresh = None, False   # recorded by the native backward in front of layer 1's attention backward
+        self.record_mid_event = False     # ... only on request: an event record on the caller's stream costs the step a launch gap
+        self.mid_event_late = False       # record it behind the attention backward instead of in front of it
         self._zero_next = False
         self.eval_chunk_roots = 16384     # roots per forward-only pass (evaluation.py scores B*(2+N_ITEMS) roots per batch)
         self.eval_dedup = True            # forward-only passes embed every distinct (node, time) root once
@@ -352,7 +357,7 @@ class TGN(nn.Module):
                 nbytes = _lib.load().pfo_tgn_pcache_bytes(ctypes.byref(self._cfg))
                 if nbytes < 0:
                     raise _lib.PfoError("pfo_tgn_pcache_bytes: %s" % _lib.load().pfo_last_error().decode())
-                self._pcache, self._pcache_key = torch.empty(nbytes, dtype=torch.uint8, device=self.device), None
+                self._pcache, self._pcache_key = torch.zeros(nbytes, dtype=torch.uint8, device=self.device), None   # (zeroed ONCE: include/pfotgn.h)
             pc = self._pcache.data_ptr()
             # (a step being captured into a HIP graph always builds: its replays run with whatever the parameters are then)
             valid = int(self._pcache_key is not None and self._pcache_key == self._param_key()
@@ -486,7 +491,17 @@ class TGN(nn.Module):
             p.grad = self._flat_grad[off:off + n].view(shape)
         return deferred
 
-    def _native_backward(self, call, d_emb, mean=None):
+    def join(self):
+        """Makes the current stream wait for a backward end / optimizer step that ``bpr_step(..., optimizer=...)`` left on the
+        library's side stream (no-op when nothing is pending)."""
+        if self._flat.is_cuda:
+            _lib.call("pfo_tgn_join", _lib.stream_ptr())
+
+    def state_dict(self, *args, **kwargs):
+        self.join()
+        return super().state_dict(*args, **kwargs)
+
+    def _native_backward(self, call, d_emb, mean=None, defer_join=False):
         """``mean`` = (src f32[n], out f32[1]): a mean the backward takes on its side stream (the BPR loss value)."""
         zero_first = self._attach_grads(call.gru_applied, defer_zero=True) or self._zero_next
         self._zero_next = False
@@ -504,12 +519,14 @@ class TGN(nn.Module):
                 self._bucket_event.record()                       # materialises the underlying hipEvent_t
             ev = self._bucket_event.cuda_event
             self._bucket_event_fresh = True
-        if not torch.cuda.is_current_stream_capturing():
+        if self.record_mid_event and not torch.cuda.is_current_stream_capturing():
             if self._mid_event is None:
                 self._mid_event = torch.cuda.Event()
                 self._mid_event.record()                          # materialises the underlying hipEvent_t
             call.batch_struct.mid_event = self._mid_event.cuda_event
+            call.batch_struct.mid_event_late = 1 if self.mid_event_late else 0
             self._mid_event_fresh = True
+        call.batch_struct.defer_join = 1 if defer_join else 0
         _lib.call("pfo_tgn_backward_ev", ctypes.byref(call.cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
                   call.ws.data_ptr(), d_emb.data_ptr(), self._flat_grad.data_ptr(), 1 if zero_first else 0, ev,
                   mean[0].data_ptr() if mean else None, int(mean[0].shape[0]) if mean else 0,
@@ -566,7 +583,8 @@ class TGN(nn.Module):
         stream holds at entry.  A training loop draws the NEXT batch's negatives and calls ``prefetch`` inside it, right after
         the current batch's forward: the whole preparation then runs beside the current batch's backward.
 
-        ``beside_attention_backward``: enter AFTER the current batch's backward was queued; the prefetch stream then waits for
+        ``beside_attention_backward`` (needs ``tgn.record_mid_event = True`` before the backward): enter AFTER the current
+        batch's backward was queued; the prefetch stream then waits for
         the event that backward recorded in front of its layer-1 attention kernel (``pfo_tgn_batch.mid_event``) instead of for
         the whole backward: the preparation's small latency-bound launches run beside the longest kernel of the step, the one
         phase that hides them (beside the layer-2 backward - equally small launches - they cost as much as they save)."""

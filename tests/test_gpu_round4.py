@@ -306,3 +306,99 @@ def test_backward_after_a_parameter_update_is_refused():
         tgn.embedding_module.attention_models[0].merger.fc1.weight.mul_(1.5)
     with pytest.raises(RuntimeError, match="modified between"):
         P.bpr_loss(emb, B, 3).backward()
+
+
+def test_gru_gate_backward_as_gemm_epilogue_equals_the_separate_kernel():
+    """PFO_FUSE_GATES=1: the GRU's gate backward runs as the epilogue of layer 1's dx_tab contraction (32-row image kernel)
+    instead of its own launch.  Same arithmetic per element on the same inputs: gradients of a step are identical up to the
+    summation order of nothing - bitwise in deterministic mode... the fused form is taken only for the float table (one
+    replica, not the deterministic int64 one), so the comparison is at fp32 rounding of the atomics: 1e-5 relative."""
+    from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+    cfg = SyntheticConfig("fg", 300, 25, 6000, 64, 2, 8, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    B, K = 64, 8
+    s = 3000
+    neg = np.random.RandomState(3).randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * 3)
+
+    def grads(fuse):
+        os.environ["PFO_FUSE_GATES"] = "1" if fuse else "0"
+        try:
+            torch.manual_seed(5)
+            tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=2, dropout=0.0,
+                        use_memory=True, memory_dimension=64, message_function="identity", n_neighbors=K)
+            tgn.train()
+            for s0 in (s - 2 * B, s - B):                     # populate memory and pending messages
+                with torch.no_grad():
+                    tgn.compute_temporal_embeddings(d.sources[s0:s0 + B], d.destinations[s0:s0 + B], neg, d.timestamps[s0:s0 + B],
+                                                    d.edge_idxs[s0:s0 + B], K)
+            emb = torch.cat(tgn.compute_temporal_embeddings(d.sources[s:s + B], d.destinations[s:s + B], neg, d.timestamps[s:s + B],
+                                                            d.edge_idxs[s:s + B], K))
+            P.bpr_loss(emb, B, 3).backward()
+            torch.cuda.synchronize()
+            return tgn.flat_grad.clone()
+        finally:
+            os.environ.pop("PFO_FUSE_GATES", None)
+    g0, g1 = grads(False), grads(True)
+    gru = slice(2 * 64, 2 * 64 + 3 * 64 * (3 * 64 + 4) + 3 * 64 * 64 + 6 * 64)      # the GRU block of the flat layout
+    assert g0[gru].abs().max().item() > 0
+    assert (g0 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item()
+
+
+@pytest.mark.parametrize("use_memory", [True, False])
+def test_fused_backward_and_optimizer_step_on_the_side_stream_equals_the_serial_order(use_memory):
+    """``bpr_step(..., optimizer=opt)``: the end of the backward and the Adam kernel stay on the library's side stream while
+    the caller's stream goes on to the next batch's sampling (pfo_tgn_batch.defer_join, pfo_tgn_adam_side); the next forward
+    joins behind its neighbour sampling.  It changes WHEN those launches run, not what they compute: eight training steps
+    (deterministic backward: bitwise), an evaluation pass and a state_dict read in between give identical embeddings,
+    parameters, Adam moments and memory to ``bpr_step(...); opt.step()``."""
+    from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+    cfg = SyntheticConfig("ft", 300, 25, 7000, 64, 2, 8, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    B, q, K = 64, 3, 8
+    rs = np.random.RandomState(12)
+    starts = [3000 + B * i for i in range(8)]
+    negs = [rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * q) for _ in starts]
+
+    def run(fused):
+        torch.manual_seed(31)
+        tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=2, dropout=0.1,
+                    use_memory=use_memory, memory_dimension=64, message_function="identity", n_neighbors=K)
+        tgn.deterministic = True
+        opt = P.FusedAdam(tgn, lr=1e-3)
+        dev = lambda a, t: tgn._to_dev(a, t)
+        out = []
+        for i, (s, neg) in enumerate(zip(starts, negs)):
+            tgn.train()
+            emb, b = tgn.embed_device(dev(d.sources[s:s + B], np.int32), dev(d.destinations[s:s + B], np.int32), [dev(neg, np.int32)], [q],
+                                      dev(d.timestamps[s:s + B], np.float64), dev(d.edge_idxs[s:s + B], np.int32), K)
+            if fused:
+                loss = P.bpr_step(tgn, emb, b, q, optimizer=opt)
+            else:
+                loss = P.bpr_step(tgn, emb, b, q)
+                opt.step()
+            opt.zero_grad(set_to_none=True)
+            if i == 3:                                   # readers of the parameters between two steps: state_dict joins by itself
+                sd = {k: v.clone() for k, v in tgn.state_dict().items()}
+                out.append(torch.cat([v.reshape(-1).float() for k, v in sorted(sd.items()) if v.is_floating_point()]))
+            if i == 5:                                   # an evaluation pass (forward only) right behind a fused step
+                tgn.eval()
+                with torch.no_grad():
+                    ev = torch.cat(tgn.compute_temporal_embeddings(d.sources[s:s + B], d.destinations[s:s + B], neg, d.timestamps[s:s + B],
+                                                                   d.edge_idxs[s:s + B], K))
+                out.append(ev.clone())
+            out.append(emb.detach().clone())
+            out.append(loss.detach().clone().reshape(1))
+        tgn.join()
+        torch.cuda.synchronize()
+        out.append(tgn.flat_parameters.detach().clone())
+        out.append(opt._m.clone()); out.append(opt._v.clone())
+        if use_memory:
+            out.append(tgn.memory.memory.detach().clone()); out.append(tgn.memory.msg_table.clone())
+        return out
+
+    a, b_ = run(False), run(True)
+    assert len(a) == len(b_)
+    for x, y in zip(a, b_):
+        assert torch.equal(x, y)
