@@ -315,6 +315,11 @@ typedef struct pfo_tgn_batch {
                                complete THERE.  The caller must then take the optimizer step with pfo_tgn_adam_side (same side
                                stream) or call pfo_tgn_join before it touches gradients or parameters on its own stream.  The
                                next pfo_tgn_forward joins by itself - behind its neighbour sampling, which reads neither. */
+  int32_t seg_in_forward;   /* training calls whose state update runs inside the forward (upd_* given): != 0 lets the forward also
+                               queue - on its side stream, beside layer 1 - what the backward's layer-1 kernels need from it and
+                               that depends on the sampled levels alone (the instance groups per touched row, the cleared
+                               level-0 gradient table); the backward (same batch struct) then forks nothing at its start and
+                               waits for nothing in front of its attention kernel */
   int32_t mid_event_late;   /* != 0: record it BEHIND the layer-1 attention backward instead - the preparation then runs beside the
                                backward's serial tail (per-row sums, the touched-table contractions, the GRU's weight gradients:
                                small launches that leave most of the chip idle) */

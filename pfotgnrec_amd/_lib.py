@@ -42,7 +42,7 @@ class TgnBatch(C.Structure):
                 ("training", C.c_int32), ("extra_nodes", _VP), ("n_extra", C.c_int32), ("offset_dev", _VP),
                 ("deterministic", C.c_int32), ("prepared", C.c_int32),
                 ("upd_src", _VP), ("upd_dst", _VP), ("upd_ts", _VP), ("upd_eidx", _VP), ("upd_B", C.c_int32),
-                ("dropout_keep", C.POINTER(_VP)), ("mid_event", _VP), ("defer_join", C.c_int32), ("mid_event_late", C.c_int32)]
+                ("dropout_keep", C.POINTER(_VP)), ("mid_event", _VP), ("defer_join", C.c_int32), ("seg_in_forward", C.c_int32), ("mid_event_late", C.c_int32)]
 
 
 class TgnDebug(C.Structure):

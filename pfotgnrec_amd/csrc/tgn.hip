@@ -444,6 +444,28 @@ static int level_sizes(const pfo_tgn_config* c, const pfo_tgn_batch* b, int64_t*
   return PFO_OK;
 }
 
+// Replicas of the level-0 gradient table the layer-1 attention backward adds into: per-XCD replicas pay off only for the
+// per-instance atomics (uniform sampling: 4 replicas 0.537 -> 0.506 ms); the run-merged kernel issues 2-3x fewer and measures
+// best on ONE table (1.656 vs 1.665 ms/step); the deterministic int64 table is always one
+static int grad_replicas(const pfo_tgn_config* c, const pfo_tgn_batch* b) {
+  const int det = b->deterministic ? 1 : 0;
+  return (det || (c->use_memory && !b->uniform && pfo_attn_bwd_runs_possible(b->K, c->D, c->n_heads))) ? 1 : PFO_GRAD_REPLICAS;
+}
+// What the backward's layer-1 kernels need and that depends on the sampled levels alone: the cleared level-0 gradient rows and
+// the layer-1 instances grouped by the touched-table row they sit on.  Queued by the backward on its side stream - or, for
+// calls with pfo_tgn_batch.seg_in_forward, by the forward on ITS side stream (beside layer 1, joined by the event layer 2 waits
+// for anyway), which takes one event record and one wait off the backward's critical path.
+static int seg_prologue(const pfo_tgn_config* c, const pfo_tgn_batch* b, const Ws& w, const Dims& d, const int64_t* n, hipStream_t ss) {
+  const int capP = (int)std::min<int64_t>(c->n_nodes, n[0] + b->n_extra);
+  const int det = b->deterministic ? 1 : 0;
+  const int64_t rep_stride = (int64_t)d.capP * d.D;
+  // (deterministic: the table holds int64 fixed-point sums - rows of 2 D floats' worth)
+  if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_core, capP, det ? 2 * d.D : d.D, grad_replicas(c, b), rep_stride, ss));
+  RUN(pfo_seg_build_launch(w.idx0, w.nodes[0], (int)n[1], capP, b->uniform ? nullptr : w.cnt1, w.seg_ptr, w.seg_cur,
+                           w.seg_tmp, w.seg_mem, w.seg_scratch, ss));
+  return PFO_OK;
+}
+
 // persist the lazily updated memory of the batch's positives + store their raw messages (tgn.py:290-317, 357-378)
 static int state_update(const pfo_tgn_config* c, const pfo_tgn_state* st, const Ws& w, const int32_t* src, const int32_t* dst,
                         const double* ts, const int32_t* eidx, int32_t B, hipStream_t s) {
@@ -812,6 +834,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
         // layer 2 waits for - persist + message store leave the critical path and are joined at no extra wait
         HIPOK(hipStreamWaitEvent(ss, sd.gru_done, 0), "event wait failed");
         RUN(state_update(c, st, w, b->upd_src, b->upd_dst, b->upd_ts, b->upd_eidx, b->upd_B, ss));
+        if (b->seg_in_forward) RUN(seg_prologue(c, b, w, d, n, ss));       // (behind gru_done: the compaction and the row pack are done)
       }
       HIPOK(hipEventRecord(sd.fold_done, ss), "event record failed");
     }
@@ -963,7 +986,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   // Per-XCD replicas of the level-0 gradient table pay off only for the per-instance atomics (uniform sampling: 4 replicas
   // 0.537 -> 0.506 ms); the run-merged kernel issues 2-3x fewer and measures best on ONE table (1.656 vs 1.665 ms/step)
   const int det = b->deterministic ? 1 : 0;
-  const int n_rep = (det || (c->use_memory && !b->uniform && pfo_attn_bwd_runs_possible(K, D, H))) ? 1 : PFO_GRAD_REPLICAS;
+  const int n_rep = grad_replicas(c, b);
   static_assert(PFO_GRAD_REPLICAS >= 2, "the deterministic int64 gradient table needs the room of two float replicas");
   int64_t det_rows = 0;                                        // slab rows written so far (deterministic mode)
 
@@ -979,14 +1002,23 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   // (the gradient buffer is cleared on the caller's stream, before the fork: every writer on any stream comes after it)
   PFO_MARK("bwd.begin", s);
   if (zero_grad_first) HIPOK(hipMemsetAsync(grad, 0, (size_t)lay.total * sizeof(float), s), "memset failed");
-  HIPOK(hipEventRecord(sd.fork, s), "event record failed");
-  HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
-  if (mean_src) RUN(pfo_mean_launch(mean_src, mean_n, mean_out, ss));     // (a reduction the caller left to this call's side stream)
-  // (deterministic: the table holds int64 fixed-point sums - rows of 2 D floats' worth)
-  if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_core, capP, det ? 2 * D : D, n_rep, rep_stride, ss));
-  RUN(pfo_seg_build_launch(idx0, w.nodes[0], (int)n[1], capP, b->uniform ? nullptr : w.cnt1, w.seg_ptr, w.seg_cur,
-                           w.seg_tmp, w.seg_mem, w.seg_scratch, ss));
-  HIPOK(hipEventRecord(sd.seg_done, ss), "event record failed");
+  // The side stream's opening work: the loss mean the caller left to this call, the cleared level-0 gradient rows and the
+  // layer-1 instance groups (seg_prologue).  A call whose forward already queued the last two (pfo_tgn_batch.seg_in_forward)
+  // forks nothing here - an event record costs the caller's stream a ~6 us bubble in front of its next kernel - and takes
+  // the mean behind the first event the side stream waits for anyway.
+  const bool seg_fwd = b->seg_in_forward && b->upd_src != nullptr && c->use_memory && L >= 2;
+  bool mean_pending = mean_src != nullptr;
+  auto side_mean_once = [&]() -> int {
+    if (mean_pending) { mean_pending = false; RUN(pfo_mean_launch(mean_src, mean_n, mean_out, ss)); }
+    return PFO_OK;
+  };
+  if (!seg_fwd) {
+    HIPOK(hipEventRecord(sd.fork, s), "event record failed");
+    HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
+    RUN(side_mean_once());
+    RUN(seg_prologue(c, b, w, d, n, ss));
+    HIPOK(hipEventRecord(sd.seg_done, ss), "event record failed");
+  }
   std::function<int()> deferred_chain;                       // a layer's chain-back launches, issued one layer later (below)
   bool gates_fused = false;                                  // the GRU gate backward ran as the epilogue of layer 1's dx_tab launch
   static const char* const bwd_names[PFO_MAX_LAYERS + 1] = {"", "backward layer 1", "backward layer 2", "backward layer 3", "backward layer 4"};
@@ -1051,6 +1083,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     auto tn_a_side = [&]() -> int {
       HIPOK(hipEventRecord(sd.tn_a, s), "event record failed");
       HIPOK(hipStreamWaitEvent(ss, sd.tn_a, 0), "event wait failed");
+      RUN(side_mean_once());
       RUN(pfo_gemm_tn_group_launch(tn, n_tn_a, N, nullptr, w.slabs2, w.slab_floats, ss));
       HIPOK(hipEventRecord(sd.tn_a_done, ss), "event record failed");
       return PFO_OK;
@@ -1098,7 +1131,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     a.dtime_part = w.dtime;
     a.det = det; a.dtime_slab = w.dtime_slab + det_rows * 2 * D;
     int n_parts = 0;
-    if (l == 1 && c->use_memory) HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");   // d_h0 is clear, the groups exist
+    if (l == 1 && c->use_memory && !seg_fwd) HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");   // d_h0 is clear, the groups exist
     if (l == 1 && c->use_memory && !b->uniform) {
       // key-side gradients of instances with identical neighbour lists leave as one set of atomics (attn.hip)
       a.members = w.seg_mem; a.seg_ptr = w.seg_ptr; a.n_rows = w.n_core; a.run_cnt = w.cnt1; a.dqk_live = w.dqk_live;
@@ -1122,6 +1155,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       // the weight gradients over the table rows go to the side stream too (beside d h0 / the GRU backward on this one)
       HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
       HIPOK(hipStreamWaitEvent(ss, sd.tn_b, 0), "event wait failed");
+      RUN(side_mean_once());
       PfoTnProblem tb[2];
       set_tn(tb[0], w.Dq, WQ, tab0, D, nullptr, HCp, D, lw.dWqk, D, lw.gqk);               // dWqk = (sum dqk')^T h0, gqk
       tb[0].c_accumulate = 0; tb[0].bias_accumulate = 0;

@@ -153,6 +153,7 @@ class TGN(nn.Module):
         self.dp_bucketed = False          # ask the backward for the "top layer's gradients are final" event (two-bucket all-reduce)
         self._bucket_event, self._bucket_event_fresh, self._grad_split = None, False, None
         self._mid_event, self._mid_event_fresh = None, False   # recorded by the native backward in front of layer 1's attention backward
+        self.seg_in_forward = os.environ.get("PFO_SEG_FWD", "1") != "0"      # the backward's instance groups are built beside the forward's layer 1
         self.record_mid_event = False     # ... only on request: an event record on the caller's stream costs the step a launch gap
         self.mid_event_late = False       # record it behind the attention backward instead of in front of it
         self._zero_next = False
@@ -754,6 +755,7 @@ class TGN(nn.Module):
                 bs = call.batch_struct
                 bs.upd_src, bs.upd_dst, bs.upd_ts, bs.upd_eidx, bs.upd_B = (src.data_ptr(), dst.data_ptr(), edge_times.data_ptr(),
                                                                            edge_idxs.data_ptr(), B)
+                bs.seg_in_forward = 1 if self.seg_in_forward else 0
                 call.keep = (getattr(call, "keep", None), src, dst, edge_times, edge_idxs)
                 self.memory._any_msg = True
                 post = None
