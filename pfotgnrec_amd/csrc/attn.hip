@@ -904,7 +904,9 @@ static int check_common(const PfoAttn& a) {
   }
 
 // minimum wavefronts per SIMD the register allocation must allow: 3 where the kernel fits 168 VGPRs without spilling
+#ifndef BWD_WAVES
 #define BWD_WAVES(NR, H, DMODE) (((H) <= 2 && (NR) <= 3) ? ((DMODE) == 1 ? 2 : 3) : (((H) == 4 && (NR) == 4) ? 1 : 2))
+#endif
 template <int NR, int H> __global__ __launch_bounds__(256, BWD_WAVES(NR, H, 0)) void attn_bwd_kernel_none(const AttnDev a) { attn_bwd_body<NR, H, 0>(a); }
 template <int NR, int H> __global__ __launch_bounds__(256, BWD_WAVES(NR, H, 1)) void attn_bwd_kernel(const AttnDev a) { attn_bwd_body<NR, H, 1>(a); }
 template <int NR, int H> __global__ __launch_bounds__(256, BWD_WAVES(NR, H, 2)) void attn_bwd_kernel_direct(const AttnDev a) { attn_bwd_body<NR, H, 2>(a); }
