@@ -886,18 +886,18 @@ static int check_common(const PfoAttn& a) {
     const dim3 g((unsigned)(grid)), b(256);                                                                   \
     bool done = true;                                                                                         \
     switch (NRv * 8 + a.H) {                                                                                  \
-      case 1 * 8 + 1: hipLaunchKernelGGL((KERNEL<1, 1>), g, b, 0, stream, d); break;                          \
-      case 1 * 8 + 2: hipLaunchKernelGGL((KERNEL<1, 2>), g, b, 0, stream, d); break;                          \
-      case 1 * 8 + 4: hipLaunchKernelGGL((KERNEL<1, 4>), g, b, 0, stream, d); break;                          \
-      case 2 * 8 + 1: hipLaunchKernelGGL((KERNEL<2, 1>), g, b, 0, stream, d); break;                          \
-      case 2 * 8 + 2: hipLaunchKernelGGL((KERNEL<2, 2>), g, b, 0, stream, d); break;                          \
-      case 2 * 8 + 4: hipLaunchKernelGGL((KERNEL<2, 4>), g, b, 0, stream, d); break;                          \
-      case 3 * 8 + 1: hipLaunchKernelGGL((KERNEL<3, 1>), g, b, 0, stream, d); break;                          \
-      case 3 * 8 + 2: hipLaunchKernelGGL((KERNEL<3, 2>), g, b, 0, stream, d); break;                          \
-      case 3 * 8 + 4: hipLaunchKernelGGL((KERNEL<3, 4>), g, b, 0, stream, d); break;                          \
-      case 4 * 8 + 1: hipLaunchKernelGGL((KERNEL<4, 1>), g, b, 0, stream, d); break;                          \
-      case 4 * 8 + 2: hipLaunchKernelGGL((KERNEL<4, 2>), g, b, 0, stream, d); break;                          \
-      case 4 * 8 + 4: hipLaunchKernelGGL((KERNEL<4, 4>), g, b, 0, stream, d); break;                          \
+      case 1 * 8 + 1: PFO_KLAUNCH((KERNEL<1, 1>), g, b, 0, stream, d); break;                          \
+      case 1 * 8 + 2: PFO_KLAUNCH((KERNEL<1, 2>), g, b, 0, stream, d); break;                          \
+      case 1 * 8 + 4: PFO_KLAUNCH((KERNEL<1, 4>), g, b, 0, stream, d); break;                          \
+      case 2 * 8 + 1: PFO_KLAUNCH((KERNEL<2, 1>), g, b, 0, stream, d); break;                          \
+      case 2 * 8 + 2: PFO_KLAUNCH((KERNEL<2, 2>), g, b, 0, stream, d); break;                          \
+      case 2 * 8 + 4: PFO_KLAUNCH((KERNEL<2, 4>), g, b, 0, stream, d); break;                          \
+      case 3 * 8 + 1: PFO_KLAUNCH((KERNEL<3, 1>), g, b, 0, stream, d); break;                          \
+      case 3 * 8 + 2: PFO_KLAUNCH((KERNEL<3, 2>), g, b, 0, stream, d); break;                          \
+      case 3 * 8 + 4: PFO_KLAUNCH((KERNEL<3, 4>), g, b, 0, stream, d); break;                          \
+      case 4 * 8 + 1: PFO_KLAUNCH((KERNEL<4, 1>), g, b, 0, stream, d); break;                          \
+      case 4 * 8 + 2: PFO_KLAUNCH((KERNEL<4, 2>), g, b, 0, stream, d); break;                          \
+      case 4 * 8 + 4: PFO_KLAUNCH((KERNEL<4, 4>), g, b, 0, stream, d); break;                          \
       default: done = false;                                                                                  \
     }                                                                                                         \
     PFO_REQUIRE(done, "unsupported (D, H) combination");                                                      \
@@ -945,7 +945,7 @@ extern "C" int pfo_attn_dropout_mask(uint64_t seed, uint64_t offset, int64_t N, 
   if (N == 0) return PFO_OK;
   const int64_t total = N * K;
   const unsigned grid = (unsigned)std::min<int64_t>(4096, pfo_ceil_div(total, 256));
-  hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, seed, offset, N, (int)K, (int)H, p, out);
+  PFO_KLAUNCH(attn_dropout_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, seed, offset, N, (int)K, (int)H, p, out);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -989,8 +989,8 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
     bool done = true;
 #define RUNS_GO(NRc, Hc)                                                                                              \
   case NRc * 8 + Hc:                                                                                                  \
-    if (a.det) hipLaunchKernelGGL((attn_bwd_runs_kernel<NRc, Hc, true>), g, b, run_lds, stream, d);                   \
-    else hipLaunchKernelGGL((attn_bwd_runs_kernel<NRc, Hc, false>), g, b, run_lds, stream, d);                        \
+    if (a.det) PFO_KLAUNCH((attn_bwd_runs_kernel<NRc, Hc, true>), g, b, run_lds, stream, d);                   \
+    else PFO_KLAUNCH((attn_bwd_runs_kernel<NRc, Hc, false>), g, b, run_lds, stream, d);                        \
     break;
     switch (NRv * 8 + a.H) {
       RUNS_GO(1, 1) RUNS_GO(1, 2) RUNS_GO(1, 4) RUNS_GO(2, 1) RUNS_GO(2, 2) RUNS_GO(2, 4)

@@ -1,6 +1,7 @@
 // Shared host/device helpers for the gfx950 kernels.  Wave size is 64 everywhere.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -33,6 +34,21 @@ void pfo_prof_begin(hipStream_t s);
 void pfo_prof_end(int kind, double work, hipStream_t s);
 // work = work_per_unit * min(*units_dev, units_cap): launches whose extent is a device-side count (read back at collect time)
 void pfo_prof_end_dev(int kind, double work_per_unit, const int32_t* units_dev, int units_cap, hipStream_t s);
+
+// Events that ride on a kernel's own completion signal (round 4).  hipEventRecord queues a marker packet, and on this part the
+// kernel behind a marker starts ~6 us late (consecutive kernels of one queue start 0.0-0.1 us apart; every record on the
+// caller's stream showed as a bubble in the per-queue trace).  hipExtLaunchKernelGGL takes a stop event that is bound to the
+// launch itself: no extra packet.  pfo_stop_event_arm(e, skip) makes the (skip+1)-th kernel launched next through PFO_KLAUNCH
+// carry `e`; pfo_stop_event_disarm(stream) records it the plain way if that launch never came (count mismatch, capture).
+void pfo_stop_event_arm(hipEvent_t e, int skip);
+void pfo_stop_event_disarm(hipStream_t stream);
+bool pfo_stop_event_take(hipEvent_t* e);
+#define PFO_KLAUNCH(kernel, grid, block, shmem, stream, ...)                                                          \
+  do {                                                                                                                \
+    hipEvent_t pe__ = nullptr;                                                                                        \
+    if (pfo_stop_event_take(&pe__)) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, pe__, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                         \
+  } while (0)
 
 // milestones on the caller's stream (include/pfotgn.h pfo_marks_*): no-op unless enabled
 bool pfo_marks_on();

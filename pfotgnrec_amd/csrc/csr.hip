@@ -185,13 +185,13 @@ extern "C" int pfo_csr_build(const int32_t* src, const int32_t* dst, const int32
   PFO_REQUIRE(src && dst && eidx && ts && adj_nbr && adj_eidx && adj_ts, "null input");
   Edges g{src, dst, eidx, ts, E};
   const int blk = (int)std::min<int64_t>(4096, pfo_ceil_div(n, 256));
-  hipLaunchKernelGGL(ts_sorted_kernel, dim3(blk), dim3(256), 0, s, ts, E, unsorted);
-  hipLaunchKernelGGL(iota_kernel, dim3(blk), dim3(256), 0, s, perm[0], n);
+  PFO_KLAUNCH(ts_sorted_kernel, dim3(blk), dim3(256), 0, s, ts, E, unsorted);
+  PFO_KLAUNCH(iota_kernel, dim3(blk), dim3(256), 0, s, perm[0], n);
   int cur = 0;
   auto pass = [&](int which, int shift, const int32_t* skip) -> int {
-    hipLaunchKernelGGL(rs_hist_kernel, dim3((unsigned)nt), dim3(64), 0, s, g, perm[cur], n, which, shift, skip, hist, (int)nt);
+    PFO_KLAUNCH(rs_hist_kernel, dim3((unsigned)nt), dim3(64), 0, s, g, perm[cur], n, which, shift, skip, hist, (int)nt);
     if (int rc = pfo_iscan_launch(hist, hist_n, base, scratch, s)) return rc;
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3((unsigned)nt), dim3(64), 0, s, g, perm[cur], n, which, shift, skip, base, (int)nt, perm[cur ^ 1]);
+    PFO_KLAUNCH(rs_scatter_kernel, dim3((unsigned)nt), dim3(64), 0, s, g, perm[cur], n, which, shift, skip, base, (int)nt, perm[cur ^ 1]);
     cur ^= 1;
     return PFO_OK;
   };
@@ -205,9 +205,9 @@ extern "C" int pfo_csr_build(const int32_t* src, const int32_t* dst, const int32
   while (((int64_t)1 << owner_bits) < n_nodes) ++owner_bits;
   for (int b = 0; b * 8 < owner_bits; ++b)
     if (int rc = pass(1, 8 * b, nullptr)) return rc;
-  hipLaunchKernelGGL(owner_count_kernel, dim3(blk), dim3(256), 0, s, g, n, n_nodes, cnt);
+  PFO_KLAUNCH(owner_count_kernel, dim3(blk), dim3(256), 0, s, g, n, n_nodes, cnt);
   if (int rc = pfo_iscan_launch(cnt, n_nodes + 1, ptr32, scratch, s)) return rc;
-  hipLaunchKernelGGL(csr_emit_kernel, dim3(blk), dim3(256), 0, s, g, perm[cur], n, ptr32, n_nodes, indptr, adj_nbr, adj_eidx, adj_ts);
+  PFO_KLAUNCH(csr_emit_kernel, dim3(blk), dim3(256), 0, s, g, perm[cur], n, ptr32, n_nodes, indptr, adj_nbr, adj_eidx, adj_ts);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -217,7 +217,7 @@ extern "C" int pfo_csr_append(const int64_t* old_indptr, const int32_t* old_nbr,
                               const double* add_ts, int64_t n_nodes, int64_t* new_indptr, int32_t* new_nbr, int32_t* new_eidx,
                               double* new_ts, void* stream) {
   PFO_REQUIRE(old_indptr && add_indptr && new_indptr && n_nodes >= n_old_nodes && n_old_nodes > 0, "bad arguments");
-  hipLaunchKernelGGL(csr_merge_kernel, dim3((unsigned)pfo_ceil_div(n_nodes + 1, 4)), dim3(256), 0, (hipStream_t)stream, old_indptr,
+  PFO_KLAUNCH(csr_merge_kernel, dim3((unsigned)pfo_ceil_div(n_nodes + 1, 4)), dim3(256), 0, (hipStream_t)stream, old_indptr,
                      old_nbr, old_eidx, old_ts, add_indptr, add_nbr, add_eidx, add_ts, n_old_nodes, n_nodes, new_indptr, new_nbr,
                      new_eidx, new_ts);
   PFO_LAUNCH_CHECK();

@@ -1199,8 +1199,8 @@ int pfo_gru_fused_launch(const PfoGruFused& f, hipStream_t stream) {
   d.gather = f.gather;
   pfo_prof_begin(stream);
   const dim3 grid((unsigned)pfo_ceil_div(f.cap_rows, BM), (unsigned)pfo_ceil_div(f.D, 32), 1);
-  if (pfo_bx_fmt()) hipLaunchKernelGGL(gru_fused_kernel<1>, grid, dim3(GEMM_THREADS), 0, stream, d);
-  else hipLaunchKernelGGL(gru_fused_kernel<0>, grid, dim3(GEMM_THREADS), 0, stream, d);
+  if (pfo_bx_fmt()) PFO_KLAUNCH(gru_fused_kernel<1>, grid, dim3(GEMM_THREADS), 0, stream, d);
+  else PFO_KLAUNCH(gru_fused_kernel<0>, grid, dim3(GEMM_THREADS), 0, stream, d);
   PFO_LAUNCH_CHECK();
   pfo_prof_end_dev(PFO_PROF_GRU_FUSED, 2.0 * 3 * f.D * ((double)f.K_msg + f.D), f.n_rows, f.cap_rows, stream);   // per-row FLOPs of the two contractions
   return PFO_OK;
@@ -1892,7 +1892,7 @@ int pfo_rank1_multi_launch(const PfoRank1* list, int n, hipStream_t stream) {
     most = std::max(most, (int64_t)r.M * r.N);
   }
   const int nb = (int)std::min<int64_t>(512, pfo_ceil_div(most, 256));
-  hipLaunchKernelGGL(rank1_kernel, dim3(nb, n), dim3(256), 0, stream, g);
+  PFO_KLAUNCH(rank1_kernel, dim3(nb, n), dim3(256), 0, stream, g);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -1923,7 +1923,7 @@ int pfo_sum_slabs_launch(const PfoSumSlabs* list, int n, hipStream_t stream) {
     most = std::max(most, list[i].count);
   }
   const int nb = (int)std::min<int64_t>(256, pfo_ceil_div(most, 256));
-  hipLaunchKernelGGL(sum_slabs_kernel, dim3(nb, n), dim3(256), 0, stream, g);
+  PFO_KLAUNCH(sum_slabs_kernel, dim3(nb, n), dim3(256), 0, stream, g);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -2072,14 +2072,14 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
   const bool use_bx = vec && bx >= 1;
   pfo_prof_begin(stream);
   static const int tn_fmt = getenv("PFO_TN_FMT") ? atoi(getenv("PFO_TN_FMT")) : PFO_DEFAULT_TN_FMT;      // A/B switch
-  if (use_bx && tn_fmt) hipLaunchKernelGGL(gemm_tn_group_bx_kernel<1>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
-  else if (use_bx) hipLaunchKernelGGL(gemm_tn_group_bx_kernel<0>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
-  else if (vec) hipLaunchKernelGGL(gemm_tn_group_kernel<true>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
-  else hipLaunchKernelGGL(gemm_tn_group_kernel<false>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
+  if (use_bx && tn_fmt) PFO_KLAUNCH(gemm_tn_group_bx_kernel<1>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
+  else if (use_bx) PFO_KLAUNCH(gemm_tn_group_bx_kernel<0>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
+  else if (vec) PFO_KLAUNCH(gemm_tn_group_kernel<true>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
+  else PFO_KLAUNCH(gemm_tn_group_kernel<false>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   PFO_LAUNCH_CHECK();
   // the GEMM kernel alone; with a device-side K bound the work is (flops per k-row) x the count read back at collect time
   if (use_bx) pfo_prof_end_dev(PFO_PROF_GEMM_TN_BX, flops / (double)K, k_dev, K, stream);
-  hipLaunchKernelGGL(tn_group_reduce_kernel, dim3((unsigned)std::min<int64_t>(1024, pfo_ceil_div(per_split, 256))), dim3(256), 0,
+  PFO_KLAUNCH(tn_group_reduce_kernel, dim3((unsigned)std::min<int64_t>(1024, pfo_ceil_div(per_split, 256))), dim3(256), 0,
                      stream, g);
   PFO_LAUNCH_CHECK();
   if (!use_bx) pfo_prof_end_dev(PFO_PROF_GEMM_TN, flops / (double)K, k_dev, K, stream);
@@ -2135,13 +2135,13 @@ int pfo_bimg_launch(const PfoBimg* list, int n, hipStream_t stream) {
     int most_rows = 0;
     bool any_trans = false;
     for (int i = 0; i < n; ++i) { most_rows = std::max(most_rows, d.rows[i]); any_trans = any_trans || d.trans[i] != 0; }
-    if (!any_trans) hipLaunchKernelGGL(bimg_h_rows_kernel, dim3((unsigned)pfo_ceil_div(most_rows, 4), n), dim3(256), 0, stream, d);
+    if (!any_trans) PFO_KLAUNCH(bimg_h_rows_kernel, dim3((unsigned)pfo_ceil_div(most_rows, 4), n), dim3(256), 0, stream, d);
     else {
-      hipLaunchKernelGGL(bimg_exp_kernel, dim3((unsigned)pfo_ceil_div(most_rows, 4), n), dim3(256), 0, stream, d);
-      hipLaunchKernelGGL(bimg_h_kernel, dim3((unsigned)pfo_ceil_div(most, 256), n), dim3(256), 0, stream, d);
+      PFO_KLAUNCH(bimg_exp_kernel, dim3((unsigned)pfo_ceil_div(most_rows, 4), n), dim3(256), 0, stream, d);
+      PFO_KLAUNCH(bimg_h_kernel, dim3((unsigned)pfo_ceil_div(most, 256), n), dim3(256), 0, stream, d);
     }
   } else
-    hipLaunchKernelGGL(bimg_kernel, dim3((unsigned)pfo_ceil_div(most, 256), n), dim3(256), 0, stream, d);
+    PFO_KLAUNCH(bimg_kernel, dim3((unsigned)pfo_ceil_div(most, 256), n), dim3(256), 0, stream, d);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -2184,8 +2184,8 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
   const int tn = (int)pfo_ceil_div(g.N, BN);
 #define GEMM_GO(AK, BK_, SM, grid)                                                                                   \
   do {                                                                                                                \
-    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, SM, true>), grid, dim3(GEMM_THREADS), 0, stream, d);        \
-    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, SM, false>), grid, dim3(GEMM_THREADS), 0, stream, d);           \
+    if (vec) PFO_KLAUNCH((gemm_f32_kernel<AK, BK_, SM, true>), grid, dim3(GEMM_THREADS), 0, stream, d);        \
+    else PFO_KLAUNCH((gemm_f32_kernel<AK, BK_, SM, false>), grid, dim3(GEMM_THREADS), 0, stream, d);           \
   } while (0)
   if (g.a_kmajor) {
     const int tm = (int)pfo_ceil_div(g.M, BM);
@@ -2229,11 +2229,11 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
       const int64_t sk_wgs = (int64_t)pfo_ceil_div(g.M, SK_ROWS) * tn;
       const dim3 g4((unsigned)pfo_ceil_div(g.M, SK_ROWS), (unsigned)pfo_ceil_div(g.N, 64), 1), g11((unsigned)pfo_ceil_div(g.M, SK_ROWS), tn, 1);
       if (sk_wgs < narrow) {
-        if (pfo_bx_fmt()) hipLaunchKernelGGL((gemm_bx_skinny_kernel<4, 1>), g4, dim3(GEMM_THREADS), 0, stream, d);
-        else hipLaunchKernelGGL((gemm_bx_skinny_kernel<4, 0>), g4, dim3(GEMM_THREADS), 0, stream, d);
+        if (pfo_bx_fmt()) PFO_KLAUNCH((gemm_bx_skinny_kernel<4, 1>), g4, dim3(GEMM_THREADS), 0, stream, d);
+        else PFO_KLAUNCH((gemm_bx_skinny_kernel<4, 0>), g4, dim3(GEMM_THREADS), 0, stream, d);
       } else {
-        if (pfo_bx_fmt()) hipLaunchKernelGGL((gemm_bx_skinny_kernel<11, 1>), g11, dim3(GEMM_THREADS), 0, stream, d);
-        else hipLaunchKernelGGL((gemm_bx_skinny_kernel<11, 0>), g11, dim3(GEMM_THREADS), 0, stream, d);
+        if (pfo_bx_fmt()) PFO_KLAUNCH((gemm_bx_skinny_kernel<11, 1>), g11, dim3(GEMM_THREADS), 0, stream, d);
+        else PFO_KLAUNCH((gemm_bx_skinny_kernel<11, 0>), g11, dim3(GEMM_THREADS), 0, stream, d);
       }
     } else if (g.b_img && (g.K[1] == 0 || g.b_img2) && a_rowvec && (g.bx_force || (bx >= 1 && big_tiles >= bx_min_tiles && force < 0))) {
       d.b_img = g.b_img; d.b_img_rows = (int)pfo_align_up(g.N, BN); d.b_img2 = g.b_img2;
@@ -2242,12 +2242,12 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
       static const int areg = getenv("PFO_GEMM_AREG") ? atoi(getenv("PFO_GEMM_AREG")) : PFO_DEFAULT_AREG;    // A/B switch
       if (areg && g.batch == 1)
       {
-        if (pfo_bx_fmt()) hipLaunchKernelGGL(gemm_bx_areg_kernel<1>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
-        else hipLaunchKernelGGL(gemm_bx_areg_kernel<0>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
+        if (pfo_bx_fmt()) PFO_KLAUNCH(gemm_bx_areg_kernel<1>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
+        else PFO_KLAUNCH(gemm_bx_areg_kernel<0>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
       }
       else {
         PFO_REQUIRE(!pfo_bx_fmt(), "the fp16x2 images are read by the row-major-A kernels only (batch 1)");
-        hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0,
+        PFO_KLAUNCH(gemm_bf16x3_kernel<true>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0,
                            stream, d);
       }
     } else if (g.K[1] > 0 && g.b_img2) {
@@ -2256,7 +2256,7 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
       return PFO_ERR_INVALID;
     } else if (bx >= 2 && !g.b_kmajor && tile == 0 && vec) {
       kind = PFO_PROF_GEMM_BX;
-      hipLaunchKernelGGL(gemm_bf16x3_kernel<false>, grid, dim3(GEMM_THREADS), 0, stream, d);
+      PFO_KLAUNCH(gemm_bf16x3_kernel<false>, grid, dim3(GEMM_THREADS), 0, stream, d);
     } else if (g.b_kmajor) {
       if (tile == 1) GEMM_GO(false, true, 1, grid); else GEMM_GO(false, true, 0, grid);
     } else {
@@ -2304,8 +2304,8 @@ int pfo_gemm_multi_launch(const PfoGemm* list, int n, hipStream_t stream) {
       vec = vec && gemm_vec_ok(s);
     }
     g.n = cnt;
-    if (vec) hipLaunchKernelGGL(gemm_multi_kernel<true>, dim3(tiles), dim3(GEMM_THREADS), 0, stream, g);
-    else hipLaunchKernelGGL(gemm_multi_kernel<false>, dim3(tiles), dim3(GEMM_THREADS), 0, stream, g);
+    if (vec) PFO_KLAUNCH(gemm_multi_kernel<true>, dim3(tiles), dim3(GEMM_THREADS), 0, stream, g);
+    else PFO_KLAUNCH(gemm_multi_kernel<false>, dim3(tiles), dim3(GEMM_THREADS), 0, stream, g);
     PFO_LAUNCH_CHECK();
   }
   return PFO_OK;

@@ -119,18 +119,18 @@ int pfo_touch_compact_launch(const int32_t* nodes0, int64_t n0, const int32_t* e
   }
   if (!marked) {
     const int mb = (int)std::min<int64_t>(2048, pfo_ceil_div(n0, 256));
-    hipLaunchKernelGGL(touch_mark_kernel, dim3(mb), dim3(256), 0, stream, nodes0, n0, n_nodes, mark, 1, 0);
+    PFO_KLAUNCH(touch_mark_kernel, dim3(mb), dim3(256), 0, stream, nodes0, n0, n_nodes, mark, 1, 0);
   }
   const bool two = extra && n_extra > 0;
   if (two) {
     const int eb = (int)std::min<int64_t>(2048, pfo_ceil_div(n_extra, 256));
-    hipLaunchKernelGGL(touch_mark_kernel, dim3(eb), dim3(256), 0, stream, extra, n_extra, n_nodes, mark, 2, 1);
+    PFO_KLAUNCH(touch_mark_kernel, dim3(eb), dim3(256), 0, stream, extra, n_extra, n_nodes, mark, 2, 1);
   }
   // class 1 -> n_counts[1] (and n_counts[0] when it is the only class); class 2 continues behind it -> n_counts[0]
-  hipLaunchKernelGGL(compact_onepass_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, mark, 1, slot, n_nodes, scratch, touched_ids,
+  PFO_KLAUNCH(compact_onepass_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, mark, 1, slot, n_nodes, scratch, touched_ids,
                      (const int32_t*)nullptr, n_counts + 1, two ? (int32_t*)nullptr : n_counts, 1);
   if (two)
-    hipLaunchKernelGGL(compact_onepass_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, mark, 2, slot, n_nodes, scratch + nb, touched_ids,
+    PFO_KLAUNCH(compact_onepass_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, mark, 2, slot, n_nodes, scratch + nb, touched_ids,
                        (const int32_t*)(n_counts + 1), n_counts, (int32_t*)nullptr, 0);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
@@ -144,7 +144,7 @@ __global__ void remap_kernel(const int32_t* __restrict__ nodes0, int64_t n0, con
 
 int pfo_remap_launch(const int32_t* nodes0, int64_t n0, const int32_t* slot, int32_t* idx0, hipStream_t stream) {
   const int mb = (int)std::min<int64_t>(2048, pfo_ceil_div(n0, 256));
-  hipLaunchKernelGGL(remap_kernel, dim3(mb), dim3(256), 0, stream, nodes0, n0, slot, idx0);
+  PFO_KLAUNCH(remap_kernel, dim3(mb), dim3(256), 0, stream, nodes0, n0, slot, idx0);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -164,7 +164,7 @@ int pfo_gather_rows_launch(const float* src, int D, const int32_t* touched_ids, 
                            hipStream_t stream) {
   PFO_REQUIRE((D % 4) == 0, "row length must be a multiple of 4");
   const int nb = (int)std::min<int64_t>(4096, std::max<int64_t>(1, pfo_ceil_div(cap, 4)));
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, stream, src, D, touched_ids, n_touched, dst);
+  PFO_KLAUNCH(gather_rows_kernel, dim3(nb), dim3(256), 0, stream, src, D, touched_ids, n_touched, dst);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -239,9 +239,9 @@ __global__ void seg_sort_kernel(const int32_t* __restrict__ seg_ptr, int n_seg, 
 int pfo_iscan_launch(const int32_t* in, int64_t n, int32_t* out, int32_t* scratch, hipStream_t stream) {
   PFO_REQUIRE(in && out && scratch && n > 0 && n < ((int64_t)1 << 31), "bad arguments");
   const int nb = (int)pfo_ceil_div(n, SCAN_BLOCK);
-  hipLaunchKernelGGL(iscan_local_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, in, (int)n, out, scratch);
-  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, scratch, nb, scratch + nb);
-  hipLaunchKernelGGL(iscan_add_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, out, (int)n, scratch, out);
+  PFO_KLAUNCH(iscan_local_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, in, (int)n, out, scratch);
+  PFO_KLAUNCH(scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, scratch, nb, scratch + nb);
+  PFO_KLAUNCH(iscan_add_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, out, (int)n, scratch, out);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -253,13 +253,13 @@ int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int ca
   PFO_REQUIRE(idx && nodes && seg_ptr && cursor && tmp && members && scratch && N > 0 && cap_rows > 0, "bad arguments");
   const int n = cap_rows + 1;
   PFO_REQUIRE(hipMemsetAsync(cursor, 0, (size_t)n * sizeof(int32_t), stream) == hipSuccess, "memset failed");
-  hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)pfo_ceil_div(N, 256)), dim3(256), 0, stream, idx, nodes, N, cursor);
+  PFO_KLAUNCH(seg_count_kernel, dim3((unsigned)pfo_ceil_div(N, 256)), dim3(256), 0, stream, idx, nodes, N, cursor);
   const int nb = (int)pfo_ceil_div(n, SCAN_BLOCK);
-  hipLaunchKernelGGL(iscan_local_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, cursor, n, seg_ptr, scratch);
-  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, scratch, nb, scratch + nb);
-  hipLaunchKernelGGL(iscan_add_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, seg_ptr, n, scratch, cursor);
-  hipLaunchKernelGGL(seg_place_kernel, dim3((unsigned)pfo_ceil_div(N, 256)), dim3(256), 0, stream, idx, nodes, N, cursor, tmp);
-  hipLaunchKernelGGL(seg_sort_kernel, dim3((unsigned)std::min<int64_t>(4096, pfo_ceil_div(cap_rows, 4))), dim3(256), 0, stream,
+  PFO_KLAUNCH(iscan_local_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, cursor, n, seg_ptr, scratch);
+  PFO_KLAUNCH(scan_blocks_kernel, dim3(1), dim3(1024), 0, stream, scratch, nb, scratch + nb);
+  PFO_KLAUNCH(iscan_add_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, seg_ptr, n, scratch, cursor);
+  PFO_KLAUNCH(seg_place_kernel, dim3((unsigned)pfo_ceil_div(N, 256)), dim3(256), 0, stream, idx, nodes, N, cursor, tmp);
+  PFO_KLAUNCH(seg_sort_kernel, dim3((unsigned)std::min<int64_t>(4096, pfo_ceil_div(cap_rows, 4))), dim3(256), 0, stream,
                      seg_ptr, cap_rows, tmp, key_src, members);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
@@ -377,9 +377,9 @@ int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, cons
   PFO_REQUIRE(!src0_live || src0_by_position, "row flags go with rows stored by position");
   const int nb = (int)std::min<int64_t>(8192, std::max<int64_t>(1, pfo_ceil_div(cap_rows, 4)));
   const bool vec = ((W0 | W1) & 3) == 0 && ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)out)) & 15) == 0;
-  if (vec) hipLaunchKernelGGL(segsum_vec_kernel, dim3(nb), dim3(256), 0, stream, src0, W0, src1, W1, seg_ptr, members, n_rows,
+  if (vec) PFO_KLAUNCH(segsum_vec_kernel, dim3(nb), dim3(256), 0, stream, src0, W0, src1, W1, seg_ptr, members, n_rows,
                               src0_by_position, src0_live, out);
-  else hipLaunchKernelGGL(segsum_kernel, dim3(nb), dim3(256), 0, stream, src0, W0, src1, W1, seg_ptr, members, n_rows,
+  else PFO_KLAUNCH(segsum_kernel, dim3(nb), dim3(256), 0, stream, src0, W0, src1, W1, seg_ptr, members, n_rows,
                           src0_by_position, src0_live, out);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
@@ -425,7 +425,7 @@ int pfo_pack_remap_launch(const float* msg_table, int M, const float* memory, in
   PFO_REQUIRE(!msg_table || (msg_rows && has_msg && hm), "null message buffers");
   const int rb = (int)std::min<int64_t>(4096, std::max<int64_t>(1, pfo_ceil_div(cap, 4)));
   const int mb = (int)std::min<int64_t>(2048, pfo_ceil_div(n0, 256));
-  hipLaunchKernelGGL(pack_remap_kernel, dim3(rb + mb), dim3(256), 0, stream, msg_table, M, memory, D, has_msg, touched_ids,
+  PFO_KLAUNCH(pack_remap_kernel, dim3(rb + mb), dim3(256), 0, stream, msg_table, M, memory, D, has_msg, touched_ids,
                      n_touched, msg_rows, h_rows, hm, rb, nodes0, n0, slot, idx0);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
@@ -528,11 +528,11 @@ int pfo_gru_gates_bwd_launch(const float* gates, float* dgi, float* dgh, const f
                    ((((uintptr_t)gates) | ((uintptr_t)dgi) | ((uintptr_t)dgh) | ((uintptr_t)h_rows) | ((uintptr_t)d_h0) | ((uintptr_t)d_extra)) & 15) == 0;
   if (vec) {
     const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div((int64_t)cap * (D / 4), 256));
-    hipLaunchKernelGGL(gru_gates_bwd_vec_kernel, dim3(nb), dim3(256), 0, stream, gates, dgi, dgh, h_rows, hm, n_touched, D, d_h0, n_rep,
+    PFO_KLAUNCH(gru_gates_bwd_vec_kernel, dim3(nb), dim3(256), 0, stream, gates, dgi, dgh, h_rows, hm, n_touched, D, d_h0, n_rep,
                        rep_stride, d_extra, det);
   } else {
     const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div((int64_t)cap * D, 256));
-    hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(nb), dim3(256), 0, stream, gates, dgi, dgh, h_rows, hm, n_touched, D, d_h0, n_rep,
+    PFO_KLAUNCH(gru_gates_bwd_kernel, dim3(nb), dim3(256), 0, stream, gates, dgi, dgh, h_rows, hm, n_touched, D, d_h0, n_rep,
                        rep_stride, d_extra, det);
   }
   PFO_LAUNCH_CHECK();
@@ -561,7 +561,7 @@ __global__ void persist_kernel(const int32_t* __restrict__ src, const int32_t* _
 int pfo_persist_launch(const int32_t* src, const int32_t* dst, int B, const int32_t* slot, const float* upd_mem,
                        const uint8_t* has_msg, const float* msg_time, float* memory, float* last_update, int D,
                        int32_t* winner, hipStream_t stream) {
-  hipLaunchKernelGGL(persist_kernel, dim3((unsigned)pfo_ceil_div(2 * B, 4)), dim3(256), 0, stream, src, dst, B, slot,
+  PFO_KLAUNCH(persist_kernel, dim3((unsigned)pfo_ceil_div(2 * B, 4)), dim3(256), 0, stream, src, dst, B, slot,
                      upd_mem, has_msg, msg_time, memory, last_update, D, winner);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
@@ -622,11 +622,11 @@ int pfo_msg_store_launch(const int32_t* src, const int32_t* dst, const double* t
   if (pfo_msg_store_needs_winner(B)) {
     PFO_REQUIRE(winner, "large batches need the winner table");
     const unsigned nb = (unsigned)pfo_ceil_div(2 * B, 256);
-    hipLaunchKernelGGL(msg_winner_max_kernel, dim3(nb), dim3(256), 0, stream, src, dst, B, winner);
+    PFO_KLAUNCH(msg_winner_max_kernel, dim3(nb), dim3(256), 0, stream, src, dst, B, winner);
   } else {
     winner = nullptr;
   }
-  hipLaunchKernelGGL(msg_write_kernel, dim3((unsigned)pfo_ceil_div(2 * B, 4)), dim3(256), 0, stream, src, dst, ts, eidx,
+  PFO_KLAUNCH(msg_write_kernel, dim3((unsigned)pfo_ceil_div(2 * B, 4)), dim3(256), 0, stream, src, dst, ts, eidx,
                      B, memory, last_update, edge_feat, tw, tb, D, Ef, msg_table, msg_time, has_msg, winner);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ dst,
 int pfo_zero_rows_launch(float* dst, const int32_t* n_rows, int cap_rows, int D, int n_rep, int64_t rep_stride, hipStream_t stream) {
   PFO_REQUIRE((D % 4) == 0 && (rep_stride % 4) == 0, "row length must be a multiple of 4");
   const int nb = (int)std::min<int64_t>(2048, pfo_ceil_div((int64_t)cap_rows * D / 4 * n_rep, 256));
-  hipLaunchKernelGGL(zero_rows_kernel, dim3(std::max(nb, 1)), dim3(256), 0, stream, dst, n_rows, D, n_rep, rep_stride);
+  PFO_KLAUNCH(zero_rows_kernel, dim3(std::max(nb, 1)), dim3(256), 0, stream, dst, n_rows, D, n_rep, rep_stride);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

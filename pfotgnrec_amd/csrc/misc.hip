@@ -94,6 +94,25 @@ extern "C" int pfo_prof_collect(double* ms, double* work, int64_t* count) {
   return PFO_OK;
 }
 // ---------------------------------------------------------------------------------------------
+// stop events bound to a launch (common.hpp)
+namespace {
+thread_local hipEvent_t g_stop_event = nullptr;
+thread_local int g_stop_skip = 0;
+const bool g_stop_enabled = !(getenv("PFO_STOP_EVENTS") && getenv("PFO_STOP_EVENTS")[0] == '0');   // A/B switch
+}  // namespace
+void pfo_stop_event_arm(hipEvent_t e, int skip) { g_stop_event = e; g_stop_skip = skip; }
+bool pfo_stop_event_take(hipEvent_t* e) {
+  if (!g_stop_event || !g_stop_enabled) return false;
+  if (g_stop_skip > 0) { --g_stop_skip; return false; }
+  *e = g_stop_event;
+  g_stop_event = nullptr;
+  return true;
+}
+void pfo_stop_event_disarm(hipStream_t stream) {
+  if (g_stop_event) { (void)hipEventRecord(g_stop_event, stream); g_stop_event = nullptr; }
+}
+
+// ---------------------------------------------------------------------------------------------
 // milestones (include/pfotgn.h)
 #include <map>
 #include <string>
@@ -195,7 +214,7 @@ extern "C" int pfo_time_encode(const float* t, int64_t n, const float* w, const 
   if (n == 0) return PFO_OK;
   PFO_REQUIRE(t && w && b && out, "null input");
   const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div(n * D, 256));
-  hipLaunchKernelGGL(time_encode_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, t, n, w, b, (int)D, out);
+  PFO_KLAUNCH(time_encode_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, t, n, w, b, (int)D, out);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -277,7 +296,7 @@ __global__ void bpr_mean_kernel(const float* __restrict__ loss_part, int64_t B, 
   if (threadIdx.x == 0) *loss_out = s / (float)B;
 }
 int pfo_mean_launch(const float* src, int64_t n, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(bpr_mean_kernel, dim3(1), dim3(64), 0, stream, src, n, out);
+  PFO_KLAUNCH(bpr_mean_kernel, dim3(1), dim3(64), 0, stream, src, n, out);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -287,9 +306,9 @@ static int bpr_launch(const float* emb, int64_t B, int32_t D, int64_t pos_off, i
   PFO_REQUIRE(B > 0 && D > 0 && n_neg > 0, "bad sizes");
   PFO_REQUIRE(pos_off >= B && pos_off + B <= R && neg_off + B * n_neg <= R && neg_off >= pos_off + B, "bad offsets");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(bpr_kernel, dim3((unsigned)pfo_ceil_div(B, 4)), dim3(256), 0, s, emb, B, (int)D, pos_off, neg_off,
+  PFO_KLAUNCH(bpr_kernel, dim3((unsigned)pfo_ceil_div(B, 4)), dim3(256), 0, s, emb, B, (int)D, pos_off, neg_off,
                      (int)n_neg, R, scale, workspace, d_emb, loss_out, ticket);
-  if (!ticket) hipLaunchKernelGGL(bpr_mean_kernel, dim3(1), dim3(64), 0, s, workspace, B, loss_out);
+  if (!ticket) PFO_KLAUNCH(bpr_mean_kernel, dim3(1), dim3(64), 0, s, workspace, B, loss_out);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -308,7 +327,7 @@ extern "C" int pfo_bpr_loss_parts(const float* emb, int64_t B, int32_t D, int64_
   PFO_REQUIRE(emb && loss_parts && d_emb, "null input");
   PFO_REQUIRE(B > 0 && D > 0 && n_neg > 0, "bad sizes");
   PFO_REQUIRE(pos_off >= B && pos_off + B <= R && neg_off + B * n_neg <= R && neg_off >= pos_off + B, "bad offsets");
-  hipLaunchKernelGGL(bpr_kernel, dim3((unsigned)pfo_ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, emb, B, (int)D, pos_off,
+  PFO_KLAUNCH(bpr_kernel, dim3((unsigned)pfo_ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, emb, B, (int)D, pos_off,
                      neg_off, (int)n_neg, R, scale, loss_parts, d_emb, (float*)nullptr, (int*)nullptr);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
@@ -347,7 +366,7 @@ __global__ void rank_metrics_kernel(const float* __restrict__ emb, int64_t B, in
 extern "C" int pfo_rank_metrics(const float* emb, int64_t B, int32_t D, int32_t n_items, int32_t* rank_out, float* hits_out,
                                 float* ndcg_out, void* stream) {
   PFO_REQUIRE(emb && B > 0 && D > 0 && n_items > 0, "bad arguments");
-  hipLaunchKernelGGL(rank_metrics_kernel, dim3((unsigned)pfo_ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, emb, B, (int)D,
+  PFO_KLAUNCH(rank_metrics_kernel, dim3((unsigned)pfo_ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, emb, B, (int)D,
                      (int)n_items, rank_out, hits_out, ndcg_out);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
@@ -374,7 +393,7 @@ extern "C" int pfo_adam_step(float* param, const float* grad, float* exp_avg, fl
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const int nb = (int)std::min<int64_t>(2048, pfo_ceil_div(n, 256));
-  hipLaunchKernelGGL(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+  PFO_KLAUNCH(adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
                      beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
   PFO_LAUNCH_CHECK();
   return PFO_OK;
@@ -415,7 +434,7 @@ extern "C" int pfo_adam_step_ranges(float* param, const float* grad, float* exp_
     longest = std::max(longest, hi[q] - lo[q]);
   }
   const int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, pfo_ceil_div(longest, 256)));
-  hipLaunchKernelGGL(adam_ranges_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, r,
+  PFO_KLAUNCH(adam_ranges_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, r,
                      beta1, beta2, eps);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
@@ -457,7 +476,7 @@ extern "C" int pfo_adam_step_ranges_dev(float* param, const float* grad, float* 
     longest = std::max(longest, hi[q] - lo[q]);
   }
   const int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, pfo_ceil_div(longest, 256)));
-  hipLaunchKernelGGL(adam_ranges_dev_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, r,
+  PFO_KLAUNCH(adam_ranges_dev_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, r,
                      step_dev, lr, beta1, beta2, eps);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
@@ -534,7 +553,7 @@ int pfo_cq_backward_launch(const float* const* gq, const float* const* Wq, int n
   CqBwdDev q;
   q.n = n_layers;
   for (int l = 0; l < n_layers; ++l) { q.gq[l] = gq[l]; q.Wq[l] = Wq[l]; q.d_bq[l] = d_bq[l]; q.d_Wq[l] = d_Wq[l]; }
-  hipLaunchKernelGGL(cq_backward_kernel, dim3(D), dim3(256), 0, stream, q, tb, D, d_tb, tb_part, tb_add, dtime, n_bins, d_tw);
+  PFO_KLAUNCH(cq_backward_kernel, dim3(D), dim3(256), 0, stream, q, tb, D, d_tb, tb_part, tb_add, dtime, n_bins, d_tw);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -592,7 +611,7 @@ int64_t pfo_fold_parts_scratch_doubles(int n) { return (int64_t)FOLD_SLICES * n;
 int pfo_fold_parts_launch(const double* parts, int n_parts, int n, float* out, int accumulate, double* scratch, int* tickets,
                           hipStream_t stream, double* out64) {
   PFO_REQUIRE(n <= 64 * 64, "too many columns for the ticket array");
-  hipLaunchKernelGGL(fold_parts_kernel, dim3((unsigned)pfo_ceil_div(n, 64), FOLD_SLICES), dim3(256), 0, stream, parts, n_parts,
+  PFO_KLAUNCH(fold_parts_kernel, dim3((unsigned)pfo_ceil_div(n, 64), FOLD_SLICES), dim3(256), 0, stream, parts, n_parts,
                      n, out, accumulate, scratch, tickets, out64);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
@@ -638,7 +657,7 @@ extern "C" int pfo_roots_assemble(const int32_t* src, const int32_t* dst, const 
     g.grp[q] = groups[q]; g.rep[q] = reps[q];
     total += (int64_t)(hi - lo) * reps[q];
   }
-  hipLaunchKernelGGL(roots_assemble_kernel, dim3((unsigned)std::min<int64_t>(1024, pfo_ceil_div(total, 256))), dim3(256), 0,
+  PFO_KLAUNCH(roots_assemble_kernel, dim3((unsigned)std::min<int64_t>(1024, pfo_ceil_div(total, 256))), dim3(256), 0,
                      (hipStream_t)stream, src, dst, ts, lo, hi, g, roots, root_ts);
   PFO_LAUNCH_CHECK();
   return PFO_OK;

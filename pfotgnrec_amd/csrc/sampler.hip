@@ -167,7 +167,7 @@ int pfo_tnbr_sample_dev(const int64_t* indptr, const int32_t* adj_nbr, const int
   const int64_t blocks = pfo_ceil_div(n_q * 16, threads);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(M)                                                                                                   \
-  hipLaunchKernelGGL(tnbr_sample_kernel<M>, dim3((unsigned)blocks), dim3(threads), 0, s, indptr, adj_nbr, adj_eidx, \
+  PFO_KLAUNCH(tnbr_sample_kernel<M>, dim3((unsigned)blocks), dim3(threads), 0, s, indptr, adj_nbr, adj_eidx, \
                      adj_ts, n_nodes, q_nodes, q_ts, n_q, (int)K, draws, seed, offset, offset_dev, out_nbr, out_eidx,  \
                      out_et, out_dt, next_nodes, next_ts, mark, out_cnt)
   pfo_prof_begin(s);
@@ -256,7 +256,7 @@ extern "C" int pfo_neg_draw_dev(const uint8_t* item_avail, int32_t n_items, cons
   PFO_REQUIRE(size >= 1 && port_stride >= 0 && B >= 0, "bad sizes");
   if (B == 0) return PFO_OK;
   PFO_REQUIRE(item_avail && port_len && out && (port_idx || port_stride == 0), "null input");
-  hipLaunchKernelGGL(neg_draw_kernel, dim3((unsigned)B), dim3(64), (size_t)n_items * sizeof(int32_t),
+  PFO_KLAUNCH(neg_draw_kernel, dim3((unsigned)B), dim3(64), (size_t)n_items * sizeof(int32_t),
                      (hipStream_t)stream, item_avail, (int)n_items, port_idx, port_len, (int)port_stride, (int)size,
                      (int)upper_u, seed, offset, offset_dev, out);
   PFO_LAUNCH_CHECK();
@@ -360,7 +360,7 @@ extern "C" int pfo_mv_select(const double* returns, int32_t n_days, int32_t n_it
   PFO_REQUIRE(n_days > 0 && n_items > 0 && B >= 0, "bad sizes");
   if (B == 0) return PFO_OK;
   PFO_REQUIRE(returns && day_idx && cand && port_len && p_pos && p_neg, "null input");
-  hipLaunchKernelGGL(mv_select_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, returns, (int)n_items,
+  PFO_KLAUNCH(mv_select_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, returns, (int)n_items,
                      (int)n_ret, day_idx, cand, (int)n_cand, port_idx, port_len, (int)port_stride, (int)upper_u, gamma,
                      lambda_mv, (int)n_pos, (int)n_neg, p_pos, p_neg, y_out, rank_out);
   PFO_LAUNCH_CHECK();

@@ -759,6 +759,9 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   const int Cp = d.Cp, HCp = H * d.Cp;
   // Everything on the side stream depends on the parameters only, so it may start at once (after whatever the main
   // stream did before this call); all layers share each launch.
+  hipStreamCaptureStatus cap_early = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap_early) != hipSuccess) cap_early = hipStreamCaptureStatusActive;
+  const bool bind_events = cap_early == hipStreamCaptureStatusNone;      // events bound to a launch (common.hpp): not under capture
   PFO_MARK("fwd.begin", s);
   HIPOK(hipEventRecord(sd.fork, s), "event record failed");
   HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
@@ -784,8 +787,12 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   const bool pack_side = pack_side_env && c->use_memory && !b->prepared;
   if (!b->prepared) {
     if (pack_side) {
+      // (comp_done rides on the compaction kernel's own completion when that is the call's only launch: no marker packet)
+      if (bind_events && b->n_extra == 0) pfo_stop_event_arm(sd.comp_done, 0);
+      else pfo_stop_event_arm(nullptr, 0);
       RUN(prepare_compact(c, b, w, s));
-      HIPOK(hipEventRecord(sd.comp_done, s), "event record failed");
+      if (bind_events && b->n_extra == 0) pfo_stop_event_disarm(s);
+      else HIPOK(hipEventRecord(sd.comp_done, s), "event record failed");
     } else {
       RUN(prepare_compact_pack(c, st, b, w, d, n, s));
     }
@@ -800,8 +807,10 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     f.b_ih = P.b_ih; f.b_hh = P.b_hh; f.hm = w.hm; f.touched = w.touched; f.node_feat = st->node_feat;
     f.upd_mem = w.upd_mem; f.h0_tab = w.h0_tab; f.gates = w.gates; f.D = D; f.cap_rows = capP; f.n_rows = w.n_touched;
     if (pack_side) { f.gather = 1; f.msg_rows = st->msg_table; f.h_rows = st->memory; f.hm = st->has_msg; }
+    if (fused_state && bind_events) pfo_stop_event_arm(sd.gru_done, 0);
     RUN(pfo_gru_fused_launch(f, s));
-    if (fused_state) HIPOK(hipEventRecord(sd.gru_done, s), "event record failed");
+    if (fused_state && bind_events) pfo_stop_event_disarm(s);
+    else if (fused_state) HIPOK(hipEventRecord(sd.gru_done, s), "event record failed");
     PFO_MARK("fwd.gru", s);
   }
   // ---- composite weights of every layer and their fp16 images (build_stage_a / _b): side stream.  Enqueued HERE, after the
@@ -1000,6 +1009,9 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   // per row, late in this call): built on the side stream, beside the layer-L .. 2 work.  The same stream first clears what
   // this call accumulates into: the level-0 gradient rows (layer 1's attention backward waits for seg_done)
   // (the gradient buffer is cleared on the caller's stream, before the fork: every writer on any stream comes after it)
+  hipStreamCaptureStatus cap_early = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap_early) != hipSuccess) cap_early = hipStreamCaptureStatusActive;
+  const bool bind_events = cap_early == hipStreamCaptureStatusNone;      // events bound to a launch (common.hpp): not under capture
   PFO_MARK("bwd.begin", s);
   if (zero_grad_first) HIPOK(hipMemsetAsync(grad, 0, (size_t)lay.total * sizeof(float), s), "memset failed");
   // The side stream's opening work: the loss mean the caller left to this call, the cleared level-0 gradient rows and the
@@ -1080,8 +1092,9 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     // the fp16 tile (49 KB, half the matrix work) does better behind d ctx', beside the attention backward: 1.4495 against
     // 1.4532 ms over four interleaved pairs.  (Behind the attention backward, beside the serial tail: +2 % per step.)
     static const int tna_mode = getenv("PFO_TNA_MODE") ? atoi(getenv("PFO_TNA_MODE")) : 0;   // A/B: 0 fork behind the d ctx' contraction (beside the attention backward), 2 beside d ctx', 1 main stream
+    bool tn_a_bound = false;                                   // tn_a already rides on the d ctx' launch
     auto tn_a_side = [&]() -> int {
-      HIPOK(hipEventRecord(sd.tn_a, s), "event record failed");
+      if (!tn_a_bound) HIPOK(hipEventRecord(sd.tn_a, s), "event record failed");
       HIPOK(hipStreamWaitEvent(ss, sd.tn_a, 0), "event wait failed");
       RUN(side_mean_once());
       RUN(pfo_gemm_tn_group_launch(tn, n_tn_a, N, nullptr, w.slabs2, w.slab_floats, ss));
@@ -1093,7 +1106,10 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     {
       PfoGemm q = g_nt(dh1, D, nullptr, W1ovT_l, D, w.dctx, HCp, N, HCp, D, nullptr);
       q.b_img = lw.iW1ovT;
+      const bool bind_tn_a = bind_events && l == 1 && tna_mode == 0 && !pfo_prof_on();
+      if (bind_tn_a) pfo_stop_event_arm(sd.tn_a, 0);
       RUN(pfo_gemm_launch(q, s));
+      if (bind_tn_a) { pfo_stop_event_disarm(s); tn_a_bound = true; }
       PFO_MARK(mk_dctx[l], s);
       if (l == 1 && b->mid_event && !b->mid_event_late) HIPOK(hipEventRecord((hipEvent_t)b->mid_event, s), "event record failed");
     }
@@ -1142,6 +1158,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     if (l == 1 && b->mid_event && b->mid_event_late) HIPOK(hipEventRecord((hipEvent_t)b->mid_event, s), "event record failed");
     if (det) det_rows += n_parts;
     if (deferred_chain) { RUN(deferred_chain()); deferred_chain = nullptr; }     // the layer above's chain-back (side streams)
+    bool layer_event_bound = false;
     // merged query/key projection: dx += dqk' Wqk, dWqk = dqk'^T x, gqk = colsum(dqk')
     if (l == 1) {
       // Layer 1: x is a row of the touched-node table shared by all instances on that node, so everything that is linear
@@ -1149,11 +1166,13 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       // weight gradients against x - is taken AFTER summing those gradients per table row: contractions over the
       // ~11 k touched rows instead of the ~54 k instances.
       if (!c->use_memory) HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");   // (with memory: awaited before the attention backward)
+      if (bind_events) pfo_stop_event_arm(sd.tn_b, 0);
       RUN(pfo_segsum_launch(dqk_l, HCp, dh1, D, w.seg_ptr, w.seg_mem, w.n_core, capP, dqk_by_member,
                             dqk_by_member ? w.dqk_live : nullptr, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
       PFO_MARK("bwd.L1.segsum", s);
       // the weight gradients over the table rows go to the side stream too (beside d h0 / the GRU backward on this one)
-      HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
+      if (bind_events) pfo_stop_event_disarm(s);
+      else HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
       HIPOK(hipStreamWaitEvent(ss, sd.tn_b, 0), "event wait failed");
       RUN(side_mean_once());
       PfoTnProblem tb[2];
@@ -1186,7 +1205,9 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
         q.A[1] = dh1; q.lda[1] = D; q.B[1] = W1b_l; q.ldb[1] = W1b_ld; q.K[1] = D;
         q.b_img = lw.iWqkT; q.b_img2 = lw.iW1bT;
         q.relu_src = xA; q.relu_ld = D;
+        if (bind_events) pfo_stop_event_arm(sd.layer[l], 0);     // (layer[l], recorded below, rides on this launch)
         RUN(pfo_gemm_launch(q, s));
+        if (bind_events) { pfo_stop_event_disarm(s); layer_event_bound = true; }
       } else {
         PfoGemm q = g_nn(dh1, D, W1b_l, W1b_ld, dx, D, N, D, D);
         q.b_img = lw.iW1bT;
@@ -1208,7 +1229,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     // launch of the caller's stream waits for: for a layer >= 2 the HOST issues them only after the next layer's data-gradient
     // launches are queued (r3 timeline: the caller's stream sat idle for ~60 us behind them while the host was the slower side);
     // the event that releases them on the device stays where it was.
-    if (folded) HIPOK(hipEventRecord(sd.layer[l], s), "event record failed");
+    if (folded && !layer_event_bound) HIPOK(hipEventRecord(sd.layer[l], s), "event record failed");
     auto chain_back = [=]() -> int {
     if (folded) {
       // First undo the fc2 fold (notation of pfo_tgn_forward: A, b = W2, b2 of layer l-1; Q = Wqk, V = W1ovT, per head):
@@ -1360,6 +1381,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   if (deferred_chain) { RUN(deferred_chain()); deferred_chain = nullptr; }
 
   // ---- GRU parameters (messages and stored memory are constants: SURVEY App. A-6)
+  bool main_done_bound = false;
   if (c->use_memory) {
     PfoRange range_gru("backward GRU");
     // (the GRU's backward covers the rows the layers read: rows only the extra list names carry no gradient)
@@ -1373,7 +1395,11 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       gp[0].C = G.w_ih; gp[0].ldc = d.M; gp[0].bias_out = G.b_ih;
       gp[1].A = w.gh; gp[1].lda = 3 * D; gp[1].B = w.h_rows; gp[1].ldb = D; gp[1].M = 3 * D; gp[1].N = D;
       gp[1].C = G.w_hh; gp[1].ldc = D; gp[1].bias_out = G.b_hh;
+      // (a deferred join's main_done event rides on the slab reduce, the caller's stream's last launch of this call)
+      main_done_bound = b->defer_join && bind_events;
+      if (main_done_bound) pfo_stop_event_arm(sd.main_done, 1);
       RUN(pfo_gemm_tn_group_launch(gp, 2, capP, w.n_core, w.slabs, w.slab_floats, s));
+      if (main_done_bound) pfo_stop_event_disarm(s);
       PFO_MARK("bwd.gru.tn", s);
     }
   }
@@ -1406,7 +1432,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   if (b->defer_join && chained) {
     // the end of the backward stays on the side stream (pfo_tgn_batch.defer_join): it waits for the caller's stream's last
     // launch instead of the other way round - the caller's stream is free for the next batch's neighbour sampling
-    HIPOK(hipEventRecord(sd.main_done, s), "event record failed");
+    if (!main_done_bound) HIPOK(hipEventRecord(sd.main_done, s), "event record failed");
     HIPOK(hipStreamWaitEvent(ss, sd.main_done, 0), "event wait failed");
     sd.side_pending = true;
   } else {
