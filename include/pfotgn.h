@@ -104,6 +104,25 @@ int pfo_attn_dropout_mask(uint64_t seed, uint64_t offset, int64_t N, int32_t K, 
                           void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Gradient rows of the instances that sit on one node, summed per node: the backward of the reference's reuse of one
+ * level-0 row [memory + features] by every instance of that node (embedding_module.py:93-98, the index by node id there;
+ * autograd's index backward is this sum).  Exposed for tests; the step calls it between layer 1's attention backward and
+ * the touched-table contraction.
+ *   out[s, :] = sum over m in [seg_ptr[s], seg_ptr[s+1]) of [ src0[p(m), 0:W0] | src1[members[m], 0:W1] ],  s < *n_rows
+ *   p(m) = m (src0_by_position != 0: rows stored in member order) or members[m]
+ *   src0_live (optional, with src0_by_position): byte per position, 0 = that src0 row holds nothing and is not read
+ *   seg_of (optional): int32 per member position, the segment it belongs to, in an array of at least
+ *   (n_members / 16 + 2) * 16 entries (the tail unused).  With it the launch is cut by members instead of by segments
+ *   (balanced whatever the segment lengths); without it, four segments per workgroup.
+ * Rows are added in member order: the result is the sequential sum, the same on every run.
+ * seg_ptr / members / seg_of / n_rows are device arrays (n_rows: one int32, <= cap_rows; n_members >= seg_ptr[*n_rows]).
+ */
+int pfo_segment_sum(const float* src0, int32_t W0, const float* src1, int32_t W1, const int32_t* seg_ptr,
+                    const int32_t* members, const int32_t* seg_of, int64_t n_members, const int32_t* n_rows,
+                    int32_t cap_rows, int32_t src0_by_position, const uint8_t* src0_live,
+                    float* out /* [cap_rows, W0+W1] */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Dense fp32 contraction on the matrix cores (v_mfma_f32_16x16x4_f32), exposed for tests.
  *   C[M,N] = A[M,K] * op(B) + bias,  op(B) = B[N,K]^T (b_kmajor = 0, the nn.Linear weight layout)
  *                                    or      B[K,N]   (b_kmajor = 1)

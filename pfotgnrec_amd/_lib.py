@@ -64,6 +64,8 @@ PROTOTYPES = {
                                 C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, _VP, _VP, _VP,
                                 _VP, _VP]),
     "pfo_time_encode": (C.c_int, [_VP, C.c_int64, _VP, _VP, C.c_int32, _VP, _VP]),
+    "pfo_segment_sum": (C.c_int, [_VP, C.c_int32, _VP, C.c_int32, _VP, _VP, _VP, C.c_int64, _VP, C.c_int32, C.c_int32, _VP, _VP,
+                                  _VP]),
     "pfo_attn_dropout_mask": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_float, _VP, _VP]),
     "pfo_gemm_f32": (C.c_int, [_VP, C.c_int64, C.c_int32, _VP, C.c_int64, C.c_int32, _VP, C.c_int64, _VP, C.c_int32,
                                C.c_int32, C.c_int32, C.c_int32, _VP, C.c_int64, _VP]),

@@ -1949,6 +1949,7 @@ struct TnProbDev {
 struct TnGroupDev {
   TnProbDev p[TN_MAX_PROBLEMS];
   int n, K, nsplit, chunk, total_tiles;
+  int xcd_map;               // bx kernel, 1-D grid: every tile of one K split on the same XCD (split s on XCD s & 7)
   const int32_t* k_dev;
   float* slabs;
 };
@@ -1984,12 +1985,25 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_group_kernel(const TnGro
 template <int FMT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_group_bx_kernel(const TnGroupDev g) {
   __shared__ __attribute__((aligned(16))) char lds[BxFmt<FMT>::NP * (TX_A_PIECE + TX_B_PIECE) + 32];
+  // Workgroups go to the XCDs round-robin by linear id.  All tiles of one K split read the same rows of A and B (a tile
+  // takes 128 of A's columns and all of B's 172): with the (tile, split) grid the six tiles of dW1ovT's split sat on six
+  // different L2s and B came from HBM six times (FETCH 188 MB per launch on average where the operands are 83 MB).  The
+  // 1-D grid puts split s on XCD s & 7: id = (s / 8) * 8 * tiles + tile * 8 + (s & 7); a last group of fewer than eight
+  // splits is laid out tile-major.
+  int tile_id = blockIdx.x, split = blockIdx.y;
+  if (g.xcd_map) {
+    const int id = blockIdx.x, T = g.total_tiles;
+    const int grp = id / (8 * T), loc = id - grp * 8 * T;
+    const int in_grp = min(8, g.nsplit - 8 * grp);
+    tile_id = loc / in_grp;
+    split = 8 * grp + loc % in_grp;
+  }
   int q = 0;
 #pragma unroll
   for (int i = 1; i < TN_MAX_PROBLEMS; ++i)
-    if (i < g.n && (int)blockIdx.x >= g.p[i].tile_begin) q = i;
+    if (i < g.n && tile_id >= g.p[i].tile_begin) q = i;
   const TnProbDev& pr = g.p[q];
-  const int t = blockIdx.x - pr.tile_begin;
+  const int t = tile_id - pr.tile_begin;
   GemmDev d;
   d.A[0] = pr.A; d.lda[0] = pr.lda; d.B[0] = pr.B; d.ldb[0] = pr.ldb; d.b_idx = pr.b_idx;
   d.K[0] = g.K; d.M = pr.M; d.N = pr.N; d.m_dev = g.k_dev;
@@ -1998,7 +2012,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_group_bx_kernel(const
   d.slab_base = g.slabs + pr.slab_off;
   d.nsplit = g.nsplit;
   d.dyn_chunk = (g.k_dev != nullptr && g.nsplit > 1) ? 1 : 0;
-  gemm_tile_tn_bx<FMT>(d, t / pr.tn, t % pr.tn, blockIdx.y, lds);
+  gemm_tile_tn_bx<FMT>(d, t / pr.tn, t % pr.tn, split, lds);
 }
 __global__ __launch_bounds__(256) void tn_group_reduce_kernel(const TnGroupDev g) {
   int K = g.K;
@@ -2072,8 +2086,11 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
   const bool use_bx = vec && bx >= 1;
   pfo_prof_begin(stream);
   static const int tn_fmt = getenv("PFO_TN_FMT") ? atoi(getenv("PFO_TN_FMT")) : PFO_DEFAULT_TN_FMT;      // A/B switch
-  if (use_bx && tn_fmt) PFO_KLAUNCH(gemm_tn_group_bx_kernel<1>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
-  else if (use_bx) PFO_KLAUNCH(gemm_tn_group_bx_kernel<0>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
+  static const int xcd_map = getenv("PFO_TN_XCD") ? atoi(getenv("PFO_TN_XCD")) : 1;                      // A/B switch
+  g.xcd_map = use_bx && xcd_map && nsplit > 1;
+  const dim3 grid_bx = g.xcd_map ? dim3(tiles * nsplit, 1) : dim3(tiles, nsplit);
+  if (use_bx && tn_fmt) PFO_KLAUNCH(gemm_tn_group_bx_kernel<1>, grid_bx, dim3(GEMM_THREADS), 0, stream, g);
+  else if (use_bx) PFO_KLAUNCH(gemm_tn_group_bx_kernel<0>, grid_bx, dim3(GEMM_THREADS), 0, stream, g);
   else if (vec) PFO_KLAUNCH(gemm_tn_group_kernel<true>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   else PFO_KLAUNCH(gemm_tn_group_kernel<false>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   PFO_LAUNCH_CHECK();

@@ -218,7 +218,7 @@ __global__ void seg_place_kernel(const int32_t* __restrict__ idx, const int32_t*
 // group in this order walks its node's history forwards.  key_src == null (uniform sampling: lists are random): the instance
 // index itself.  Instance indices are distinct, so ranks are too; the order is reproducible.
 __global__ void seg_sort_kernel(const int32_t* __restrict__ seg_ptr, int n_seg, const int32_t* __restrict__ in,
-                                const int32_t* __restrict__ key_src, int32_t* __restrict__ out) {
+                                const int32_t* __restrict__ key_src, int32_t* __restrict__ out, int32_t* __restrict__ seg_of) {
   const int lane = threadIdx.x & 63;
   for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < n_seg; s += (gridDim.x * blockDim.x) >> 6) {
     const int lo = seg_ptr[s], cnt = seg_ptr[s + 1] - lo;
@@ -233,6 +233,7 @@ __global__ void seg_sort_kernel(const int32_t* __restrict__ seg_ptr, int n_seg, 
         rank += (ky < kx) || (ky == kx && y < x);
       }
       out[lo + rank] = x;
+      if (seg_of) seg_of[lo + i] = s;                       // (optional: the group of every member position)
     }
   }
 }
@@ -248,7 +249,7 @@ int pfo_iscan_launch(const int32_t* in, int64_t n, int32_t* out, int32_t* scratc
 
 int64_t pfo_seg_scratch_ints(int cap_rows) { return pfo_ceil_div(cap_rows + 1, SCAN_BLOCK) + 8; }
 int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int cap_rows, const int32_t* key_src,
-                         int32_t* seg_ptr, int32_t* cursor, int32_t* tmp, int32_t* members, int32_t* scratch,
+                         int32_t* seg_ptr, int32_t* cursor, int32_t* tmp, int32_t* members, int32_t* seg_of, int32_t* scratch,
                          hipStream_t stream) {
   PFO_REQUIRE(idx && nodes && seg_ptr && cursor && tmp && members && scratch && N > 0 && cap_rows > 0, "bad arguments");
   const int n = cap_rows + 1;
@@ -260,7 +261,7 @@ int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int ca
   PFO_KLAUNCH(iscan_add_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, stream, seg_ptr, n, scratch, cursor);
   PFO_KLAUNCH(seg_place_kernel, dim3((unsigned)pfo_ceil_div(N, 256)), dim3(256), 0, stream, idx, nodes, N, cursor, tmp);
   PFO_KLAUNCH(seg_sort_kernel, dim3((unsigned)std::min<int64_t>(4096, pfo_ceil_div(cap_rows, 4))), dim3(256), 0, stream,
-                     seg_ptr, cap_rows, tmp, key_src, members);
+                     seg_ptr, cap_rows, tmp, key_src, members, seg_of);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }
@@ -316,73 +317,198 @@ __global__ __launch_bounds__(256) void segsum_kernel(const float* __restrict__ s
     }
   }
 }
-// The same sums with 16-byte loads and four member rows in flight (every row start a multiple of 4 floats): a lane owns the
-// float4 columns lane, lane + 64, .. of the output row, so a 876-float row is 4 loads per member instead of 14.
-#define SEGSUM_V 4
+// The same sums with 16-byte loads, organised around the MEMBER LIST instead of the segment (every row start a multiple of
+// 4 floats).  A workgroup owns SEGSUM_NSEG consecutive segments = one contiguous range of the member list; each of its
+// waves owns 64 float4 columns of the row (4 waves = 256 columns = the whole 876-float row of C2 in one pass) and walks the
+// range in member order, SEGSUM_ROWS row loads in flight, storing its slice of an output row whenever a segment ends.
+//   - the ids and flags of up to 64 members arrive in ONE vector load (lane i holds member i) and are broadcast with
+//     v_readlane: a segment costs three dependent memory latencies (pointers, ids, rows) whatever its length up to
+//     SEGSUM_ROWS, where a wave that owned a whole segment paid three per four members - the kernel was latency-bound
+//     (C2, alone: 82-95 us for ~50 MB read + 47 MB written; tools/probes/segsum_bench.py)
+//   - every load is a full 1 KB wave access, no partial rows; no LDS, no barrier
+//   - rows are added strictly in member order: the sum is the sequential one, the same on every run.
+#define SEGSUM_NSEG 4
+#define SEGSUM_ROWS 8
 __global__ __launch_bounds__(256) void segsum_vec_kernel(const float* __restrict__ src0, int W0, const float* __restrict__ src1, int W1,
                                                          const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ members,
                                                          const int32_t* __restrict__ n_rows, int src0_by_position,
                                                          const uint8_t* __restrict__ src0_live, float* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int V0 = W0 >> 2, V = (W0 + W1) >> 2;
   const int nr = *n_rows;
   const float4 zero = {0.f, 0.f, 0.f, 0.f};
-  for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < nr; s += (gridDim.x * blockDim.x) >> 6) {
-    const int lo = seg_ptr[s], hi = seg_ptr[s + 1];
-    for (int v0 = 0; v0 < V; v0 += 64 * SEGSUM_V) {
-      float4 acc[SEGSUM_V];
+  for (int sb = blockIdx.x * SEGSUM_NSEG; sb < nr; sb += gridDim.x * SEGSUM_NSEG) {            // (workgroup-uniform)
+    const int ns = min(SEGSUM_NSEG, nr - sb);
+    const int my_ptr = lane <= ns ? seg_ptr[sb + lane] : 0;
+    const int m_lo = __builtin_amdgcn_readlane(my_ptr, 0), m_hi = __builtin_amdgcn_readlane(my_ptr, ns);
+    for (int v0 = 0; v0 < V; v0 += 256) {
+      const int c = v0 + wave * 64 + lane;
+      const bool in0 = c < V0, in1 = c >= V0 && c < V;
+      float4* const orow = reinterpret_cast<float4*>(out + (int64_t)sb * (W0 + W1)) + c;
+      const int64_t ostep = (W0 + W1) >> 2;
+      int seg = 0;
+      int seg_end = __builtin_amdgcn_readlane(my_ptr, 1);
+      float4 acc = zero;
+      for (int mb = m_lo; mb < m_hi; mb += 64) {
+        const int nb = min(64, m_hi - mb);
+        const int mid = lane < nb ? members[mb + lane] : 0;
+        const int lv = (lane < nb && src0_live) ? (int)src0_live[mb + lane] : 1;
+        for (int j0 = 0; j0 < nb; j0 += SEGSUM_ROWS) {
+          // (ids and flags to scalars FIRST: a v_readlane between the row loads makes the compiler drain the load queue
+          //  in front of it, one row in flight)
+          int rn[SEGSUM_ROWS], rl[SEGSUM_ROWS];
 #pragma unroll
-      for (int r = 0; r < SEGSUM_V; ++r) acc[r] = zero;
-      auto row = [&](int m, float4 (&v)[SEGSUM_V]) {
-        const int64_t n = members[m];
-        const int64_t pos = src0_by_position ? m : n;
-        const bool live = !src0_live || src0_live[m] != 0;                    // wave-uniform
-        const float4* r0 = reinterpret_cast<const float4*>(src0 + pos * W0);
-        const float4* r1 = reinterpret_cast<const float4*>(src1 + n * W1);
+          for (int j = 0; j < SEGSUM_ROWS; ++j) {
+            const int jj = min(j0 + j, nb - 1);                              // (wave-uniform; rows past the end: the last one again, not added)
+            rn[j] = __builtin_amdgcn_readlane(mid, jj);
+            rl[j] = __builtin_amdgcn_readlane(lv, jj);
+          }
+          float4 v[SEGSUM_ROWS];
 #pragma unroll
-        for (int r = 0; r < SEGSUM_V; ++r) {
-          const int c = v0 + lane + 64 * r;
-          v[r] = c < V0 ? (live ? r0[c] : zero) : (c < V ? r1[c - V0] : zero);
+          for (int j = 0; j < SEGSUM_ROWS; ++j) {
+            const int64_t pos = src0_by_position ? (int64_t)(mb + min(j0 + j, nb - 1)) : (int64_t)rn[j];
+            const float4* p = in0 ? reinterpret_cast<const float4*>(src0 + pos * W0) + c
+                                  : reinterpret_cast<const float4*>(src1 + (int64_t)rn[j] * W1) + (in1 ? c - V0 : 0);
+            v[j] = (in0 ? rl[j] != 0 : in1) ? *p : zero;
+          }
+#pragma unroll
+          for (int j = 0; j < SEGSUM_ROWS; ++j) {
+            const int m = mb + j0 + j;
+            if (m < m_hi) {
+              while (m >= seg_end) {                                         // a segment ended in front of this member
+                if (c < V) orow[seg * ostep] = acc;
+                acc = zero;
+                ++seg;
+                seg_end = __builtin_amdgcn_readlane(my_ptr, seg + 1);
+              }
+              acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w;
+            }
+          }
         }
-      };
-      auto add = [&](const float4 (&v)[SEGSUM_V]) {
-#pragma unroll
-        for (int r = 0; r < SEGSUM_V; ++r) { acc[r].x += v[r].x; acc[r].y += v[r].y; acc[r].z += v[r].z; acc[r].w += v[r].w; }
-      };
-      int m = lo;
-      for (; m + 3 < hi; m += 4) {                         // four member rows in flight, added in member order
-        float4 a[SEGSUM_V], b[SEGSUM_V], c[SEGSUM_V], d[SEGSUM_V];
-        row(m, a); row(m + 1, b); row(m + 2, c); row(m + 3, d);
-        add(a); add(b); add(c); add(d);
       }
-      if (m + 1 < hi) {
-        float4 a[SEGSUM_V], b[SEGSUM_V];
-        row(m, a); row(m + 1, b);
-        add(a); add(b);
-        m += 2;
-      }
-      if (m < hi) { float4 a[SEGSUM_V]; row(m, a); add(a); }
-#pragma unroll
-      for (int r = 0; r < SEGSUM_V; ++r) {
-        const int c = v0 + lane + 64 * r;
-        if (c < V) reinterpret_cast<float4*>(out + (int64_t)s * (W0 + W1))[c] = acc[r];
+      for (; seg < ns; ++seg) {                                              // the last segment (and empty ones behind it)
+        if (c < V) orow[seg * ostep] = acc;
+        acc = zero;
       }
     }
   }
 }
+// The same walk with the work cut by MEMBERS, not by segments (seg_of given: the segment of every member position, written
+// by pfo_seg_build_launch).  A workgroup takes SEGSUM_CHUNK consecutive member positions and OWNS the segments that start
+// inside them - it sums those to their ends, wherever that is - so every workgroup has about the same number of rows to
+// read whatever the shape of the segments, no row is summed by two workgroups, and there is no atomic and no second pass.
+// (with the segment-cut kernel above the 500 item segments of C2, 15-41 members each and all at the end of the table, were
+//  the last 125 workgroups of the launch and ran after everything else: 64 us alone, 30 of them that tail.)
+// Empty segments start nowhere: their rows are cleared by a sweep over the pointer array in front of the walk.
+#define SEGSUM_CHUNK 16
+__global__ __launch_bounds__(256) void segsum_chunk_kernel(const float* __restrict__ src0, int W0, const float* __restrict__ src1, int W1,
+                                                           const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ members,
+                                                           const int32_t* __restrict__ seg_of, const int32_t* __restrict__ n_rows,
+                                                           int src0_by_position, const uint8_t* __restrict__ src0_live,
+                                                           float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int V0 = W0 >> 2, V = (W0 + W1) >> 2;
+  const int nr = *n_rows;
+  const float4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int m0 = blockIdx.x * SEGSUM_CHUNK;
+  // (speculative: seg_of holds gridDim.x * SEGSUM_CHUNK entries, the ones behind the last member are not used)
+  int t0 = seg_of[m0], t1 = seg_of[m0 + SEGSUM_CHUNK - 1];
+  const int M = seg_ptr[nr];
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nr; s += gridDim.x * blockDim.x) {
+    if (seg_ptr[s] == seg_ptr[s + 1]) {
+      float4* o = reinterpret_cast<float4*>(out + (int64_t)s * (W0 + W1));
+      for (int c = 0; c < V; ++c) o[c] = zero;
+    }
+  }
+  if (m0 >= M) return;
+  if (m0 + SEGSUM_CHUNK > M) t1 = seg_of[M - 1];
+  const int s_first = t0 + (seg_ptr[t0] != m0 ? 1 : 0);    // a segment that started in front of the chunk belongs to an earlier one
+  const int ns = t1 - s_first + 1;                         // (empty segments between them included: they cost a store)
+  if (ns <= 0) return;
+  const int my_ptr = lane <= min(ns, 63) ? seg_ptr[s_first + lane] : 0;
+  const int m_lo = __builtin_amdgcn_readlane(my_ptr, 0);
+  const int m_hi = ns <= 63 ? __builtin_amdgcn_readlane(my_ptr, ns) : seg_ptr[s_first + ns];
+  for (int v0 = 0; v0 < V; v0 += 256) {
+    const int c = v0 + wave * 64 + lane;
+    const bool in0 = c < V0, in1 = c >= V0 && c < V;
+    float4* const orow = reinterpret_cast<float4*>(out + (int64_t)s_first * (W0 + W1)) + c;
+    const int64_t ostep = (W0 + W1) >> 2;
+    int seg = 0;
+    int seg_end = __builtin_amdgcn_readlane(my_ptr, 1);
+    float4 acc = zero;
+    for (int mb = m_lo; mb < m_hi; mb += 64) {
+      const int nb = min(64, m_hi - mb);
+      const int mid = lane < nb ? members[mb + lane] : 0;
+      const int lv = (lane < nb && src0_live) ? (int)src0_live[mb + lane] : 1;
+      for (int j0 = 0; j0 < nb; j0 += SEGSUM_ROWS) {
+        int rn[SEGSUM_ROWS], rl[SEGSUM_ROWS];
+#pragma unroll
+        for (int j = 0; j < SEGSUM_ROWS; ++j) {
+          const int jj = min(j0 + j, nb - 1);
+          rn[j] = __builtin_amdgcn_readlane(mid, jj);
+          rl[j] = __builtin_amdgcn_readlane(lv, jj);
+        }
+        float4 v[SEGSUM_ROWS];
+#pragma unroll
+        for (int j = 0; j < SEGSUM_ROWS; ++j) {
+          const int64_t pos = src0_by_position ? (int64_t)(mb + min(j0 + j, nb - 1)) : (int64_t)rn[j];
+          const float4* p = in0 ? reinterpret_cast<const float4*>(src0 + pos * W0) + c
+                                : reinterpret_cast<const float4*>(src1 + (int64_t)rn[j] * W1) + (in1 ? c - V0 : 0);
+          v[j] = (in0 ? rl[j] != 0 : in1) ? *p : zero;
+        }
+#pragma unroll
+        for (int j = 0; j < SEGSUM_ROWS; ++j) {
+          const int m = mb + j0 + j;
+          if (m < m_hi) {
+            while (m >= seg_end) {
+              if (c < V) orow[seg * ostep] = acc;
+              acc = zero;
+              ++seg;
+              seg_end = seg + 1 <= 63 ? __builtin_amdgcn_readlane(my_ptr, seg + 1) : seg_ptr[s_first + seg + 1];
+            }
+            acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w;
+          }
+        }
+      }
+    }
+    for (; seg < ns; ++seg) {
+      if (c < V) orow[seg * ostep] = acc;
+      acc = zero;
+    }
+  }
+}
+
+int64_t pfo_seg_of_ints(int64_t n_members) { return (pfo_ceil_div(n_members, SEGSUM_CHUNK) + 1) * SEGSUM_CHUNK; }
 int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, const int32_t* seg_ptr, const int32_t* members,
-                      const int32_t* n_rows, int cap_rows, int src0_by_position, const uint8_t* src0_live, float* out,
-                      hipStream_t stream) {
+                      const int32_t* seg_of, int64_t cap_members, const int32_t* n_rows, int cap_rows, int src0_by_position,
+                      const uint8_t* src0_live, float* out, hipStream_t stream) {
   PFO_REQUIRE(src0 && src1 && seg_ptr && members && n_rows && out && W0 > 0 && W1 > 0, "bad arguments");
   PFO_REQUIRE(!src0_live || src0_by_position, "row flags go with rows stored by position");
-  const int nb = (int)std::min<int64_t>(8192, std::max<int64_t>(1, pfo_ceil_div(cap_rows, 4)));
   const bool vec = ((W0 | W1) & 3) == 0 && ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)out)) & 15) == 0;
+  static const int chunked = getenv("PFO_SEGSUM_CHUNKED") ? atoi(getenv("PFO_SEGSUM_CHUNKED")) : 1;   // A/B switch
+  if (vec && seg_of && cap_members > 0 && chunked) {
+    const int nbm = (int)pfo_ceil_div(cap_members, SEGSUM_CHUNK);
+    PFO_KLAUNCH(segsum_chunk_kernel, dim3(nbm), dim3(256), 0, stream, src0, W0, src1, W1, seg_ptr, members, seg_of, n_rows,
+                src0_by_position, src0_live, out);
+    PFO_LAUNCH_CHECK();
+    return PFO_OK;
+  }
+  const int nb = (int)std::min<int64_t>(8192, std::max<int64_t>(1, pfo_ceil_div(cap_rows, vec ? SEGSUM_NSEG : 4)));
   if (vec) PFO_KLAUNCH(segsum_vec_kernel, dim3(nb), dim3(256), 0, stream, src0, W0, src1, W1, seg_ptr, members, n_rows,
                               src0_by_position, src0_live, out);
   else PFO_KLAUNCH(segsum_kernel, dim3(nb), dim3(256), 0, stream, src0, W0, src1, W1, seg_ptr, members, n_rows,
                           src0_by_position, src0_live, out);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
+}
+
+extern "C" int pfo_segment_sum(const float* src0, int32_t W0, const float* src1, int32_t W1, const int32_t* seg_ptr,
+                               const int32_t* members, const int32_t* seg_of, int64_t n_members, const int32_t* n_rows,
+                               int32_t cap_rows, int32_t src0_by_position, const uint8_t* src0_live, float* out,
+                               void* stream) {
+  PFO_REQUIRE(cap_rows > 0 && n_members >= 0, "bad arguments");
+  return pfo_segsum_launch(src0, W0, src1, W1, seg_ptr, members, seg_of, n_members, n_rows, cap_rows, src0_by_position,
+                           src0_live, out, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -36,13 +36,16 @@ int64_t pfo_seg_scratch_ints(int cap_rows);
 // inside a group the members are ordered by (key_src[instance], instance): key = the number of row entries before the
 // instance's time (equal keys <=> identical most-recent neighbour lists), or the instance index when key_src is null
 int pfo_seg_build_launch(const int32_t* idx, const int32_t* nodes, int N, int cap_rows, const int32_t* key_src,
-                         int32_t* seg_ptr, int32_t* cursor, int32_t* tmp, int32_t* members, int32_t* scratch,
+                         int32_t* seg_ptr, int32_t* cursor, int32_t* tmp, int32_t* members, int32_t* seg_of, int32_t* scratch,
                          hipStream_t stream);
+// (seg_of, optional: pfo_seg_of_ints(N) ints - seg_of[m] = the group of member position m, for pfo_segsum_launch)
+int64_t pfo_seg_of_ints(int64_t n_members);
 // out[s] = [ sum_{n in group s} src0[n] | sum_{n in group s} src1[n] ]  (row widths W0, W1; s < *n_rows).
 // src0_by_position: src0's rows are stored in MEMBER order (row m belongs to members[m]) - contiguous per group
+// seg_of (optional, with cap_members = the most members there can be): the work is cut by members instead of by groups
 int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, const int32_t* seg_ptr, const int32_t* members,
-                      const int32_t* n_rows, int cap_rows, int src0_by_position, const uint8_t* src0_live, float* out,
-                      hipStream_t stream);
+                      const int32_t* seg_of, int64_t cap_members, const int32_t* n_rows, int cap_rows, int src0_by_position,
+                      const uint8_t* src0_live, float* out, hipStream_t stream);
 // (src0_live: optional byte flags per position; rows flagged 0 are not read)
 int pfo_zero_rows_launch(float* dst, const int32_t* n_rows, int cap_rows, int D, int n_rep, int64_t rep_stride, hipStream_t stream);
 

@@ -138,13 +138,28 @@ extern "C" int64_t pfo_marks_dump(char* out, int64_t cap) {
   (void)hipDeviceSynchronize();
   std::vector<std::string> order;
   std::map<std::string, std::pair<double, int64_t>> acc;
-  for (size_t i = 1; i < g_marks.size(); ++i) {
+  // names that start with '@' are marks on OTHER streams: they take no part in the chain of consecutive differences and
+  // are reported, like every mark, as an offset from the latest "step.begin"
+  std::vector<std::string> off_order;
+  std::map<std::string, std::pair<double, int64_t>> off;
+  long prev = -1, begin = -1;
+  for (size_t i = 0; i < g_marks.size(); ++i) {
+    const bool side = g_marks[i].name[0] == '@';
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, g_marks[i - 1].ev, g_marks[i].ev) != hipSuccess) continue;
-    std::string key = std::string(g_marks[i - 1].name) + " -> " + g_marks[i].name;
-    auto it = acc.find(key);
-    if (it == acc.end()) { order.push_back(key); acc[key] = {ms, 1}; }
-    else { it->second.first += ms; it->second.second += 1; }
+    if (!strcmp(g_marks[i].name, "step.begin")) begin = (long)i;
+    else if (begin >= 0 && hipEventElapsedTime(&ms, g_marks[begin].ev, g_marks[i].ev) == hipSuccess) {
+      auto it = off.find(g_marks[i].name);
+      if (it == off.end()) { off_order.push_back(g_marks[i].name); off[g_marks[i].name] = {ms, 1}; }
+      else { it->second.first += ms; it->second.second += 1; }
+    }
+    if (side) continue;
+    if (prev >= 0 && hipEventElapsedTime(&ms, g_marks[prev].ev, g_marks[i].ev) == hipSuccess) {
+      std::string key = std::string(g_marks[prev].name) + " -> " + g_marks[i].name;
+      auto it = acc.find(key);
+      if (it == acc.end()) { order.push_back(key); acc[key] = {ms, 1}; }
+      else { it->second.first += ms; it->second.second += 1; }
+    }
+    prev = (long)i;
   }
   for (auto& m : g_marks) g_mark_pool.push_back(m.ev);
   g_marks.clear();
@@ -153,6 +168,18 @@ extern "C" int64_t pfo_marks_dump(char* out, int64_t cap) {
     char line[256];
     const int len = snprintf(line, sizeof(line), "%-44s %9.2f us  n=%lld\n", k.c_str(), 1e3 * acc[k].first / (double)acc[k].second,
                              (long long)acc[k].second);
+    if (len <= 0 || n + len >= cap) break;
+    memcpy(out + n, line, (size_t)len);
+    n += len;
+  }
+  std::sort(off_order.begin(), off_order.end(), [&](const std::string& a, const std::string& b) {
+    return off[a].first / (double)off[a].second < off[b].first / (double)off[b].second; });
+  for (size_t k = 0; k <= off_order.size() && !off_order.empty(); ++k) {
+    char line[256];
+    const int len = k == 0 ? snprintf(line, sizeof(line), "offsets from step.begin (@ = another stream):\n")
+                           : snprintf(line, sizeof(line), "  %-42s %9.2f us  n=%lld\n", off_order[k - 1].c_str(),
+                                      1e3 * off[off_order[k - 1]].first / (double)off[off_order[k - 1]].second,
+                                      (long long)off[off_order[k - 1]].second);
     if (len <= 0 || n + len >= cap) break;
     memcpy(out + n, line, (size_t)len);
     n += len;

@@ -51,7 +51,7 @@ struct Ws {
   // (the query-side projections of all instances that sit on node s), Dq = per-row sums of the instances' gradients
   float *QX, *Dq, *dx_tab, *l1_bias;
   void* iQX;
-  int32_t *seg_ptr, *seg_cur, *seg_tmp, *seg_mem, *seg_scratch;
+  int32_t *seg_ptr, *seg_cur, *seg_tmp, *seg_mem, *seg_of, *seg_scratch;
   uint8_t* dqk_live;           // per layer-1 member position: does dQK row m hold a sum (attn.hip, run-merged backward)
   int32_t* cnt1;               // per layer-1 instance: entries of its node's row before its time (the run key, sampler.hip)
   LayerWs layer[PFO_MAX_LAYERS + 1];
@@ -147,6 +147,7 @@ Ws carve(const pfo_tgn_config* c, void* base) {
     w.seg_cur = take<int32_t>(p, d.capP + 1);
     w.seg_tmp = take<int32_t>(p, d.ncap[1]);
     w.seg_mem = take<int32_t>(p, d.ncap[1]);
+    w.seg_of = take<int32_t>(p, pfo_seg_of_ints(d.ncap[1]));
     w.seg_scratch = take<int32_t>(p, pfo_seg_scratch_ints((int)d.capP));
     w.cnt1 = take<int32_t>(p, d.ncap[1]);
     w.dqk_live = take<uint8_t>(p, d.ncap[1]);
@@ -462,7 +463,7 @@ static int seg_prologue(const pfo_tgn_config* c, const pfo_tgn_batch* b, const W
   // (deterministic: the table holds int64 fixed-point sums - rows of 2 D floats' worth)
   if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_core, capP, det ? 2 * d.D : d.D, grad_replicas(c, b), rep_stride, ss));
   RUN(pfo_seg_build_launch(w.idx0, w.nodes[0], (int)n[1], capP, b->uniform ? nullptr : w.cnt1, w.seg_ptr, w.seg_cur,
-                           w.seg_tmp, w.seg_mem, w.seg_scratch, ss));
+                           w.seg_tmp, w.seg_mem, w.seg_of, w.seg_scratch, ss));
   return PFO_OK;
 }
 
@@ -770,6 +771,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   // a deferred backward end + optimizer step of the previous step may still be running on the side stream: the sampling above
   // reads neither its buffers nor the parameters; everything below does (compaction counts, the GRU's weights ...)
   RUN(side_join(sd, s));
+  PFO_MARK("fwd.side_joined", s);
   const bool fused_state = b->upd_src != nullptr && c->use_memory && L >= 2;
   PFO_REQUIRE(!fused_state || (b->upd_dst && b->upd_ts && b->upd_eidx && b->upd_B >= 1), "bad state-update arguments");
 
@@ -1097,7 +1099,9 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       if (!tn_a_bound) HIPOK(hipEventRecord(sd.tn_a, s), "event record failed");
       HIPOK(hipStreamWaitEvent(ss, sd.tn_a, 0), "event wait failed");
       RUN(side_mean_once());
+      PFO_MARK("@side1.tn_a.begin", ss);
       RUN(pfo_gemm_tn_group_launch(tn, n_tn_a, N, nullptr, w.slabs2, w.slab_floats, ss));
+      PFO_MARK("@side1.tn_a.end", ss);
       HIPOK(hipEventRecord(sd.tn_a_done, ss), "event record failed");
       return PFO_OK;
     };
@@ -1167,7 +1171,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       // ~11 k touched rows instead of the ~54 k instances.
       if (!c->use_memory) HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");   // (with memory: awaited before the attention backward)
       if (bind_events) pfo_stop_event_arm(sd.tn_b, 0);
-      RUN(pfo_segsum_launch(dqk_l, HCp, dh1, D, w.seg_ptr, w.seg_mem, w.n_core, capP, dqk_by_member,
+      RUN(pfo_segsum_launch(dqk_l, HCp, dh1, D, w.seg_ptr, w.seg_mem, w.seg_of, n[1], w.n_core, capP, dqk_by_member,
                             dqk_by_member ? w.dqk_live : nullptr, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
       PFO_MARK("bwd.L1.segsum", s);
       // the weight gradients over the table rows go to the side stream too (beside d h0 / the GRU backward on this one)
@@ -1180,7 +1184,9 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       tb[0].c_accumulate = 0; tb[0].bias_accumulate = 0;
       set_tn(tb[1], w.Dq + HCp, WQ, tab0, D, nullptr, D, D, g.w1 + E, E + D, g.b1);        // dW1[:, E:], db1
       // (the layer's chain-back on the side stream needs dWqk / gqk: this launch stays there also while profiling)
+      PFO_MARK("@side1.tn_b.begin", ss);
       RUN(pfo_gemm_tn_group_launch(tb, 2, capP, w.n_core, w.slabs2, w.slab_floats, ss));
+      PFO_MARK("@side1.tn_b.end", ss);
       if (c->use_memory) {
         // d h0_tab (query side) = Dq [Wqk ; W1[:, E:]]; the GRU backward adds it to the key-side rows the attention scattered
         PfoGemm q = g_nn(w.Dq, WQ, lw.Wqk, D, w.dx_tab, D, capP, D, HCp);
@@ -1356,11 +1362,16 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
         sb = ss;
         HIPOK(hipStreamWaitEvent(sa, sd.tn_a_done, 0), "event wait failed");
       }
+      if (l == 1) PFO_MARK("@side2.L1.chainA.begin", sa);
       RUN(pfo_gemm_multi_launch(ca, 3, sa));
       RUN(pfo_rank1_multi_launch(ra, H + 1, sa));
       RUN(pfo_gemm_multi_launch(c2, 3, sa));
+      if (l == 1) PFO_MARK("@side2.L1.chainA.end", sa);
+      else PFO_MARK("@side2.L2.chainA.end", sa);
       RUN(pfo_gemm_multi_launch(cb, 3, sb));
       RUN(pfo_rank1_multi_launch(rb, H, sb));
+      if (l == 1) PFO_MARK("@side1.L1.chainB.end", sb);
+      else PFO_MARK("@side2.L2.chainB.end", sb);
       if (l == L && L >= 2) {
         // The top layer's folded query-bias backward runs here, on the stream of its chain, with its time-bias term parked in
         // tb_part (the final launch adds it): from this point every gradient of the top layer's parameter block
@@ -1429,6 +1440,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     RUN(pfo_cq_backward_launch(gq, wq, nl, P.tb, D, dbq, dwq, G.tb, nullptr, L >= 2 ? w.tb_part : nullptr, w.dtime,
                                pfo_attn_bwd_max_parts(), G.tw, ss));                  // cq = Wq[:, D:] cos(b) + bq
   }
+  PFO_MARK("@side1.cq.end", ss);
   if (b->defer_join && chained) {
     // the end of the backward stays on the side stream (pfo_tgn_batch.defer_join): it waits for the caller's stream's last
     // launch instead of the other way round - the caller's stream is free for the next batch's neighbour sampling
@@ -1449,7 +1461,9 @@ extern "C" int pfo_tgn_adam_side(float* param, const float* grad, float* exp_avg
   Side& sd = side();
   PFO_REQUIRE(sd.ok, "could not create the side stream");
   PFO_REQUIRE(sd.side_pending, "pfo_tgn_adam_side follows a backward that ran with pfo_tgn_batch.defer_join");
-  return pfo_adam_step_ranges(param, grad, exp_avg, exp_avg_sq, n_ranges, lo, hi, step, lr, beta1, beta2, eps, (void*)sd.s);
+  const int rc = pfo_adam_step_ranges(param, grad, exp_avg, exp_avg_sq, n_ranges, lo, hi, step, lr, beta1, beta2, eps, (void*)sd.s);
+  PFO_MARK("@side1.adam.end", sd.s);
+  return rc;
 }
 
 extern "C" int pfo_tgn_join(void* stream) {

@@ -402,3 +402,67 @@ def test_fused_backward_and_optimizer_step_on_the_side_stream_equals_the_serial_
     assert len(a) == len(b_)
     for x, y in zip(a, b_):
         assert torch.equal(x, y)
+
+
+# ---------------------------------------------------------------------------------------------
+# pfo_segment_sum (the per-node sum of the instances' gradient rows: embedding_module.py:93-98 under autograd)
+def _segment_sum_case(lens, W0, W1, by_pos, live_frac, with_seg_of, seed):
+    import numpy as np
+    from pfotgnrec_amd import _lib
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(seed)
+    lens = np.asarray(lens, np.int64)
+    S, M = len(lens), int(lens.sum())
+    N = M + 7                                                   # instances: more than the members (padding instances are in no segment)
+    mem = rng.permutation(N)[:M].astype(np.int32)
+    seg_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    live = (rng.rand(M) < live_frac).astype(np.uint8) if by_pos else None
+    src0 = rng.randn(M if by_pos else N, W0).astype(np.float32)
+    src1 = rng.randn(N, W1).astype(np.float32)
+    rows0 = (src0 * live[:, None]) if by_pos else src0[mem]
+    rows = np.concatenate([rows0, src1[mem]], 1).astype(np.float64)
+    ref = np.zeros((S, W0 + W1))
+    for s in range(S):
+        ref[s] = rows[seg_ptr[s]:seg_ptr[s + 1]].sum(0)
+    so = np.full((M // 16 + 2) * 16, -12345, np.int32)          # (the tail is never used: poison it)
+    so[:M] = np.repeat(np.arange(S), lens)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_src0, d_src1, d_ptr, d_mem, d_so = t(src0), t(src1), t(seg_ptr), t(mem), t(so)
+    d_live = t(live) if live is not None else None
+    cap = S + 3
+    out = torch.full((cap, W0 + W1), float("nan"), device=dev)
+    n_rows = torch.tensor([S], dtype=torch.int32, device=dev)
+    _lib.call("pfo_segment_sum", _lib.ptr(d_src0), W0, _lib.ptr(d_src1), W1, _lib.ptr(d_ptr), _lib.ptr(d_mem),
+              _lib.ptr(d_so) if with_seg_of else None, M, _lib.ptr(n_rows), cap, 1 if by_pos else 0,
+              _lib.ptr(d_live) if d_live is not None else None, _lib.ptr(out), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.isnan(got[S:]).all()                              # rows past *n_rows are not written
+    mag = np.abs(rows).max() * max(1, lens.max())
+    assert np.abs(got[:S] - ref).max() <= 4e-7 * mag, (np.abs(got[:S] - ref).max(), mag)
+    return got[:S]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_seg_of", [False, True])
+def test_segment_sum_ragged_empty_and_long_segments(with_seg_of):
+    import numpy as np
+    rng = np.random.RandomState(3)
+    # empty segments (first, middle, last), singletons, one segment longer than a member batch (64) and than a chunk (16)
+    lens = [0, 1, 3, 0, 0, 70, 1, 17, 16, 15, 2, 0] + list(rng.randint(0, 6, size=200)) + [130, 0]
+    a = _segment_sum_case(lens, 704, 172, True, 0.3, with_seg_of, 1)      # the step's shape: flagged rows stored by position
+    b = _segment_sum_case(lens, 704, 172, True, 0.3, with_seg_of, 1)
+    assert np.array_equal(a, b)                                           # the same sum on every run
+    _segment_sum_case(lens, 8, 4, False, 1.0, with_seg_of, 2)            # rows picked by member id, narrow rows
+    _segment_sum_case(lens, 1200, 100, True, 1.0, with_seg_of, 3)        # wider than one 256-column pass
+    _segment_sum_case([5], 704, 172, True, 1.0, with_seg_of, 4)
+    _segment_sum_case(lens, 7, 5, False, 1.0, with_seg_of, 5)            # unaligned widths: the scalar kernel
+
+
+@pytest.mark.gpu
+def test_segment_sum_member_cut_equals_segment_cut_bitwise():
+    import numpy as np
+    lens = list(np.random.RandomState(9).randint(0, 45, size=300))
+    a = _segment_sum_case(lens, 704, 172, True, 0.5, False, 7)
+    b = _segment_sum_case(lens, 704, 172, True, 0.5, True, 7)
+    assert np.array_equal(a, b)                                           # both add the rows of a segment in member order
