@@ -764,8 +764,13 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   if (hipStreamIsCapturing(s, &cap_early) != hipSuccess) cap_early = hipStreamCaptureStatusActive;
   const bool bind_events = cap_early == hipStreamCaptureStatusNone;      // events bound to a launch (common.hpp): not under capture
   PFO_MARK("fwd.begin", s);
-  HIPOK(hipEventRecord(sd.fork, s), "event record failed");
-  HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
+  // (with a deferred backward end in flight the side stream already waits for the caller's stream's last launch of that
+  //  backward, and everything this call gives it either reads parameters only or sits behind an event of this call: no fork)
+  static const int skip_fork = getenv("PFO_SKIP_FORK") ? atoi(getenv("PFO_SKIP_FORK")) : 1;      // A/B switch
+  if (!(skip_fork && sd.side_pending && bind_events)) {
+    HIPOK(hipEventRecord(sd.fork, s), "event record failed");
+    HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
+  }
   if (!b->prepared) RUN(prepare_sample(c, st, b, w, n, s));
   PFO_MARK("fwd.sampled", s);
   // a deferred backward end + optimizer step of the previous step may still be running on the side stream: the sampling above
