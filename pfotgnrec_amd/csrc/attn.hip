@@ -24,6 +24,7 @@ struct AttnDev {
   const int32_t* members; const int32_t* seg_ptr; const int32_t* n_rows; const int32_t* run_cnt;
   int det; double* dtime_slab;   // deterministic mode (attn.hpp)
   uint8_t* dqk_live;             // run-merged kernel: [members] 1 = dQK row m holds a sum, 0 = folded into a later row / nothing
+  int xcd_g;    // run-merged backward: G consecutive chunks of members per XCD turn (0 = chunks round-robin over the XCDs)
   int abl;      // timing-only ablation switch (PFO_ATTN_ABL): 1 = spread the atomic destinations (wrong results)
 };
 
@@ -538,7 +539,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
   const float* const edge_feat = a.edge_feat;
   const uint32_t nbr_ld = (uint32_t)a.nbr_ld;
 
-  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  // Workgroups go to the XCDs round-robin by their id.  Consecutive chunks hold members of the same table row or of
+  // neighbouring ones (the list is ordered by row): with xcd_g = G > 0 every XCD takes G consecutive chunks at a time (block b ->
+  // chunk (b / 8G) 8G + (b mod 8) G + (b mod 8G) / 8), so the shifted neighbour lists of one node's members, its query row and
+  // the rows its atomics land on stay in ONE L2 instead of being fetched by up to eight.
+  const int G8 = 8 * a.xcd_g;
+  const int n_walk = G8 > 0 ? (n_chunks + G8 - 1) / G8 * G8 : n_chunks;
+  for (int blk = blockIdx.x; blk < n_walk; blk += gridDim.x) {
+    int chunk = blk;
+    if (G8 > 0) {
+      const int grp = blk / G8, r = blk - grp * G8;
+      chunk = grp * G8 + (r & 7) * a.xcd_g + (r >> 3);
+      if (chunk >= n_chunks) continue;
+    }
     float dwc[NR], dbc[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) { dwc[r] = 0.f; dbc[r] = 0.f; }
@@ -858,6 +871,7 @@ static void to_dev(const PfoAttn& a, AttnDev& d) {
   d.scale = a.scale; d.dropout_p = a.dropout_p; d.seed = a.seed; d.offset = a.offset; d.offset_dev = a.offset_dev; d.keep_inject = a.keep_inject;
   static const int abl = getenv("PFO_ATTN_ABL") ? atoi(getenv("PFO_ATTN_ABL")) : 0;
   d.abl = abl;
+  d.xcd_g = 0;
   d.ctx = a.ctx; d.attw = a.attw; d.inv = a.inv;
   d.dctx = a.dctx; d.dQK = a.dQK; d.d_nbr = a.d_nbr; d.d_nbr_ld = a.d_nbr_ld; d.d_nbr_rep = a.d_nbr_rep; d.d_nbr_nrep = a.d_nbr_nrep > 0 ? a.d_nbr_nrep : 1;
   d.dtime_part = a.dtime_part;
@@ -981,7 +995,10 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
     // run-merged form: single-wavefront workgroups, one chunk of members each (the grid-stride loop only matters when the
     // grid is capped for an experiment)
     static const int rblocks = getenv("PFO_ATTN_RUNS_BLOCKS") ? atoi(getenv("PFO_ATTN_RUNS_BLOCKS")) : 0;
-    const int64_t all_chunks = pfo_ceil_div(a.N, RUN_CHUNK);
+    static const int xcd_g = getenv("PFO_ATTN_XCD_G") ? atoi(getenv("PFO_ATTN_XCD_G")) : 16;              // A/B switch (counter pass: FETCH 625 -> 487 MB per launch at 16, 512 at 4; the launch time does not move)
+    d.xcd_g = a.det ? 0 : std::max(0, xcd_g);                  // (deterministic mode: slab row = chunk = workgroup id)
+    int64_t all_chunks = pfo_ceil_div(a.N, RUN_CHUNK);
+    if (d.xcd_g > 0) all_chunks = pfo_align_up(all_chunks, 8 * d.xcd_g);
     const int rgrid = (int)((rblocks > 0 && !a.det) ? std::min<int64_t>(rblocks, all_chunks) : all_chunks);
     pfo_prof_begin(stream);
     const int NRv = (a.D + 63) / 64;

@@ -25,7 +25,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AS_FLOATS 4608   // max(128*34, 32*144)
 #define BS_FLOATS 5984   // max(176*34, 32*176)
 
+// XCD-aware tile order of a (row tiles x column tiles) launch flattened into a 1-D grid: workgroups go to the XCDs round-robin
+// by id, so id = (t / 8) * 8 * tiles_n + c * 8 + (t mod 8) puts every column tile c of row tile t on XCD t & 7 - the A rows
+// the column tiles share come from HBM once and from that XCD's L2 for the others.  false: no such tile (the last group).
+__device__ __forceinline__ bool xcd_tile(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int per = 8 * tiles_n, grp = id / per, r = id - grp * per;
+  tn = r >> 3;
+  tm = grp * 8 + (r & 7);
+  return tm < tiles_m;
+}
 struct GemmDev {
+  int xcd_tm, xcd_tn;              // > 0: 1-D grid in xcd_tile order (row tiles, column tiles); 0: (row tile, column tile) = blockIdx.(x, y)
   const float* A[2]; int64_t lda[2]; const int32_t* a_idx[2];
   const float* B[2]; int64_t ldb[2]; const int32_t* b_idx;
   int K[2];
@@ -826,7 +836,9 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * (32 * WAVES), n0 = blockIdx.y * BN;
+  int tile_m = blockIdx.x, tile_n = blockIdx.y;
+  if (p.xcd_tn > 0 && !xcd_tile(blockIdx.x, p.xcd_tm, p.xcd_tn, tile_m, tile_n)) return;
+  const int m0 = tile_m * (32 * WAVES), n0 = tile_n * BN;
   int Mlim = p.M;
   if (p.m_dev) Mlim = min(Mlim, *p.m_dev);
   if (m0 >= Mlim || n0 >= p.N) return;
@@ -1012,6 +1024,7 @@ struct GruFusedDev {
   const float* msg_rows; int64_t ld_msg; int K0;
   const float* h_rows; int64_t ld_h; int K1;
   const void* img0; const void* img1; int img_rows;
+  int xcd_tm, xcd_tn;              // as in GemmDev
   const float* b_ih; const float* b_hh;
   const uint8_t* hm; const int32_t* touched; const float* node_feat;
   float* upd_mem; float* h0_tab; float* gates;
@@ -1034,7 +1047,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * GF_BN;
+  int tile_m = blockIdx.x, tile_n = blockIdx.y;
+  if (p.xcd_tn > 0 && !xcd_tile(blockIdx.x, p.xcd_tm, p.xcd_tn, tile_m, tile_n)) return;
+  const int m0 = tile_m * BM, n0 = tile_n * GF_BN;
   const int Mlim = min(p.M, p.m_dev ? *p.m_dev : p.M);
   if (m0 >= Mlim) return;
   const int wrow = 32 * wave;
@@ -1156,7 +1171,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int u0 = 32 * (int)blockIdx.y + 16 * q + 4 * g;
+      const int u0 = 32 * tile_n + 16 * q + 4 * g;
       if (u0 >= D) continue;                                    // D % 4 == 0: a lane's four units are all inside or all outside
       const float4 h4 = *reinterpret_cast<const float4*>(p.h_rows + srow * p.ld_h + u0);
       const float4 nf = *reinterpret_cast<const float4*>(p.node_feat + id * D + u0);
@@ -1198,7 +1213,11 @@ int pfo_gru_fused_launch(const PfoGruFused& f, hipStream_t stream) {
   d.upd_mem = f.upd_mem; d.h0_tab = f.h0_tab; d.gates = f.gates; d.D = f.D; d.M = f.cap_rows; d.m_dev = f.n_rows;
   d.gather = f.gather;
   pfo_prof_begin(stream);
-  const dim3 grid((unsigned)pfo_ceil_div(f.cap_rows, BM), (unsigned)pfo_ceil_div(f.D, 32), 1);
+  static const int xcd = getenv("PFO_GEMM_XCD") ? atoi(getenv("PFO_GEMM_XCD")) : 1;                        // A/B switch
+  const int tmr = (int)pfo_ceil_div(f.cap_rows, BM), tnc = (int)pfo_ceil_div(f.D, 32);
+  dim3 grid((unsigned)tmr, (unsigned)tnc, 1);
+  d.xcd_tm = d.xcd_tn = 0;
+  if (xcd && tnc > 1) { d.xcd_tm = tmr; d.xcd_tn = tnc; grid = dim3((unsigned)(pfo_ceil_div(tmr, 8) * 8 * tnc), 1, 1); }
   if (pfo_bx_fmt()) PFO_KLAUNCH(gru_fused_kernel<1>, grid, dim3(GEMM_THREADS), 0, stream, d);
   else PFO_KLAUNCH(gru_fused_kernel<0>, grid, dim3(GEMM_THREADS), 0, stream, d);
   PFO_LAUNCH_CHECK();
@@ -2105,6 +2124,7 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
 
 
 static void to_dev(const PfoGemm& g, GemmDev& d) {
+  d.xcd_tm = d.xcd_tn = 0;
   for (int s = 0; s < 2; ++s) {
     d.A[s] = g.A[s]; d.lda[s] = g.lda[s]; d.a_idx[s] = g.a_idx[s];
     d.B[s] = g.B[s]; d.ldb[s] = g.ldb[s]; d.K[s] = g.K[s];
@@ -2259,8 +2279,12 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
       static const int areg = getenv("PFO_GEMM_AREG") ? atoi(getenv("PFO_GEMM_AREG")) : PFO_DEFAULT_AREG;    // A/B switch
       if (areg && g.batch == 1)
       {
-        if (pfo_bx_fmt()) PFO_KLAUNCH(gemm_bx_areg_kernel<1>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
-        else PFO_KLAUNCH(gemm_bx_areg_kernel<0>, dim3((unsigned)pfo_ceil_div(g.M, BM), tn, 1), dim3(GEMM_THREADS), 0, stream, d);
+        static const int xcd = getenv("PFO_GEMM_XCD") ? atoi(getenv("PFO_GEMM_XCD")) : 1;                  // A/B switch
+        const int tmr = (int)pfo_ceil_div(g.M, BM);
+        dim3 grid((unsigned)tmr, tn, 1);
+        if (xcd && tn > 1) { d.xcd_tm = tmr; d.xcd_tn = (int)tn; grid = dim3((unsigned)(pfo_ceil_div(tmr, 8) * 8 * tn), 1, 1); }
+        if (pfo_bx_fmt()) PFO_KLAUNCH(gemm_bx_areg_kernel<1>, grid, dim3(GEMM_THREADS), 0, stream, d);
+        else PFO_KLAUNCH(gemm_bx_areg_kernel<0>, grid, dim3(GEMM_THREADS), 0, stream, d);
       }
       else {
         PFO_REQUIRE(!pfo_bx_fmt(), "the fp16x2 images are read by the row-major-A kernels only (batch 1)");
