@@ -34,6 +34,13 @@ import os
 import sys
 import time
 
+# The step overlaps three internal side streams with the caller's stream.  The HIP runtime multiplexes ALL streams of a
+# process onto GPU_MAX_HW_QUEUES hardware queues (default 4): as soon as a process group exists (RCCL and c10d bring their own
+# streams) the library's side streams share a hardware queue with the caller's stream, and "beside" silently becomes "behind"
+# (measured on the rank path at world 1: 1.65 ms per step against 1.40 with eight queues; the single-GPU path, with three
+# streams in all, is unaffected).  Read by the runtime when it initialises - i.e. before anything touches the GPU.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -66,9 +73,13 @@ def parse():
                     help="replay the step from a captured HIP graph (one launch per step instead of ~85).  auto (one GPU, per-GPU "
                          "batch <= 256): capture, time ten steps either way during set-up and keep the faster form - the graph "
                          "wins where the host's launch rate bounds the step (C1), the eager queue where the GPU does")
-    ap.add_argument("--allreduce", default="single", choices=["single", "buckets"],
-                    help="N > 1: one all-reduce of the flat gradient after the backward, or two pieces with the top layer's "
-                         "block reduced on a side stream while the lower layers are still being differentiated")
+    ap.add_argument("--allreduce", default="fused", choices=["single", "buckets", "fused"],
+                    help="N > 1: 'fused' (default): backward + all-reduce + Adam as one call whose end - the collective included - "
+                         "stays on the library's side stream while the caller's stream starts the next batch "
+                         "(bpr_step(..., optimizer=, collective=)): the exchange of step n runs beside step n+1's sampling; "
+                         "'single': one all-reduce of the flat gradient on the caller's stream after the backward; 'buckets': two "
+                         "pieces, the top layer's block reduced on a communication stream while the lower layers are still being "
+                         "differentiated.  Every N > 1 line carries 1 s runs of the other two forms (secondary.allreduce_*)")
     ap.add_argument("--emulate-ranks", default=None,
                     help="ONE process, no collective: time rank 0's share of the step (its shard's roots + the global state "
                          "update) for each listed world size, e.g. 1,2,4,8 - the compute-side ceiling of the scaling curve, "
@@ -401,8 +412,21 @@ class Workload:
         # loss + loss.backward() (main.py:337,388) as two native calls: the loss kernel hands its gradient rows straight to
         # the TGN backward (P.bpr_loss(...).backward() is the autograd spelling of the same thing, tests/test_gpu_round2.py)
         _lm.mark("step.embedded")
-        fused_opt = self.overlap_tail and not (self.dist_on and (self.world > 1 or self.force_dist)) and not self.prefetch
-        loss = P.bpr_step(tgn, emb, b, n_neg, pos_block=pos_block, optimizer=self.opt if fused_opt else None)
+        ranks = self.dist_on and (self.world > 1 or self.force_dist)
+        fused_coll = ranks and self.allreduce_mode == "fused" and self.overlap_tail and not self.prefetch
+        fused_opt = self.overlap_tail and (not ranks or fused_coll) and not self.prefetch
+        coll = None
+        if fused_coll:
+            def coll():                                           # runs on the library's side stream (bpr_step): bracketed THERE
+                ev = None
+                if self.time_collective:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                allreduce_flat_grad(tgn.flat_grad, self.world, force=True)
+                if ev is not None:
+                    ev[1].record()
+                    self.coll_events.append(ev)
+        loss = P.bpr_step(tgn, emb, b, n_neg, pos_block=pos_block, optimizer=self.opt if fused_opt else None, collective=coll)
         _lm.mark("step.backward_done")
         if self.prefetch in (2, 3) and self.mvs is None:
             # the next batch's negatives, frontier, compaction and packed rows: queued behind the backward's "attention backward
@@ -416,7 +440,7 @@ class Workload:
                 if tgn.prefetch(self.src_all[s2], self.dst_all[s2], [neg2], [n_neg], self.ts_all[s2], self.eidx_all[s2],
                                 cfg.n_neighbors):
                     self._next = (i + 1, neg2)
-        if self.dist_on and (self.world > 1 or self.force_dist):     # (set_world(0, 1): rank 0 alone, no collective)
+        if ranks and not fused_coll:                                # (set_world(0, 1): rank 0 alone, no collective)
             ev = None
             if self.time_collective:                          # sampled steps: the collective bracketed by events on the caller's stream
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -704,8 +728,12 @@ def main():
     coll_ms, coll_n = wl.collective_ms()
     if coll_ms is not None:
         out["config"]["collective_ms_per_step"] = round(coll_ms, 4)
-        out["config"]["compute_ms_per_step"] = round(1e3 * elapsed / n_timed - coll_ms, 4)
+        # ('fused': the collective runs on the library's side stream beside the next batch's sampling - its time is not part
+        #  of the caller's stream's step; the other forms hold the caller's stream for it)
+        out["config"]["collective_on_callers_stream"] = wl.allreduce_mode != "fused"
+        out["config"]["compute_ms_per_step"] = round(1e3 * elapsed / n_timed - (coll_ms if wl.allreduce_mode != "fused" else 0.0), 4)
         out["config"]["collective_samples"] = coll_n
+    if world > 1 or wl.force_dist:
         out["config"]["allreduce"] = wl.allreduce_mode
         out["config"]["predicted_scaling_efficiency"] = {"weak_C2_512_per_gpu": {"2": 0.90, "4": 0.87, "8": 0.86},
                                                          "strong_C4_4096_global": {"2": 0.89, "4": 0.76, "8": 0.54},
@@ -718,14 +746,16 @@ def main():
         try:
             # (0) the same workload with the OTHER all-reduce form (one piece after the backward / two pieces, the top layer's
             #     block on a communication stream beside the backward): single vs. bucketed decided by data
-            other = "buckets" if wl.allreduce_mode == "single" else "single"
-            if cfg_layers(cfg_name) >= 2:
+            for other in [m for m in ("single", "buckets", "fused") if m != wl.allreduce_mode]:
+                if other == "buckets" and cfg_layers(cfg_name) < 2:
+                    continue
                 wl.allreduce_mode, wl.tgn.dp_bucketed = other, other == "buckets"
                 el, nb, _, _, _ = wl.timed(args.steps, 5, min(args.min_seconds, 1.0), 0, first_step=50000)
                 cms, cn = wl.collective_ms()
                 sec["allreduce_" + other] = {"n_gpus": world, "value": round(nb * B / el, 1), "ms_per_step": round(1e3 * el / nb, 4),
                                             "collective_ms_per_step": None if cms is None else round(cms, 4),
                                             "workload": "the main line's workload, all-reduce form '%s'" % other}
+                wl.tgn.join()
                 wl.allreduce_mode, wl.tgn.dp_bucketed = args.allreduce, args.allreduce == "buckets"
             want_other_case = world > 1 and (args.secondary or world == 8)
             # (1) the same workload on ONE of these GPUs (rank 0 alone, the others wait): the denominator of the strong-scaling

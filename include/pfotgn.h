@@ -411,6 +411,11 @@ int pfo_tgn_debug_views(const pfo_tgn_config* cfg, void* workspace, pfo_tgn_debu
 int pfo_tgn_adam_side(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
                       const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1, float beta2, float eps);
 int pfo_tgn_join(void* stream);
+/* The library's first side stream (hipStream_t; null on failure): the stream a deferred backward end is left on and
+ * pfo_tgn_adam_side runs on.  A data-parallel caller queues its gradient all-reduce THERE, between pfo_tgn_backward
+ * (defer_join) and pfo_tgn_adam_side - ordered behind the backward's last launch, in front of the optimizer's kernel, and off the
+ * caller's stream, which goes on to the next batch's sampling.  One stream per device, valid for the life of the process. */
+void* pfo_tgn_side_stream(void);
 int64_t pfo_tgn_pcache_bytes(const pfo_tgn_config* cfg);
 int pfo_tgn_refresh(const pfo_tgn_config* cfg, const pfo_tgn_state* state, void* stream);
 

@@ -6,6 +6,15 @@ Public surface mirrors the reference's: ``TGN`` (model/tgn.py), ``NeighborFinder
 """
 __version__ = "0.1.0"
 
+import os as _os
+
+# The library overlaps three internal side streams with the caller's stream; the HIP runtime maps all streams of a process onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4) - with a process group (RCCL + c10d streams) or other extra streams around, a
+# side stream ends up behind the caller's stream in ONE hardware queue and the overlap is lost (bench.py, DESIGN 6: +18 % per
+# step on the rank path).  The runtime reads the variable when it initialises: import this package (or set the variable)
+# before the first use of the GPU.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .data import Data, compute_time_statistics, get_data  # noqa: F401
 from .neighbor_finder import NeighborFinder, get_neighbor_finder  # noqa: F401
 from .rand_edge_sampler import RandEdgeSampler, DeviceNegativeSampler  # noqa: F401

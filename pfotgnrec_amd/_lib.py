@@ -94,6 +94,7 @@ PROTOTYPES = {
     "pfo_tgn_workspace_bytes": (C.c_int64, [C.POINTER(TgnConfig)]),
     "pfo_tgn_adam_side": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int32), C.c_float, C.c_float, C.c_float, C.c_float]),
+    "pfo_tgn_side_stream": (_VP, []),
     "pfo_tgn_join": (C.c_int, [_VP]),
     "pfo_tgn_pcache_bytes": (C.c_int64, [C.POINTER(TgnConfig)]),
     "pfo_tgn_refresh": (C.c_int, [C.POINTER(TgnConfig), C.POINTER(TgnState), _VP]),

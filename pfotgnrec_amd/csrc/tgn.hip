@@ -1471,6 +1471,12 @@ extern "C" int pfo_tgn_adam_side(float* param, const float* grad, float* exp_avg
   return rc;
 }
 
+extern "C" void* pfo_tgn_side_stream(void) {
+  Side& sd = side();
+  if (!sd.ok) { pfo_set_error("pfo_tgn_side_stream: could not create the side stream"); return nullptr; }
+  return (void*)sd.s;
+}
+
 extern "C" int pfo_tgn_join(void* stream) {
   Side& sd = side();
   PFO_REQUIRE(sd.ok, "could not create the side stream");

@@ -53,7 +53,7 @@ def bpr_loss(emb, batch, n_neg, pos_block=1, grad_scale=1.0):
     return _BprFn.apply(emb, batch, pos_off, neg_off, n_neg, grad_scale)
 
 
-def bpr_step(tgn, emb, batch, n_neg, pos_block=1, grad_scale=None, optimizer=None):
+def bpr_step(tgn, emb, batch, n_neg, pos_block=1, grad_scale=None, optimizer=None, collective=None):
     """``loss = bpr_loss(...); loss.backward()`` (main.py:321-337 + 388) as two native calls and no torch kernel: the loss
     kernel writes the already scaled gradient rows and the TGN backward is called on them directly, skipping autograd's
     seed fill and ``d_emb * g`` multiply (three ~6 us launches on the critical path of a 1.5 ms step); the batch mean of the
@@ -67,11 +67,20 @@ def bpr_step(tgn, emb, batch, n_neg, pos_block=1, grad_scale=None, optimizer=Non
     next batch's candidate draw and neighbour sampling, and the next forward joins where it first needs parameters.
     Gradients and parameters are IN FLIGHT on that stream afterwards: read them only after ``tgn.join()`` (``state_dict()``
     joins by itself).  ``optimizer.zero_grad(set_to_none=True)`` afterwards is fine (host side only).
+    ``collective`` (a data-parallel rank, with ``optimizer``): a callable that all-reduces ``tgn.flat_grad`` in place
+    (``lambda: allreduce_flat_grad(tgn.flat_grad, world)``).  It is issued on the library's side stream between the end of
+    the backward and the optimizer's kernel there: the gradient exchange of step n then runs beside step n+1's candidate
+    draw and neighbour sampling instead of holding the caller's stream.  Every rank issues it exactly once per call - also a
+    rank whose shard is empty (no native backward: the serial order on the caller's stream, same collective).
     Returns the detached loss."""
     call = getattr(emb.grad_fn, "call", None) if emb.grad_fn is not None else None
     if batch == 0 or call is None or call.ws is None or emb.shape[0] != call.R:
         loss = bpr_loss(emb, batch, n_neg, pos_block, tgn.dp_grad_scale if grad_scale is None else grad_scale)
         loss.backward()
+        if optimizer is not None and getattr(optimizer, "tgn", None) is tgn:
+            if collective is not None:
+                collective()
+            optimizer.step()
         return loss.detach()
     scale = tgn.dp_grad_scale if grad_scale is None else grad_scale
     e = emb.detach().contiguous()
@@ -81,10 +90,17 @@ def bpr_step(tgn, emb, batch, n_neg, pos_block=1, grad_scale=None, optimizer=Non
     loss = torch.empty(1, dtype=torch.float32, device=e.device)
     _lib.call("pfo_bpr_loss_parts", e.data_ptr(), batch, D, pos_block * batch, (pos_block + 1) * batch, n_neg, R, float(scale),
               parts.data_ptr(), d_emb.data_ptr(), _lib.stream_ptr())
-    fused_opt = (optimizer is not None and getattr(optimizer, "tgn", None) is tgn and tgn.dp_world == 1
+    ours = optimizer is not None and getattr(optimizer, "tgn", None) is tgn
+    fused_opt = (ours and (tgn.dp_world == 1 or collective is not None)
                  and not torch.cuda.is_current_stream_capturing() and not _lib.prof_is_on())
     tgn._native_backward(call, d_emb, mean=(parts, loss), defer_join=fused_opt)     # the batch mean of the losses: on the backward's side stream
     call.release()
+    if collective is not None and ours:
+        if fused_opt:
+            with torch.cuda.stream(tgn.side_stream()):      # behind the backward's last side-stream launch, in front of Adam there
+                collective()
+        else:
+            collective()
     if optimizer is not None:
         optimizer.step(side=fused_opt)
     return loss[0]

@@ -132,6 +132,7 @@ class TGN(nn.Module):
         self._adj_cache = None
         self.dp_grad_scale = 1.0
         self._ws_pool = []        # free workspaces: [(caps, tensor)]
+        self._side_stream = None
         self._prefetched, self._pre_stream, self._pre_main = None, None, None
         self.fuse_state_update = os.environ.get("PFO_FUSE_STATE", "1") != "0"      # training calls: persist + message store inside the native forward, on its side stream
         self._ws_caps = (0, 0, 0)
@@ -259,6 +260,7 @@ class TGN(nn.Module):
             raise TypeError("the native path is fp32 only (1e-4 parity bar)")
         self._flat = new_flat.contiguous()
         self._flat_grad = None
+        self._side_stream = None
         for p, off, n, shape in self._views:
             p.data = self._flat[off:off + n].view(shape)
             p.grad = None
@@ -491,6 +493,16 @@ class TGN(nn.Module):
                 continue
             p.grad = self._flat_grad[off:off + n].view(shape)
         return deferred
+
+    def side_stream(self):
+        """The library's first side stream as a torch stream (``pfo_tgn_side_stream``): work a caller must order between a
+        deferred backward end and the optimizer step there - a data-parallel rank's gradient all-reduce (``bpr_step``)."""
+        if self._side_stream is None:
+            ptr = _lib.load().pfo_tgn_side_stream()
+            if not ptr:
+                raise _lib.PfoError("pfo_tgn_side_stream: %s" % _lib.load().pfo_last_error().decode())
+            self._side_stream = torch.cuda.ExternalStream(ptr, device=self.device)
+        return self._side_stream
 
     def join(self):
         """Makes the current stream wait for a backward end / optimizer step that ``bpr_step(..., optimizer=...)`` left on the

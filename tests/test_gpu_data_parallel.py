@@ -14,7 +14,7 @@ from conftest import REPO, has_gpu
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")]
 
 
-def _run(rank, world, port, out_dir, n_steps, B=48, buckets=False, det=False):
+def _run(rank, world, port, out_dir, n_steps, B=48, buckets=False, det=False, fused=False):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import torch.distributed as dist
@@ -44,6 +44,16 @@ def _run(rank, world, port, out_dir, n_steps, B=48, buckets=False, det=False):
                                   t(d.timestamps[s:s + B], np.float64), t(d.edge_idxs[s:s + B], np.int32), 6)
         assert b == (rank + 1) * B // world - rank * B // world         # balanced shards; empty when B < world
         assert emb.shape[0] == 5 * b
+        if fused:
+            # backward + all-reduce + Adam as ONE call: the end of the backward, the collective and the optimizer's kernel stay
+            # on the library's side stream (functional.bpr_step); an empty shard takes the serial order inside the same call
+            P.bpr_step(tgn, emb, b, 3, optimizer=opt, collective=lambda: allreduce_flat_grad(tgn.flat_grad, world))
+            if step == 0:
+                tgn.join()
+                grad0 = tgn.flat_grad.cpu().numpy().copy()
+                mem0 = tgn.memory.memory.cpu().numpy().copy()
+            opt.zero_grad(set_to_none=True)
+            continue
         loss = P.bpr_loss(emb, b, 3, grad_scale=tgn.dp_grad_scale)      # local mean * (b / B): shard sums = global mean
         loss.backward()
         if buckets:
@@ -56,8 +66,9 @@ def _run(rank, world, port, out_dir, n_steps, B=48, buckets=False, det=False):
             mem0 = tgn.memory.memory.cpu().numpy().copy()
         opt.step()
         opt.zero_grad(set_to_none=True)
+    tgn.join()
     torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, "w%d_r%d_B%d%s.npz" % (world, rank, B, "_buckets" if buckets else "")), params=tgn.flat_parameters.cpu().numpy(), grad0=grad0, mem0=mem0,
+    np.savez(os.path.join(out_dir, "w%d_r%d_B%d%s.npz" % (world, rank, B, "_buckets" if buckets else ("_fused" if fused else ""))), params=tgn.flat_parameters.cpu().numpy(), grad0=grad0, mem0=mem0,
              memory=tgn.memory.memory.cpu().numpy(), last_update=tgn.memory.last_update.cpu().numpy(),
              msg=tgn.memory.msg_table.cpu().numpy(), msg_t=tgn.memory.msg_time.cpu().numpy(), has=tgn.memory.has_msg.cpu().numpy())
     if world > 1:
@@ -65,9 +76,9 @@ def _run(rank, world, port, out_dir, n_steps, B=48, buckets=False, det=False):
         dist.destroy_process_group()
 
 
-def _spawn(world, port, tmp_path, n_steps, B, buckets=False, det=False):
+def _spawn(world, port, tmp_path, n_steps, B, buckets=False, det=False, fused=False):
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_run, args=(r, world, port, str(tmp_path), n_steps, B, buckets, det)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, str(tmp_path), n_steps, B, buckets, det, fused)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -147,3 +158,19 @@ def test_bucketed_allreduce_with_an_empty_shard(tmp_path):
     for k in a.files:
         assert np.array_equal(a[k], b[k]), "replicas diverged: " + k
     assert np.abs(a["grad0"]).max() > 0
+
+
+@pytest.mark.parametrize("B", [48, 1])
+def test_fused_step_with_the_collective_on_the_side_stream_equals_the_serial_order(tmp_path, B):
+    """bpr_step(..., optimizer=, collective=) on a data-parallel rank: the end of the backward, the gradient all-reduce and the
+    Adam kernel stay on the library's side stream while the caller's stream goes on to the next batch.  Same arithmetic in the
+    same order per element as backward -> all-reduce -> step: gradients of step 1, parameters, memory and message tables are
+    BIT-identical (two ranks, gloo, one GPU, deterministic backward); B = 1: rank 1's shard is empty - it joins the same single
+    collective through the serial path inside the call."""
+    port = 29730 + (os.getpid() % 40) + 3 * B
+    _spawn(2, port, tmp_path, 3, B, det=True)
+    _spawn(2, port + 1, tmp_path, 3, B, det=True, fused=True)
+    for r in (0, 1):
+        one, two = np.load(tmp_path / ("w2_r%d_B%d.npz" % (r, B))), np.load(tmp_path / ("w2_r%d_B%d_fused.npz" % (r, B)))
+        for k in one.files:
+            assert np.array_equal(one[k], two[k]), (r, k)
