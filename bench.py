@@ -416,6 +416,8 @@ class Workload:
         fused_coll = ranks and self.allreduce_mode == "fused" and self.overlap_tail and not self.prefetch
         fused_opt = self.overlap_tail and (not ranks or fused_coll) and not self.prefetch
         coll = None
+        if self.emulate and self.world > 1 and fused_opt and self.allreduce_mode == "fused":
+            coll = lambda: None                                   # an emulated rank keeps the ranks' step schedule: the collective is a stub
         if fused_coll:
             def coll():                                           # runs on the library's side stream (bpr_step): bracketed THERE
                 ev = None
@@ -637,6 +639,15 @@ def emulate_ranks(args, dev):
                          "interactions_per_s_if_all_ranks_like_this": round(wl.B / (ms * 1e-3), 1),
                          "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4)})
             desc = wl.describe()
+            if args.marks > 0:                                # milestones of this emulated rank (stderr)
+                from pfotgnrec_amd import _lib
+                torch.cuda.synchronize()
+                _lib.marks_enable(True)
+                for k in range(args.marks):
+                    wl.step(900005 + k)
+                torch.cuda.synchronize()
+                _lib.marks_enable(False)
+                sys.stderr.write("milestones (emulated rank 0 of %d, mean over %d steps):\n%s" % (n, args.marks, _lib.marks_dump()))
             del wl
             torch.cuda.empty_cache()
         for r in rows:
