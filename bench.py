@@ -39,7 +39,7 @@ import time
 # streams) the library's side streams share a hardware queue with the caller's stream, and "beside" silently becomes "behind"
 # (measured on the rank path at world 1: 1.65 ms per step against 1.40 with eight queues; the single-GPU path, with three
 # streams in all, is unaffected).  Read by the runtime when it initialises - i.e. before anything touches the GPU.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 

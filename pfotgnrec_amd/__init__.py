@@ -13,7 +13,7 @@ import os as _os
 # side stream ends up behind the caller's stream in ONE hardware queue and the overlap is lost (bench.py, DESIGN 6: +18 % per
 # step on the rank path).  The runtime reads the variable when it initialises: import this package (or set the variable)
 # before the first use of the GPU.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from .data import Data, compute_time_statistics, get_data  # noqa: F401
 from .neighbor_finder import NeighborFinder, get_neighbor_finder  # noqa: F401

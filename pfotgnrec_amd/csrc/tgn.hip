@@ -340,8 +340,16 @@ Side& side() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PFO_MAX_DEVICES) dev = 0;
   Side& sd = sds[dev];
   if (!sd.ok) {
-    bool good = hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) == hipSuccess;
-    good = good && hipStreamCreateWithFlags(&sd.s2, hipStreamNonBlocking) == hipSuccess;
+    // The side streams live in the HIGH and the LOW priority class: the runtime multiplexes all streams of a process onto
+    // GPU_MAX_HW_QUEUES hardware queues (default 4) PER PRIORITY CLASS, and once a process holds more streams than that (a
+    // process group: RCCL, c10d) a normal-priority side stream shares a hardware queue with the caller's stream - every
+    // "beside" of this file silently becomes "behind" (rank path at world 1 on RCCL: 1.65 ms per step against 1.39).  In
+    // classes of their own they cannot.  (Dispatch priority itself changes nothing measurable: round 3.)  PFO_SIDE_PRIO=0: A/B.
+    static const int prio = getenv("PFO_SIDE_PRIO") ? atoi(getenv("PFO_SIDE_PRIO")) : 1;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = least (numerically largest), hi = greatest
+    bool good = (prio ? hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking)) == hipSuccess;
+    good = good && (prio ? hipStreamCreateWithPriority(&sd.s2, hipStreamNonBlocking, lo) : hipStreamCreateWithFlags(&sd.s2, hipStreamNonBlocking)) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.tn_a_done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.done2, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess;

@@ -1,5 +1,5 @@
 import os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # as bench.py / pfotgnrec_amd do (side streams need hardware queues of their own)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # as bench.py / pfotgnrec_amd do (side streams need hardware queues of their own)
 import sys
 
 import numpy as np
