@@ -73,13 +73,15 @@ def parse():
                     help="replay the step from a captured HIP graph (one launch per step instead of ~85).  auto (one GPU, per-GPU "
                          "batch <= 256): capture, time ten steps either way during set-up and keep the faster form - the graph "
                          "wins where the host's launch rate bounds the step (C1), the eager queue where the GPU does")
-    ap.add_argument("--allreduce", default="fused", choices=["single", "buckets", "fused"],
+    ap.add_argument("--allreduce", default="fused", choices=["single", "buckets", "fused", "fused_buckets"],
                     help="N > 1: 'fused' (default): backward + all-reduce + Adam as one call whose end - the collective included - "
                          "stays on the library's side stream while the caller's stream starts the next batch "
                          "(bpr_step(..., optimizer=, collective=)): the exchange of step n runs beside step n+1's sampling; "
                          "'single': one all-reduce of the flat gradient on the caller's stream after the backward; 'buckets': two "
                          "pieces, the top layer's block reduced on a communication stream while the lower layers are still being "
-                         "differentiated.  Every N > 1 line carries 1 s runs of the other two forms (secondary.allreduce_*)")
+                         "differentiated; 'fused_buckets': the fused call with the two-piece exchange (the top layer's block "
+                         "is reduced beside the rest of the backward, only the lower block waits for its end).  Every N > 1 line "
+                         "carries 1 s runs of the other forms (secondary.allreduce_*)")
     ap.add_argument("--emulate-ranks", default=None,
                     help="ONE process, no collective: time rank 0's share of the step (its shard's roots + the global state "
                          "update) for each listed world size, e.g. 1,2,4,8 - the compute-side ceiling of the scaling curve, "
@@ -302,7 +304,7 @@ class Workload:
                                message_function="identity", n_neighbors=cfg.n_neighbors)
         tgn.set_data_parallel(rank, world)
         tgn.deterministic = bool(args.deterministic)
-        tgn.dp_bucketed = (world > 1 or os.environ.get("PFO_DIST_FORCE") == "1") and args.allreduce == "buckets"
+        tgn.dp_bucketed = (world > 1 or os.environ.get("PFO_DIST_FORCE") == "1") and args.allreduce in ("buckets", "fused_buckets")
         self.emulate = emulate                                # --emulate-ranks: a rank's compute without the collective
         import torch.distributed as _dist
         self.dist_on = (not emulate) and _dist.is_available() and _dist.is_initialized()   # world 1 with PFO_DIST_FORCE=1: the rank path on one GPU
@@ -413,10 +415,10 @@ class Workload:
         # the TGN backward (P.bpr_loss(...).backward() is the autograd spelling of the same thing, tests/test_gpu_round2.py)
         _lm.mark("step.embedded")
         ranks = self.dist_on and (self.world > 1 or self.force_dist)
-        fused_coll = ranks and self.allreduce_mode == "fused" and self.overlap_tail and not self.prefetch
+        fused_coll = ranks and self.allreduce_mode in ("fused", "fused_buckets") and self.overlap_tail and not self.prefetch
         fused_opt = self.overlap_tail and (not ranks or fused_coll) and not self.prefetch
         coll = None
-        if self.emulate and self.world > 1 and fused_opt and self.allreduce_mode == "fused":
+        if self.emulate and self.world > 1 and fused_opt and self.allreduce_mode in ("fused", "fused_buckets"):
             coll = lambda: None                                   # an emulated rank keeps the ranks' step schedule: the collective is a stub
         if fused_coll:
             def coll():                                           # runs on the library's side stream (bpr_step): bracketed THERE
@@ -424,7 +426,10 @@ class Workload:
                 if self.time_collective:
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record()
-                allreduce_flat_grad(tgn.flat_grad, self.world, force=True)
+                if self.allreduce_mode == "fused_buckets":
+                    allreduce_flat_grad_buckets(tgn, self.world, force=True)    # (the caller's stream of that call = the side stream)
+                else:
+                    allreduce_flat_grad(tgn.flat_grad, self.world, force=True)
                 if ev is not None:
                     ev[1].record()
                     self.coll_events.append(ev)
@@ -741,8 +746,8 @@ def main():
         out["config"]["collective_ms_per_step"] = round(coll_ms, 4)
         # ('fused': the collective runs on the library's side stream beside the next batch's sampling - its time is not part
         #  of the caller's stream's step; the other forms hold the caller's stream for it)
-        out["config"]["collective_on_callers_stream"] = wl.allreduce_mode != "fused"
-        out["config"]["compute_ms_per_step"] = round(1e3 * elapsed / n_timed - (coll_ms if wl.allreduce_mode != "fused" else 0.0), 4)
+        out["config"]["collective_on_callers_stream"] = not wl.allreduce_mode.startswith("fused")
+        out["config"]["compute_ms_per_step"] = round(1e3 * elapsed / n_timed - (0.0 if wl.allreduce_mode.startswith("fused") else coll_ms), 4)
         out["config"]["collective_samples"] = coll_n
     if world > 1 or wl.force_dist:
         out["config"]["allreduce"] = wl.allreduce_mode
@@ -758,17 +763,17 @@ def main():
         try:
             # (0) the same workload with the OTHER all-reduce form (one piece after the backward / two pieces, the top layer's
             #     block on a communication stream beside the backward): single vs. bucketed decided by data
-            for other in [m for m in ("single", "buckets", "fused") if m != wl.allreduce_mode]:
-                if other == "buckets" and cfg_layers(cfg_name) < 2:
+            for other in [m for m in ("single", "buckets", "fused", "fused_buckets") if m != wl.allreduce_mode]:
+                if other.endswith("buckets") and cfg_layers(cfg_name) < 2:
                     continue
-                wl.allreduce_mode, wl.tgn.dp_bucketed = other, other == "buckets"
+                wl.allreduce_mode, wl.tgn.dp_bucketed = other, other.endswith("buckets")
                 el, nb, _, _, _ = wl.timed(args.steps, 5, min(args.min_seconds, 1.0), 0, first_step=50000)
                 cms, cn = wl.collective_ms()
                 sec["allreduce_" + other] = {"n_gpus": world, "value": round(nb * B / el, 1), "ms_per_step": round(1e3 * el / nb, 4),
                                             "collective_ms_per_step": None if cms is None else round(cms, 4),
                                             "workload": "the main line's workload, all-reduce form '%s'" % other}
                 wl.tgn.join()
-                wl.allreduce_mode, wl.tgn.dp_bucketed = args.allreduce, args.allreduce == "buckets"
+                wl.allreduce_mode, wl.tgn.dp_bucketed = args.allreduce, args.allreduce.endswith("buckets")
             want_other_case = world > 1 and (args.secondary or world == 8)
             # (1) the same workload on ONE of these GPUs (rank 0 alone, the others wait): the denominator of the strong-scaling
             #     figure.  (2) the other scaling case.

@@ -47,7 +47,8 @@ def _run(rank, world, port, out_dir, n_steps, B=48, buckets=False, det=False, fu
         if fused:
             # backward + all-reduce + Adam as ONE call: the end of the backward, the collective and the optimizer's kernel stay
             # on the library's side stream (functional.bpr_step); an empty shard takes the serial order inside the same call
-            P.bpr_step(tgn, emb, b, 3, optimizer=opt, collective=lambda: allreduce_flat_grad(tgn.flat_grad, world))
+            P.bpr_step(tgn, emb, b, 3, optimizer=opt,
+                       collective=(lambda: allreduce_flat_grad_buckets(tgn, world)) if buckets else (lambda: allreduce_flat_grad(tgn.flat_grad, world)))
             if step == 0:
                 tgn.join()
                 grad0 = tgn.flat_grad.cpu().numpy().copy()
@@ -68,7 +69,7 @@ def _run(rank, world, port, out_dir, n_steps, B=48, buckets=False, det=False, fu
         opt.zero_grad(set_to_none=True)
     tgn.join()
     torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, "w%d_r%d_B%d%s.npz" % (world, rank, B, "_buckets" if buckets else ("_fused" if fused else ""))), params=tgn.flat_parameters.cpu().numpy(), grad0=grad0, mem0=mem0,
+    np.savez(os.path.join(out_dir, "w%d_r%d_B%d%s.npz" % (world, rank, B, ("_buckets" if buckets else "") + ("_fused" if fused else ""))), params=tgn.flat_parameters.cpu().numpy(), grad0=grad0, mem0=mem0,
              memory=tgn.memory.memory.cpu().numpy(), last_update=tgn.memory.last_update.cpu().numpy(),
              msg=tgn.memory.msg_table.cpu().numpy(), msg_t=tgn.memory.msg_time.cpu().numpy(), has=tgn.memory.has_msg.cpu().numpy())
     if world > 1:
@@ -160,17 +161,18 @@ def test_bucketed_allreduce_with_an_empty_shard(tmp_path):
     assert np.abs(a["grad0"]).max() > 0
 
 
-@pytest.mark.parametrize("B", [48, 1])
-def test_fused_step_with_the_collective_on_the_side_stream_equals_the_serial_order(tmp_path, B):
+@pytest.mark.parametrize("B,buckets", [(48, False), (1, False), (48, True), (1, True)])
+def test_fused_step_with_the_collective_on_the_side_stream_equals_the_serial_order(tmp_path, B, buckets):
     """bpr_step(..., optimizer=, collective=) on a data-parallel rank: the end of the backward, the gradient all-reduce and the
     Adam kernel stay on the library's side stream while the caller's stream goes on to the next batch.  Same arithmetic in the
     same order per element as backward -> all-reduce -> step: gradients of step 1, parameters, memory and message tables are
     BIT-identical (two ranks, gloo, one GPU, deterministic backward); B = 1: rank 1's shard is empty - it joins the same single
     collective through the serial path inside the call."""
-    port = 29730 + (os.getpid() % 40) + 3 * B
+    port = 29730 + (os.getpid() % 40) + 3 * B + (11 if buckets else 0)
     _spawn(2, port, tmp_path, 3, B, det=True)
-    _spawn(2, port + 1, tmp_path, 3, B, det=True, fused=True)
+    _spawn(2, port + 1, tmp_path, 3, B, det=True, fused=True, buckets=buckets)        # (buckets: the two-piece exchange inside the fused call)
     for r in (0, 1):
-        one, two = np.load(tmp_path / ("w2_r%d_B%d.npz" % (r, B))), np.load(tmp_path / ("w2_r%d_B%d_fused.npz" % (r, B)))
+        one = np.load(tmp_path / ("w2_r%d_B%d.npz" % (r, B)))
+        two = np.load(tmp_path / ("w2_r%d_B%d%s_fused.npz" % (r, B, "_buckets" if buckets else "")))
         for k in one.files:
             assert np.array_equal(one[k], two[k]), (r, k)

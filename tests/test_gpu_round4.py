@@ -20,7 +20,7 @@ if has_gpu():
 
 
 # ------------------------------------------------------------------ bench.py as a rank
-@pytest.mark.parametrize("allreduce", ["single", "buckets", "fused"])
+@pytest.mark.parametrize("allreduce", ["single", "buckets", "fused", "fused_buckets"])
 def test_bench_rank_path_on_rccl_world1(allreduce):
     """`bench.py --gpus 1` under a torchrun-style environment (RANK=0, WORLD_SIZE=1, MASTER_*) with PFO_DIST_FORCE=1: the
     process group is initialised on RCCL (device bound, explicit timeout), every step all-reduces the real flat gradient
@@ -28,7 +28,7 @@ def test_bench_rank_path_on_rccl_world1(allreduce):
     barriers and a MAX all-reduce, and the line carries collective_ms_per_step / compute_ms_per_step and the secondary run
     with the other all-reduce form.  A child process with a hard limit: a hang cannot take the suite down."""
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(29300 + (os.getpid() % 200) + {"single": 0, "buckets": 7, "fused": 13}[allreduce]), PFO_DIST_FORCE="1")
+               MASTER_PORT=str(29300 + (os.getpid() % 200) + {"single": 0, "buckets": 7, "fused": 13, "fused_buckets": 19}[allreduce]), PFO_DIST_FORCE="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.pop("PFO_DIST_BACKEND", None)
     out = subprocess.run(["timeout", "-k", "10", "420", sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--config", "C2",
@@ -41,14 +41,14 @@ def test_bench_rank_path_on_rccl_world1(allreduce):
     assert cfg["collective"].startswith("rccl all-reduce"), cfg["collective"]
     assert cfg["allreduce"] == allreduce
     assert cfg["collective_samples"] >= 1 and 0 < cfg["collective_ms_per_step"] < rec["ms_per_step"]
-    if allreduce != "fused":       # (fused: ncclAllReduce runs on the library's side stream inside bpr_step, beside the next batch's head)
+    if not allreduce.startswith("fused"):       # (fused: ncclAllReduce runs on the library's side stream inside bpr_step, beside the next batch's head)
         assert cfg["collective_on_callers_stream"]
         assert abs(cfg["compute_ms_per_step"] + cfg["collective_ms_per_step"] - rec["ms_per_step"]) < 1e-3
     else:
         assert not cfg["collective_on_callers_stream"] and abs(cfg["compute_ms_per_step"] - rec["ms_per_step"]) < 1e-3
     sec = rec["secondary"]
     assert "error" not in sec, sec
-    for other in ("single", "buckets", "fused"):
+    for other in ("single", "buckets", "fused", "fused_buckets"):
         if other != allreduce:
             assert sec["allreduce_" + other]["value"] > 0
             assert sec["allreduce_" + other]["collective_ms_per_step"] > 0

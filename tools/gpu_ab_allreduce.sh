@@ -5,7 +5,7 @@ out=gpurun_out/ab_allreduce; mkdir -p $out
 export RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 PFO_DIST_FORCE=1
 p=29310
 for rep in 1 2; do
-for m in single buckets fused; do
+for m in single buckets fused fused_buckets; do
   p=$((p+1))
   echo "== $m"
   MASTER_PORT=$p python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-prof --min-seconds 1.0 --no-secondary --allreduce $m ${BENCH_ARGS} 2>/dev/null | python -c "
