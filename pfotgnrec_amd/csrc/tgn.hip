@@ -802,11 +802,12 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   const bool pack_side = pack_side_env && c->use_memory && !b->prepared;
   if (!b->prepared) {
     if (pack_side) {
-      // (comp_done rides on the compaction kernel's own completion when that is the call's only launch: no marker packet)
-      if (bind_events && b->n_extra == 0) pfo_stop_event_arm(sd.comp_done, 0);
+      // (comp_done rides on the completion of the compaction's LAST launch - its only one, or the third when the caller's extra
+      //  list is marked and compacted too (data-parallel ranks: memory.hip pfo_touch_compact_launch): no marker packet)
+      if (bind_events) pfo_stop_event_arm(sd.comp_done, b->n_extra > 0 ? 2 : 0);
       else pfo_stop_event_arm(nullptr, 0);
       RUN(prepare_compact(c, b, w, s));
-      if (bind_events && b->n_extra == 0) pfo_stop_event_disarm(s);
+      if (bind_events) pfo_stop_event_disarm(s);
       else HIPOK(hipEventRecord(sd.comp_done, s), "event record failed");
     } else {
       RUN(prepare_compact_pack(c, st, b, w, d, n, s));
