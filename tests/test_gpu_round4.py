@@ -472,3 +472,26 @@ def test_segment_sum_member_cut_equals_segment_cut_bitwise():
     a = _segment_sum_case(lens, 704, 172, True, 0.5, False, 7)
     b = _segment_sum_case(lens, 704, 172, True, 0.5, True, 7)
     assert np.array_equal(a, b)                                           # both add the rows of a segment in member order
+
+
+# ------------------------------------------------------------------ the side streams keep hardware queues of their own
+@pytest.mark.gpu
+def test_side_stream_sits_in_a_priority_class_of_its_own():
+    """with more streams in the process than GPU_MAX_HW_QUEUES (a process group brings RCCL's and c10d's), a
+    normal-priority side stream shares a hardware queue with the caller's stream and every overlap of the step is lost.  The
+    library's first side stream is created in the HIGH priority class (its own pool of hardware queues), and importing the
+    package raises the number of hardware queues unless the caller set it."""
+    import ctypes
+    import pfotgnrec_amd  # noqa: F401
+    from pfotgnrec_amd import _lib
+    assert int(os.environ["GPU_MAX_HW_QUEUES"]) >= 8
+    ptr = _lib.load().pfo_tgn_side_stream()
+    assert ptr
+    hip = ctypes.CDLL("libamdhip64.so")
+    lo, hi = ctypes.c_int(0), ctypes.c_int(0)
+    assert hip.hipDeviceGetStreamPriorityRange(ctypes.byref(lo), ctypes.byref(hi)) == 0
+    prio = ctypes.c_int(99)
+    assert hip.hipStreamGetPriority(ctypes.c_void_p(ptr), ctypes.byref(prio)) == 0
+    assert hi.value < lo.value, (lo.value, hi.value)           # the device has priority classes
+    assert prio.value == hi.value, (prio.value, lo.value, hi.value)
+    assert _lib.load().pfo_tgn_side_stream() == ptr             # one stream for the life of the process
