@@ -176,3 +176,15 @@ def test_fused_step_with_the_collective_on_the_side_stream_equals_the_serial_ord
         two = np.load(tmp_path / ("w2_r%d_B%d%s_fused.npz" % (r, B, "_buckets" if buckets else "")))
         for k in one.files:
             assert np.array_equal(one[k], two[k]), (r, k)
+
+
+def test_fused_step_on_three_ranks_with_uneven_shards(tmp_path):
+    """world 3, global batch 7 (shards of 2, 2, 3): the fused backward + all-reduce + Adam call against the serial order, bit for
+    bit on every rank (gloo, one GPU, deterministic backward)."""
+    port = 29560 + (os.getpid() % 60)
+    _spawn(3, port, tmp_path, 3, 7, det=True)
+    _spawn(3, port + 1, tmp_path, 3, 7, det=True, fused=True)
+    for r in range(3):
+        one, two = np.load(tmp_path / ("w3_r%d_B7.npz" % r)), np.load(tmp_path / ("w3_r%d_B7_fused.npz" % r))
+        for k in one.files:
+            assert np.array_equal(one[k], two[k]), (r, k)
