@@ -68,7 +68,7 @@ def parse():
                     help="N > 1: also run the other scaling case (C4 at a fixed global batch of 4 096 with its one-GPU reference, or the "
                          "weak-scaling C2 figure when the main line is C4) - a second 10 M-edge graph per rank.  ON by default at N = 8 "
                          "(BASELINE.json configs[3] names exactly that machine), 1 s budget; every N > 1 line also carries a 1 s run of "
-                         "the main workload with the other all-reduce form (secondary.allreduce_buckets / _single)")
+                         "the main workload with each other all-reduce form (secondary.allreduce_single / _buckets / _fused / _fused_buckets)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step from a captured HIP graph (one launch per step instead of ~85).  auto (one GPU, per-GPU "
                          "batch <= 256): capture, time ten steps either way during set-up and keep the faster form - the graph "
