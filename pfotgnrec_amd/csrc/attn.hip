@@ -480,22 +480,26 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
 #define RUN_CHUNK 4     // measured at C2 (round 2): 2: 399, 3: 370, 4: 365, 6: 402, 8: 417 us (a wavefront walks its chunk serially:
 #endif                  // long chunks merge more atomics but leave a tail)
 
+#ifndef RUN_CPW
+#define RUN_CPW 1      // consecutive chunks per wavefront: one prologue (member ids -> query rows / counts) for all their members
+#endif
 #ifndef KC_RUNS
 #define KC_RUNS 2      // keys in flight per wavefront
 #endif
 #ifndef RUNS_WAVES
 #define RUNS_WAVES(NR, H) ((NR) * (H) <= 6 ? 3 : 2)
 #endif
-// RUNS_PREFETCH (round 4): a member's d ctx' and ctx' rows (2 x 2.8 KB at C2) are streamed from HBM exactly once, by this
-// kernel, and the member's setup needs them before its first key can be scored: with three wavefronts per SIMD that round trip
-// was exposed once per member (~4 us of work each).  While member m is processed one LDS-DMA instruction touches every
-// 128-byte line of member m+1's two rows (lanes 0-31: d ctx', 32-63: ctx'; one dword per line into a landing pad nobody
-// reads - no registers, no wait): the rows are on their way when m+1's setup asks for them.  Measured: the kernel 322-324 ->
-// 315-318 us (-2 %), but the counter pass shows FETCH_SIZE +36 % (the touched 64-byte sectors are fetched again by the real
-// loads: the pad warms the Infinity Cache, not the L2) - 6 us for 224 MB of extra fabric reads.  OFF by default.
-#ifndef RUNS_PREFETCH
-#define RUNS_PREFETCH 0
-#endif
+// MEMBER STAGING (round 5).  In-kernel stamps (tools/probes/runs_stamps.py, -DRUNS_STAMPS=1) showed where a wavefront's life
+// went: 47 % in the member set-up, 32 % walking the 20 keys, 12 % in the flush - the set-up is a chain of dependent round trips
+// (members[m] -> qk_row[n] / run_cnt[n] -> the query row; then d ctx' and ctx', streamed from HBM exactly once by this kernel,
+// ~9 us per member against ~6 us for the walk), paid once per member with three wavefronts per SIMD to hide it.  Now:
+//  * a chunk prologue resolves the indirections of ALL its members at once (one lane per member: two dependent loads per chunk);
+//  * the rows of member i+1 (d ctx', ctx', the node's query row: 3 x H Cp floats) and its per-slot metadata (neighbour ids, table
+//    rows, edge ids, dt, the attention weights: (4 + H) x K words) travel by LDS-DMA (global_load_lds: no registers, no wait)
+//    into a wavefront-private staging image while member i is walked; the set-up of member i+1 reads LDS.  EXEC masks the
+//    lanes behind a row's end (tools/probes/lds_dma_mask.hip: masked lanes write nothing);
+//  * the flush takes the run's member ids from the prologue's register instead of re-loading members[].
+// The r4 one-dword-per-line touch of the next rows (-2 %, +36 % fetched bytes) is gone.
 // How a wavefront spends its cycles (round 3; measured against the round-2 loop, 357 vs 363 us at equal atomics - the atomic
 // rate, not the issue rate, bounds this kernel):
 //  * the gathers of key chunk c+1 are issued before chunk c is scored (two register sets used alternately, as in the forward);
@@ -506,14 +510,33 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
 //    (wave-uniform), not per chunk on every argument;
 //  * the per-key softmax-backward scalars of a chunk are reduced together (one interleaved DPP tree for KC*H sums), the running
 //    sum of cB per key lives in a register (select on lane == key) instead of an LDS read-modify-write.
+// RUNS_STAMPS (diagnostic build only, -DRUNS_STAMPS=1): shader cycles a wavefront spends per section, summed over the launch into
+// pfo_runs_stamps (0 whole wavefront, 1 member set-up, 2 key walk, 3 flush, 4 row-sum store, 5 members, 6 chunks); the stamps
+// go to a buffer of their own and no output is computed from them (MI355X_MICROARCH.md, DVFS give-back item 6)
+#ifndef RUNS_STAMPS
+#define RUNS_STAMPS 0
+#endif
+#if RUNS_STAMPS
+__device__ unsigned long long pfo_runs_stamps[8];
+extern "C" int pfo_attn_runs_stamps(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pfo_runs_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return PFO_ERR_HIP;
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pfo_runs_stamps), z, sizeof(z)) != hipSuccess) return PFO_ERR_HIP; }
+  return PFO_OK;
+}
+#define STAMP() ((unsigned long long)__builtin_amdgcn_s_memtime())
+#endif
 template <int NR, int H, bool DET>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(NR, H)))) void attn_bwd_runs_kernel(const AttnDev a) {
+#if RUNS_STAMPS
+  const unsigned long long st_begin = STAMP();
+  unsigned long long st_setup = 0, st_walk = 0, st_flush = 0, st_store = 0, st_members = 0, st_chunks = 0;
+#endif
   __shared__ float s_tw[NR * 64], s_tb[NR * 64];
   __shared__ float s_cA[RUN_CHUNK][H][64];     // [instance of the group][head][slot]: cA of that key; zero where the slot is empty
   __shared__ int s_delta[RUN_CHUNK];            // [instance of the group]: its shift (count - the group's first count)
-#if RUNS_PREFETCH
-  __shared__ float s_pf[64];                    // landing pad of the next member's row prefetch (never read)
-#endif
+  __shared__ int s_ch[3][RUN_CPW * RUN_CHUNK];  // the wavefront's members: instance id, query row, history count (prologue)
+  // staging image (dynamic LDS, sized by the launcher: pfo_attn_runs_lds_bytes): [d ctx' row | ctx' row | query row | metadata]
+  extern __shared__ __align__(16) unsigned char s_stage[];
   const int lane = threadIdx.x;
   const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef, Cp = a.Cp;
   float wmax = 0.f, bmax = 0.f;
@@ -538,20 +561,79 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
   const float* const nbr_tab = a.nbr_tab;
   const float* const edge_feat = a.edge_feat;
   const uint32_t nbr_ld = (uint32_t)a.nbr_ld;
+  // the staging image and the LDS-DMA that fills it (one member at a time; the issuing wavefront's vmcnt covers it)
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const uint32_t row_bytes = (uint32_t)(H * Cp) * 4u;             // a multiple of 16 (Cp is a multiple of 4)
+  const float* const st_dc = reinterpret_cast<const float*>(s_stage);
+  const float* const st_cx = reinterpret_cast<const float*>(s_stage + row_bytes);
+  const float* const st_qk = reinterpret_cast<const float*>(s_stage + 2 * row_bytes);
+  unsigned char* const st_meta = s_stage + 3 * row_bytes;        // (4 + H) arrays of K words: ids, table rows, edge ids, dt, weights
+  auto stage = [&](int64_t n, int slot) {
+    const char* g_dc = reinterpret_cast<const char*>(a.dctx + n * H * Cp);
+    const char* g_cx = reinterpret_cast<const char*>(a.ctx + n * H * Cp);
+    const char* g_qk = reinterpret_cast<const char*>(a.QK + (int64_t)slot * a.qk_ld);
+    // (the lane offset is made opaque: hoisted out of the member loop, the per-lane addresses of nine loads would be kept alive
+    // as 64-bit register pairs across the key walk - the kernel sits at its register limit, they went to scratch)
+    uint32_t lo = (uint32_t)lane * 4u;
+    asm volatile("" : "+v"(lo));
+    for (uint32_t k = 0; k * 1024u < row_bytes; ++k) {
+      const uint32_t off = k * 1024u + lo * 4u;
+      if (off < row_bytes) {                                     // lanes behind the row's end stay off: they write nothing
+        __builtin_amdgcn_global_load_lds((gptr_t)(g_dc + off), (lptr_t)(s_stage + k * 1024u), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(g_cx + off), (lptr_t)(s_stage + row_bytes + k * 1024u), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(g_qk + off), (lptr_t)(s_stage + 2 * row_bytes + k * 1024u), 16, 0, 0);
+      }
+    }
+    if (lane < K) {
+      // wave-uniform row starts + ONE 32-bit lane offset (the scalar-base form of the load: no per-lane 64-bit pointers to keep)
+      const uint32_t kb = (uint32_t)K * 4u;
+      const int64_t s0 = n * K;
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.nbr_ids + s0) + lo), (lptr_t)(st_meta), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.nbr_row + s0) + lo), (lptr_t)(st_meta + kb), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.eidx + s0) + lo), (lptr_t)(st_meta + 2 * kb), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.dt + s0) + lo), (lptr_t)(st_meta + 3 * kb), 4, 0, 0);
+#pragma unroll
+      for (int h = 0; h < H; ++h)
+        __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.attw + (n * H + h) * K) + lo), (lptr_t)(st_meta + (4 + h) * kb), 4, 0, 0);
+    }
+  };
 
   // Workgroups go to the XCDs round-robin by their id.  Consecutive chunks hold members of the same table row or of
   // neighbouring ones (the list is ordered by row): with xcd_g = G > 0 every XCD takes G consecutive chunks at a time (block b ->
   // chunk (b / 8G) 8G + (b mod 8) G + (b mod 8G) / 8), so the shifted neighbour lists of one node's members, its query row and
   // the rows its atomics land on stay in ONE L2 instead of being fetched by up to eight.
+  // A wavefront takes a UNIT of RUN_CPW consecutive chunks.  The chunk stays the scope of a run (its rows leave at the chunk's
+  // end at the latest) and of the time-encoder partial sums; the unit is the scope of the prologue and of the member staging.
+  constexpr int UM = RUN_CPW * RUN_CHUNK;                          // members per wavefront
+  const int n_units = (n_chunks + RUN_CPW - 1) / RUN_CPW;
   const int G8 = 8 * a.xcd_g;
-  const int n_walk = G8 > 0 ? (n_chunks + G8 - 1) / G8 * G8 : n_chunks;
+  const int n_walk = G8 > 0 ? (n_units + G8 - 1) / G8 * G8 : n_units;
   for (int blk = blockIdx.x; blk < n_walk; blk += gridDim.x) {
-    int chunk = blk;
+    int unit = blk;
     if (G8 > 0) {
       const int grp = blk / G8, r = blk - grp * G8;
-      chunk = grp * G8 + (r & 7) * a.xcd_g + (r >> 3);
-      if (chunk >= n_chunks) continue;
+      unit = grp * G8 + (r & 7) * a.xcd_g + (r >> 3);
+      if (unit >= n_units) continue;
     }
+    // prologue: the members' instance ids, query rows and history counts, one lane per member (two dependent loads per
+    // WAVEFRONT; the member list is read at a clamped index, so the load does not wait for the members' count), and the first
+    // member's rows on their way
+    const int u0 = unit * UM;
+    const int u_end = min(M, u0 + UM);
+    {
+      const bool ch_on = lane < UM && u0 + lane < u_end;
+      const int ch_raw = a.members[min(u0 + min(lane, UM - 1), a.N - 1)];
+      const int ch_n = ch_on ? ch_raw : 0;
+      const int ch_slot = ch_on ? a.qk_row[ch_n] : -1;
+      const int ch_cnt = ch_on ? a.run_cnt[ch_n] : 0;
+      if (lane < UM) { s_ch[0][lane] = ch_n; s_ch[1][lane] = ch_slot; s_ch[2][lane] = ch_cnt; }   // (one wavefront: no barrier)
+      if (u0 < u_end) stage(rl_i(ch_n, 0), rl_i(ch_slot, 0));
+    }
+    auto ch_get = [&](int which, int i) { return __builtin_amdgcn_readfirstlane(s_ch[which][i]); };
+    for (int chunk = unit * RUN_CPW; chunk < min(n_chunks, (unit + 1) * RUN_CPW); ++chunk) {
+    const int m0 = chunk * RUN_CHUNK;
+    const int m_end = min(M, m0 + RUN_CHUNK);
     float dwc[NR], dbc[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) { dwc[r] = 0.f; dbc[r] = 0.f; }
@@ -571,21 +653,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         dqe[h] = 0.f;
       }
     };
+    // (acc_store, flush and stage address their rows as a wave-uniform base + ONE 32-bit lane offset that is opaque to the
+    // optimiser: hoisted out of the member loop, their per-lane 64-bit element offsets lived across the key walk - a dozen
+    // register pairs at a kernel that sits on its register limit, i.e. scratch reloads in front of every store)
     auto acc_store = [&]() {
       if (acc_m >= 0) {
-        float* dqk_out = a.dQK + (int64_t)acc_m * H * Cp;          // row m, not n: the per-row sums then stream contiguous rows
+        char* out = reinterpret_cast<char*>(a.dQK + (int64_t)acc_m * H * Cp);      // row m, not n: the per-row sums then stream contiguous rows
+        uint32_t lo = (uint32_t)lane * 4u;
+        asm volatile("" : "+v"(lo));
 #pragma unroll
         for (int h = 0; h < H; ++h) {
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
-            const int c = lane + 64 * r;
-            if (c < D) {
-              dqk_out[h * Cp + c] = dqn[h][r];
-              dqk_out[h * Cp + D + Ef + c] = dqt[h][r];
+            if (lo < (uint32_t)(D - 64 * r) * 4u) {              // column lane + 64 r < D (64 r < D for every r < NR)
+              *reinterpret_cast<float*>(out + (uint32_t)(h * Cp + 64 * r) * 4u + lo) = dqn[h][r];
+              *reinterpret_cast<float*>(out + (uint32_t)(h * Cp + D + Ef + 64 * r) * 4u + lo) = dqt[h][r];
             }
           }
-          if (lane < Ef) dqk_out[h * Cp + D + lane] = dqe[h];
-          if (lane < Cp - C) dqk_out[h * Cp + C + lane] = 0.f;
+          if (lo < (uint32_t)Ef * 4u) *reinterpret_cast<float*>(out + (uint32_t)(h * Cp + D) * 4u + lo) = dqe[h];
+          if (lo < (uint32_t)(Cp - C) * 4u) *reinterpret_cast<float*>(out + (uint32_t)(h * Cp + C) * 4u + lo) = 0.f;
         }
         if (lane == 0) a.dqk_live[acc_m] = 1;
       }
@@ -598,29 +684,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
     for (int h = 0; h < H; ++h) sBr[h] = 0.f;
     auto flush = [&]() {                                           // the run's rows: one float atomic per element
       if (run_valid != 0ull && run_len > 0) {
-        const float* qk = a.QK + (int64_t)run_slot * a.qk_ld;
+        const char* qk = reinterpret_cast<const char*>(a.QK + (int64_t)run_slot * a.qk_ld);
+        uint32_t lo = (uint32_t)lane * 4u;
+        asm volatile("" : "+v"(lo));
         float qn[H][NR], g[RUN_CHUNK][H][NR];
 #pragma unroll
         for (int h = 0; h < H; ++h)
 #pragma unroll
-          for (int r = 0; r < NR; ++r) {
-            const int c = lane + 64 * r;
-            qn[h][r] = c < D ? qk[h * Cp + c] : 0.f;
-          }
+          for (int r = 0; r < NR; ++r)
+            qn[h][r] = lo < (uint32_t)(D - 64 * r) * 4u ? *reinterpret_cast<const float*>(qk + (uint32_t)(h * Cp + 64 * r) * 4u + lo) : 0.f;
         float cAr[RUN_CHUNK][H];                                   // lane q: cA of the slot instance i has on history entry q
 #pragma unroll
         for (int i = 0; i < RUN_CHUNK; ++i) {
           const bool on = i < run_len;                             // wave-uniform
-          const float* dc = a.dctx + (int64_t)a.members[on ? run_first + i : run_first] * H * Cp;
+          const char* dc = reinterpret_cast<const char*>(a.dctx + (int64_t)ch_get(0, (on ? run_first + i : run_first) - u0) * H * Cp);
           const int sl = lane - (on ? s_delta[i] : 0);             // the instance's slot on this lane (may lie outside [0, K): zero)
 #pragma unroll
           for (int h = 0; h < H; ++h) {
             cAr[i][h] = (on && sl >= 0) ? s_cA[i][h][sl < 0 ? 0 : sl] : 0.f;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-              const int c = lane + 64 * r;
-              g[i][h][r] = (on && c < D) ? dc[h * Cp + c] : 0.f;
-            }
+            for (int r = 0; r < NR; ++r)
+              g[i][h][r] = (on && lo < (uint32_t)(D - 64 * r) * 4u) ? *reinterpret_cast<const float*>(dc + (uint32_t)(h * Cp + 64 * r) * 4u + lo) : 0.f;
           }
         }
         unsigned long long vmask = run_valid;
@@ -628,7 +712,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
           const int j = __ffsll((long long)vmask) - 1;
           vmask &= vmask - 1ull;
           const int64_t drow = (int64_t)rl_i(run_rows, j) * a.d_nbr_ld;
-          float* dst = d_nbr_x + drow;
+          char* dst = reinterpret_cast<char*>(d_nbr_x + drow);
           float row[NR];
 #pragma unroll
           for (int r = 0; r < NR; ++r) row[r] = 0.f;
@@ -646,9 +730,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
           }
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
-            const int cc = lane + 64 * r;
-            if ((r < NR - 1 || cc < D) && a.abl != 2) {
-              if (DET) det_add(a.d_nbr, drow + cc, row[r]); else atomicAdd(dst + cc, row[r]);
+            if ((r < NR - 1 || lo < (uint32_t)(D - 64 * r) * 4u) && a.abl != 2) {
+              if (DET) det_add(a.d_nbr, drow + lane + 64 * r, row[r]); else atomicAdd(reinterpret_cast<float*>(dst + (uint32_t)(256 * r) + lo), row[r]);
             }
           }
         }
@@ -658,39 +741,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
       run_len = 0;
     };
 
-    const int m_end = min(M, (chunk + 1) * RUN_CHUNK);
-#if RUNS_PREFETCH
-    // the chunk's member ids in lanes 0 .. RUN_CHUNK-1 (one load per chunk instead of a dependent scalar load per member)
-    const int mem_ids = (lane < RUN_CHUNK && chunk * RUN_CHUNK + lane < m_end) ? a.members[chunk * RUN_CHUNK + lane] : 0;
-    const uint32_t row_bytes = (uint32_t)(H * Cp) * 4u;
-    const uint32_t pf_off = min((uint32_t)(lane & 31) * 128u, row_bytes - 4u);
+#if RUNS_STAMPS
+    st_chunks += 1;
 #endif
-    for (int m = chunk * RUN_CHUNK; m < m_end; ++m) {
-#if RUNS_PREFETCH
-      const int64_t n = rl_i(mem_ids, m - chunk * RUN_CHUNK);
-      if (m + 1 < m_end) {
-        typedef __attribute__((address_space(1))) const void* gptr_t;
-        typedef __attribute__((address_space(3))) void* lptr_t;
-        const int64_t n2 = rl_i(mem_ids, m + 1 - chunk * RUN_CHUNK);
-        const char* src = reinterpret_cast<const char*>(lane < 32 ? a.dctx : a.ctx) + n2 * (int64_t)row_bytes + pf_off;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)s_pf, 4, 0, 0);
-      }
-#else
-      const int64_t n = a.members[m];
+    for (int m = m0; m < m_end; ++m) {
+#if RUNS_STAMPS
+      unsigned long long st0 = STAMP();
+      st_members += 1;
 #endif
-      const int64_t slot0 = n * K;
+      const int64_t n = ch_get(0, m - u0);
+      const int slot = ch_get(1, m - u0);
+      const int cnt_n = ch_get(2, m - u0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this member's staging image has landed
       const bool inK = lane < K;
-      const int my_id = inK ? a.nbr_ids[slot0 + lane] : 0;
-      const int my_row = inK ? a.nbr_row[slot0 + lane] : 0;
-      const int my_e = inK ? a.eidx[slot0 + lane] : 0;
-      const float my_dt = inK ? a.dt[slot0 + lane] : 0.f;
+      const int* const mi = reinterpret_cast<const int*>(st_meta);
+      const int my_id = inK ? mi[lane] : 0;
+      const int my_row = inK ? mi[K + lane] : 0;
+      const int my_e = inK ? mi[2 * K + lane] : 0;
+      const float my_dt = inK ? __int_as_float(mi[3 * K + lane]) : 0.f;
       const unsigned long long valid = __ballot(inK && my_id != 0);
-      const int slot = a.qk_row[n];
-      const int cnt_n = a.run_cnt[n];
       int delta = cnt_n - run_cnt0;                              // members of a row arrive by ascending count
       if (slot != run_slot || delta < 0 || delta > 64 - K) {     // another node, or the lanes run out: the group's rows leave
+#if RUNS_STAMPS
+        const unsigned long long sa = STAMP();
+#endif
         acc_store();                                             // (the query-side sums too: never live across a flush)
+#if RUNS_STAMPS
+        const unsigned long long sb = STAMP();
+#endif
         flush();
+#if RUNS_STAMPS
+        const unsigned long long sc = STAMP();
+        st_store += sb - sa; st_flush += sc - sb; st0 += sc - sa;
+#endif
         run_slot = slot; run_cnt0 = cnt_n; run_rows = 0; run_valid = 0ull;
         delta = 0;
       }
@@ -702,7 +785,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         run_valid |= vs;
       }
       if (lane == 0) a.dqk_live[m] = 0;                         // (set when this member's position receives a stored sum)
-      if (valid == 0ull) continue;                               // no neighbour: nothing to add to the row's sums
+      if (valid == 0ull) {                                       // no neighbour: nothing to add to the row's sums
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (m + 1 < u_end) stage(ch_get(0, m + 1 - u0), ch_get(1, m + 1 - u0));
+        continue;
+      }
       acc_m = m;
       if (run_len == 0) run_first = m;                           // the group's instances with a neighbour are consecutive members
       const int run_i = run_len;                                 // (an instance without history has count 0: first of its row)
@@ -711,9 +798,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
 #pragma unroll
       for (int h = 0; h < H; ++h) s_cA[run_i][h][lane] = 0.f;
       float qt[H][NR], gn[H][NR], gt[H][NR], ge[H], tds[2 * H];
-      const float* qk = a.QK + (int64_t)slot * a.qk_ld;
-      const float* dc = a.dctx + n * H * Cp;
-      const float* cx = a.ctx + n * H * Cp;
+      float dsb[H], cxs[H], my_a[H];
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         float part = 0.f;
@@ -721,26 +806,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         for (int r = 0; r < NR; ++r) {
           const int c = lane + 64 * r;
           const bool ok = c < D;
-          qt[h][r] = ok ? qk[h * Cp + D + Ef + c] : 0.f;
-          gn[h][r] = ok ? dc[h * Cp + c] : 0.f;
-          gt[h][r] = ok ? dc[h * Cp + D + Ef + c] : 0.f;
-          if (ok) part = fmaf(gn[h][r], cx[h * Cp + c], fmaf(gt[h][r], cx[h * Cp + D + Ef + c], part));
+          qt[h][r] = ok ? st_qk[h * Cp + D + Ef + c] : 0.f;
+          gn[h][r] = ok ? st_dc[h * Cp + c] : 0.f;
+          gt[h][r] = ok ? st_dc[h * Cp + D + Ef + c] : 0.f;
+          if (ok) part = fmaf(gn[h][r], st_cx[h * Cp + c], fmaf(gt[h][r], st_cx[h * Cp + D + Ef + c], part));
         }
-        ge[h] = lane < Ef ? dc[h * Cp + D + lane] : 0.f;
-        if (lane < Ef) part = fmaf(ge[h], cx[h * Cp + D + lane], part);
+        ge[h] = lane < Ef ? st_dc[h * Cp + D + lane] : 0.f;
+        if (lane < Ef) part = fmaf(ge[h], st_cx[h * Cp + D + lane], part);
         tds[h] = part;
+        dsb[h] = st_dc[h * Cp + C];          // d loss / d (sum_j a'_jh): one address for the wavefront (an LDS broadcast)
+        cxs[h] = st_cx[h * Cp + C];
+        my_a[h] = inK ? __int_as_float(mi[(4 + h) * K + lane]) : 0.f;
       }
+      // the image is free again: the next member's rows start their trip now and land while this member is walked
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (m + 1 < u_end) stage(ch_get(0, m + 1 - u0), ch_get(1, m + 1 - u0));
       pfo_wave_sum_scalar_n<H>(reinterpret_cast<float(&)[H]>(tds));     // delta_h = dctx_h . ctx_h (+ the extra column below)
-      float t[H], dsb[H];
+      float t[H];
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        dsb[h] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(dc[h * Cp + C])));
-        t[h] = fmaf(dsb[h], __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cx[h * Cp + C]))), tds[h]);
+        dsb[h] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(dsb[h])));
+        t[h] = fmaf(dsb[h], __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cxs[h]))), tds[h]);
       }
       const unsigned keep = attn_keep_for(a, rng_off, n, lane);
-      float my_a[H];
-#pragma unroll
-      for (int h = 0; h < H; ++h) my_a[h] = inK ? a.attw[(n * H + h) * K + lane] : 0.f;
       // one range test per instance: |fma(dt, w, b)| <= max|dt| max|w| + max|b| < 2e7 -> the fp32 reduction holds for every key
       const bool fast = fmaf(pfo_wave_max(fabsf(my_dt)), wmax, bmax) < 2.0e7f;
 
@@ -838,10 +926,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         if (jsA[0] < 0) break;
       }
       };
+#if RUNS_STAMPS
+      const unsigned long long st1 = STAMP();
+#endif
       if (fast) walk(std::true_type{}); else walk(std::false_type{});
+#if RUNS_STAMPS
+      const unsigned long long st2 = STAMP();
+      st_setup += st1 - st0; st_walk += st2 - st1;
+#endif
     }
+#if RUNS_STAMPS
+    const unsigned long long se0 = STAMP();
+#endif
     acc_store();                                                 // the chunk's last row sums
+#if RUNS_STAMPS
+    const unsigned long long se1 = STAMP();
+#endif
     flush();                                                     // the chunk's last run
+#if RUNS_STAMPS
+    const unsigned long long se2 = STAMP();
+    st_store += se1 - se0; st_flush += se2 - se1;
+#endif
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int c = lane + 64 * r;
@@ -856,13 +961,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         }
       }
     }
+    }   // chunks of the unit
+    // deterministic mode: every slab row is written - the chunks of this unit beyond the members' count own zero rows
+    if (DET)
+      for (int chunk = max(n_chunks, unit * RUN_CPW); chunk < (unit + 1) * RUN_CPW; ++chunk)
+        for (int c = lane; c < 2 * D; c += 64) a.dtime_slab[(int64_t)chunk * 2 * D + c] = 0.0;
   }
-  // deterministic mode: the launch has one workgroup per POSSIBLE chunk; those beyond the members' count own a zero row
-  if (DET && (int)blockIdx.x >= n_chunks)
-    for (int c = lane; c < 2 * D; c += 64) a.dtime_slab[(int64_t)blockIdx.x * 2 * D + c] = 0.0;
+  // (the deterministic launch has one workgroup per POSSIBLE unit; those beyond the members' count own zero rows too)
+  if (DET && (int)blockIdx.x >= n_units)
+    for (int chunk = (int)blockIdx.x * RUN_CPW; chunk < ((int)blockIdx.x + 1) * RUN_CPW; ++chunk)
+      for (int c = lane; c < 2 * D; c += 64) a.dtime_slab[(int64_t)chunk * 2 * D + c] = 0.0;
+#if RUNS_STAMPS
+  if (lane == 0) {
+    atomicAdd(&pfo_runs_stamps[0], STAMP() - st_begin);
+    atomicAdd(&pfo_runs_stamps[1], st_setup); atomicAdd(&pfo_runs_stamps[2], st_walk); atomicAdd(&pfo_runs_stamps[3], st_flush);
+    atomicAdd(&pfo_runs_stamps[4], st_store); atomicAdd(&pfo_runs_stamps[5], st_members); atomicAdd(&pfo_runs_stamps[6], st_chunks);
+  }
+#endif
 }
 
-int64_t pfo_attn_bwd_det_parts(int64_t N) { return std::max<int64_t>(pfo_ceil_div(N, RUN_CHUNK), std::min<int64_t>(ATTN_BWD_MAX_BLOCKS, pfo_ceil_div(N, 4))); }
+int64_t pfo_attn_bwd_det_parts(int64_t N) {
+  return std::max<int64_t>(pfo_align_up(pfo_ceil_div(N, RUN_CHUNK), RUN_CPW), std::min<int64_t>(ATTN_BWD_MAX_BLOCKS, pfo_ceil_div(N, 4)));
+}
 
 static void to_dev(const PfoAttn& a, AttnDev& d) {
   d.N = a.N; d.K = a.K; d.D = a.D; d.Ef = a.Ef; d.H = a.H; d.Cp = a.Cp;
@@ -972,8 +1092,11 @@ bool pfo_attn_bwd_runs_possible(int K, int D, int H) {
   return runs_on && K <= 64 && fits;
 }
 bool pfo_attn_bwd_uses_runs(const PfoAttn& a) {
+  // (the staging LDS-DMA moves 16 bytes per lane: rows must start on 16-byte boundaries)
+  const int64_t qk_ld = a.qk_ld > 0 ? a.qk_ld : (int64_t)a.H * a.Cp;
+  const bool aligned = (qk_ld % 4) == 0 && (((uintptr_t)a.QK | (uintptr_t)a.dctx | (uintptr_t)a.ctx) & 15u) == 0;
   return a.d_nbr && a.nbr_row && pfo_attn_bwd_runs_possible(a.K, a.D, a.H) && a.members && a.seg_ptr && a.n_rows && a.qk_row && a.run_cnt &&
-         a.dqk_live;
+         a.dqk_live && aligned;
 }
 
 int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
@@ -990,16 +1113,17 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
   const double bytes = (double)a.N * (a.K * (8.0 * a.D + 4.0 * a.Ef + 12.0) + 4.0 * a.H * C * 4.0 + 4.0 * a.H * a.K);
   const int dmode = !a.d_nbr ? 0 : (a.nbr_row ? 1 : 2);
   static const int lds_pad = getenv("PFO_ATTN_RUNS_LDSPAD") ? atoi(getenv("PFO_ATTN_RUNS_LDSPAD")) : 0;   // occupancy probe
-  const size_t run_lds = (size_t)lds_pad;
+  // the run-merged kernel's staging image: three rows of H Cp floats + (4 + H) metadata arrays of K words (attn_bwd_runs_kernel)
+  const size_t run_lds = (size_t)lds_pad + 3 * (size_t)a.H * a.Cp * 4 + (size_t)(4 + a.H) * a.K * 4;
   if (pfo_attn_bwd_uses_runs(a)) {
     // run-merged form: single-wavefront workgroups, one chunk of members each (the grid-stride loop only matters when the
     // grid is capped for an experiment)
     static const int rblocks = getenv("PFO_ATTN_RUNS_BLOCKS") ? atoi(getenv("PFO_ATTN_RUNS_BLOCKS")) : 0;
     static const int xcd_g = getenv("PFO_ATTN_XCD_G") ? atoi(getenv("PFO_ATTN_XCD_G")) : 16;              // A/B switch (counter pass: FETCH 625 -> 487 MB per launch at 16, 512 at 4; the launch time does not move)
     d.xcd_g = a.det ? 0 : std::max(0, xcd_g);                  // (deterministic mode: slab row = chunk = workgroup id)
-    int64_t all_chunks = pfo_ceil_div(a.N, RUN_CHUNK);
-    if (d.xcd_g > 0) all_chunks = pfo_align_up(all_chunks, 8 * d.xcd_g);
-    const int rgrid = (int)((rblocks > 0 && !a.det) ? std::min<int64_t>(rblocks, all_chunks) : all_chunks);
+    int64_t all_units = pfo_ceil_div(pfo_ceil_div(a.N, RUN_CHUNK), RUN_CPW);       // a wavefront takes RUN_CPW chunks
+    if (d.xcd_g > 0) all_units = pfo_align_up(all_units, 8 * d.xcd_g);
+    const int rgrid = (int)((rblocks > 0 && !a.det) ? std::min<int64_t>(rblocks, all_units) : all_units);
     pfo_prof_begin(stream);
     const int NRv = (a.D + 63) / 64;
     const dim3 g((unsigned)rgrid), b(64);
@@ -1018,7 +1142,7 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
     PFO_REQUIRE(done, "unsupported (D, H) combination");
     PFO_LAUNCH_CHECK();
     pfo_prof_end(PFO_PROF_ATTN_BWD_RUNS, bytes, stream);
-    if (n_parts) *n_parts = a.det ? rgrid : ATTN_TIME_BINS;       // deterministic: slab rows written (one per workgroup)
+    if (n_parts) *n_parts = a.det ? rgrid * RUN_CPW : ATTN_TIME_BINS;   // deterministic: slab rows written (one per chunk, RUN_CPW per workgroup)
     return PFO_OK;
   }
   pfo_prof_begin(stream);

@@ -328,7 +328,25 @@ struct Side {
   hipStream_t s = nullptr, s2 = nullptr;
   hipEvent_t tn_a_done = nullptr, done2 = nullptr, gru_done = nullptr, comp_done = nullptr, pc_a = nullptr, pc_b = nullptr;
   hipEvent_t main_done = nullptr, side_done = nullptr;
-  bool side_pending = false;     // a deferred backward end / optimizer step is in flight on `s` (pfo_tgn_batch.defer_join)
+  // Deferred work on `s` (a backward end, the optimizer step behind it: pfo_tgn_batch.defer_join) is counted in GENERATIONS:
+  // side_gen grows when work is queued there, every joining stream remembers the generation it last waited for.  (One
+  // "pending" flag that the first joiner cleared let a prepare call on the prefetch stream consume the join: tgn.join(),
+  // state_dict() and the next backward on the caller's stream then read parameters the side stream was still writing.)
+  uint64_t side_gen = 0, recorded_gen = 0;
+  bool last_backward_deferred = false;                           // pfo_tgn_adam_side may only follow such a backward
+  struct Joined { hipStream_t s; uint64_t gen; } joined[8] = {};
+  int n_joined = 0;
+  bool pending_for(hipStream_t s) const {
+    if (side_gen == 0) return false;
+    for (int i = 0; i < n_joined; ++i) if (joined[i].s == s) return joined[i].gen != side_gen;
+    return true;
+  }
+  void mark_joined(hipStream_t s) {
+    for (int i = 0; i < n_joined; ++i) if (joined[i].s == s) { joined[i].gen = side_gen; return; }
+    if (n_joined < 8) { joined[n_joined].s = s; joined[n_joined].gen = side_gen; ++n_joined; return; }
+    for (int i = 1; i < 8; ++i) joined[i - 1] = joined[i];       // more streams than slots: the oldest entry goes (it will wait again)
+    joined[7].s = s; joined[7].gen = side_gen;
+  }
   hipEvent_t fork = nullptr, done = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr, fold_done = nullptr;
   hipEvent_t layer[PFO_MAX_LAYERS + 1] = {};
   bool ok = false;
@@ -372,10 +390,13 @@ Side& side() {
 #define HIPOK(expr, msg) PFO_REQUIRE((expr) == hipSuccess, msg)
 // `s` waits for whatever a deferred backward end / side-stream optimizer step left in flight (pfo_tgn_batch.defer_join)
 int side_join(Side& sd, hipStream_t s) {
-  if (!sd.side_pending) return PFO_OK;
-  HIPOK(hipEventRecord(sd.side_done, sd.s), "event record failed");
+  if (!sd.pending_for(s)) return PFO_OK;
+  if (sd.recorded_gen != sd.side_gen) {                          // one record per generation, shared by every joiner
+    HIPOK(hipEventRecord(sd.side_done, sd.s), "event record failed");
+    sd.recorded_gen = sd.side_gen;
+  }
   HIPOK(hipStreamWaitEvent(s, sd.side_done, 0), "event wait failed");
-  sd.side_pending = false;
+  sd.mark_joined(s);
   return PFO_OK;
 }
 
@@ -775,7 +796,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   // (with a deferred backward end in flight the side stream already waits for the caller's stream's last launch of that
   //  backward, and everything this call gives it either reads parameters only or sits behind an event of this call: no fork)
   static const int skip_fork = getenv("PFO_SKIP_FORK") ? atoi(getenv("PFO_SKIP_FORK")) : 1;      // A/B switch
-  if (!(skip_fork && sd.side_pending && bind_events)) {
+  if (!(skip_fork && sd.pending_for(s) && bind_events)) {
     HIPOK(hipEventRecord(sd.fork, s), "event record failed");
     HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
   }
@@ -1460,8 +1481,10 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     // launch instead of the other way round - the caller's stream is free for the next batch's neighbour sampling
     if (!main_done_bound) HIPOK(hipEventRecord(sd.main_done, s), "event record failed");
     HIPOK(hipStreamWaitEvent(ss, sd.main_done, 0), "event wait failed");
-    sd.side_pending = true;
+    sd.side_gen += 1;
+    sd.last_backward_deferred = true;
   } else {
+    sd.last_backward_deferred = false;
     HIPOK(hipEventRecord(sd.done, ss), "event record failed");
     HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
   }
@@ -1474,8 +1497,9 @@ extern "C" int pfo_tgn_adam_side(float* param, const float* grad, float* exp_avg
                                  float eps) {
   Side& sd = side();
   PFO_REQUIRE(sd.ok, "could not create the side stream");
-  PFO_REQUIRE(sd.side_pending, "pfo_tgn_adam_side follows a backward that ran with pfo_tgn_batch.defer_join");
+  PFO_REQUIRE(sd.last_backward_deferred, "pfo_tgn_adam_side follows a backward that ran with pfo_tgn_batch.defer_join");
   const int rc = pfo_adam_step_ranges(param, grad, exp_avg, exp_avg_sq, n_ranges, lo, hi, step, lr, beta1, beta2, eps, (void*)sd.s);
+  sd.side_gen += 1;                                              // (a stream that joined between the backward and this call joins again)
   PFO_MARK("@side1.adam.end", sd.s);
   return rc;
 }

@@ -137,9 +137,10 @@ class TGN(nn.Module):
         self.fuse_state_update = os.environ.get("PFO_FUSE_STATE", "1") != "0"      # training calls: persist + message store inside the native forward, on its side stream
         self._ws_caps = (0, 0, 0)
         # Parameter cache (pfo_tgn_state.pcache): composite weights + fp16 weight images, rebuilt only when the parameters
-        # changed.  "Changed" = the torch version counter of the flat buffer (shared by every nn.Parameter view: in-place ops
-        # of any torch optimizer, load_state_dict, copy_ ... bump it) or ``parameters_changed()`` (native writers: FusedAdam,
-        # graph replays).  Writes through ``p.data`` bypass the counter: call ``parameters_changed()`` after them.
+        # changed.  "Changed" = the torch version counters of the flat buffer AND of every nn.Parameter (in-place ops of any
+        # torch optimizer, load_state_dict, copy_ ... bump them; after a real device move the parameters keep counters of their
+        # own - ``p.data = view`` does not share the new buffer's) or ``parameters_changed()`` (native writers: FusedAdam,
+        # graph replays).  Writes through ``p.data`` bypass the counters: call ``parameters_changed()`` after them.
         self.param_cache = os.environ.get("PFO_PCACHE", "1") != "0"
         # FusedAdam may rebuild the cache right behind its kernel (pfo_tgn_refresh, second side stream) instead of leaving it to
         # the next forward.  Off by default: measured at C2, 1.461 ms per step with, 1.454 without - the ~15 launches are hidden
@@ -256,6 +257,7 @@ class TGN(nn.Module):
         return self._flat_grad
 
     def _apply(self, fn, recurse=True):
+        self.join()                                               # a side-stream optimizer step may still be writing the buffer
         new_flat = fn(self._flat)
         if new_flat.dtype != torch.float32:
             raise TypeError("the native path is fp32 only (1e-4 parity bar)")
@@ -333,7 +335,8 @@ class TGN(nn.Module):
         return _lib.TgnConfig(c.n_nodes, c.n_edges_p1, c.D, c.Ef, c.n_layers, c.n_heads, c.use_memory, caps[0], caps[1], caps[2])
 
     def _param_key(self):
-        return (self._flat._version, self._param_epoch, self._flat.data_ptr())
+        # every parameter's own counter too: after .to(device) / .float() they no longer share the flat buffer's
+        return (self._flat._version, sum(v[0]._version for v in self._views), self._param_epoch, self._flat.data_ptr())
 
     def parameters_changed(self, refresh=False):
         """Tells the model that something outside torch's view wrote the parameters (a native optimizer kernel, a graph replay,
@@ -450,8 +453,19 @@ class TGN(nn.Module):
         c.gru_applied = self._gru_applied_now
         return c
 
+    def _torch_versions(self):
+        return (self._flat._version, sum(v[0]._version for v in self._views))
+
     def _native_forward(self, call, out=None):
         _lib.require_gpu(self.device)
+        # torch wrote the parameters on the caller's stream since the last native forward (p.copy_(), a torch optimizer ...):
+        # that write is ordered against nothing the library left on its side stream, and the forward would not fork from
+        # the caller's stream while a deferred step is pending there - join first (a no-op when nothing is pending)
+        tv = self._torch_versions()
+        if tv != getattr(self, "_seen_versions", None):
+            self._seen_versions = tv
+            if not torch.cuda.is_current_stream_capturing():
+                self.join()
         st = self._state_struct()
         emb = out if out is not None else torch.empty((call.R, self.n_node_features), dtype=torch.float32, device=self.device)
         _lib.call("pfo_tgn_forward", ctypes.byref(call.cfg), ctypes.byref(st), ctypes.byref(call.batch_struct),
@@ -514,6 +528,14 @@ class TGN(nn.Module):
     def state_dict(self, *args, **kwargs):
         self.join()
         return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        # the copy runs on the caller's stream: it must not race a side-stream optimizer step, and the next forward must not
+        # skip its fork (the parameters were written on THIS stream)
+        self.join()
+        out = super().load_state_dict(*args, **kwargs)
+        self.parameters_changed()
+        return out
 
     def _native_backward(self, call, d_emb, mean=None, defer_join=False):
         """``mean`` = (src f32[n], out f32[1]): a mean the backward takes on its side stream (the BPR loss value)."""

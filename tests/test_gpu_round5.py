@@ -1,0 +1,236 @@
+"""Round-5 GPU tests: C1 at its exact workload (incl. the HIP-graph replay the bench prefers there), the parameter cache after
+a real device move, the side-stream join seen from several streams, the member staging of the layer-1
+attention backward at ragged shapes."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")]
+
+if has_gpu():
+    import pfotgnrec_amd as P
+    from pfotgnrec_amd import _lib
+    DEV = torch.device("cuda:0")
+
+RTOL_EMB = 1e-4            # north_star: embeddings within 1e-4 relative
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# ------------------------------------------------------------------ C1 at its exact size
+def test_c1_exact_workload_three_steps_against_oracle_and_graph_replay():
+    """BASELINE.json configs[0]: 1 k users x 100 items, 10 k edges, TGN 1 layer, K = 10, D = 32, 2 heads, batch 128 - the
+    reference's own CPU-runnable case, which bench.py --config C1 times through a captured HIP graph.  Three training steps
+    on the HIP path against the oracle (embeddings 1e-4, loss 1e-5, parameters after Adam), then the same three batches again
+    through GraphedTrainStep: the replayed step must land on the eager step's parameters and memory."""
+    from pfotgnrec_amd.synthetic import CONFIGS, make_graph
+    from pfotgnrec_amd.rand_edge_sampler import item_availability, DeviceNegativeSampler
+    from oracle import tgn_oracle as T
+    from oracle.neighbor_finder import OracleNeighborFinder, build_adjacency
+    cfg = CONFIGS["C1"]
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    B, q, K = cfg.batch, 3, cfg.n_neighbors
+    assert (cfg.n_users, cfg.n_items, cfg.n_edges, cfg.dim, cfg.n_layers, K, B) == (1000, 100, 10000, 32, 1, 10, 128)
+    start = cfg.n_edges // 2
+
+    def build():
+        torch.manual_seed(5)
+        tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=1, n_heads=2, dropout=0.0,
+                    use_memory=True, memory_dimension=32, message_function="identity", n_neighbors=K)
+        return tgn, P.FusedAdam(tgn, lr=1e-3)
+
+    # --- eager steps against the oracle
+    tgn, opt = build()
+    onf = OracleNeighborFinder(*build_adjacency(d.sources, d.destinations, d.edge_idxs, d.timestamps))
+    params = {k: v.detach().cpu().numpy() for k, v in tgn.state_dict().items() if "layer_norm" not in k and not k.startswith("memory.")}
+    ref = T.OracleTGN(onf, g.node_features, g.edge_features, params, 1, 2, use_memory=True)
+    rs = np.random.RandomState(3)
+    for step in range(3):
+        s = start + step * B
+        sb, db, tb, eb = d.sources[s:s + B], d.destinations[s:s + B], d.timestamps[s:s + B], d.edge_idxs[s:s + B]
+        neg = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * q)
+        ref.P = {k: v.detach().cpu().numpy() for k, v in tgn.state_dict().items() if k in ref.P}
+        tgn.train()
+        opt.zero_grad()
+        emb = torch.cat(tgn.compute_temporal_embeddings(sb, db, neg, tb, eb, K))
+        rse, rde, rne = ref.compute_temporal_embeddings(sb, db, neg, tb, eb, K)
+        assert relerr(emb.detach().cpu().numpy(), np.concatenate([rse, rde, rne])) < RTOL_EMB
+        loss = P.bpr_loss(emb, B, q)
+        rloss, _ = T.bpr_loss(rse, rde.reshape(B, 1, -1), rne.reshape(B, q, -1))
+        assert abs(float(loss) - float(rloss)) < 1e-5
+        loss.backward()
+        opt.step()
+    eager_params = tgn.flat_parameters.detach().clone()
+    eager_mem = tgn.memory.memory.detach().clone()
+
+    # --- the same three batches, device-side negatives, eager vs graph replay (bench.py --config C1 --graph on)
+    def run(graphed):
+        tgn, opt = build()
+        tgn.deterministic = True                                  # run-to-run reproducible sums: eager and replay must agree to the bit
+        sampler = DeviceNegativeSampler(item_availability(d.destinations, g.upper_u, cfg.n_items), g.upper_u, DEV, seed=1)
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(DEV)
+        src, dst, ts, eidx = t(d.sources, np.int32), t(d.destinations, np.int32), t(d.timestamps, np.float64), t(d.edge_idxs, np.int32)
+        pidx, plen = t(g.portfolio_idx, np.int32), t(g.portfolio_len, np.int32)
+        tgn.train()
+        gs = P.GraphedTrainStep(tgn, opt, sampler, B, K, n_neg=q, port_width=pidx.shape[1])
+        batch = lambda i: tuple(x[start + i * B:start + (i + 1) * B] for x in (src, dst, ts, eidx, pidx, plen)) + (None,)
+        if graphed:
+            gs.capture(*batch(0), warmup=3)                       # three REAL training steps on batch 0, then the capture
+        else:
+            for _ in range(3):
+                gs.eager(*batch(0))
+            gs._fold_steps()
+        losses = []
+        for i in range(3):
+            losses.append(float((gs if graphed else gs.eager)(*batch(i))))
+        tgn.join()
+        torch.cuda.synchronize()
+        return losses, tgn.flat_parameters.detach().clone(), tgn.memory.memory.detach().clone()
+
+    le, pe, me = run(False)
+    lg, pg, mg = run(True)
+    assert le == lg, (le, lg)
+    assert torch.equal(pg, pe) and torch.equal(mg, me)
+    assert torch.isfinite(eager_params).all() and torch.isfinite(eager_mem).all()
+
+
+# ------------------------------------------------------------------ parameter cache after a real move (tgn.py:335)
+@pytest.mark.parametrize("opt_kind", ["torch", "fused"])
+def test_parameter_cache_follows_the_parameters_after_a_device_move(opt_kind):
+    """A model built on the CPU and moved with .to('cuda') keeps nn.Parameters whose version counters are no longer the flat
+    buffer's: torch.optim.Adam.step / load_state_dict then bump counters the cache key never saw, and the forward kept using
+    the stale composite weights.  The key now sums every parameter's own counter: four steps + a reload give the same
+    embeddings as the per-step rebuild (PFO_PCACHE off)."""
+    from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+    cfg = SyntheticConfig("mv", 300, 25, 6000, 64, 2, 8, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    B, q, K = 64, 3, 8
+    rs = np.random.RandomState(4)
+    starts = [3000 + B * i for i in range(4)]
+    negs = [rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * q) for _ in starts]
+
+    def run(cache):
+        torch.manual_seed(77)
+        tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, torch.device("cpu"), n_layers=2, n_heads=2,
+                    dropout=0.0, use_memory=True, memory_dimension=64, message_function="identity", n_neighbors=K)
+        tgn = tgn.to(DEV)
+        tgn.param_cache = cache
+        tgn.deterministic = True
+        opt = torch.optim.Adam(tgn.parameters(), lr=1e-2) if opt_kind == "torch" else P.FusedAdam(tgn, lr=1e-2)
+        out, saved = [], None
+        for i, (s, neg) in enumerate(zip(starts, negs)):
+            tgn.train()
+            emb = torch.cat(tgn.compute_temporal_embeddings(d.sources[s:s + B], d.destinations[s:s + B], neg, d.timestamps[s:s + B],
+                                                            d.edge_idxs[s:s + B], K))
+            P.bpr_loss(emb, B, q).backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            out.append(emb.detach().clone())
+            if i == 0:
+                saved = {k: v.clone() for k, v in tgn.state_dict().items()}
+            if i == 2:
+                tgn.load_state_dict(saved)
+        torch.cuda.synchronize()
+        return out
+
+    base, got = run(False), run(True)
+    for i, (x, y) in enumerate(zip(base, got)):
+        assert torch.equal(x, y), "step %d: stale parameter cache" % i
+    assert not torch.equal(base[0], base[1])                     # (lr 1e-2: the steps really move the embeddings)
+
+
+# ------------------------------------------------------------------ side-stream join, several joiners (tgn.hip:374)
+def test_join_still_waits_after_another_stream_joined_first():
+    """bpr_step(optimizer=...) leaves the backward's end and the Adam kernel on the library's side stream.  A prepare call on the
+    prefetch stream joins it too; that used to clear ONE flag, after which tgn.join() / state_dict() on the caller's stream
+    were no-ops while the side stream was still writing.  With per-stream generations every stream waits once per deferred
+    step: the parameters read behind join() equal the serial run's, bitwise, with a prefetch in between."""
+    from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+    cfg = SyntheticConfig("jn", 300, 25, 7000, 64, 2, 8, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    B, q, K = 64, 3, 8
+    rs = np.random.RandomState(9)
+    starts = [3000 + B * i for i in range(5)]
+    negs = [rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * q) for _ in starts]
+
+    def run(fused):
+        torch.manual_seed(13)
+        tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=2, dropout=0.0,
+                    use_memory=True, memory_dimension=64, message_function="identity", n_neighbors=K)
+        tgn.deterministic = True
+        opt = P.FusedAdam(tgn, lr=1e-3)
+        dev = lambda a, t: tgn._to_dev(a, t)
+        reads = []
+        for i, (s, neg) in enumerate(zip(starts, negs)):
+            tgn.train()
+            args = lambda s_, n_: (dev(d.sources[s_:s_ + B], np.int32), dev(d.destinations[s_:s_ + B], np.int32), [dev(n_, np.int32)], [q],
+                                   dev(d.timestamps[s_:s_ + B], np.float64), dev(d.edge_idxs[s_:s_ + B], np.int32), K)
+            emb, b = tgn.embed_device(*args(s, neg))
+            if fused:
+                P.bpr_step(tgn, emb, b, q, optimizer=opt)
+                if i + 1 < len(starts):
+                    with tgn.prefetching():                       # another stream joins the deferred step first
+                        tgn.prefetch(*args(starts[i + 1], negs[i + 1]))
+                tgn.join()                                        # ... and the caller's stream must still wait
+                reads.append(tgn.flat_parameters.detach().clone())
+            else:
+                P.bpr_step(tgn, emb, b, q)
+                opt.step()
+                reads.append(tgn.flat_parameters.detach().clone())
+            opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        return reads
+
+    for x, y in zip(run(False), run(True)):
+        assert torch.equal(x, y)
+
+
+# ------------------------------------------------------------------ member staging of the layer-1 attention backward
+@pytest.mark.parametrize("D,H,K,B", [(172, 2, 20, 96), (32, 2, 10, 37), (64, 4, 5, 50), (100, 1, 3, 20), (172, 2, 1, 33)])
+def test_layer1_attention_backward_staging_at_ragged_shapes(D, H, K, B):
+    """The run-merged layer-1 backward stages each member's rows (d ctx', ctx', query row) and per-slot metadata through LDS
+    by LDS-DMA, RUN_CPW chunks per wavefront.  Shapes whose rows are not a multiple of the 1 KB DMA pieces, one neighbour, odd
+    member counts and a memory-backed two-layer step: the float-atomic launch and the deterministic launch (its own template
+    instance, fixed-point sums, one slab row per chunk) must agree to summation-order noise, embeddings bitwise.  (Oracle
+    parity of the same kernel at these and other shapes: test_gpu_tgn_step.py, test_gpu_full_size.py.)"""
+    from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+    cfg = SyntheticConfig("stg", 150, 20, 4000, D, 2, K, H)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    q, s = 3, 2500
+    neg = np.random.RandomState(1).randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * q)
+
+    def grads(det):
+        torch.manual_seed(3)
+        tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=H, dropout=0.0,
+                    use_memory=True, memory_dimension=D, message_function="identity", n_neighbors=K)
+        tgn.deterministic = det
+        # two warm-up steps so that memory and pending messages are populated
+        for w in range(2):
+            s0 = s - (2 - w) * B
+            tgn.train()
+            e = torch.cat(tgn.compute_temporal_embeddings(d.sources[s0:s0 + B], d.destinations[s0:s0 + B], neg, d.timestamps[s0:s0 + B],
+                                                          d.edge_idxs[s0:s0 + B], K))
+            P.bpr_loss(e, B, q).backward()
+            tgn.zero_grad(set_to_none=True)
+            tgn.memory.detach_memory()
+        tgn.train()
+        emb = torch.cat(tgn.compute_temporal_embeddings(d.sources[s:s + B], d.destinations[s:s + B], neg, d.timestamps[s:s + B],
+                                                        d.edge_idxs[s:s + B], K))
+        P.bpr_loss(emb, B, q).backward()
+        torch.cuda.synchronize()
+        return emb.detach().cpu().numpy(), tgn.flat_grad.detach().cpu().numpy().copy()
+
+    e0, g0 = grads(False)
+    e1, g1 = grads(True)
+    assert np.array_equal(e0, e1)
+    assert relerr(g0, g1) < 2e-5, relerr(g0, g1)
+    assert np.isfinite(g0).all() and np.abs(g0).max() > 0
