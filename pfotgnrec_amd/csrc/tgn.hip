@@ -391,6 +391,12 @@ Side& side() {
 // `s` waits for whatever a deferred backward end / side-stream optimizer step left in flight (pfo_tgn_batch.defer_join)
 int side_join(Side& sd, hipStream_t s) {
   if (!sd.pending_for(s)) return PFO_OK;
+  // A capturing stream does not join: a capture starts from a synchronised device (torch.cuda.graph, GraphedTrainStep.capture),
+  // so nothing deferred is still in flight, and the calls below would be captured - by the time a forward joins, the side stream
+  // belongs to the capture (it waited for the fork event), a record on it would turn side_done into a capture-only event and
+  // every later plain wait on it would fail.  (A backward under capture never defers its end: pfo_tgn_backward_ev.)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { sd.mark_joined(s); return PFO_OK; }
   if (sd.recorded_gen != sd.side_gen) {                          // one record per generation, shared by every joiner
     HIPOK(hipEventRecord(sd.side_done, sd.s), "event record failed");
     sd.recorded_gen = sd.side_gen;
@@ -1476,7 +1482,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
                                pfo_attn_bwd_max_parts(), G.tw, ss));                  // cq = Wq[:, D:] cos(b) + bq
   }
   PFO_MARK("@side1.cq.end", ss);
-  if (b->defer_join && chained) {
+  if (b->defer_join && chained && bind_events) {               // (bind_events: not under capture - side_join)
     // the end of the backward stays on the side stream (pfo_tgn_batch.defer_join): it waits for the caller's stream's last
     // launch instead of the other way round - the caller's stream is free for the next batch's neighbour sampling
     if (!main_done_bound) HIPOK(hipEventRecord(sd.main_done, s), "event record failed");
