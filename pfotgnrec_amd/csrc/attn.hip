@@ -24,6 +24,7 @@ struct AttnDev {
   const int32_t* members; const int32_t* seg_ptr; const int32_t* n_rows; const int32_t* run_cnt;
   int det; double* dtime_slab;   // deterministic mode (attn.hpp)
   uint8_t* dqk_live;             // run-merged kernel: [members] 1 = dQK row m holds a sum, 0 = folded into a later row / nothing
+  float* dq_rows; int64_t dq_ld; // run-merged kernel: per-table-row sums of dQK, added to atomically (attn.hpp)
   int xcd_g;    // run-merged backward: G consecutive chunks of members per XCD turn (0 = chunks round-robin over the XCDs)
   int abl;      // timing-only ablation switch (PFO_ATTN_ABL): 1 = spread the atomic destinations (wrong results)
 };
@@ -657,7 +658,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
     // optimiser: hoisted out of the member loop, their per-lane 64-bit element offsets lived across the key walk - a dozen
     // register pairs at a kernel that sits on its register limit, i.e. scratch reloads in front of every store)
     auto acc_store = [&]() {
-      if (acc_m >= 0) {
+      if (acc_m >= 0 && !DET && a.dq_rows) {
+        // added straight into the table row's sum (the members of a row sit in several chunks: float atomics, ~20 k rows of
+        // H Cp floats per launch at C2 beside the ~275 k neighbour rows)
+        char* out = reinterpret_cast<char*>(a.dq_rows + (int64_t)run_slot * a.dq_ld);
+        uint32_t lo = (uint32_t)lane * 4u;
+        asm volatile("" : "+v"(lo));
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            if (lo < (uint32_t)(D - 64 * r) * 4u) {
+              atomicAdd(reinterpret_cast<float*>(out + (uint32_t)(h * Cp + 64 * r) * 4u + lo), dqn[h][r]);
+              atomicAdd(reinterpret_cast<float*>(out + (uint32_t)(h * Cp + D + Ef + 64 * r) * 4u + lo), dqt[h][r]);
+            }
+          }
+          if (lo < (uint32_t)Ef * 4u) atomicAdd(reinterpret_cast<float*>(out + (uint32_t)(h * Cp + D) * 4u + lo), dqe[h]);
+        }
+      } else if (acc_m >= 0) {
         char* out = reinterpret_cast<char*>(a.dQK + (int64_t)acc_m * H * Cp);      // row m, not n: the per-row sums then stream contiguous rows
         uint32_t lo = (uint32_t)lane * 4u;
         asm volatile("" : "+v"(lo));
@@ -784,7 +802,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         run_rows = ((vs >> lane) & 1ull) ? rows_sh : run_rows;
         run_valid |= vs;
       }
-      if (lane == 0) a.dqk_live[m] = 0;                         // (set when this member's position receives a stored sum)
+      if (lane == 0 && (DET || !a.dq_rows)) a.dqk_live[m] = 0;  // (set when this member's position receives a stored sum)
       if (valid == 0ull) {                                       // no neighbour: nothing to add to the row's sums
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (m + 1 < u_end) stage(ch_get(0, m + 1 - u0), ch_get(1, m + 1 - u0));
@@ -996,6 +1014,7 @@ static void to_dev(const PfoAttn& a, AttnDev& d) {
   d.dctx = a.dctx; d.dQK = a.dQK; d.d_nbr = a.d_nbr; d.d_nbr_ld = a.d_nbr_ld; d.d_nbr_rep = a.d_nbr_rep; d.d_nbr_nrep = a.d_nbr_nrep > 0 ? a.d_nbr_nrep : 1;
   d.dtime_part = a.dtime_part;
   d.det = a.det; d.dtime_slab = a.dtime_slab; d.dqk_live = a.dqk_live;
+  d.dq_rows = a.det ? nullptr : a.dq_rows; d.dq_ld = a.dq_ld;
   d.members = a.members; d.seg_ptr = a.seg_ptr; d.n_rows = a.n_rows; d.run_cnt = a.run_cnt;
 }
 
@@ -1096,7 +1115,7 @@ bool pfo_attn_bwd_uses_runs(const PfoAttn& a) {
   const int64_t qk_ld = a.qk_ld > 0 ? a.qk_ld : (int64_t)a.H * a.Cp;
   const bool aligned = (qk_ld % 4) == 0 && (((uintptr_t)a.QK | (uintptr_t)a.dctx | (uintptr_t)a.ctx) & 15u) == 0;
   return a.d_nbr && a.nbr_row && pfo_attn_bwd_runs_possible(a.K, a.D, a.H) && a.members && a.seg_ptr && a.n_rows && a.qk_row && a.run_cnt &&
-         a.dqk_live && aligned;
+         (a.dqk_live || (a.dq_rows && !a.det)) && aligned;
 }
 
 int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {

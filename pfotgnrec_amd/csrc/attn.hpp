@@ -56,6 +56,11 @@ struct PfoAttn {
   // (PFO_DET_SCALE) in a table of d_nbr_ld int64 per row at d_nbr
   int det = 0;
   double* dtime_slab = nullptr;
+  // run-merged kernel, non-deterministic launches: the query-side gradient rows are ADDED to the per-table-row sums directly
+  // (float atomics into dq_rows[qk_row[n] * dq_ld + column], cleared by the caller) instead of being stored per member for
+  // pfo_segsum_launch - that pass and its 94 us on the serial tail of the step disappear.  dQK / dqk_live are then unused.
+  float* dq_rows = nullptr;
+  int64_t dq_ld = 0;
   uint8_t* dqk_live = nullptr;      // run-merged kernel (members given): [members] flags of the dQK rows that hold a sum - consecutive
                                     // members on one table row are summed on chip and stored once (pfo_segsum_launch src0_live)
   // optional (layer 1 over the touched-node table, atomically added rows, most-recent sampling): the instances ordered by

@@ -405,7 +405,8 @@ __global__ __launch_bounds__(256) void segsum_chunk_kernel(const float* __restri
                                                            const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ members,
                                                            const int32_t* __restrict__ seg_of, const int32_t* __restrict__ n_rows,
                                                            int src0_by_position, const uint8_t* __restrict__ src0_live,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, int64_t out_ld) {
+  // (out_ld: row stride of `out` in floats - the sums may be a column block of wider rows; W1 = 0: one source only)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int V0 = W0 >> 2, V = (W0 + W1) >> 2;
   const int nr = *n_rows;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256) void segsum_chunk_kernel(const float* __restri
   const int M = seg_ptr[nr];
   for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nr; s += gridDim.x * blockDim.x) {
     if (seg_ptr[s] == seg_ptr[s + 1]) {
-      float4* o = reinterpret_cast<float4*>(out + (int64_t)s * (W0 + W1));
+      float4* o = reinterpret_cast<float4*>(out + (int64_t)s * out_ld);
       for (int c = 0; c < V; ++c) o[c] = zero;
     }
   }
@@ -431,8 +432,8 @@ __global__ __launch_bounds__(256) void segsum_chunk_kernel(const float* __restri
   for (int v0 = 0; v0 < V; v0 += 256) {
     const int c = v0 + wave * 64 + lane;
     const bool in0 = c < V0, in1 = c >= V0 && c < V;
-    float4* const orow = reinterpret_cast<float4*>(out + (int64_t)s_first * (W0 + W1)) + c;
-    const int64_t ostep = (W0 + W1) >> 2;
+    float4* const orow = reinterpret_cast<float4*>(out + (int64_t)s_first * out_ld) + c;
+    const int64_t ostep = out_ld >> 2;
     int seg = 0;
     int seg_end = __builtin_amdgcn_readlane(my_ptr, 1);
     float4 acc = zero;
@@ -489,7 +490,7 @@ int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, cons
   if (vec && seg_of && cap_members > 0 && chunked) {
     const int nbm = (int)pfo_ceil_div(cap_members, SEGSUM_CHUNK);
     PFO_KLAUNCH(segsum_chunk_kernel, dim3(nbm), dim3(256), 0, stream, src0, W0, src1, W1, seg_ptr, members, seg_of, n_rows,
-                src0_by_position, src0_live, out);
+                src0_by_position, src0_live, out, (int64_t)(W0 + W1));
     PFO_LAUNCH_CHECK();
     return PFO_OK;
   }
@@ -498,6 +499,19 @@ int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, cons
                               src0_by_position, src0_live, out);
   else PFO_KLAUNCH(segsum_kernel, dim3(nb), dim3(256), 0, stream, src0, W0, src1, W1, seg_ptr, members, n_rows,
                           src0_by_position, src0_live, out);
+  PFO_LAUNCH_CHECK();
+  return PFO_OK;
+}
+
+// One source, the sums written as a column block of wider rows: out[s * out_ld + 0 .. W) = sum of src[members of s] (layer-1
+// backward: the d h1 half of Dq, taken beside the attention backward whose float atomics fill the d qk' half - attn.hpp dq_rows)
+int pfo_segsum_cols_launch(const float* src, int W, const int32_t* seg_ptr, const int32_t* members, const int32_t* seg_of,
+                           int64_t cap_members, const int32_t* n_rows, float* out, int64_t out_ld, hipStream_t stream) {
+  PFO_REQUIRE(src && seg_ptr && members && seg_of && n_rows && out && W > 0 && cap_members > 0, "bad arguments");
+  PFO_REQUIRE((W & 3) == 0 && (out_ld & 3) == 0 && ((((uintptr_t)src) | ((uintptr_t)out)) & 15) == 0, "rows must be float4-aligned");
+  const int nbm = (int)pfo_ceil_div(cap_members, SEGSUM_CHUNK);
+  PFO_KLAUNCH(segsum_chunk_kernel, dim3(nbm), dim3(256), 0, stream, src, W, (const float*)nullptr, 0, seg_ptr, members, seg_of, n_rows,
+              0, (const uint8_t*)nullptr, out, out_ld);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

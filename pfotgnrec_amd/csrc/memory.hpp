@@ -46,6 +46,8 @@ int64_t pfo_seg_of_ints(int64_t n_members);
 int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, const int32_t* seg_ptr, const int32_t* members,
                       const int32_t* seg_of, int64_t cap_members, const int32_t* n_rows, int cap_rows, int src0_by_position,
                       const uint8_t* src0_live, float* out, hipStream_t stream);
+int pfo_segsum_cols_launch(const float* src, int W, const int32_t* seg_ptr, const int32_t* members, const int32_t* seg_of,
+                           int64_t cap_members, const int32_t* n_rows, float* out, int64_t out_ld, hipStream_t stream);
 // (src0_live: optional byte flags per position; rows flagged 0 are not read)
 int pfo_zero_rows_launch(float* dst, const int32_t* n_rows, int cap_rows, int D, int n_rep, int64_t rep_stride, hipStream_t stream);
 

@@ -347,7 +347,7 @@ struct Side {
     for (int i = 1; i < 8; ++i) joined[i - 1] = joined[i];       // more streams than slots: the oldest entry goes (it will wait again)
     joined[7].s = s; joined[7].gen = side_gen;
   }
-  hipEvent_t fork = nullptr, done = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr, fold_done = nullptr;
+  hipEvent_t fork = nullptr, done = nullptr, seg_done = nullptr, tn_a = nullptr, tn_b = nullptr, fold_done = nullptr, dh1_sum = nullptr;
   hipEvent_t layer[PFO_MAX_LAYERS + 1] = {};
   bool ok = false;
 };
@@ -376,6 +376,7 @@ Side& side() {
     good = good && hipEventCreateWithFlags(&sd.tn_a, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.tn_b, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.fold_done, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.dh1_sum, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.gru_done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.comp_done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.pc_a, hipEventDisableTiming) == hipSuccess;
@@ -487,6 +488,17 @@ static int grad_replicas(const pfo_tgn_config* c, const pfo_tgn_batch* b) {
   const int det = b->deterministic ? 1 : 0;
   return (det || (c->use_memory && !b->uniform && pfo_attn_bwd_runs_possible(b->K, c->D, c->n_heads))) ? 1 : PFO_GRAD_REPLICAS;
 }
+// Layer-1 backward, run-merged attention kernel, non-deterministic calls (PFO_DQ_ATOMIC=1): the attention kernel adds the
+// query-side gradient rows straight into the per-table-row sums Dq[:, :H Cp] (float atomics, attn.hpp dq_rows) and the d h1
+// half Dq[:, H Cp:] is summed on the side stream beside it - no segment-sum pass on the serial tail.  OFF by default: measured
+// at C2 (round 5, one box, interleaved) 1.382 / 1.392 ms per step against 1.302 / 1.303 - the ~20 k extra rows of atomics
+// cost the attention kernel 36 us (270 -> 306 alone), and the table-row contraction that now follows it directly runs
+// beside the tail of the instance weight-gradient launch (114 us instead of 49) where the HBM-bound segment sum used to
+// overlap with it for free: this phase is bound by the chip's total work, not by the order of its launches.
+static bool dq_atomic_mode(const pfo_tgn_config* c, const pfo_tgn_batch* b) {
+  static const int on = getenv("PFO_DQ_ATOMIC") ? atoi(getenv("PFO_DQ_ATOMIC")) : 0;          // A/B switch
+  return on && c->use_memory && !b->uniform && !b->deterministic && pfo_attn_bwd_runs_possible(b->K, c->D, c->n_heads);
+}
 // What the backward's layer-1 kernels need and that depends on the sampled levels alone: the cleared level-0 gradient rows and
 // the layer-1 instances grouped by the touched-table row they sit on.  Queued by the backward on its side stream - or, for
 // calls with pfo_tgn_batch.seg_in_forward, by the forward on ITS side stream (beside layer 1, joined by the event layer 2 waits
@@ -497,6 +509,7 @@ static int seg_prologue(const pfo_tgn_config* c, const pfo_tgn_batch* b, const W
   const int64_t rep_stride = (int64_t)d.capP * d.D;
   // (deterministic: the table holds int64 fixed-point sums - rows of 2 D floats' worth)
   if (c->use_memory) RUN(pfo_zero_rows_launch(w.d_h0, w.n_core, capP, det ? 2 * d.D : d.D, grad_replicas(c, b), rep_stride, ss));
+  if (dq_atomic_mode(c, b)) RUN(pfo_zero_rows_launch(w.Dq, w.n_core, capP, d.H * d.Cp + d.D, 1, 0, ss));   // the row sums the attention backward adds into
   RUN(pfo_seg_build_launch(w.idx0, w.nodes[0], (int)n[1], capP, b->uniform ? nullptr : w.cnt1, w.seg_ptr, w.seg_cur,
                            w.seg_tmp, w.seg_mem, w.seg_of, w.seg_scratch, ss));
   return PFO_OK;
@@ -1136,10 +1149,18 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     // 1.4532 ms over four interleaved pairs.  (Behind the attention backward, beside the serial tail: +2 % per step.)
     static const int tna_mode = getenv("PFO_TNA_MODE") ? atoi(getenv("PFO_TNA_MODE")) : 0;   // A/B: 0 fork behind the d ctx' contraction (beside the attention backward), 2 beside d ctx', 1 main stream
     bool tn_a_bound = false;                                   // tn_a already rides on the d ctx' launch
+    const bool dq_atomic = l == 1 && dq_atomic_mode(c, b);
+    bool dh1_summed = false;
     auto tn_a_side = [&]() -> int {
       if (!tn_a_bound) HIPOK(hipEventRecord(sd.tn_a, s), "event record failed");
       HIPOK(hipStreamWaitEvent(ss, sd.tn_a, 0), "event wait failed");
       RUN(side_mean_once());
+      if (dq_atomic && l == 1) {
+        // the d h1 half of the per-row sums, here beside the attention backward (whose atomics fill the other half)
+        RUN(pfo_segsum_cols_launch(dh1, D, w.seg_ptr, w.seg_mem, w.seg_of, n[1], w.n_core, w.Dq + HCp, WQ, ss));
+        HIPOK(hipEventRecord(sd.dh1_sum, ss), "event record failed");
+        dh1_summed = true;
+      }
       PFO_MARK("@side1.tn_a.begin", ss);
       RUN(pfo_gemm_tn_group_launch(tn, n_tn_a, N, nullptr, w.slabs2, w.slab_floats, ss));
       PFO_MARK("@side1.tn_a.end", ss);
@@ -1197,8 +1218,17 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       // key-side gradients of instances with identical neighbour lists leave as one set of atomics (attn.hip)
       a.members = w.seg_mem; a.seg_ptr = w.seg_ptr; a.n_rows = w.n_core; a.run_cnt = w.cnt1; a.dqk_live = w.dqk_live;
     }
+    if (dq_atomic) { a.dq_rows = w.Dq; a.dq_ld = WQ; }
     const int dqk_by_member = pfo_attn_bwd_uses_runs(a) ? 1 : 0;
+    const bool dq_added = dq_atomic && dqk_by_member;         // (the alignment test of pfo_attn_bwd_uses_runs may still say no)
+    if (dq_added && !dh1_summed) {
+      // serial forms (bracketed steps, PFO_TNA_MODE): the d h1 half on this stream, in front of the attention backward
+      // (the groups exist: seg_done was awaited above, or the forward built them)
+      RUN(pfo_segsum_cols_launch(dh1, D, w.seg_ptr, w.seg_mem, w.seg_of, n[1], w.n_core, w.Dq + HCp, WQ, s));
+    }
+    if (dq_added && bind_events) pfo_stop_event_arm(sd.tn_b, 0);   // tn_b rides on the attention launch (no segment sum behind it)
     RUN(pfo_attn_bwd_launch(a, &n_parts, s));
+    if (dq_added && bind_events) pfo_stop_event_disarm(s);
     PFO_MARK(mk_battn[l], s);
     if (l == 1 && b->mid_event && b->mid_event_late) HIPOK(hipEventRecord((hipEvent_t)b->mid_event, s), "event record failed");
     if (det) det_rows += n_parts;
@@ -1211,13 +1241,19 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       // weight gradients against x - is taken AFTER summing those gradients per table row: contractions over the
       // ~11 k touched rows instead of the ~54 k instances.
       if (!c->use_memory) HIPOK(hipStreamWaitEvent(s, sd.seg_done, 0), "event wait failed");   // (with memory: awaited before the attention backward)
+      if (dq_added) {
+        // Dq is complete when the attention launch and the side stream's d h1 sum are (the latter fired long ago)
+        if (!bind_events) HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
+        if (dh1_summed) HIPOK(hipStreamWaitEvent(s, sd.dh1_sum, 0), "event wait failed");
+      } else {
       if (bind_events) pfo_stop_event_arm(sd.tn_b, 0);
       RUN(pfo_segsum_launch(dqk_l, HCp, dh1, D, w.seg_ptr, w.seg_mem, w.seg_of, n[1], w.n_core, capP, dqk_by_member,
                             dqk_by_member ? w.dqk_live : nullptr, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
-      PFO_MARK("bwd.L1.segsum", s);
       // the weight gradients over the table rows go to the side stream too (beside d h0 / the GRU backward on this one)
       if (bind_events) pfo_stop_event_disarm(s);
       else HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
+      }
+      PFO_MARK("bwd.L1.segsum", s);
       HIPOK(hipStreamWaitEvent(ss, sd.tn_b, 0), "event wait failed");
       RUN(side_mean_once());
       PfoTnProblem tb[2];
