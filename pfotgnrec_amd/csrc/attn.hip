@@ -540,14 +540,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
   extern __shared__ __align__(16) unsigned char s_stage[];
   const int lane = threadIdx.x;
   const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef, Cp = a.Cp;
+  // Two chains of dependent loads open a wavefront's life: (A) *n_rows -> seg_ptr[.] = the members' count M, (B) the
+  // wavefront's member ids -> their query rows / history counts.  (B) is issued speculatively - clamped indices, no dependence
+  // on M - so the two chains overlap instead of queueing (a wavefront lives ~35 us: every round trip is 3-4 % of it).
+  constexpr int UM = RUN_CPW * RUN_CHUNK;                          // members per wavefront
+  const int G8 = 8 * a.xcd_g;
+  auto unit_of = [&](int blk) {
+    if (G8 <= 0) return blk;
+    const int grp = blk / G8, r = blk - grp * G8;
+    return grp * G8 + (r & 7) * a.xcd_g + (r >> 3);
+  };
+  auto spec_member = [&](int unit) { return a.members[min(unit * UM + min(lane, UM - 1), a.N - 1)]; };
+  int sp_raw = spec_member(unit_of((int)blockIdx.x));
+  const int nr_rows = *a.n_rows;
   float wmax = 0.f, bmax = 0.f;
+  {
+    // (clamped addresses, not predicated loads: the six loads leave together - predicated, each 64-column group waited for
+    // its own round trip at the head of every wavefront's life)
+    float wv[NR], bv[NR];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const int c = lane + 64 * r;
-    const float w = c < D ? a.tw[c] : 0.f, b = c < D ? a.tb[c] : 0.f;
-    s_tw[c] = w; s_tb[c] = b;
-    wmax = fmaxf(wmax, fabsf(w)); bmax = fmaxf(bmax, fabsf(b));
+    for (int r = 0; r < NR; ++r) { const int cc = min(lane + 64 * r, D - 1); wv[r] = a.tw[cc]; bv[r] = a.tb[cc]; }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int c = lane + 64 * r;
+      const float w = c < D ? wv[r] : 0.f, b = c < D ? bv[r] : 0.f;
+      s_tw[c] = w; s_tb[c] = b;
+      wmax = fmaxf(wmax, fabsf(w)); bmax = fmaxf(bmax, fabsf(b));
+    }
   }
+  sp_raw = min(max(sp_raw, 0), a.N - 1);                           // (behind the members' count the list holds anything)
+  int sp_slot = a.qk_row[sp_raw], sp_cnt = a.run_cnt[sp_raw];
+  const int M = a.seg_ptr[nr_rows];                                // members = instances that sit on a real node
+  const int n_chunks = (M + RUN_CHUNK - 1) / RUN_CHUNK;
   wmax = pfo_wave_max(wmax); bmax = pfo_wave_max(bmax);
   // clamped column of this lane in each 64-column group, and the edge column
   int colr[NR];
@@ -556,8 +580,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
   const int cole = min(lane, max(Ef, 1) - 1);
   const float keep_scale = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
   float* const d_nbr_x = a.d_nbr + (int64_t)(__builtin_amdgcn_s_getreg(6164) & (a.d_nbr_nrep - 1)) * a.d_nbr_rep;
-  const int M = a.seg_ptr[*a.n_rows];                            // members = instances that sit on a real node
-  const int n_chunks = (M + RUN_CHUNK - 1) / RUN_CHUNK;
   const uint64_t rng_off = a.offset + (a.offset_dev ? *a.offset_dev : 0ull);
   const float* const nbr_tab = a.nbr_tab;
   const float* const edge_feat = a.edge_feat;
@@ -606,28 +628,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
   // the rows its atomics land on stay in ONE L2 instead of being fetched by up to eight.
   // A wavefront takes a UNIT of RUN_CPW consecutive chunks.  The chunk stays the scope of a run (its rows leave at the chunk's
   // end at the latest) and of the time-encoder partial sums; the unit is the scope of the prologue and of the member staging.
-  constexpr int UM = RUN_CPW * RUN_CHUNK;                          // members per wavefront
   const int n_units = (n_chunks + RUN_CPW - 1) / RUN_CPW;
-  const int G8 = 8 * a.xcd_g;
   const int n_walk = G8 > 0 ? (n_units + G8 - 1) / G8 * G8 : n_units;
   for (int blk = blockIdx.x; blk < n_walk; blk += gridDim.x) {
-    int unit = blk;
-    if (G8 > 0) {
-      const int grp = blk / G8, r = blk - grp * G8;
-      unit = grp * G8 + (r & 7) * a.xcd_g + (r >> 3);
-      if (unit >= n_units) continue;
+    const int unit = unit_of(blk);
+    if (blk != (int)blockIdx.x) {                                  // (a capped grid only: later units load their prologue here)
+      sp_raw = min(max(spec_member(unit), 0), a.N - 1);
+      sp_slot = a.qk_row[sp_raw]; sp_cnt = a.run_cnt[sp_raw];
     }
-    // prologue: the members' instance ids, query rows and history counts, one lane per member (two dependent loads per
-    // WAVEFRONT; the member list is read at a clamped index, so the load does not wait for the members' count), and the first
-    // member's rows on their way
+    if (unit >= n_units) continue;
+    // prologue: the members' instance ids, query rows and history counts, one lane per member, and the first member's rows
+    // on their way
     const int u0 = unit * UM;
     const int u_end = min(M, u0 + UM);
     {
       const bool ch_on = lane < UM && u0 + lane < u_end;
-      const int ch_raw = a.members[min(u0 + min(lane, UM - 1), a.N - 1)];
-      const int ch_n = ch_on ? ch_raw : 0;
-      const int ch_slot = ch_on ? a.qk_row[ch_n] : -1;
-      const int ch_cnt = ch_on ? a.run_cnt[ch_n] : 0;
+      const int ch_n = ch_on ? sp_raw : 0;
+      const int ch_slot = ch_on ? sp_slot : -1;
+      const int ch_cnt = ch_on ? sp_cnt : 0;
       if (lane < UM) { s_ch[0][lane] = ch_n; s_ch[1][lane] = ch_slot; s_ch[2][lane] = ch_cnt; }   // (one wavefront: no barrier)
       if (u0 < u_end) stage(rl_i(ch_n, 0), rl_i(ch_slot, 0));
     }
