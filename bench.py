@@ -86,6 +86,9 @@ def parse():
                     help="ONE process, no collective: time rank 0's share of the step (its shard's roots + the global state "
                          "update) for each listed world size, e.g. 1,2,4,8 - the compute-side ceiling of the scaling curve, "
                          "measurable on one GPU.  Prints one JSON line with a per-world-size table")
+    ap.add_argument("--emulate-sleep", type=int, default=1, choices=[0, 1],
+                    help="--emulate-ranks: 1 (default) the stub collective spins on the side stream for the predicted ring all-reduce "
+                         "time of the flat gradient over xGMI (predicted_ring_allreduce_us); 0 it returns at once")
     ap.add_argument("--deterministic", action="store_true",
                     help="bitwise run-to-run reproducible backward (fixed-point level-0 gradient rows, slab-folded time partials)")
     ap.add_argument("--launcher-selftest", action="store_true",
@@ -97,6 +100,8 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=512, help="interactions per oracle step in the CPU baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=4, help="timed oracle steps (one more runs first, untimed)")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event bracketing of kernel launches")
+    ap.add_argument("--no-drop-in", action="store_true",
+                    help="one GPU: skip secondary.drop_in_surface (the literal main.py:160-394 loop on the drop-in classes, ~1 s per optimizer)")
     ap.add_argument("--overlap-tail", type=int, default=1, choices=[0, 1],
                     help="1 (default, one rank): backward + optimizer step as ONE fused call whose end - the last side-stream launches "
                          "of the backward and the Adam kernel - stays on the library's side stream while the caller's stream goes on to "
@@ -117,38 +122,107 @@ def parse():
     return ap.parse_args()
 
 
-VALU_ISSUE_PEAK_GINST = 1024 * 2.4 / 4   # 256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles at 2.4 GHz: 614.4 G wave-instructions/s
+# 256 CUs x 4 SIMD-32, one wave64 vector instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md:54,473) = 1 228.8 G
+# wave-instructions/s.  Measured on this pool: tools/probes/mfma4x4_probe.hip, independent v_fma_f32 at four wavefronts per SIMD
+# = 1.96 cycles per instruction per SIMD (profiles/r5_probe_mfma4x4.txt); a single wavefront issues one per ~7 cycles.
+VALU_ISSUE_PEAK_GINST = 1024 * 2.4 / 2
 
-# family (one PFO_PROF_* kind = one kernel, every launch of it) -> the kernel's name in the rocprofv3 summaries of profiles/
-PMC_KERNEL = {"gemm_bx": "void gemm_bx_areg_kernel<1>", "gemm_tn_bx": "void gemm_tn_group_bx_kernel<1>",
-              "gru_fused": "void gru_fused_kernel<1>",
-              "gemm_bx_skinny": "void gemm_bx_skinny_kernel<4, 1>",
-              "gemm_nt": "void gemm_f32_kernel<false, false, 0, true>",
-              "gemm_nn": "void gemm_f32_kernel<false, true, 0, true>",
-              "gemm_tn": "void gemm_tn_group_kernel<true>",
-              "attn_fwd": "void attn_fwd_kernel<3, 2>", "attn_bwd": "void attn_bwd_kernel_direct<3, 2>",
-              "attn_bwd_runs": "void attn_bwd_runs_kernel<3, 2, false>"}
+# family (one PFO_PROF_* kind) -> the kernel(s) of that kind as named in the rocprofv3 summaries of profiles/ (template
+# arguments differ between configurations: matched by the name in front of them)
+FAMILY_KERNEL = {"gemm_bx": "gemm_bx_areg_kernel", "gemm_tn_bx": "gemm_tn_group_bx_kernel", "gru_fused": "gru_fused_kernel",
+                 "gemm_bx_skinny": "gemm_bx_skinny_kernel", "gemm_nt": "gemm_f32_kernel", "gemm_nn": "gemm_f32_kernel",
+                 "gemm_devm": "gemm_f32_kernel", "gemm_tn": "gemm_tn_group_kernel", "gemm_multi": "gemm_multi_kernel",
+                 "attn_fwd": "attn_fwd_kernel", "attn_bwd": "attn_bwd_kernel", "attn_bwd_runs": "attn_bwd_runs_kernel",
+                 "sampler": "tnbr_sample_kernel", "segsum": "segsum_chunk_kernel", "tn_reduce": "tn_group_reduce_kernel",
+                 "gru_gates_bwd": "gru_gates_bwd_vec_kernel"}
+WORKLOAD_KEY = [None]      # "C2@512": set by main() - the committed counter passes are keyed by (configuration, batch per GPU)
+
+
+def _kernel_base(name):
+    n = name.split("(")[0].strip()
+    n = n[5:] if n.startswith("void ") else n
+    return n.split("<")[0].split("::")[-1]
+
+
+def _summary_for(key):
+    """The newest committed profile summary of this workload: profiles/r*_summary_<key>.json (tools/profile_round.sh +
+    tools/summarize_profile.py); C2@512 also accepts the unkeyed files of rounds 1-4."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_summary_%s.json" % key)))
+    if not files and key == "C2@512":
+        files = sorted(glob.glob(os.path.join(REPO, "profiles", "r?_summary.json")))
+    return files[-1] if files else None
 
 
 def pmc_counters(family):
-    """Counters per launch of the family's kernel from the newest committed PMC passes (profiles/r*_summary.json: separate
-    --pmc runs; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950; ``sq`` = the SQ instruction counts of the same
-    kernel).  (bytes or None, {counter: value} or {}, file name)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_summary.json")))
-    if not files:
-        return None, {}, None
+    """Counters per launch of the family's kernel(s) from the newest committed PMC passes of THIS workload (separate --pmc
+    runs; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950; ``sq`` = the SQ instruction counts of the same launches).
+    Several template instances of one family are averaged by their launch counts.
+    (bytes or None, {counter: value} or {}, file name, kernel names)."""
+    f = _summary_for(WORKLOAD_KEY[0]) if WORKLOAD_KEY[0] else None
+    if not f:
+        return None, {}, None, []
     try:
-        k = json.load(open(files[-1]))["pmc"]["kernels"].get(PMC_KERNEL.get(family, ""))
-        if not k:
-            return None, {}, os.path.basename(files[-1])
-        return int(k["hbm_bytes_per_launch_corrected"]), dict(k.get("sq", {})), os.path.basename(files[-1])
+        d = json.load(open(f))
+        base = FAMILY_KERNEL.get(family, family)
+        rows = [(k, v) for k, v in d["pmc"]["kernels"].items() if _kernel_base(k) == base]
+        if family == "attn_bwd":
+            rows = [(k, v) for k, v in rows if "runs" not in k]
+        if not rows:
+            return None, {}, os.path.basename(f), []
+        w = [max(1, d.get("kernels", {}).get(k, {}).get("launches", 1)) for k, _ in rows]
+        tot = float(sum(w))
+        hbm = sum(v["hbm_bytes_per_launch_corrected"] * wi for (_, v), wi in zip(rows, w)) / tot
+        sq = {}
+        for c in set().union(*[set(v.get("sq", {})) for _, v in rows]):
+            sq[c] = sum(v.get("sq", {}).get(c, 0.0) * wi for (_, v), wi in zip(rows, w)) / tot
+        return int(hbm), sq, os.path.basename(f), [k for k, _ in rows]
     except Exception:
-        return None, {}, None
+        return None, {}, None, []
 
 
 def pmc_traffic(family):
     return pmc_counters(family)[0]
+
+
+def trace_dominant(prof, n_prof_steps):
+    """The kernel with the largest summed device time in the committed kernel trace of this workload (profiles/
+    r*_kernel_stats_bench_<key>.csv: every launch as the step runs it, co-scheduled launches included), with the family's
+    live algorithmic work over that resident time - the rate the kernel sustains in production, beside the bracketed-alone
+    figures of ``roofline``."""
+    import csv
+    import glob
+    key = WORKLOAD_KEY[0]
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_kernel_stats_bench_%s.csv" % key))) if key else []
+    if not files and key == "C2@512":
+        files = sorted(glob.glob(os.path.join(REPO, "profiles", "r?_kernel_stats_bench_C2.csv")))
+    if not files:
+        return None
+    try:
+        steps = 25
+        sf = _summary_for(key)
+        if sf:
+            steps = int(json.load(open(sf)).get("steps_in_trace", 25))
+        rows = [r for r in csv.DictReader(open(files[-1])) if not r["Name"].startswith("__amd_rocclr")]
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        r = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+        base = _kernel_base(r["Name"])
+        fam = next((k for k, v in FAMILY_KERNEL.items() if v == base and k in prof and prof[k]["count"] > 0), None)
+        out = {"kernel_name": r["Name"].split("(")[0], "launches_per_step": round(int(r["Calls"]) / steps, 2),
+               "avg_launch_us_resident": round(float(r["AverageNs"]) / 1e3, 2),
+               "ms_per_step_resident": round(float(r["TotalDurationNs"]) / steps / 1e6, 4),
+               "share_of_kernel_time": round(float(r["TotalDurationNs"]) / tot, 4), "from": os.path.basename(files[-1])}
+        if fam:
+            v = prof[fam]
+            unit = 1e12 if (fam.startswith("gemm") or fam == "gru_fused") else 1e9
+            work_per_step = v["work"] / max(1, n_prof_steps)
+            out["family"] = fam
+            out["co_scheduled_rate"] = round(work_per_step / (out["ms_per_step_resident"] * 1e-3) / unit, 2)
+            out["co_scheduled_rate_unit"] = "TFLOP/s" if unit == 1e12 else "GB/s"
+            out["alone_rate"] = round(v["work"] / max(1e-12, v["ms"] * 1e-3) / unit, 2)
+        return out
+    except Exception as e:
+        return {"error": repr(e)[:200]}
 
 
 def steady_state_init(tgn, rs):
@@ -287,6 +361,7 @@ class Workload:
         import pfotgnrec_amd as P
         from pfotgnrec_amd.distributed import broadcast_parameters
         from pfotgnrec_amd.synthetic import CONFIGS, make_graph
+        t_build0 = time.perf_counter()
         from pfotgnrec_amd.rand_edge_sampler import item_availability, DeviceNegativeSampler
         self.P, self.torch, self.args, self.dev, self.rank, self.world = P, torch, args, dev, rank, world
         cfg = self.cfg = CONFIGS[cfg_name]
@@ -335,6 +410,8 @@ class Workload:
         self.span = cfg.n_edges - self.start - self.B         # batches wrap inside the second half of the edge list
         assert self.span > 0, "batch larger than the timed half of the graph"
         tgn.train()
+        torch.cuda.synchronize()
+        self.build_s = time.perf_counter() - t_build0          # synthetic graph (host) + device CSR + model + state upload
         # a HIP graph of the whole step for the launch-bound regime (pfotgnrec_amd/graph.py)
         self.gstep, self.graph_note = None, "off"
         want = args.graph == "on" or (args.graph == "auto" and world == 1 and self.B <= 256)
@@ -419,7 +496,12 @@ class Workload:
         fused_opt = self.overlap_tail and (not ranks or fused_coll) and not self.prefetch
         coll = None
         if self.emulate and self.world > 1 and fused_opt and self.allreduce_mode in ("fused", "fused_buckets"):
-            coll = lambda: None                                   # an emulated rank keeps the ranks' step schedule: the collective is a stub
+            # an emulated rank keeps the ranks' step schedule: the collective is a stub that holds the side stream for the
+            # predicted ring time (--emulate-sleep 0: returns at once)
+            if getattr(self, "sleep_coll", None) is None or self.sleep_coll_world != self.world:
+                us = predicted_ring_allreduce_us(tgn.flat_parameters.numel() * 4, self.world) if getattr(self.args, "emulate_sleep", 1) else 0.0
+                self.sleep_coll, self.sleep_coll_world = SleepCollective(us), self.world
+            coll = self.sleep_coll
         if fused_coll:
             def coll():                                           # runs on the library's side stream (bpr_step): bracketed THERE
                 ev = None
@@ -531,16 +613,107 @@ class Workload:
                    "%d/GPU" % self.per_gpu if self.scaling == "weak" else "%d global (fixed), %d shards" % (self.B, self.world)))
 
 
+def drop_in_surface(wl, budget_s=1.0):
+    """Throughput through the LITERAL drop-in surface - what a maintainer gets after the four-import swap of INTEGRATION.md, with
+    the reference's loop otherwise untouched (main.py:160-394, baseline branch): numpy batch slices, ``RandEdgeSampler(...)``
+    constructed per batch (main.py:347-348), ``compute_temporal_embeddings`` on numpy arrays, the BPR loss as the reference's
+    torch expression (main.py:364-381), ``loss.backward()``, ``optimizer.step()``, ``loss.item()`` (main.py:388-390: a device
+    sync per batch), ``detach_memory()`` (main.py:394) - once with torch.optim.Adam (main.py:123), once with the package's
+    FusedAdam.  Wall time per step with the host part itemised (the host cannot run ahead: the loop synchronises twice per batch)."""
+    import torch
+    P, cfg, g, tgn = wl.P, wl.cfg, wl.graph, wl.tgn
+    d = g.data
+    B, K, q = wl.per_gpu, cfg.n_neighbors, 3
+    codes = g.codes
+    n_batches = 64
+    span = (cfg.n_edges - wl.start - B) // B
+    # the reference slices a prebuilt object array of stock-code lists (utils/data.py:18-72): built here for the batches the loop visits
+    port = {}
+    for i in range(n_batches):
+        s = wl.start + (i % span) * B
+        pl = g.portfolio_len[s:s + B]
+        pi = g.portfolio_idx[s:s + B]
+        arr = np.empty(B, dtype=object)
+        for r in range(B):
+            arr[r] = [codes[j] for j in pi[r, :pl[r]]] if pl[r] > 0 else [""]
+        port[i] = arr
+    out = {"workload": wl.describe(), "loop": "main.py:160-394 (baseline branch) on pfotgnrec_amd's drop-in classes, numpy batches"}
+    was_training = tgn.training
+    for name in ("torch.optim.Adam", "FusedAdam"):
+        tgn.join()
+        torch.cuda.synchronize()
+        opt = torch.optim.Adam(tgn.parameters(), lr=wl.args.lr) if name == "torch.optim.Adam" else P.FusedAdam(tgn, lr=wl.args.lr)
+        t_sampler = t_embed = t_loss = t_bwd = t_opt = t_item = 0.0
+        n, i, t_all0 = 0, 0, None
+        while True:
+            if i == 3:                                           # three untimed steps (allocator, caches)
+                torch.cuda.synchronize()
+                t_sampler = t_embed = t_loss = t_bwd = t_opt = t_item = 0.0
+                n, t_all0 = 0, time.perf_counter()
+            s = wl.start + (i % span) * B
+            t0 = time.perf_counter()
+            optimizer = opt
+            optimizer.zero_grad()
+            sources_batch, destinations_batch = d.sources[s:s + B], d.destinations[s:s + B]
+            edge_idxs_batch, timestamps_batch = d.edge_idxs[s:s + B], d.timestamps[s:s + B]
+            portfolios_batch = port[i % n_batches]
+            train_rand_sampler = P.RandEdgeSampler(sources_batch, d.destinations, portfolios_batch, g.upper_u, g.map_item_id)
+            negatives_batch = train_rand_sampler.sample(size=q)
+            t1 = time.perf_counter()
+            tgn = tgn.train()
+            source_embedding, destination_embedding, negative_embedding = tgn.compute_temporal_embeddings(
+                sources_batch, destinations_batch, negatives_batch.flatten(), timestamps_batch, edge_idxs_batch, K)
+            t2 = time.perf_counter()
+            bsbs = source_embedding.shape[0]
+            source_embedding = source_embedding.view(bsbs, 1, -1)
+            destination_embedding = destination_embedding.view(bsbs, 1, -1)
+            negative_embedding = negative_embedding.view(bsbs, q, -1)
+            pos_scores = torch.sum(source_embedding * destination_embedding, dim=2)
+            neg_scores = torch.matmul(source_embedding, negative_embedding.transpose(1, 2)).squeeze()
+            score_diff = pos_scores - neg_scores
+            score_diff_mean = torch.mean(score_diff, dim=1)
+            log_and_sigmoid = torch.log(torch.sigmoid(score_diff_mean))
+            loss = -torch.mean(log_and_sigmoid)
+            t3 = time.perf_counter()
+            loss.backward()
+            t4 = time.perf_counter()
+            optimizer.step()
+            t5 = time.perf_counter()
+            loss_value = loss.item()
+            tgn.memory.detach_memory() if tgn.memory is not None else None
+            t6 = time.perf_counter()
+            t_sampler += t1 - t0; t_embed += t2 - t1; t_loss += t3 - t2; t_bwd += t4 - t3; t_opt += t5 - t4; t_item += t6 - t5
+            n += 1
+            i += 1
+            if t_all0 is not None and time.perf_counter() - t_all0 >= budget_s and n >= 10:
+                break
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t_all0
+        ms = lambda x: round(1e3 * x / n, 4)
+        out[name] = {"value": round(n * B / wall, 1), "unit": "interactions/s", "ms_per_step": ms(wall), "timed_steps": n,
+                     "final_loss": round(float(loss_value), 5),
+                     "host_ms_per_step": {"RandEdgeSampler(...) + sample() [incl. its device sync]": ms(t_sampler),
+                                          "compute_temporal_embeddings [enqueue]": ms(t_embed), "BPR expression [enqueue]": ms(t_loss),
+                                          "loss.backward() [enqueue]": ms(t_bwd), "optimizer.step() [enqueue]": ms(t_opt),
+                                          "loss.item() + detach_memory() [wait for the device]": ms(t_item)}}
+        if isinstance(opt, P.FusedAdam):
+            opt.zero_grad(set_to_none=True)
+    tgn.train(was_training)
+    tgn.join()
+    torch.cuda.synchronize()
+    return out
+
+
 def family_roofline(fam, v, profiled_workload=True):
     """Roofline record of ONE kernel family (= one kernel, every launch of it over the sampled steps).
     Split contractions: MFMA, against the dense 16-bit peak / the piece products one fp32 product costs (three for the
     two-piece fp16 split, six for bf16x3); fp32-MFMA kernels against the fp32 MFMA peak.  The attention kernels gather rows
     that sit in L2 / Infinity Cache and are bound by their vector instruction stream: ``bound: "valu"`` - achieved = vector
-    wave-instructions per launch (SQ_INSTS_VALU of the committed counter pass) / the live launch time, peak = 1024 SIMDs x
-    2.4 GHz / 4 cycles; the HBM view (counter bytes / time) and the no-reuse algorithmic bytes of SURVEY 8(d) ride along.  The
+    wave-instructions per launch (SQ_INSTS_VALU of the committed counter pass) / the live launch time, peak = 1024 SIMD-32 x
+    2.4 GHz / 2 cycles (VALU_ISSUE_PEAK_GINST); the HBM view (counter bytes / time) and the no-reuse algorithmic bytes of SURVEY 8(d) ride along.  The
     sampler is priced against HBM."""
     per_launch_s = v["ms"] / v["count"] * 1e-3
-    traffic, sq, src = pmc_counters(fam) if profiled_workload else (None, {}, None)
+    traffic, sq, src, names = pmc_counters(fam) if profiled_workload else (None, {}, None, [])
     if fam.startswith("gemm") or fam == "gru_fused":
         products = bx_products(fam)
         peak = MFMA_BF16_PEAK_TF / products if products else MFMA_F32_PEAK_TF
@@ -564,37 +737,76 @@ def family_roofline(fam, v, profiled_workload=True):
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic}
         if fam.startswith("attn"):
-            roof["note"] = "no committed SQ pass for this kernel: no-reuse algorithmic bytes (SURVEY 8d) over 8 TB/s, not a tight bound"
+            # (no committed counter pass of this workload: the gathered rows sit in L2 / Infinity Cache, so the no-reuse
+            #  algorithmic bytes of SURVEY 8(d) over the HBM peak are NOT a bound and would print above 1 - no fraction then)
+            roof["frac"] = None
+            roof["note"] = ("no committed counter pass for this workload (profiles/r*_summary_%s.json): the kernel is bound by its "
+                            "vector instruction stream, and the no-reuse algorithmic bytes are not an HBM bound" % WORKLOAD_KEY[0])
     if traffic:
         roof["hbm_gbs_from_traffic"] = round(traffic / per_launch_s / 1e9, 1)
         roof["hbm_frac_from_traffic"] = round(traffic / per_launch_s / 1e9 / HBM_PEAK_GBS, 4)
     roof["counters_from"] = src
     roof["kernel"] = fam
-    roof["kernel_name"] = PMC_KERNEL.get(fam, fam)
+    roof["kernel_name"] = ", ".join(names) if names else FAMILY_KERNEL.get(fam, fam)
     roof["avg_launch_us"] = round(per_launch_s * 1e6, 2)
     roof["launches"] = int(v["count"])
     return roof
 
 
+def trace_family_ms(prof):
+    """Resident device time per step of every family in the committed kernel trace of this workload ({} without one)."""
+    import csv
+    import glob
+    key = WORKLOAD_KEY[0]
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_kernel_stats_bench_%s.csv" % key))) if key else []
+    if not files:
+        return {}, None
+    try:
+        sf = _summary_for(key)
+        steps = int(json.load(open(sf)).get("steps_in_trace", 25)) if sf else 25
+        out = {}
+        for r in csv.DictReader(open(files[-1])):
+            base = _kernel_base(r["Name"])
+            for fam, kb in FAMILY_KERNEL.items():
+                if kb != base or fam not in prof or prof[fam]["count"] <= 0:
+                    continue
+                if fam == "attn_bwd" and "runs" in r["Name"]:
+                    continue
+                if base == "gemm_f32_kernel":
+                    continue            # (three families share this kernel name: they keep their bracketed times)
+                out[fam] = out.get(fam, 0.0) + float(r["TotalDurationNs"]) / steps / 1e6
+        return out, os.path.basename(files[-1])
+    except Exception:
+        return {}, None
+
+
 def roofline_of(prof, n_prof_steps, profiled_workload=True):
-    """Dominant KERNEL by summed device time over the sampled steps (a family is ONE kernel name, every launch of it; the
-    library reads the device-side row counts of the touched-table launches back, so every launch carries its work), priced
-    by ``family_roofline``; the runner-up rides along in full so that a near-tie between two kernels cannot hide either."""
+    """Dominant KERNEL of the step, priced by ``family_roofline`` (a family is ONE kernel name, every launch of it; the library
+    reads the device-side row counts of the touched-table launches back, so every launch carries its work).  The families
+    are ranked by the device time they hold in the committed kernel trace of this workload (resident time, co-scheduled
+    launches as the step runs them: ``ranked_by`` names the file) and, without a trace, by the summed live brackets; the rate
+    that is priced is always the live bracketed one (the kernel alone).  The runner-up rides along in full."""
     fam = {k: v for k, v in prof.items() if v["count"] > 0}
     if not fam:
         return None
-    order = sorted(fam, key=lambda k: -fam[k]["ms"])
+    resident, trace_file = trace_family_ms(prof) if profiled_workload else ({}, None)
+    rank_ms = {k: resident.get(k, fam[k]["ms"] / max(1, n_prof_steps)) for k in fam}
+    order = sorted(fam, key=lambda k: -rank_ms[k])
     dom = order[0]
     roof = family_roofline(dom, fam[dom], profiled_workload)
     v = fam[dom]
     roof["launches_per_step"] = round(v["count"] / max(1, n_prof_steps), 2)
     roof["ms_per_step"] = round(v["ms"] / max(1, n_prof_steps), 4)
+    roof["ms_per_step_resident"] = round(rank_ms[dom], 4)
+    roof["ranked_by"] = ("resident time in profiles/%s" % trace_file) if trace_file else "summed live brackets (no committed trace of this workload)"
     roof["sampled_steps"] = n_prof_steps
     if len(order) > 1:
         ru = family_roofline(order[1], fam[order[1]], profiled_workload)
         ru["launches_per_step"] = round(fam[order[1]]["count"] / max(1, n_prof_steps), 2)
         ru["ms_per_step"] = round(fam[order[1]]["ms"] / max(1, n_prof_steps), 4)
+        ru["ms_per_step_resident"] = round(rank_ms[order[1]], 4)
         roof["runner_up"] = ru
+    roof["families_ms_per_step_resident"] = {k: round(x, 4) for k, x in resident.items()}
     roof["families_ms_per_step"] = {k: round(x["ms"] / max(1, n_prof_steps), 4) for k, x in prof.items() if x["count"] > 0}
     roof["families_launches_per_step"] = {k: round(x["count"] / max(1, n_prof_steps), 2) for k, x in prof.items() if x["count"] > 0}
     is_flop = lambda k: k.startswith("gemm") or k == "gru_fused"
@@ -603,6 +815,10 @@ def roofline_of(prof, n_prof_steps, profiled_workload=True):
     tot = lambda ks: (sum(prof[k]["work"] for k in ks if k in prof) / max(1e-9, sum(prof[k]["ms"] for k in ks if k in prof) * 1e-3))
     roof["gemm_all_tflops"] = round(tot([k for k in prof if is_flop(k)]) / 1e12, 2)
     roof["attn_all_gbs"] = round(tot([k for k in prof if k.startswith("attn")]) / 1e9, 1)
+    roof["bracketed_ms_per_step"] = round(sum(x["ms"] for x in prof.values()) / max(1, n_prof_steps), 4)
+    td = trace_dominant(prof, n_prof_steps) if profiled_workload else None
+    if td:
+        roof["trace_dominant"] = td
     return roof
 
 
@@ -624,6 +840,77 @@ def bx_products(family):
     return 6 if os.environ.get("PFO_BX_FMT", "1") == "0" else 3
 
 
+XGMI_LINK_GBS = 153.0      # per-link, per direction (task statement: 7 links x ~153 GB/s per GPU)
+
+
+def predicted_ring_allreduce_us(n_bytes, world, hop_us=6.0):
+    """Ring all-reduce of n_bytes over xGMI at `world` ranks: 2 (N-1)/N of the buffer crosses each rank's link in each
+    direction + 2 (N-1) hop latencies.  A prediction, never measured on this pool."""
+    if world <= 1:
+        return 0.0
+    return 2.0 * (world - 1) / world * n_bytes / (XGMI_LINK_GBS * 1e3) + 2.0 * (world - 1) * hop_us
+
+
+class SleepCollective:
+    """--emulate-ranks: a stand-in for the gradient all-reduce that holds the library's side stream for the predicted ring
+    time (a device-side spin, torch.cuda._sleep, calibrated once against events), so that the fused schedule's join behind a
+    ~100 us exchange is rehearsed on one GPU: what it costs the NEXT step's head, not what the exchange itself costs."""
+
+    def __init__(self, us):
+        import torch
+        self.us = float(us)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000)
+        torch.cuda.synchronize()
+        a.record(); torch.cuda._sleep(2_000_000); b.record()
+        torch.cuda.synchronize()
+        self.cycles_per_us = 2_000_000 / (a.elapsed_time(b) * 1e3)
+        self.calls = 0
+
+    def __call__(self):
+        import torch
+        if self.us > 0:
+            torch.cuda._sleep(int(self.us * self.cycles_per_us))     # (runs on the current stream = the side stream inside bpr_step)
+        self.calls += 1
+
+
+def multi_gpu_line_fields(ms_per_step, coll_ms, coll_n, allreduce_mode):
+    """The fields a rank-path line carries about its collective (also built from synthetic numbers by the CPU tests)."""
+    fused = allreduce_mode.startswith("fused")
+    return {"collective_ms_per_step": round(coll_ms, 4), "collective_on_callers_stream": not fused,
+            "compute_ms_per_step": round(ms_per_step - (0.0 if fused else coll_ms), 4), "collective_samples": coll_n}
+
+
+def strong_scaling_entry(value, ms_per_step, world, workload, global_batch, collective_ms, one_gpu_value=None, one_gpu_ms=None):
+    e = {"n_gpus": world, "value": round(value, 1), "ms_per_step": round(ms_per_step, 4),
+         "collective_ms_per_step": None if collective_ms is None else round(collective_ms, 4),
+         "workload": workload, "global_batch": global_batch, "scaling": "strong"}
+    if one_gpu_value is not None:
+        e["one_gpu_reference"] = {"value": round(one_gpu_value, 1), "ms_per_step": round(one_gpu_ms, 4)}
+        e["efficiency_vs_one_gpu"] = round(value / (world * one_gpu_value), 4)
+    return e
+
+
+def check_line_schema(line, n_gpus):
+    """What the driver's N-GPU record must hold (tests/test_host_logic.py builds a synthetic N = 8 line and runs this)."""
+    need = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config"]
+    miss = [k for k in need if k not in line]
+    if line.get("n_gpus") != n_gpus:
+        miss.append("n_gpus == %d" % n_gpus)
+    if n_gpus > 1:
+        for k in ("collective_ms_per_step", "compute_ms_per_step", "collective_on_callers_stream", "allreduce", "collective"):
+            if k not in line.get("config", {}):
+                miss.append("config." + k)
+        sec = line.get("secondary", {})
+        if n_gpus == 8:
+            sc = sec.get("strong_scaling_C4", {})
+            for k in ("value", "one_gpu_reference", "efficiency_vs_one_gpu", "collective_ms_per_step"):
+                if k not in sc:
+                    miss.append("secondary.strong_scaling_C4." + k)
+    return miss
+
+
 def emulate_ranks(args, dev):
     """Compute-side ceiling of the data-parallel scaling curve on ONE GPU: for each world size N the step of rank 0 -
     sampler / forward / loss / backward for its B/N interactions, the state update and the lazy GRU rows of ALL B global
@@ -641,6 +928,7 @@ def emulate_ranks(args, dev):
             el, nt, _, _, _ = wl.timed(args.steps, args.warmup, min(args.min_seconds, 1.0), 0, first_step=1000 * n, collective=False)
             ms = 1e3 * el / nt
             rows.append({"world": n, "rank": 0, "local_batch": wl.per_gpu, "global_batch": wl.B, "ms_per_step": round(ms, 4),
+                         "stub_collective_us_on_side_stream": round(getattr(wl, "sleep_coll", None).us, 1) if getattr(wl, "sleep_coll", None) else 0.0,
                          "interactions_per_s_if_all_ranks_like_this": round(wl.B / (ms * 1e-3), 1),
                          "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4)})
             desc = wl.describe()
@@ -657,7 +945,7 @@ def emulate_ranks(args, dev):
             torch.cuda.empty_cache()
         for r in rows:
             r["compute_scaling_efficiency_vs_first"] = round(rows[0]["ms_per_step"] / r["ms_per_step"], 4)
-        print(json.dumps({"emulated_ranks": True, "scaling": "weak", "workload": desc, "collective": "none (stubbed)",
+        print(json.dumps({"emulated_ranks": True, "scaling": "weak", "workload": desc, "collective": "stub: a device-side spin of the predicted ring time on the library's side stream (fused schedule)" if args.emulate_sleep else "none (stubbed)",
                           "device": torch.cuda.get_device_name(dev), "table": rows}), flush=True)
         return
     cfg_name = args.config or "C4"
@@ -669,6 +957,7 @@ def emulate_ranks(args, dev):
         el, nt, _, _, _ = wl.timed(args.steps, args.warmup, min(args.min_seconds, 1.0), 0, first_step=1000 * n, collective=False)
         ms = 1e3 * el / nt
         rows.append({"world": n, "rank": 0, "local_batch": wl.B // n, "ms_per_step": round(ms, 4),
+                     "stub_collective_us_on_side_stream": round(wl.sleep_coll.us, 1) if getattr(wl, "sleep_coll", None) and n > 1 else 0.0,
                      "interactions_per_s_if_all_ranks_like_this": round(wl.B / (ms * 1e-3), 1),
                      "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4)})
     base = rows[0]["ms_per_step"] * rows[0]["world"]
@@ -730,25 +1019,23 @@ def main():
                    "block_ms_per_step": {"first": round(wl.block_ms[0], 4), "min": round(min(wl.block_ms), 4),
                                          "median": round(float(np.median(wl.block_ms)), 4), "last": round(wl.block_ms[-1], 4)},
                    **({"block_ms_all": [round(x, 4) for x in wl.block_ms]} if os.environ.get("PFO_BENCH_BLOCKS") else {}),
-                   "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4), "hip_graph": wl.graph_note, "deterministic_backward": bool(args.deterministic),
+                   "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4), "workload_build_s": round(wl.build_s, 2), "hip_graph": wl.graph_note, "deterministic_backward": bool(args.deterministic),
                    "next_batch_prepared_beside_backward": bool(wl.prefetch and wl.gstep is None and wl.mvs is None),
                    "collective": ("%s all-reduce of the flat fp32 gradient, world %d"
                                   % ("rccl" if dist.get_backend() == "nccl" else dist.get_backend(), dist.get_world_size())) if dist.is_initialized() else None},
     }
     if prof is not None:
-        roof = roofline_of(prof, n_prof_steps, profiled_workload=(cfg_name == "C2" and wl.mvs is None and
-                                                                    (wl.per_gpu if scaling == "weak" else wl.B // world) == 512))
+        WORKLOAD_KEY[0] = "%s@%d" % (cfg_name, wl.per_gpu if scaling == "weak" else wl.B // world)
+        roof = roofline_of(prof, n_prof_steps, profiled_workload=_summary_for(WORKLOAD_KEY[0]) is not None)
         if roof:
             out["roofline"] = roof
 
+    wl_gone = False
     coll_ms, coll_n = wl.collective_ms()
     if coll_ms is not None:
-        out["config"]["collective_ms_per_step"] = round(coll_ms, 4)
         # ('fused': the collective runs on the library's side stream beside the next batch's sampling - its time is not part
         #  of the caller's stream's step; the other forms hold the caller's stream for it)
-        out["config"]["collective_on_callers_stream"] = not wl.allreduce_mode.startswith("fused")
-        out["config"]["compute_ms_per_step"] = round(1e3 * elapsed / n_timed - (0.0 if wl.allreduce_mode.startswith("fused") else coll_ms), 4)
-        out["config"]["collective_samples"] = coll_n
+        out["config"].update(multi_gpu_line_fields(1e3 * elapsed / n_timed, coll_ms, coll_n, wl.allreduce_mode))
     if world > 1 or wl.force_dist:
         out["config"]["allreduce"] = wl.allreduce_mode
         out["config"]["predicted_scaling_efficiency"] = {"weak_C2_512_per_gpu": {"2": 0.96, "4": 0.94, "8": 0.90},
@@ -805,22 +1092,29 @@ def main():
                 w4 = Workload(args, "C4", dev, rank, world, "strong")
                 el, n4, _, _, _ = w4.timed(args.steps, args.warmup, min(args.min_seconds, 1.0), 0)
                 cms, _ = w4.collective_ms()
-                sec["strong_scaling_C4"] = {"n_gpus": world, "value": round(n4 * w4.B / el, 1), "ms_per_step": round(1e3 * el / n4, 4),
-                                            "collective_ms_per_step": None if cms is None else round(cms, 4),
-                                            "workload": w4.describe(), "global_batch": w4.B, "scaling": "strong"}
+                v4, ms4 = n4 * w4.B / el, 1e3 * el / n4
+                sec["strong_scaling_C4"] = strong_scaling_entry(v4, ms4, world, w4.describe(), w4.B, cms)
+                sec["strong_scaling_C4"]["workload_build_s"] = round(w4.build_s, 2)
                 dist.barrier()
                 if rank == 0:
                     w4.set_world(0, 1)
                     el, n1, _, _, _ = w4.timed(args.steps, 2, min(args.min_seconds, 1.0), 0, first_step=100000, collective=False)
-                    sec["strong_scaling_C4"]["one_gpu_reference"] = {"value": round(n1 * w4.B / el, 1), "ms_per_step": round(1e3 * el / n1, 4)}
-                    sec["strong_scaling_C4"]["efficiency_vs_one_gpu"] = round(sec["strong_scaling_C4"]["value"] /
-                                                                               (world * sec["strong_scaling_C4"]["one_gpu_reference"]["value"]), 4)
+                    sec["strong_scaling_C4"] = dict(strong_scaling_entry(v4, ms4, world, w4.describe(), w4.B, cms, n1 * w4.B / el, 1e3 * el / n1),
+                                                    workload_build_s=round(w4.build_s, 2))
                 dist.barrier()
                 del w4
         except Exception as e:                                  # the secondary figures never cost the main line
             sec["error"] = repr(e)[:300]
         out["secondary"] = sec
 
+    if world == 1 and not wl_gone and not args.no_drop_in and not (wl.force_dist or args.deterministic) and wl.mvs is None and wl.cfg.use_memory and wl.gstep is None and not args.emulate_ranks:
+        try:
+            out.setdefault("secondary", {})["drop_in_surface"] = drop_in_surface(wl)
+            di = out["secondary"]["drop_in_surface"]
+            for k in ("torch.optim.Adam", "FusedAdam"):
+                di[k]["vs_device_resident_step"] = round(di[k]["ms_per_step"] / out["ms_per_step"], 3)
+        except Exception as e:                                  # a secondary figure never costs the main line
+            out.setdefault("secondary", {})["drop_in_surface"] = {"error": repr(e)[:300]}
     if rank != 0:
         if dist.is_initialized():
             dist.barrier()

@@ -437,7 +437,11 @@ int pfo_tgn_refresh(const pfo_tgn_config* cfg, const pfo_tgn_state* state, void*
 #define PFO_PROF_GEMM_BX_SKINNY 9 /* the 32-row bf16x3 kernel of the short (layer-2) launches           */
 #define PFO_PROF_ATTN_BWD_RUNS 10 /* layer-1 attention backward, run-merged kernel (attn_bwd_runs_kernel)  */
 #define PFO_PROF_GRU_FUSED 11 /* gru_fused_kernel: both GRUCell contractions + gates (flops = per-row FLOPs x touched rows read back) */
-#define PFO_PROF_KINDS 12
+#define PFO_PROF_GEMM_MULTI 12 /* gemm_multi_kernel: the grouped small fp32 products of the composite-weight builds and their chain-back (FLOP) */
+#define PFO_PROF_SEGSUM 13     /* segsum_*_kernel: per-table-row sums of the layer-1 gradient rows (bytes: every member row once + the sums) */
+#define PFO_PROF_TN_REDUCE 14  /* tn_group_reduce_kernel: the split-K slabs of a grouped weight-gradient launch folded (bytes: slabs in, matrices out) */
+#define PFO_PROF_GRU_GATES_BWD 15 /* gru_gates_bwd_*_kernel: GRU gate backward (bytes: gates, h, d h in; dgi, dgh out) */
+#define PFO_PROF_KINDS 16
 /* Milestones: while enabled (pfo_marks_enable(1)) the step's native calls record a timing event on the CALLER's stream at
  * named points of the critical path (sampling done, lazy GRU done, every large launch of every layer ...; callers may add
  * their own with pfo_mark).  pfo_marks_dump waits for them and writes one line per consecutive pair "from -> to  mean_us  n"

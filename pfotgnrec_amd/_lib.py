@@ -115,7 +115,7 @@ PROTOTYPES = {
 }
 
 PROF_KINDS = ["gemm_nt", "gemm_nn", "gemm_tn", "gemm_devm", "attn_fwd", "attn_bwd", "sampler", "gemm_bx", "gemm_tn_bx", "gemm_bx_skinny",
-              "attn_bwd_runs", "gru_fused"]
+              "attn_bwd_runs", "gru_fused", "gemm_multi", "segsum", "tn_reduce", "gru_gates_bwd"]
 
 
 _MARK_NAMES = {}

@@ -2115,10 +2115,12 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
   PFO_LAUNCH_CHECK();
   // the GEMM kernel alone; with a device-side K bound the work is (flops per k-row) x the count read back at collect time
   if (use_bx) pfo_prof_end_dev(PFO_PROF_GEMM_TN_BX, flops / (double)K, k_dev, K, stream);
+  if (use_bx) pfo_prof_begin(stream);                           // the slab fold is a family of its own: slabs in, matrices out
   PFO_KLAUNCH(tn_group_reduce_kernel, dim3((unsigned)std::min<int64_t>(1024, pfo_ceil_div(per_split, 256))), dim3(256), 0,
                      stream, g);
   PFO_LAUNCH_CHECK();
   if (!use_bx) pfo_prof_end_dev(PFO_PROF_GEMM_TN, flops / (double)K, k_dev, K, stream);
+  else pfo_prof_end(PFO_PROF_TN_REDUCE, (double)per_split * (nsplit + 1) * sizeof(float), stream);
   return PFO_OK;
 }
 
@@ -2345,9 +2347,13 @@ int pfo_gemm_multi_launch(const PfoGemm* list, int n, hipStream_t stream) {
       vec = vec && gemm_vec_ok(s);
     }
     g.n = cnt;
+    double mflops = 0;
+    for (int i = 0; i < cnt; ++i) mflops += 2.0 * list[base + i].M * list[base + i].N * (double)list[base + i].K[0] * list[base + i].batch;
+    pfo_prof_begin(stream);
     if (vec) PFO_KLAUNCH(gemm_multi_kernel<true>, dim3(tiles), dim3(GEMM_THREADS), 0, stream, g);
     else PFO_KLAUNCH(gemm_multi_kernel<false>, dim3(tiles), dim3(GEMM_THREADS), 0, stream, g);
     PFO_LAUNCH_CHECK();
+    pfo_prof_end(PFO_PROF_GEMM_MULTI, mflops, stream);
   }
   return PFO_OK;
 }

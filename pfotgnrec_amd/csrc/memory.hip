@@ -489,9 +489,12 @@ int pfo_segsum_launch(const float* src0, int W0, const float* src1, int W1, cons
   static const int chunked = getenv("PFO_SEGSUM_CHUNKED") ? atoi(getenv("PFO_SEGSUM_CHUNKED")) : 1;   // A/B switch
   if (vec && seg_of && cap_members > 0 && chunked) {
     const int nbm = (int)pfo_ceil_div(cap_members, SEGSUM_CHUNK);
+    pfo_prof_begin(stream);
     PFO_KLAUNCH(segsum_chunk_kernel, dim3(nbm), dim3(256), 0, stream, src0, W0, src1, W1, seg_ptr, members, seg_of, n_rows,
                 src0_by_position, src0_live, out, (int64_t)(W0 + W1));
     PFO_LAUNCH_CHECK();
+    // every member row read once (the launch's capacity: a ~10 % over-count of the members; row flags skip part of src0) + the sums
+    pfo_prof_end(PFO_PROF_SEGSUM, ((double)cap_members + (double)cap_rows) * (W0 + W1) * sizeof(float), stream);
     return PFO_OK;
   }
   const int nb = (int)std::min<int64_t>(8192, std::max<int64_t>(1, pfo_ceil_div(cap_rows, vec ? SEGSUM_NSEG : 4)));
@@ -666,6 +669,7 @@ int pfo_gru_gates_bwd_launch(const float* gates, float* dgi, float* dgh, const f
                              const float* d_extra, int det, hipStream_t stream) {
   const bool vec = (D & 3) == 0 && (rep_stride & 3) == 0 &&
                    ((((uintptr_t)gates) | ((uintptr_t)dgi) | ((uintptr_t)dgh) | ((uintptr_t)h_rows) | ((uintptr_t)d_h0) | ((uintptr_t)d_extra)) & 15) == 0;
+  pfo_prof_begin(stream);
   if (vec) {
     const int nb = (int)std::min<int64_t>(4096, pfo_ceil_div((int64_t)cap * (D / 4), 256));
     PFO_KLAUNCH(gru_gates_bwd_vec_kernel, dim3(nb), dim3(256), 0, stream, gates, dgi, dgh, h_rows, hm, n_touched, D, d_h0, n_rep,
@@ -676,6 +680,8 @@ int pfo_gru_gates_bwd_launch(const float* gates, float* dgi, float* dgh, const f
                        rep_stride, d_extra, det);
   }
   PFO_LAUNCH_CHECK();
+  // per touched row: 4 D gate values + D memory + (n_rep + 1) D gradient floats in, 6 D floats out
+  pfo_prof_end_dev(PFO_PROF_GRU_GATES_BWD, (double)D * (4 + 1 + n_rep + (d_extra ? 1 : 0) + 6) * sizeof(float), n_touched, cap, stream);
   return PFO_OK;
 }
 

@@ -188,7 +188,7 @@ extern "C" int64_t pfo_marks_dump(char* out, int64_t cap) {
   return n;
 }
 
-extern "C" int pfo_abi_version(void) { return 4; }   // 3: pfo_tgn_batch.dropout_keep, pfo_attn_dropout_mask, PFO_PROF_GRU_FUSED; 4: pfo_segment_sum, pfo_tgn_side_stream, defer_join / pcache fields
+extern "C" int pfo_abi_version(void) { return 5; }   // 3: pfo_tgn_batch.dropout_keep, pfo_attn_dropout_mask, PFO_PROF_GRU_FUSED; 4: pfo_segment_sum, pfo_tgn_side_stream, defer_join / pcache fields; 5: PFO_PROF_KINDS 12 -> 16 (pfo_prof_collect arrays)
 
 // ---------------------------------------------------------------------------------------------
 // roctx ranges (common.hpp)

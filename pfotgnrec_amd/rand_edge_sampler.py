@@ -32,15 +32,24 @@ def item_availability(dst_list, upper_u, n_items):
 
 
 def pack_portfolios(portfolio_list, map_item_id, width=None):
-    """List of stock-code lists -> (i32[B,width] item indices padded with -1, i32[B] lengths); '' dropped (:76)."""
-    rows = [[map_item_id[c] for c in sub if c] for sub in portfolio_list]
+    """List of stock-code lists -> (i32[B,width] item indices padded with -1, i32[B] lengths); '' dropped (:76).
+    One pass over the flattened codes and one scatter (the per-row Python loops of the first version were the largest host
+    item of a batch on the drop-in surface: 0.3 ms of a 2.3 ms step at C2, bench.py secondary.drop_in_surface)."""
+    n = len(portfolio_list)
+    lens_all = np.fromiter((len(sub) for sub in portfolio_list), np.int64, n)
+    total = int(lens_all.sum())
+    get = map_item_id.__getitem__
+    flat = np.fromiter((get(c) if c else -1 for sub in portfolio_list for c in sub), np.int64, total)
+    row = np.repeat(np.arange(n), lens_all)
+    keep = flat >= 0
+    flat, row = flat[keep], row[keep]
+    lens = np.bincount(row, minlength=n).astype(np.int32)
     if width is None:
-        width = max(1, max((len(r) for r in rows), default=1))
-    out = np.full((len(rows), width), -1, np.int32)
-    lens = np.zeros(len(rows), np.int32)
-    for i, r in enumerate(rows):
-        out[i, :len(r)] = r
-        lens[i] = len(r)
+        width = max(1, int(lens.max()) if n else 1)
+    out = np.full((n, width), -1, np.int32)
+    start = np.cumsum(lens) - lens
+    col = np.arange(flat.shape[0]) - np.repeat(start, lens)
+    out[row, col] = flat
     return out, lens
 
 

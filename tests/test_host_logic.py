@@ -196,3 +196,56 @@ def test_rand_edge_sampler_availability_cache_follows_content():
     s3 = P.RandEdgeSampler(src, a, ports, upper_u, map_item_id)
     assert s3.item_avail.tolist() == item_availability(a, upper_u, 10).tolist()
     assert s3.port_len.tolist() == [0, 1, 2]                              # '' dropped (utils.py:76)
+
+
+# ------------------------------------------------------------------ the N-GPU record of bench.py
+def _bench():
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    return importlib.import_module("bench")
+
+
+def test_synthetic_eight_gpu_line_carries_the_fields_the_driver_reads():
+    """No 8-GPU node is available to this build: the line a rank-path run prints is assembled here from synthetic numbers
+    through the SAME helpers bench.main() uses (multi_gpu_line_fields, strong_scaling_entry) and checked against the schema
+    (check_line_schema): collective / compute split, the all-reduce form, the C4 strong-scaling case with its one-GPU
+    reference and efficiency."""
+    b = _bench()
+    for mode in ("single", "buckets", "fused", "fused_buckets"):
+        line = {"metric": "interactions/sec (TGN fwd+BPR step)", "value": 8 * 360000.0, "unit": "interactions/s", "n_gpus": 8,
+                "steps": 20, "warmup": 5, "ms_per_step": 1.42, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "C2 ...", "global_batch": 4096, "parallelism": "dp8", "allreduce": mode,
+                           "collective": "rccl all-reduce of the flat fp32 gradient, world 8"}}
+        line["config"].update(b.multi_gpu_line_fields(1.42, 0.11, 5, mode))
+        line["secondary"] = {"strong_scaling_C4": b.strong_scaling_entry(1.9e6, 2.15, 8, "C4 ...", 4096, 0.12, 4.1e5, 9.99)}
+        assert b.check_line_schema(line, 8) == []
+        cfg = line["config"]
+        if mode.startswith("fused"):          # the collective sits on the side stream: the caller's stream's step is all compute
+            assert not cfg["collective_on_callers_stream"] and cfg["compute_ms_per_step"] == 1.42
+        else:
+            assert cfg["collective_on_callers_stream"] and abs(cfg["compute_ms_per_step"] + 0.11 - 1.42) < 1e-9
+        eff = line["secondary"]["strong_scaling_C4"]["efficiency_vs_one_gpu"]
+        assert abs(eff - 1.9e6 / (8 * 4.1e5)) < 1e-3
+    # a line that lost a field is caught
+    del line["config"]["collective_ms_per_step"]
+    del line["secondary"]["strong_scaling_C4"]["one_gpu_reference"]
+    miss = b.check_line_schema(line, 8)
+    assert "config.collective_ms_per_step" in miss and "secondary.strong_scaling_C4.one_gpu_reference" in miss
+    # one GPU: no collective fields asked for
+    assert b.check_line_schema({k: line[k] for k in line if k != "secondary"} | {"n_gpus": 1, "config": {}}, 1) == []
+
+
+def test_predicted_ring_time_of_the_gradient_all_reduce():
+    """The stub collective of --emulate-ranks spins for this long on the side stream: 6.2 MB of fp32 gradients, ring over xGMI
+    (2 (N-1)/N of the buffer per link direction at ~153 GB/s + 2 (N-1) hops)."""
+    b = _bench()
+    n_bytes = 1_551_000 * 4
+    assert b.predicted_ring_allreduce_us(n_bytes, 1) == 0.0
+    t2, t4, t8 = (b.predicted_ring_allreduce_us(n_bytes, w) for w in (2, 4, 8))
+    assert 40 < t2 < t4 < t8 < 200               # DESIGN.md 6 quotes 70-110 us for the exchange at 2-8 ranks
+    assert abs(t8 - (2 * 7 / 8 * n_bytes / 153e3 + 14 * 6.0)) < 1e-6

@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""Condenses gpurun_out/<tag>/ (tools/profile_round.sh) into profiles/<tag>_kernel_stats_bench_C2.csv and
-profiles/<tag>_summary.json: per-kernel launches / average duration from the kernel trace and HBM bytes per launch
+"""Condenses gpurun_out/<tag>_<key>/ (tools/profile_round.sh <tag> <key> ...) into profiles/<tag>_kernel_stats_bench_<key>.csv
+and profiles/<tag>_summary_<key>.json (key = configuration@batch per GPU, e.g. C2@512 - bench.py looks its own key up): per-kernel launches / average duration from the kernel trace and HBM bytes per launch
 from the FETCH_SIZE / WRITE_SIZE passes (separate runs: they do not fit one pass) with the gfx950 correction of
 MI355X_MICROARCH.md: the counters are in KiB, and FETCH_SIZE reports half of the bytes of wide coalesced reads
 (128-byte requests tallied at 64 B), so HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
 import csv, glob, json, os, sys, collections
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+key = sys.argv[2] if len(sys.argv) > 2 else "C2@512"
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 25
+bench_args = sys.argv[4] if len(sys.argv) > 4 else ""
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", tag)
+src = os.path.join(root, "gpurun_out", "%s_%s" % (tag, key))
 
 
 def find(sub, pat):
@@ -29,7 +31,7 @@ kern = {k: {"launches": len(v), "avg_us": round(sum(v) / len(v), 2), "ms_per_ste
         for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))}
 stats = find("trace", "*kernel_stats.csv")
 if stats:
-    dst = os.path.join(root, "profiles", "%s_kernel_stats_bench_C2.csv" % tag)
+    dst = os.path.join(root, "profiles", "%s_kernel_stats_bench_%s.csv" % (tag, key))
     open(dst, "w").write(open(stats).read())
 
 
@@ -59,17 +61,15 @@ for sub, names in (("pmc_sq1", ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"
             if k in pmc:
                 pmc[k].setdefault("sq", {})[name] = round(v, 1)
 bench_line = None
-try:
-    bench_line = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-except Exception:
-    pass
-out = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 "
-                  "--no-cpu-baseline --no-prof --min-seconds 0   (+ separate --pmc passes: FETCH_SIZE; WRITE_SIZE; "
-                  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS; SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES)",
+out = {"workload": key,
+       "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 "
+                  "--no-cpu-baseline --no-prof --min-seconds 0 %s  (+ separate --pmc passes: FETCH_SIZE; WRITE_SIZE; "
+                  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS; SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES; "
+                  "GPU_MAX_HW_QUEUES=16 exported)" % bench_args,
        "steps_in_trace": steps, "kernels": kern,
        "pmc": {"correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes (gfx950, MI355X_MICROARCH.md)", "kernels": pmc},
        "bench_line_same_build": bench_line}
-json.dump(out, open(os.path.join(root, "profiles", "%s_summary.json" % tag), "w"), indent=1)
+json.dump(out, open(os.path.join(root, "profiles", "%s_summary_%s.json" % (tag, key)), "w"), indent=1)
 top = list(kern.items())[:12]
 for k, v in top:
     print("%-50s n=%5d avg %8.1f us  %7.4f ms/step  hbm/launch %s" % (k[:50], v["launches"], v["avg_us"], v["ms_per_step"],
