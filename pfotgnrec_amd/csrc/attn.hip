@@ -831,8 +831,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
       const int run_i = run_len;                                 // (an instance without history has count 0: first of its row)
       run_len += 1;
       s_delta[run_i] = delta;
-#pragma unroll
-      for (int h = 0; h < H; ++h) s_cA[run_i][h][lane] = 0.f;
       float qt[H][NR], gn[H][NR], gt[H][NR], ge[H], tds[2 * H];
       float dsb[H], cxs[H], my_a[H];
 #pragma unroll
@@ -864,7 +862,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         dsb[h] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(dsb[h])));
         t[h] = fmaf(dsb[h], __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cxs[h]))), tds[h]);
       }
-      const unsigned keep = attn_keep_for(a, rng_off, n, lane);
+      // Per slot, once per member: the dropout multiplier ks_jh (0 or 1 / (1 - p)) and with it cA_jh = a_jh ks_jh - the
+      // coefficient of d ctx'_h in the key-side rows does not depend on the backward at all: it goes to the group's LDS table
+      // here (one store per head) instead of from inside the key loop (compare + exec-masked store per key), and the loop reads
+      // ks with one v_readlane per head instead of unpacking a bit mask (scalar and / compare / select + a vector select)
+      float my_ks[H];
+      {
+        const unsigned keep = attn_keep_for(a, rng_off, n, lane);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          my_ks[h] = ((keep >> h) & 1u) ? keep_scale : 0.f;
+          s_cA[run_i][h][lane] = ((valid >> lane) & 1ull) ? my_a[h] * my_ks[h] : 0.f;
+        }
+      }
       // one range test per instance: |fma(dt, w, b)| <= max|dt| max|w| + max|b| < 2e7 -> the fp32 reduction holds for every key
       const bool fast = fmaf(pfo_wave_max(fabsf(my_dt)), wmax, bmax) < 2.0e7f;
 
@@ -915,12 +925,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
 #pragma unroll
         for (int c = 0; c < KC_RUNS; ++c) {
           if (js[c] < 0) continue;
-          const unsigned kb = (unsigned)rl_i((int)keep, js[c]);
           const bool mine = lane == js[c] + delta;              // the lane of this key's history entry
           float cA[H], cB[H];
 #pragma unroll
           for (int h = 0; h < H; ++h) {
-            const float ks_h = ((kb >> h) & 1u) ? keep_scale : 0.f;
+            const float ks_h = rl_f(my_ks[h], js[c]);
             const float da = (part[c * H + h] + dsb[h]) * ks_h;
             const float aj = rl_f(my_a[h], js[c]);
             const float dscore = aj * (da - t[h]);
@@ -933,10 +942,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
               dqt[h][r] = fmaf(cB[h], kt[c][r], dqt[h][r]);
             }
             dqe[h] = fmaf(cB[h], ke[c], dqe[h]);
-          }
-          if (lane == js[c]) {
-#pragma unroll
-            for (int h = 0; h < H; ++h) s_cA[run_i][h][lane] = cA[h];
           }
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
