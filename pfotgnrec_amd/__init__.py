@@ -13,7 +13,22 @@ import os as _os
 # side stream ends up behind the caller's stream in ONE hardware queue and the overlap is lost (bench.py, DESIGN 6: +18 % per
 # step on the rank path).  The runtime reads the variable when it initialises: import this package (or set the variable)
 # before the first use of the GPU.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
+    _os.environ["GPU_MAX_HW_QUEUES"] = "16"
+    # The assignment only takes effect if the HIP runtime has not been initialised yet in this process: torch.cuda was used
+    # before the import, or the process runs under `rocprofv3 --pmc ...` whose preloaded library initialises the GPU before
+    # Python starts (tools/profile_round.sh therefore exports the variable itself).  Say so instead of silently running on
+    # the default 4 queues (the side streams sit in priority classes of their own, so the loss is small on one GPU; on the
+    # rank path with c10d / RCCL streams it is not).
+    try:
+        import sys as _sys
+        _t = _sys.modules.get("torch")
+        if _t is not None and _t.cuda.is_initialized():
+            import warnings as _warnings
+            _warnings.warn("pfotgnrec_amd: the GPU was initialised before this import, so GPU_MAX_HW_QUEUES=16 cannot take effect; "
+                           "export GPU_MAX_HW_QUEUES=16 in the environment (INTEGRATION.md)", RuntimeWarning, stacklevel=2)
+    except Exception:
+        pass
 
 from .data import Data, compute_time_statistics, get_data  # noqa: F401
 from .neighbor_finder import NeighborFinder, get_neighbor_finder  # noqa: F401

@@ -42,7 +42,18 @@ void pfo_prof_end_dev(int kind, double work_per_unit, const int32_t* units_dev, 
 // carry `e`; pfo_stop_event_disarm(stream) records it the plain way if that launch never came (count mismatch, capture).
 void pfo_stop_event_arm(hipEvent_t e, int skip);
 void pfo_stop_event_disarm(hipStream_t stream);
+void pfo_stop_event_cancel();
 bool pfo_stop_event_take(hipEvent_t* e);
+// arm -> run -> disarm as ONE statement: the error return of `expr` cancels the armed event instead of leaving it (thread-local
+// state) for the next unrelated launch of this thread
+#define PFO_RUN_BOUND(enable, ev, skip, stream, expr)                                            \
+  do {                                                                                           \
+    const bool on__ = (enable);                                                                  \
+    if (on__) pfo_stop_event_arm((ev), (skip));                                                  \
+    const int rcb__ = (expr);                                                                    \
+    if (on__) { if (rcb__ != PFO_OK) pfo_stop_event_cancel(); else pfo_stop_event_disarm(stream); } \
+    if (rcb__ != PFO_OK) return rcb__;                                                           \
+  } while (0)
 #define PFO_KLAUNCH(kernel, grid, block, shmem, stream, ...)                                                          \
   do {                                                                                                                \
     hipEvent_t pe__ = nullptr;                                                                                        \

@@ -111,6 +111,7 @@ bool pfo_stop_event_take(hipEvent_t* e) {
 void pfo_stop_event_disarm(hipStream_t stream) {
   if (g_stop_event) { (void)hipEventRecord(g_stop_event, stream); g_stop_event = nullptr; }
 }
+void pfo_stop_event_cancel() { g_stop_event = nullptr; g_stop_skip = 0; }   // error path: nothing may stay armed for an unrelated launch
 
 // ---------------------------------------------------------------------------------------------
 // milestones (include/pfotgn.h)

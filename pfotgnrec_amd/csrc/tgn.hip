@@ -844,11 +844,8 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     if (pack_side) {
       // (comp_done rides on the completion of the compaction's LAST launch - its only one, or the third when the caller's extra
       //  list is marked and compacted too (data-parallel ranks: memory.hip pfo_touch_compact_launch): no marker packet)
-      if (bind_events) pfo_stop_event_arm(sd.comp_done, b->n_extra > 0 ? 2 : 0);
-      else pfo_stop_event_arm(nullptr, 0);
-      RUN(prepare_compact(c, b, w, s));
-      if (bind_events) pfo_stop_event_disarm(s);
-      else HIPOK(hipEventRecord(sd.comp_done, s), "event record failed");
+      PFO_RUN_BOUND(bind_events, sd.comp_done, b->n_extra > 0 ? 2 : 0, s, prepare_compact(c, b, w, s));
+      if (!bind_events) HIPOK(hipEventRecord(sd.comp_done, s), "event record failed");
     } else {
       RUN(prepare_compact_pack(c, st, b, w, d, n, s));
     }
@@ -863,10 +860,8 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     f.b_ih = P.b_ih; f.b_hh = P.b_hh; f.hm = w.hm; f.touched = w.touched; f.node_feat = st->node_feat;
     f.upd_mem = w.upd_mem; f.h0_tab = w.h0_tab; f.gates = w.gates; f.D = D; f.cap_rows = capP; f.n_rows = w.n_touched;
     if (pack_side) { f.gather = 1; f.msg_rows = st->msg_table; f.h_rows = st->memory; f.hm = st->has_msg; }
-    if (fused_state && bind_events) pfo_stop_event_arm(sd.gru_done, 0);
-    RUN(pfo_gru_fused_launch(f, s));
-    if (fused_state && bind_events) pfo_stop_event_disarm(s);
-    else if (fused_state) HIPOK(hipEventRecord(sd.gru_done, s), "event record failed");
+    PFO_RUN_BOUND(fused_state && bind_events, sd.gru_done, 0, s, pfo_gru_fused_launch(f, s));
+    if (fused_state && !bind_events) HIPOK(hipEventRecord(sd.gru_done, s), "event record failed");
     PFO_MARK("fwd.gru", s);
   }
   // ---- composite weights of every layer and their fp16 images (build_stage_a / _b): side stream.  Enqueued HERE, after the
@@ -1173,9 +1168,8 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       PfoGemm q = g_nt(dh1, D, nullptr, W1ovT_l, D, w.dctx, HCp, N, HCp, D, nullptr);
       q.b_img = lw.iW1ovT;
       const bool bind_tn_a = bind_events && l == 1 && tna_mode == 0 && !pfo_prof_on();
-      if (bind_tn_a) pfo_stop_event_arm(sd.tn_a, 0);
-      RUN(pfo_gemm_launch(q, s));
-      if (bind_tn_a) { pfo_stop_event_disarm(s); tn_a_bound = true; }
+      PFO_RUN_BOUND(bind_tn_a, sd.tn_a, 0, s, pfo_gemm_launch(q, s));
+      if (bind_tn_a) tn_a_bound = true;
       PFO_MARK(mk_dctx[l], s);
       if (l == 1 && b->mid_event && !b->mid_event_late) HIPOK(hipEventRecord((hipEvent_t)b->mid_event, s), "event record failed");
     }
@@ -1226,9 +1220,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       // (the groups exist: seg_done was awaited above, or the forward built them)
       RUN(pfo_segsum_cols_launch(dh1, D, w.seg_ptr, w.seg_mem, w.seg_of, n[1], w.n_core, w.Dq + HCp, WQ, s));
     }
-    if (dq_added && bind_events) pfo_stop_event_arm(sd.tn_b, 0);   // tn_b rides on the attention launch (no segment sum behind it)
-    RUN(pfo_attn_bwd_launch(a, &n_parts, s));
-    if (dq_added && bind_events) pfo_stop_event_disarm(s);
+    PFO_RUN_BOUND(dq_added && bind_events, sd.tn_b, 0, s, pfo_attn_bwd_launch(a, &n_parts, s));   // (atomic row sums: tn_b rides on the attention launch, no segment sum behind it)
     PFO_MARK(mk_battn[l], s);
     if (l == 1 && b->mid_event && b->mid_event_late) HIPOK(hipEventRecord((hipEvent_t)b->mid_event, s), "event record failed");
     if (det) det_rows += n_parts;
@@ -1246,12 +1238,11 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
         if (!bind_events) HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
         if (dh1_summed) HIPOK(hipStreamWaitEvent(s, sd.dh1_sum, 0), "event wait failed");
       } else {
-      if (bind_events) pfo_stop_event_arm(sd.tn_b, 0);
-      RUN(pfo_segsum_launch(dqk_l, HCp, dh1, D, w.seg_ptr, w.seg_mem, w.seg_of, n[1], w.n_core, capP, dqk_by_member,
-                            dqk_by_member ? w.dqk_live : nullptr, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
+      PFO_RUN_BOUND(bind_events, sd.tn_b, 0, s,
+                    pfo_segsum_launch(dqk_l, HCp, dh1, D, w.seg_ptr, w.seg_mem, w.seg_of, n[1], w.n_core, capP, dqk_by_member,
+                                      dqk_by_member ? w.dqk_live : nullptr, w.Dq, s));   // Dq = [sum dqk' | sum dh1]
       // the weight gradients over the table rows go to the side stream too (beside d h0 / the GRU backward on this one)
-      if (bind_events) pfo_stop_event_disarm(s);
-      else HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
+      if (!bind_events) HIPOK(hipEventRecord(sd.tn_b, s), "event record failed");
       }
       PFO_MARK("bwd.L1.segsum", s);
       HIPOK(hipStreamWaitEvent(ss, sd.tn_b, 0), "event wait failed");
@@ -1288,9 +1279,8 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
         q.A[1] = dh1; q.lda[1] = D; q.B[1] = W1b_l; q.ldb[1] = W1b_ld; q.K[1] = D;
         q.b_img = lw.iWqkT; q.b_img2 = lw.iW1bT;
         q.relu_src = xA; q.relu_ld = D;
-        if (bind_events) pfo_stop_event_arm(sd.layer[l], 0);     // (layer[l], recorded below, rides on this launch)
-        RUN(pfo_gemm_launch(q, s));
-        if (bind_events) { pfo_stop_event_disarm(s); layer_event_bound = true; }
+        PFO_RUN_BOUND(bind_events, sd.layer[l], 0, s, pfo_gemm_launch(q, s));     // (layer[l], recorded below, rides on this launch)
+        if (bind_events) layer_event_bound = true;
       } else {
         PfoGemm q = g_nn(dh1, D, W1b_l, W1b_ld, dx, D, N, D, D);
         q.b_img = lw.iW1bT;
@@ -1485,9 +1475,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       gp[1].C = G.w_hh; gp[1].ldc = D; gp[1].bias_out = G.b_hh;
       // (a deferred join's main_done event rides on the slab reduce, the caller's stream's last launch of this call)
       main_done_bound = b->defer_join && bind_events;
-      if (main_done_bound) pfo_stop_event_arm(sd.main_done, 1);
-      RUN(pfo_gemm_tn_group_launch(gp, 2, capP, w.n_core, w.slabs, w.slab_floats, s));
-      if (main_done_bound) pfo_stop_event_disarm(s);
+      PFO_RUN_BOUND(main_done_bound, sd.main_done, 1, s, pfo_gemm_tn_group_launch(gp, 2, capP, w.n_core, w.slabs, w.slab_floats, s));
       PFO_MARK("bwd.gru.tn", s);
     }
   }

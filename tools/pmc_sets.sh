@@ -1,6 +1,9 @@
 #!/bin/bash
 # counter passes of the caller's choosing for kernels of the bench step (GPU box; kernels run one at a time under --pmc, so
 # GRBM_GUI_ACTIVE is a kernel's duration ALONE).  Usage: SETS="A B;C" tools/pmc_sets.sh <kernel-substring[,more]> [outdir]
+# The wait / back-pressure set of rounds 4-5 (profiles/r*_pmc_wait_counters_attn.txt):
+#   SETS="SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_IFETCH;SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL;SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH;SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INSTS_VALU_TRANS_F32;SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_SMEM;SQ_WAVES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU"
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}     # (the profiler initialises the GPU before Python: the package's default comes too late)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 kern=$1
 out=${2:-gpurun_out/pmc_sets}
