@@ -1221,6 +1221,7 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       RUN(pfo_segsum_cols_launch(dh1, D, w.seg_ptr, w.seg_mem, w.seg_of, n[1], w.n_core, w.Dq + HCp, WQ, s));
     }
     PFO_RUN_BOUND(dq_added && bind_events, sd.tn_b, 0, s, pfo_attn_bwd_launch(a, &n_parts, s));   // (atomic row sums: tn_b rides on the attention launch, no segment sum behind it)
+    if (l == 1 && tna_mode == 3 && !pfo_prof_on()) RUN(tn_a_side());     // A/B: the instance weight gradients BEHIND the attention backward, beside the serial tail
     PFO_MARK(mk_battn[l], s);
     if (l == 1 && b->mid_event && b->mid_event_late) HIPOK(hipEventRecord((hipEvent_t)b->mid_event, s), "event record failed");
     if (det) det_rows += n_parts;

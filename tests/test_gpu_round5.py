@@ -234,3 +234,53 @@ def test_layer1_attention_backward_staging_at_ragged_shapes(D, H, K, B):
     assert np.array_equal(e0, e1)
     assert relerr(g0, g1) < 2e-5, relerr(g0, g1)
     assert np.isfinite(g0).all() and np.abs(g0).max() > 0
+
+
+# ------------------------------------------------------------------ the atomic row-sum switch (off by default, still a tested path)
+def test_atomic_query_side_row_sums_switch_gives_the_same_gradients():
+    """PFO_DQ_ATOMIC=1: the layer-1 attention backward adds its query-side rows straight into the per-table-row sums (float
+    atomics) and the d h1 half is summed on the side stream - no segment-sum pass.  Measured slower at C2, so it
+    is off by default; the switch is read once per process, hence a child process per setting.  Gradients must agree to
+    summation-order noise, embeddings and loss bitwise."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from conftest import REPO
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import pfotgnrec_amd as P
+from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+cfg = SyntheticConfig("dq", 300, 25, 7000, 64, 2, 8, 2)
+g = make_graph(cfg, with_prices=False); d = g.data
+torch.manual_seed(3)
+tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, torch.device("cuda:0"), n_layers=2, n_heads=2, dropout=0.0,
+            use_memory=True, memory_dimension=64, message_function="identity", n_neighbors=8)
+B, q, K = 96, 3, 8
+rs = np.random.RandomState(5)
+out = []
+for i in range(3):
+    s = 3000 + i * B
+    neg = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * q)
+    tgn.train(); tgn.zero_grad(set_to_none=True)
+    emb = torch.cat(tgn.compute_temporal_embeddings(d.sources[s:s + B], d.destinations[s:s + B], neg, d.timestamps[s:s + B], d.edge_idxs[s:s + B], K))
+    loss = P.bpr_loss(emb, B, q); loss.backward()
+    out += [emb.detach().cpu().numpy(), np.array([float(loss)]), tgn.flat_grad.detach().cpu().numpy().copy()]
+    tgn.memory.detach_memory()
+np.savez(sys.argv[1], *out)
+''' % REPO
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for flag in ("0", "1"):
+            path = os.path.join(tmp, "o%s.npz" % flag)
+            env = dict(os.environ, PFO_DQ_ATOMIC=flag)
+            r = subprocess.run(["timeout", "-k", "10", "300", sys.executable, "-c", code, path], env=env, capture_output=True)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            z = np.load(path)
+            res[flag] = [z[k] for k in z.files]
+    for i, (x, y) in enumerate(zip(res["0"], res["1"])):
+        if i % 3 == 2:                          # gradients: atomics in another order
+            assert relerr(y, x) < 2e-5, (i, relerr(y, x))
+        else:                                   # embeddings, loss: the forward is untouched
+            assert np.array_equal(x, y)
