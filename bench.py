@@ -144,6 +144,15 @@ def _kernel_base(name):
     return n.split("<")[0].split("::")[-1]
 
 
+def _family_has(family, kernel_name):
+    """Is this kernel (a name of the rocprofv3 tables) one of the family's?  The per-instance attention backward has three
+    entry points (attn_bwd_kernel, _none, _direct, _det) behind one PFO_PROF kind; the run-merged kernel is a family of its own."""
+    base = _kernel_base(kernel_name)
+    if family == "attn_bwd":
+        return base.startswith("attn_bwd_kernel")
+    return base == FAMILY_KERNEL.get(family, family)
+
+
 def _summary_for(key):
     """The newest committed profile summary of this workload: profiles/r*_summary_<key>.json (tools/profile_round.sh +
     tools/summarize_profile.py); C2@512 also accepts the unkeyed files of rounds 1-4."""
@@ -164,10 +173,7 @@ def pmc_counters(family):
         return None, {}, None, []
     try:
         d = json.load(open(f))
-        base = FAMILY_KERNEL.get(family, family)
-        rows = [(k, v) for k, v in d["pmc"]["kernels"].items() if _kernel_base(k) == base]
-        if family == "attn_bwd":
-            rows = [(k, v) for k, v in rows if "runs" not in k]
+        rows = [(k, v) for k, v in d["pmc"]["kernels"].items() if _family_has(family, k)]
         if not rows:
             return None, {}, os.path.basename(f), []
         w = [max(1, d.get("kernels", {}).get(k, {}).get("launches", 1)) for k, _ in rows]
@@ -206,8 +212,7 @@ def trace_dominant(prof, n_prof_steps):
         rows = [r for r in csv.DictReader(open(files[-1])) if not r["Name"].startswith("__amd_rocclr")]
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
         r = max(rows, key=lambda r: float(r["TotalDurationNs"]))
-        base = _kernel_base(r["Name"])
-        fam = next((k for k, v in FAMILY_KERNEL.items() if v == base and k in prof and prof[k]["count"] > 0), None)
+        fam = next((k for k in FAMILY_KERNEL if _family_has(k, r["Name"]) and k in prof and prof[k]["count"] > 0), None)
         out = {"kernel_name": r["Name"].split("(")[0], "launches_per_step": round(int(r["Calls"]) / steps, 2),
                "avg_launch_us_resident": round(float(r["AverageNs"]) / 1e3, 2),
                "ms_per_step_resident": round(float(r["TotalDurationNs"]) / steps / 1e6, 4),
@@ -745,6 +750,10 @@ def family_roofline(fam, v, profiled_workload=True):
     if traffic:
         roof["hbm_gbs_from_traffic"] = round(traffic / per_launch_s / 1e9, 1)
         roof["hbm_frac_from_traffic"] = round(traffic / per_launch_s / 1e9 / HBM_PEAK_GBS, 4)
+    if fam == "gemm_multi":
+        roof["note"] = ("grouped 32 x 64-tile fp32-MFMA products of the composite-weight builds and their gradient chain: ~40 MFLOP each, "
+                        "launch- and k-chain-latency bound, queued on the library's side streams - their brackets and their resident "
+                        "time include waiting for workgroup slots beside the caller's stream's kernels; none is on the critical path")
     roof["counters_from"] = src
     roof["kernel"] = fam
     roof["kernel_name"] = ", ".join(names) if names else FAMILY_KERNEL.get(fam, fam)
@@ -767,10 +776,8 @@ def trace_family_ms(prof):
         out = {}
         for r in csv.DictReader(open(files[-1])):
             base = _kernel_base(r["Name"])
-            for fam, kb in FAMILY_KERNEL.items():
-                if kb != base or fam not in prof or prof[fam]["count"] <= 0:
-                    continue
-                if fam == "attn_bwd" and "runs" in r["Name"]:
+            for fam in FAMILY_KERNEL:
+                if not _family_has(fam, r["Name"]) or fam not in prof or prof[fam]["count"] <= 0:
                     continue
                 if base == "gemm_f32_kernel":
                     continue            # (three families share this kernel name: they keep their bracketed times)

@@ -3,7 +3,7 @@
 # Usage (GPU box): tools/bench_all_configs.sh <out.jsonl>
 out=${1:-gpurun_out/bench_all.jsonl}
 : > $out
-run() { python bench.py --steps 20 --warmup 5 --no-cpu-baseline --min-seconds 1.0 "$@" 2>/dev/null | tail -1 >> $out; }
+run() { python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-drop-in --min-seconds 1.0 "$@" 2>/dev/null | tail -1 >> $out; }
 run --config C1
 run --config C2
 run --config C2 --batch 128

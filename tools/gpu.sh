@@ -27,11 +27,11 @@ case $mode in
       echo "== $v"
       envs=""; [ "$v" != "-" ] && envs=${v//,/ }
       case $v in lib:*) envs="PFOTGN_LIB=$GRAFT_REPO_ROOT/pfotgnrec_amd/lib/libpfotgn_${v#lib:}.so" ;; esac
-      env $envs timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --min-seconds 1.0 "$@" 2>/dev/null | line
+      env $envs timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-drop-in --min-seconds 1.0 "$@" 2>/dev/null | line
     done; done 2>&1 | tee $out/ab.txt ;;
   stamps)
     PFOTGN_LIB=$GRAFT_REPO_ROOT/pfotgnrec_amd/lib/libpfotgn_stamps.so timeout -k 10 300 python tools/probes/runs_stamps.py "$@" 2>&1 | grep -v amdgpu.ids | tee $out/stamps.txt ;;
   marks)
-    timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-prof --min-seconds 1.0 --marks 100 "$@" > $out/marks.txt 2>&1; tail -80 $out/marks.txt ;;
+    timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-prof --no-drop-in --min-seconds 1.0 --marks 100 "$@" > $out/marks.txt 2>&1; tail -80 $out/marks.txt ;;
   *) echo "unknown mode $mode"; exit 2 ;;
 esac

@@ -7,7 +7,7 @@ export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}     # (the profiler initialise
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 kern=$1
 out=${2:-gpurun_out/pmc_sets}
-CMD="python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-prof --min-seconds 0 ${BENCH_ARGS}"
+CMD="python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-prof --no-drop-in --min-seconds 0 ${BENCH_ARGS}"
 IFS=';' read -ra sets <<< "${SETS:-FETCH_SIZE;WRITE_SIZE;GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES}"
 for set in "${sets[@]}"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)

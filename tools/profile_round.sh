@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
 out=gpurun_out/${tag}_${key}
 mkdir -p $out
-CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-prof --min-seconds 0 $*"
+CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-prof --no-drop-in --min-seconds 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- $CMD > $out/bench_under_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o p -- $CMD > $out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o p -- $CMD > $out/pmc_write.log 2>&1
