@@ -17,7 +17,16 @@ __global__ __launch_bounds__(256) void tnbr_sample_kernel(
     const double* __restrict__ q_ts, int64_t n_q, int K, const int64_t* __restrict__ draws, uint64_t seed,
     uint64_t offset, const uint64_t* __restrict__ offset_dev, int32_t* __restrict__ out_nbr, int32_t* __restrict__ out_eidx,
     float* __restrict__ out_et, float* __restrict__ out_dt, int32_t* __restrict__ next_nodes, double* __restrict__ next_ts,
-    int32_t* __restrict__ mark, int32_t* __restrict__ out_cnt) {
+    int32_t* __restrict__ mark, int32_t* __restrict__ out_cnt, int32_t* __restrict__ clear_ptr, int64_t clear_ints) {
+  // clear_ptr (optional; never the launch that sets `mark`): clear_ints words zeroed by this launch - the step's touched-node
+  // flags and compaction scratch are cleared by the UPPER level's sampler launch instead of by a memset of their own in front
+  // of it (one launch boundary off the head of the step)
+  if (clear_ptr) {
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    int4* c4 = reinterpret_cast<int4*>(clear_ptr);
+    for (int64_t i = gtid; i < (clear_ints >> 2); i += gsz) c4[i] = int4{0, 0, 0, 0};
+    for (int64_t i = (clear_ints & ~3ll) + gtid; i < clear_ints; i += gsz) clear_ptr[i] = 0;
+  }
   // mark (optional, with next_nodes): mark[v] = 1 for every node written to the next level - the touched-node flags of the
   // step's compaction, set here instead of by a pass of their own over the level-0 list
   // out_cnt (optional): entries of the node's row strictly before the query time.  Under most-recent sampling slot j of the
@@ -154,8 +163,9 @@ int pfo_tnbr_sample_dev(const int64_t* indptr, const int32_t* adj_nbr, const int
                         int64_t n_nodes, const int32_t* q_nodes, const double* q_ts, int64_t n_q, int32_t K, int32_t mode,
                         const int64_t* draws, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int32_t* out_nbr,
                         int32_t* out_eidx, float* out_et, float* out_dt, int32_t* next_nodes, double* next_ts, int32_t* mark,
-                        int32_t* out_cnt, void* stream) {
+                        int32_t* out_cnt, void* stream, int32_t* clear_ptr, int64_t clear_ints) {
   PFO_REQUIRE(mark == nullptr || next_nodes != nullptr, "mark needs next_nodes");
+  PFO_REQUIRE(clear_ptr == nullptr || (mark == nullptr && (((uintptr_t)clear_ptr) & 15) == 0 && n_q > 0), "clear_ptr: 16-byte aligned, not with mark");
   PFO_REQUIRE(K >= 1 && K <= PFO_MAX_NEIGHBORS, "K must be in [1, 64]");
   PFO_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0, 1 or 2");
   PFO_REQUIRE(mode != 1 || draws != nullptr, "mode 1 needs injected draws");
@@ -169,7 +179,7 @@ int pfo_tnbr_sample_dev(const int64_t* indptr, const int32_t* adj_nbr, const int
 #define LAUNCH(M)                                                                                                   \
   PFO_KLAUNCH(tnbr_sample_kernel<M>, dim3((unsigned)blocks), dim3(threads), 0, s, indptr, adj_nbr, adj_eidx, \
                      adj_ts, n_nodes, q_nodes, q_ts, n_q, (int)K, draws, seed, offset, offset_dev, out_nbr, out_eidx,  \
-                     out_et, out_dt, next_nodes, next_ts, mark, out_cnt)
+                     out_et, out_dt, next_nodes, next_ts, mark, out_cnt, clear_ptr, clear_ints)
   pfo_prof_begin(s);
   if (mode == 0) LAUNCH(0);
   else if (mode == 1) LAUNCH(1);
@@ -187,7 +197,7 @@ extern "C" int pfo_tnbr_sample(const int64_t* indptr, const int32_t* adj_nbr, co
                                uint64_t offset, int32_t* out_nbr, int32_t* out_eidx, float* out_et, float* out_dt,
                                int32_t* next_nodes, double* next_ts, void* stream) {
   return pfo_tnbr_sample_dev(indptr, adj_nbr, adj_eidx, adj_ts, n_nodes, q_nodes, q_ts, n_q, K, mode, draws, seed, offset,
-                             nullptr, out_nbr, out_eidx, out_et, out_dt, next_nodes, next_ts, nullptr, nullptr, stream);
+                             nullptr, out_nbr, out_eidx, out_et, out_dt, next_nodes, next_ts, nullptr, nullptr, stream, nullptr, 0);
 }
 
 // ---------------------------------------------------------------------------------------------

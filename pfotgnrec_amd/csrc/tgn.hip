@@ -19,7 +19,8 @@
 
 int pfo_tnbr_sample_dev(const int64_t*, const int32_t*, const int32_t*, const double*, int64_t, const int32_t*, const double*,
                         int64_t, int32_t, int32_t, const int64_t*, uint64_t, uint64_t, const uint64_t*, int32_t*, int32_t*,
-                        float*, float*, int32_t*, double*, int32_t*, int32_t*, void*);
+                        float*, float*, int32_t*, double*, int32_t*, int32_t*, void*, int32_t*, int64_t);
+
 
 namespace {
 
@@ -538,7 +539,12 @@ static int prepare_sample(const pfo_tgn_config* c, const pfo_tgn_state* st, cons
   void* stream = (void*)s;
   // The compaction's flags are cleared on THIS stream (4 us): a wait for a side-stream memset costs the waiting stream 5-17 us
   // on this part (r3 timeline), more than the memset itself.  Same reasoning for the GRU's two weight images below.
-  HIPOK(hipMemsetAsync(w.mark, 0, w.mark_bytes, s), "memset failed");
+  // With two or more levels the UPPER level's sampler launch clears the flags (it does not mark) and the memset is gone
+  // (fwd.begin -> fwd.sampled 40.4 -> 35.6 us).  Both levels of most-recent sampling in ONE launch (a workgroup per root: its
+  // own query, then the 1 + K queries that depend on it) was built and measured too: it marks, so the memset comes back, and
+  // the step does not move (1.302 / 1.308 against 1.297 / 1.305 ms, round 5) - removed again.
+  const bool clear_in_sampler = L >= 2 && (w.mark_bytes % 4) == 0;
+  if (!clear_in_sampler) HIPOK(hipMemsetAsync(w.mark, 0, w.mark_bytes, s), "memset failed");
   // ---- frontier expansion: K1 per level (utils.py:163-219 called from embedding_module.py:125).  Enqueued before the
   // side-stream work below: it depends on nothing else, and the GPU samples while the host is still enqueueing
   for (int l = L; l >= 1; --l) {
@@ -552,7 +558,8 @@ static int prepare_sample(const pfo_tgn_config* c, const pfo_tgn_state* st, cons
     RUN(pfo_tnbr_sample_dev(st->indptr, st->adj_nbr, st->adj_eidx, st->adj_ts, c->n_nodes, lvl_nodes, lvl_ts, n[l], K,
                             b->uniform, dr, b->seed, b->offset + (uint64_t)l * 0x100000000ull, b->offset_dev, nullptr,
                             w.eidx[l], nullptr, w.dt[l], w.nodes[l - 1], l > 1 ? w.ts[l - 1] : nullptr, l == 1 ? w.mark : nullptr,
-                            l == 1 ? w.cnt1 : nullptr, stream));
+                            l == 1 ? w.cnt1 : nullptr, stream, (clear_in_sampler && l == L) ? w.mark : nullptr,
+                            (clear_in_sampler && l == L) ? (int64_t)(w.mark_bytes / 4) : 0));
   }
 
   return PFO_OK;
