@@ -27,6 +27,10 @@ trace = find("trace", "*kernel_trace.csv")
 dur = collections.defaultdict(list)
 for r in csv.DictReader(open(trace)):
     dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+# steps in the trace = launches of a once-per-step kernel (the BPR loss): configurations whose bench first times the HIP-graph form
+# against the eager one (batch <= 256) run more steps than --steps + --warmup
+if "bpr_kernel" in dur:
+    steps = len(dur["bpr_kernel"])
 kern = {k: {"launches": len(v), "avg_us": round(sum(v) / len(v), 2), "ms_per_step": round(sum(v) / steps / 1e3, 4)}
         for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))}
 stats = find("trace", "*kernel_stats.csv")
