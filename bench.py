@@ -630,18 +630,16 @@ def drop_in_surface(wl, budget_s=1.0):
     d = g.data
     B, K, q = wl.per_gpu, cfg.n_neighbors, 3
     codes = g.codes
-    n_batches = 64
+    n_batches = 256
     span = (cfg.n_edges - wl.start - B) // B
-    # the reference slices a prebuilt object array of stock-code lists (utils/data.py:18-72): built here for the batches the loop visits
-    port = {}
-    for i in range(n_batches):
-        s = wl.start + (i % span) * B
-        pl = g.portfolio_len[s:s + B]
-        pi = g.portfolio_idx[s:s + B]
-        arr = np.empty(B, dtype=object)
-        for r in range(B):
-            arr[r] = [codes[j] for j in pi[r, :pl[r]]] if pl[r] > 0 else [""]
-        port[i] = arr
+    # the reference slices ONE prebuilt object array of stock-code lists per batch (train_data.portfolios[s_idx:e_idx],
+    # main.py:186; utils/data.py:18-72): built here for the range of edges the loop visits, sliced below the same way
+    n_rows = min(n_batches, span) * B
+    portfolios_all = np.empty(n_rows, dtype=object)
+    pl_all, pi_all = g.portfolio_len[wl.start:wl.start + n_rows], g.portfolio_idx[wl.start:wl.start + n_rows]
+    for r in range(n_rows):
+        portfolios_all[r] = [codes[j] for j in pi_all[r, :pl_all[r]]] if pl_all[r] > 0 else [""]
+    n_vis = n_rows // B
     out = {"workload": wl.describe(), "loop": "main.py:160-394 (baseline branch) on pfotgnrec_amd's drop-in classes, numpy batches"}
     was_training = tgn.training
     for name in ("torch.optim.Adam", "FusedAdam"):
@@ -655,13 +653,13 @@ def drop_in_surface(wl, budget_s=1.0):
                 torch.cuda.synchronize()
                 t_sampler = t_embed = t_loss = t_bwd = t_opt = t_item = 0.0
                 n, t_all0 = 0, time.perf_counter()
-            s = wl.start + (i % span) * B
+            s = wl.start + (i % n_vis) * B
             t0 = time.perf_counter()
             optimizer = opt
             optimizer.zero_grad()
             sources_batch, destinations_batch = d.sources[s:s + B], d.destinations[s:s + B]
             edge_idxs_batch, timestamps_batch = d.edge_idxs[s:s + B], d.timestamps[s:s + B]
-            portfolios_batch = port[i % n_batches]
+            portfolios_batch = portfolios_all[s - wl.start:s - wl.start + B]
             train_rand_sampler = P.RandEdgeSampler(sources_batch, d.destinations, portfolios_batch, g.upper_u, g.map_item_id)
             negatives_batch = train_rand_sampler.sample(size=q)
             t1 = time.perf_counter()

@@ -249,3 +249,32 @@ def test_predicted_ring_time_of_the_gradient_all_reduce():
     t2, t4, t8 = (b.predicted_ring_allreduce_us(n_bytes, w) for w in (2, 4, 8))
     assert 40 < t2 < t4 < t8 < 200               # DESIGN.md 6 quotes 70-110 us for the exchange at 2-8 ranks
     assert abs(t8 - (2 * 7 / 8 * n_bytes / 153e3 + 14 * 6.0)) < 1e-6
+
+
+def test_portfolios_packed_once_for_slices_of_one_long_lived_array():
+    """main.py:186 slices ``train_data.portfolios`` every batch: the whole array is packed once and a batch is a slice of the packed
+    form (rand_edge_sampler.packed_portfolios_of) - identical to packing the slice itself, also for the [''] rows, with a wider
+    pad; an in-place edit of the dataset that changes a list's length is caught; small arrays and copies are packed directly."""
+    from pfotgnrec_amd.rand_edge_sampler import pack_portfolios, packed_portfolios_of, _PORT_CACHE
+    m = {("%06d" % (i + 1)): i for i in range(60)}
+    rs = np.random.RandomState(3)
+    N = 5000
+    arr = np.empty(N, dtype=object)
+    for r in range(N):
+        L = rs.randint(0, 8)
+        arr[r] = [("%06d" % (j + 1)) for j in rs.choice(60, L, replace=False)] if L else [""]
+    _PORT_CACHE[:] = []
+    for s in (0, 100, 4321, N - 37):
+        sl = arr[s:s + 128]
+        a, b = pack_portfolios(sl, m), packed_portfolios_of(sl, m)
+        W = a[0].shape[1]
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0][:, :W]) and (b[0][:, W:] == -1).all()
+    assert _PORT_CACHE and _PORT_CACHE[0][0] is arr
+    arr[150] = ["000001", "000002", "000003", "000004", "000005", "000006", "000007", "000008", "000009"]
+    a, b = pack_portfolios(arr[100:228], m), packed_portfolios_of(arr[100:228], m)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])                     # repacked directly
+    small = arr[:10].copy()
+    a, b = pack_portfolios(small, m), packed_portfolios_of(small, m)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    a, b = pack_portfolios(list(arr[:5]), m), packed_portfolios_of(list(arr[:5]), m)    # a plain list of lists
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
