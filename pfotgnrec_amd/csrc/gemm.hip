@@ -70,6 +70,33 @@ static bool aligned4(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 #ifndef PFO_DEFAULT_AREG
 #define PFO_DEFAULT_AREG 1
 #endif
+#ifndef BXA_NT
+#define BXA_NT 0         // A/B: nontemporal stores in the image kernels' epilogue
+#endif
+#ifndef BXA_STAGGER
+#define BXA_STAGGER 0    // A/B: the second workgroup of every CU's first round starts BXA_STAGGER x 3.4 us late (phases of the two differ)
+#endif
+#ifndef PFO_DEFAULT_AREG8
+#define PFO_DEFAULT_AREG8 512 // the image kernel's large form as eight single-strip wavefronts (gemm_bx_areg8_kernel) from this many workgroups on
+#endif
+#ifndef BXA_EPI
+#define BXA_EPI 1        // gemm_bx_areg_kernel: loads of the epilogue in front of its stores (0 = the round-3 form, kept for the A/B)
+#endif
+#ifndef BXA_STAMPS
+#define BXA_STAMPS 0     // diagnostic build: per-workgroup wall-clock stamps (100 MHz) of gemm_bx_areg_kernel, read by pfo_debug_bxa_stamps
+#endif
+#if BXA_STAMPS
+__device__ uint64_t g_bxa_stamps[4096 * 8];
+extern "C" int pfo_debug_bxa_stamps(uint64_t* host_out, int n_words) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_bxa_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#define BXA_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) g_bxa_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define BXA_STAMP(k) do { } while (0)
+#endif
+#ifndef BXA_ABL
+#define BXA_ABL 0        // timing-only ablations of gemm_bx_areg_kernel (wrong results), bits: 1 no MFMA, 2 no stores, 4 A rows of tile 0 only
+#endif                   //   (cache hits), 8 no image DMA after the first tile, 16 no row split after the first tile
 #ifndef PFO_BX_MIN_TILES
 #define PFO_BX_MIN_TILES 400
 #endif
@@ -524,6 +551,18 @@ __device__ __forceinline__ f32x4 bx_mma(const u32x4 (&x)[BxFmt<FMT>::NP], const 
   }
   return c;
 }
+// product Q of bx_mma's list alone (two accumulators interleaved: a dependent MFMA waits for its predecessor's result)
+template <int FMT, int Q>
+__device__ __forceinline__ f32x4 bx_mma_q(const u32x4 (&x)[BxFmt<FMT>::NP], const u32x4 (&y)[BxFmt<FMT>::NP], f32x4 c) {
+  if constexpr (FMT == 0) {
+    typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+    constexpr int qx[6] = {0, 2, 1, 0, 1, 0}, qy[6] = {2, 0, 1, 1, 0, 0};
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8, x[qx[Q]]), __builtin_bit_cast(v8, y[qy[Q]]), c, 0, 0, 0);
+  } else {
+    constexpr int qx[3] = {0, 1, 0}, qy[3] = {1, 0, 0};
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x[qx[Q]]), __builtin_bit_cast(f16x8, y[qy[Q]]), c, 0, 0, 0);
+  }
+}
 __device__ __forceinline__ f32x4 hx_scale4(const f32x4 a, const int4 e, int base) {          // a[c] * 2^(base + e[c])
   return f32x4{__builtin_amdgcn_ldexpf(a[0], base + e.x), __builtin_amdgcn_ldexpf(a[1], base + e.y),
                __builtin_amdgcn_ldexpf(a[2], base + e.z), __builtin_amdgcn_ldexpf(a[3], base + e.w)};
@@ -531,11 +570,11 @@ __device__ __forceinline__ f32x4 hx_scale4(const f32x4 a, const int4 e, int base
 
 // The A fragments of one k-tile from the raw rows a lane holds ([strip][half]: 8 consecutive k of one row per strip).  FMT 1
 // keeps the running row scale (rowE) and moves the row's accumulators when a larger value arrives.
-template <int FMT, int NJ>
-__device__ __forceinline__ void bx_split_rows(const float4 (&a_raw)[2][2], u32x4 (&a)[2][BxFmt<FMT>::NP], int (&rowE)[2], f32x4 (&acc)[2][NJ],
+template <int FMT, int NJ, int S = 2>
+__device__ __forceinline__ void bx_split_rows(const float4 (&a_raw)[S][2], u32x4 (&a)[S][BxFmt<FMT>::NP], int (&rowE)[S], f32x4 (&acc)[S][NJ],
                                               const bool first) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < S; ++i) {
     if constexpr (FMT == 0) {
       uint2 lo[3], hi[3];
       bx_split4(a_raw[i][0], lo[0], lo[1], lo[2]);
@@ -619,7 +658,8 @@ __device__ __forceinline__ void bx_store4(const GemmDev& p, float* Cb, int64_t l
       const float4 m = *reinterpret_cast<const float4*>(p.relu_src + (int64_t)row * p.relu_ld + col);
       v[0] = m.x > 0.f ? v[0] : 0.f; v[1] = m.y > 0.f ? v[1] : 0.f; v[2] = m.z > 0.f ? v[2] : 0.f; v[3] = m.w > 0.f ? v[3] : 0.f;
     }
-    *reinterpret_cast<float4*>(cp) = float4{v[0], v[1], v[2], v[3]};
+    if (BXA_NT) __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(cp));
+    else *reinterpret_cast<float4*>(cp) = float4{v[0], v[1], v[2], v[3]};
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -827,26 +867,42 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16x3_kernel(const Gemm
 // straight in MFMA fragment order (lane (r, g): row r, k = 8g..8g+7 = two float4), splits them in registers into the
 // three bf16x8 fragments, and only the shared B image goes through LDS - double-buffered, so a k-tile costs ONE barrier
 // and the copy of tile t+1 into the other buffer runs beside the MFMAs of tile t.
-template <int WAVES, int FMT>
+template <int WAVES, int FMT, int S = 2>
 __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
   constexpr int NP = BxFmt<FMT>::NP;
-  constexpr int NTHR = 64 * WAVES;                   // threads per workgroup; 32 rows per wavefront
+  constexpr int NTHR = 64 * WAVES;                   // threads per workgroup; S strips of 16 rows per wavefront
   constexpr int UNITS = NP * (BX_B_PIECE / 16);      // 16-byte units of one B image tile (a multiple of 64)
   constexpr int NDMA = (UNITS + NTHR - 1) / NTHR;    // rounds of 16-byte units per thread
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   int tile_m = blockIdx.x, tile_n = blockIdx.y;
+  BXA_STAMP(0);
+#if BXA_STAMPS
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_bxa_stamps[blockIdx.x * 8 + 7] = ((uint64_t)xcc << 32) | hw;
+  }
+#endif
+  if (BXA_STAGGER > 0) {
+    const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+    if (lin < 512 && ((lin >> 8) & 1)) {
+#pragma unroll 1
+      for (int k = 0; k < BXA_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+  }
   if (p.xcd_tn > 0 && !xcd_tile(blockIdx.x, p.xcd_tm, p.xcd_tn, tile_m, tile_n)) return;
-  const int m0 = tile_m * (32 * WAVES), n0 = tile_n * BN;
+  const int m0 = tile_m * (16 * S * WAVES), n0 = tile_n * BN;
   int Mlim = p.M;
   if (p.m_dev) Mlim = min(Mlim, *p.m_dev);
   if (m0 >= Mlim || n0 >= p.N) return;
-  const int wrow = 32 * wave;
+  const int wrow = 16 * S * wave;
 
-  f32x4 acc[2][11];
+  f32x4 acc[S][11];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < S; ++i)
 #pragma unroll
     for (int j = 0; j < 11; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -856,10 +912,10 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
   const float* safe = p.A[0];
   const int64_t img_piece = (int64_t)p.b_img_rows * 64;
   // rows of this lane (one per strip) for both sources
-  const float* a_row[2][2];
-  bool a_ok[2];
+  const float* a_row[2][S];
+  bool a_ok[S];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < S; ++i) {
     const int gm = m0 + wrow + 16 * i + r;
     a_ok[i] = gm < Mlim;
 #pragma unroll
@@ -876,7 +932,7 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
                             T1 > 0 ? reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.b_img2) + (int64_t)T1 * NP * img_piece) + n0
                                    : nullptr};
 
-  float4 a_raw[2][2][2];              // [set][strip][half]: k = k0 + 8g + 4*half ..; tile t lives in set t & 1
+  float4 a_raw[2][S][2];              // [set][strip][half]: k = k0 + 8g + 4*half ..; tile t lives in set t & 1
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   // A rows of tile t -> registers, two tiles ahead of the MFMAs (HBM latency under load exceeds one k-tile of MFMAs now that a
@@ -887,15 +943,17 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
     const int ts = src == 0 ? t : t - T0;
     const int k = ts * BK + 8 * g;
     const int Ks = p.K[src];
+    const int toff = (BXA_ABL & 4) ? 0 : ts * BK;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < S; ++i)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
-        a_raw[set][i][h] = ld4<true>(a_row[src][i] + ts * BK + 4 * h, a_ok[i] ? Ks - (k + 4 * h) : 0, safe);
+        a_raw[set][i][h] = ld4<true>(a_row[src][i] + toff + 4 * h, a_ok[i] ? Ks - (k + 4 * h) : 0, safe);
   };
   // B image tile -> LDS by asynchronous global->LDS loads (the LDS image IS the global image: a lane-linear copy, no
   // staging registers, no ds_write); `buf` is the buffer being filled for tile t
   auto load_b = [&](int t, int buf) {
+    if ((BXA_ABL & 8) && t > 0) return;
     const int src = t < T0 ? 0 : 1;
     const int ts = src == 0 ? t : t - T0;
     const char* tile = img[src] + (int64_t)ts * NP * img_piece;
@@ -911,9 +969,20 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
       }
     });
   };
-  u32x4 a[2][NP];
-  int rowE[2] = {HX_EMIN, HX_EMIN};    // FMT 1: biased exponent of the running maximum of this lane's two rows
-  auto split_a = [&](auto setc, bool first) { bx_split_rows<FMT, 11>(a_raw[decltype(setc)::value], a, rowE, acc, first); };
+  u32x4 a[S][NP];
+  int rowE[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) rowE[i] = HX_EMIN;    // FMT 1: biased exponent of the running maximum of this lane's two rows
+  auto split_a = [&](auto setc, bool first) {
+    if ((BXA_ABL & 16) && !first) {
+#pragma unroll
+      for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) asm volatile("" :: "v"(a_raw[decltype(setc)::value][i][h].x), "v"(a_raw[decltype(setc)::value][i][h].w));
+      return;
+    }
+    bx_split_rows<FMT, 11, S>(a_raw[decltype(setc)::value], a, rowE, acc, first);
+  };
   const int frag_off = r * 64 + ((g ^ bx_swz(r)) << 4);
   auto compute_tile = [&](int buf) {
     const char* Bs = lds + buf * NP * BX_B_PIECE;
@@ -922,9 +991,36 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
       for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const u32x4*>(Bs + q * BX_B_PIECE + (16 * j) * 64 + frag_off);
     };
     auto mma = [&](const u32x4 (&b)[NP], int j) {
+      if (BXA_ABL & 1) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][j] = bx_mma<FMT>(b, a[i], acc[i][j]);     // operands swapped: image rows = accumulator columns
+        for (int q = 0; q < NP; ++q) asm volatile("" :: "v"(b[q]), "v"(a[0][q]), "v"(a[1][q]));
+        return;
+      }
+#pragma unroll
+      for (int i = 0; i < S; ++i) acc[i][j] = bx_mma<FMT>(b, a[i], acc[i][j]);     // operands swapped: image rows = accumulator columns
     };
+    if constexpr (S == 1) {
+      // one strip: the products of a column tile are ONE dependent chain - two column tiles are multiplied product by product
+      // in turn, and the fragments of the next pair are read meanwhile (four register sets)
+      constexpr int NQ = FMT == 0 ? 6 : 3;
+      u32x4 bb[4][NP];
+      ldb(bb[0], 0); ldb(bb[1], 1);
+      bx_for<6>([&](auto pc) {
+        constexpr int j = 2 * decltype(pc)::value, cs = (decltype(pc)::value & 1) * 2;
+        if constexpr (j + 2 < 11) ldb(bb[2 - cs], j + 2);
+        if constexpr (j + 3 < 11) ldb(bb[3 - cs], j + 3);
+        if (BXA_ABL & 1) {
+#pragma unroll
+          for (int q = 0; q < NP; ++q) asm volatile("" :: "v"(bb[cs][q]), "v"(bb[cs + 1][q]), "v"(a[0][q]));
+        } else {
+          bx_for<NQ>([&](auto qc) {
+            constexpr int Q = decltype(qc)::value;
+            acc[0][j] = bx_mma_q<FMT, Q>(bb[cs], a[0], acc[0][j]);
+            if constexpr (j + 1 < 11) acc[0][j + 1] = bx_mma_q<FMT, Q>(bb[cs + 1], a[0], acc[0][j + 1]);
+          });
+        }
+      });
+    } else {
     u32x4 b0[NP], b1[NP];
     ldb(b0, 0);
 #pragma unroll
@@ -934,10 +1030,15 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
       if (j + 2 < 11) ldb(b0, j + 2);
       if (j + 1 < 11) mma(b1, j + 1);
     }
+    }
   };
 
   using C0 = std::integral_constant<int, 0>;
   using C1 = std::integral_constant<int, 1>;
+#if BXA_STAMPS
+  uint32_t st_acc[4] = {0, 0, 0, 0};      // shader cycles of wavefront 0 in: MFMA + LDS reads | wait for the loads | row split | barrier
+  uint64_t st_loop0 = 0;
+#endif
   // one k-tile: the fragments of tile t are in `a`; queue the image of t+1 and the rows of t+2, multiply, split the rows of t+1
   auto step = [&](int t, auto curc) {
     constexpr int cur = decltype(curc)::value;                 // == t & 1
@@ -952,30 +1053,62 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
           const int4 e2 = *reinterpret_cast<const int4*>(bexp[1] + 16 * j + 4 * g);
           const int4 d = {e1.x - e2.x, e1.y - e2.y, e1.z - e2.z, e1.w - e2.w};
 #pragma unroll
-          for (int i = 0; i < 2; ++i) acc[i][j] = hx_scale4(acc[i][j], d, 0);
+          for (int i = 0; i < S; ++i) acc[i][j] = hx_scale4(acc[i][j], d, 0);
         }
       }
     }
+#if BXA_STAMPS
+    const uint64_t c0 = __builtin_amdgcn_s_memtime();
+#endif
     compute_tile(cur);
+#if BXA_STAMPS
+    asm volatile("s_nop 0" ::: "memory");
+    const uint64_t c1 = __builtin_amdgcn_s_memtime();
+    uint64_t c2 = c1, c3 = c1;
+#endif
     if (more) {
       // the DMA is ordered only by the issuing wave's vmcnt + the barrier; the four row loads of tile t+2 were issued last
-      if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (more2) { if constexpr (S == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if BXA_STAMPS
+      c2 = __builtin_amdgcn_s_memtime();
+#endif
       split_a(std::integral_constant<int, 1 - cur>{}, false);  // this wavefront's own fragments for tile t+1
+#if BXA_STAMPS
+      asm volatile("s_nop 0" ::: "memory");
+      c3 = __builtin_amdgcn_s_memtime();
+#endif
     }
     __syncthreads();
+#if BXA_STAMPS
+    const uint64_t c4 = __builtin_amdgcn_s_memtime();
+    st_acc[0] += (uint32_t)(c1 - c0); st_acc[1] += (uint32_t)(c2 - c1); st_acc[2] += (uint32_t)(c3 - c2); st_acc[3] += (uint32_t)(c4 - c3);
+#endif
   };
   if (T > 0) {
     load_a(0, C0{});
     load_b(0, 0);
-    if (T > 1) { load_a(1, C1{}); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    if (T > 1) { load_a(1, C1{}); if constexpr (S == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     split_a(C0{}, true);
     __syncthreads();
+    BXA_STAMP(1);
+#if BXA_STAMPS
+    st_loop0 = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = 0; t < T; t += 2) {
       step(t, C0{});
       if (t + 1 < T) step(t + 1, C1{});
     }
   }
+  BXA_STAMP(2);
+#if BXA_STAMPS
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
+    g_bxa_stamps[blockIdx.x * 8 + 5] = ((uint64_t)st_acc[1] << 32) | st_acc[0];
+    g_bxa_stamps[blockIdx.x * 8 + 6] = ((uint64_t)st_acc[3] << 32) | st_acc[2];
+    g_bxa_stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memtime() - st_loop0;      // (overwritten by stamp 3 unless BXA_STAMPS == 2)
+  }
+#endif
 
   float* Cb = p.C;
   const int64_t ldc = p.ldc;
@@ -983,8 +1116,90 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
   const float* rs = p.row_scale;
   const bool n4 = bx_n4(p, Cb, ldc, bias);
   const int32_t* bexp_last = T1 > 0 ? bexp[1] : bexp[0];
+  if ((BXA_ABL & 2) && p.K[0] >= 0) return;
+  if (BXA_EPI && n4) {
+    // Every load of the epilogue BEFORE the first store.  The compiler may not move a load above a store that could alias it,
+    // so "load the column's exponents, scale, store" 22 times over was a chain of 22 load latencies per wavefront, each behind
+    // the previous store (in-kernel stamps, profiles/r5_areg_stamps.txt: 11 of a workgroup's 25 us at the d ctx' shape).
+    // Per-COLUMN values (image-row exponents, bias) go through LDS - the image buffers are free after the last k-tile's
+    // barrier; per-ROW sources (accumulate / addend rows / ReLU source) are read one source at a time for both strips.
+    int* s_exp = reinterpret_cast<int*>(lds);
+    float* s_bias = reinterpret_cast<float*>(lds) + BN;
+    for (int c = tid; c < BN; c += NTHR) {
+      const bool in = n0 + c < p.N;
+      if constexpr (FMT == 1) s_exp[c] = in ? bexp_last[c] : 0;
+      s_bias[c] = (bias && in) ? bias[n0 + c] : 0.f;
+    }
+    __syncthreads();
+    int row[S]; bool ok[S];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < S; ++i) { row[i] = m0 + wrow + 16 * i + r; ok[i] = row[i] < Mlim; if (!ok[i]) row[i] = m0; }
+    float rscale[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) rscale[i] = rs ? rs[(int64_t)row[i] * p.rs_ld] : 1.f;
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+#pragma unroll
+      for (int j = 0; j < 11; ++j) {
+        const int c = 16 * j + 4 * g;
+        if constexpr (FMT == 1) acc[i][j] = hx_scale4(acc[i][j], *reinterpret_cast<const int4*>(s_exp + c), rowE[i] - 2 * HX_TOP);
+      }
+    auto each_row_source = [&](const float* src, int64_t ld, const int32_t* idx, auto&& apply) {
+      const float* rp[S];
+#pragma unroll
+      for (int i = 0; i < S; ++i) rp[i] = src + (int64_t)(idx ? idx[row[i]] : row[i]) * ld + n0 + 4 * g;
+      const int lastc = p.N - n0 - 4 - 4 * g;                  // offset of the last in-range float4 from rp (n4: N is a multiple of 4)
+      float4 t[S][11];                                         // (columns past N: the row's last four instead - never stored)
+#pragma unroll
+      for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int j = 0; j < 11; ++j) t[i][j] = *reinterpret_cast<const float4*>(rp[i] + min(16 * j, lastc));
+#pragma unroll
+      for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int j = 0; j < 11; ++j) apply(acc[i][j], t[i][j]);
+    };
+    if (p.accumulate) each_row_source(Cb, ldc, nullptr, [](f32x4& a, const float4 o) { a[0] += o.x; a[1] += o.y; a[2] += o.z; a[3] += o.w; });
+    if (bias) {
+#pragma unroll
+      for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+          const float4 bv = *reinterpret_cast<const float4*>(s_bias + 16 * j + 4 * g);
+          acc[i][j][0] = fmaf(bv.x, rscale[i], acc[i][j][0]); acc[i][j][1] = fmaf(bv.y, rscale[i], acc[i][j][1]);
+          acc[i][j][2] = fmaf(bv.z, rscale[i], acc[i][j][2]); acc[i][j][3] = fmaf(bv.w, rscale[i], acc[i][j][3]);
+        }
+    }
+    if (p.add_src) each_row_source(p.add_src, p.add_ld, p.add_idx, [](f32x4& a, const float4 o) { a[0] += o.x; a[1] += o.y; a[2] += o.z; a[3] += o.w; });
+    if (p.row_zero) {
+#pragma unroll
+      for (int i = 0; i < S; ++i)
+        if (p.row_zero[row[i]] != 0) {
+#pragma unroll
+          for (int j = 0; j < 11; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int j = 0; j < 11; ++j)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[i][j][c] = fmaxf(acc[i][j][c], 0.f);
+    }
+    if (p.relu_src) each_row_source(p.relu_src, p.relu_ld, nullptr, [](f32x4& a, const float4 m) {
+      a[0] = m.x > 0.f ? a[0] : 0.f; a[1] = m.y > 0.f ? a[1] : 0.f; a[2] = m.z > 0.f ? a[2] : 0.f; a[3] = m.w > 0.f ? a[3] : 0.f; });
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      if (!ok[i]) continue;
+      float* cp = Cb + (int64_t)row[i] * ldc + n0 + 4 * g;
+#pragma unroll
+      for (int j = 0; j < 11; ++j)
+        if (n0 + 16 * j + 4 * g < p.N) *reinterpret_cast<f32x4*>(cp + 16 * j) = acc[i][j];
+    }
+  } else {
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
     const int row = m0 + wrow + 16 * i + r;
     if (row >= Mlim) continue;
     const float rscale = rs ? rs[(int64_t)row * p.rs_ld] : 1.f;
@@ -1000,11 +1215,26 @@ __device__ __forceinline__ void bx_areg_body(const GemmDev& p, char* lds) {
       }
     }
   }
+  }
+#if BXA_STAMPS
+  if (BXA_STAMPS != 2) BXA_STAMP(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BXA_STAMP(4);
+#endif
 }
 template <int FMT>
 __global__ __launch_bounds__(GEMM_THREADS, FMT == 1 ? BX_AREG_OCC : 2) void gemm_bx_areg_kernel(const GemmDev p) {
   __shared__ __attribute__((aligned(16))) char lds[2 * BxFmt<FMT>::NP * BX_B_PIECE];
   bx_areg_body<4, FMT>(p, lds);
+}
+// The same 128-row workgroup as EIGHT wavefronts of one 16-row strip each: half the registers per wavefront (<= 128), so four
+// wavefronts per SIMD instead of two - the row split (vector pipe) of one wavefront runs beside the MFMAs of another and a
+// wavefront waiting for its rows leaves three to issue.  In-kernel stamps of the four-wavefront form (profiles/r5_areg_stamps.txt):
+// per k-tile 1 370 cycles of MFMAs, 330 waiting for rows, 650-740 splitting rows, 150-180 at the barrier, one after the other.
+template <int FMT>
+__global__ __launch_bounds__(512, 2) void gemm_bx_areg8_kernel(const GemmDev p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * BxFmt<FMT>::NP * BX_B_PIECE];
+  bx_areg_body<8, FMT, 1>(p, lds);
 }
 // ---------------------------------------------------------------------------------------------
 // The lazy GRU of the touched rows in ONE launch (memory_updater.py:18-61: torch.nn.GRUCell on [message | memory]): both
@@ -1156,13 +1386,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
     __syncthreads();
   }
   // gates.  lane (r, g), strip i: row m0 + wrow + 16 i + r; group q: hidden units u0 .. u0 + 3, u0 = 32 by + 16 q + 4 g
+  // Two passes: every load and the gate math of all four (strip, group) pairs first, the 24 stores after them - a load may not
+  // pass a store that could alias it, so "load, compute, store" four times over was four load latencies one after the other.
   const int D = p.D;
+  float hn_[2][2][4], h0_[2][2][4];
+  bool live[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = m0 + wrow + 16 * i + r;
-    if (row >= Mlim) continue;
-    const int64_t id = p.touched[row];
-    const int64_t srow = p.gather ? id : row;                  // row of the state operands (tables or packed copies)
+    const bool rok = row < Mlim;
+    const int64_t id = p.touched[rok ? row : m0];
+    const int64_t srow = p.gather ? id : (rok ? row : m0);     // row of the state operands (tables or packed copies)
     const bool has = p.hm[srow] != 0;
     if constexpr (FMT == 1) {                         // back to plain fp32: r, z and n_h carry W_hh's row scales, n_i W_ih's
 #pragma unroll
@@ -1172,30 +1406,48 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int u0 = 32 * tile_n + 16 * q + 4 * g;
-      if (u0 >= D) continue;                                    // D % 4 == 0: a lane's four units are all inside or all outside
-      const float4 h4 = *reinterpret_cast<const float4*>(p.h_rows + srow * p.ld_h + u0);
-      const float4 nf = *reinterpret_cast<const float4*>(p.node_feat + id * D + u0);
-      const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
-      float rr[4], zz[4], nn[4], gh[4], hn[4];
+      live[i][q] = rok && u0 < D;                               // D % 4 == 0: a lane's four units are all inside or all outside
+      const int uc = u0 < D ? u0 : 0;
+      const float4 h4 = *reinterpret_cast<const float4*>(p.h_rows + srow * p.ld_h + uc);
+      const float4 nf = *reinterpret_cast<const float4*>(p.node_feat + id * D + uc);
+      const float hv[4] = {h4.x, h4.y, h4.z, h4.w}, nfv[4] = {nf.x, nf.y, nf.z, nf.w};
+      float b_r[4], b_z[4], b_n[4], b_g[4];                     // (the bias vectors sit anywhere in the parameter buffer: scalar loads)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int u = u0 + e;
-        const float pr = acc[i][4 * q + 0][e] + p.b_ih[u] + p.b_hh[u];
-        const float pz = acc[i][4 * q + 1][e] + p.b_ih[D + u] + p.b_hh[D + u];
-        const float pn = acc[i][4 * q + 2][e] + p.b_ih[2 * D + u];
-        gh[e] = acc[i][4 * q + 3][e] + p.b_hh[2 * D + u];
-        rr[e] = gf_sigmoid(pr);
-        zz[e] = gf_sigmoid(pz);
-        nn[e] = gf_tanh(pn + rr[e] * gh[e]);
-        hn[e] = has ? (1.f - zz[e]) * nn[e] + zz[e] * hv[e] : hv[e];      // no pending message: the memory row is kept
+        b_r[e] = p.b_ih[uc + e] + p.b_hh[uc + e];
+        b_z[e] = p.b_ih[D + uc + e] + p.b_hh[D + uc + e];
+        b_n[e] = p.b_ih[2 * D + uc + e];
+        b_g[e] = p.b_hh[2 * D + uc + e];
       }
-      *reinterpret_cast<float4*>(p.upd_mem + (int64_t)row * D + u0) = float4{hn[0], hn[1], hn[2], hn[3]};
-      *reinterpret_cast<float4*>(p.h0_tab + (int64_t)row * D + u0) = float4{hn[0] + nf.x, hn[1] + nf.y, hn[2] + nf.z, hn[3] + nf.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pr = acc[i][4 * q + 0][e] + b_r[e];
+        const float pz = acc[i][4 * q + 1][e] + b_z[e];
+        const float pn = acc[i][4 * q + 2][e] + b_n[e];
+        const float gh = acc[i][4 * q + 3][e] + b_g[e];
+        const float rr = gf_sigmoid(pr);
+        const float zz = gf_sigmoid(pz);
+        const float nn = gf_tanh(pn + rr * gh);
+        const float hn = has ? (1.f - zz) * nn + zz * hv[e] : hv[e];      // no pending message: the memory row is kept
+        acc[i][4 * q + 0][e] = rr; acc[i][4 * q + 1][e] = zz; acc[i][4 * q + 2][e] = nn; acc[i][4 * q + 3][e] = gh;
+        hn_[i][q][e] = hn; h0_[i][q][e] = hn + nfv[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = m0 + wrow + 16 * i + r;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (!live[i][q]) continue;
+      const int u0 = 32 * tile_n + 16 * q + 4 * g;
+      *reinterpret_cast<float4*>(p.upd_mem + (int64_t)row * D + u0) = float4{hn_[i][q][0], hn_[i][q][1], hn_[i][q][2], hn_[i][q][3]};
+      *reinterpret_cast<float4*>(p.h0_tab + (int64_t)row * D + u0) = float4{h0_[i][q][0], h0_[i][q][1], h0_[i][q][2], h0_[i][q][3]};
       float* gs = p.gates + (int64_t)row * 4 * D + u0;           // kept for the backward: r | z | n | gh_n
-      *reinterpret_cast<float4*>(gs) = float4{rr[0], rr[1], rr[2], rr[3]};
-      *reinterpret_cast<float4*>(gs + D) = float4{zz[0], zz[1], zz[2], zz[3]};
-      *reinterpret_cast<float4*>(gs + 2 * D) = float4{nn[0], nn[1], nn[2], nn[3]};
-      *reinterpret_cast<float4*>(gs + 3 * D) = float4{gh[0], gh[1], gh[2], gh[3]};
+      *reinterpret_cast<f32x4*>(gs) = acc[i][4 * q + 0];
+      *reinterpret_cast<f32x4*>(gs + D) = acc[i][4 * q + 1];
+      *reinterpret_cast<f32x4*>(gs + 2 * D) = acc[i][4 * q + 2];
+      *reinterpret_cast<f32x4*>(gs + 3 * D) = acc[i][4 * q + 3];
     }
   }
 }
@@ -1406,6 +1658,62 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_skinny_kernel(const G
   float* Cb = p.C;
   const int64_t ldc = p.ldc;
   const bool n4 = bx_n4(p, Cb, ldc, p.bias);
+  if (BXA_EPI && n4 && !p.gg_gates) {
+    // every load of the epilogue in front of its first store (see bx_areg_body: a load may not pass a store that could alias
+    // it, so the per-tile "exponents, addends, store" was a chain of load latencies)
+    int colv[NJW]; bool okc[NJW];
+    int4 ex[NJW]; float4 bs[NJW];
+#pragma unroll
+    for (int jj = 0; jj < NJW; ++jj) {
+      const int j = wave + 4 * jj;
+      const int col = n0 + 16 * j + 4 * g;
+      okc[jj] = j < NT && col < p.N;
+      colv[jj] = okc[jj] ? col : n0;                           // (n0 < N: a valid quad to read instead)
+      ex[jj] = int4{0, 0, 0, 0}; bs[jj] = float4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (FMT == 1) ex[jj] = *reinterpret_cast<const int4*>(bexp1 + colv[jj]);
+      if (p.bias) bs[jj] = *reinterpret_cast<const float4*>(p.bias + colv[jj]);
+    }
+    int rowv[2]; bool okr[2]; float rscale[2]; bool zero[2];
+    float4 tc[2][NJW], ta[2][NJW], tr[2][NJW];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = m0 + 16 * i + r;
+      okr[i] = row < Mlim;
+      rowv[i] = okr[i] ? row : m0;
+      rscale[i] = p.row_scale ? p.row_scale[(int64_t)rowv[i] * p.rs_ld] : 1.f;
+      zero[i] = p.row_zero ? (p.row_zero[rowv[i]] != 0) : false;
+      const float* addrow = p.add_src ? p.add_src + (int64_t)(p.add_idx ? p.add_idx[rowv[i]] : rowv[i]) * p.add_ld : nullptr;
+#pragma unroll
+      for (int jj = 0; jj < NJW; ++jj) {
+        if (p.accumulate) tc[i][jj] = *reinterpret_cast<const float4*>(Cb + (int64_t)rowv[i] * ldc + colv[jj]);
+        if (addrow) ta[i][jj] = *reinterpret_cast<const float4*>(addrow + colv[jj]);
+        if (p.relu_src) tr[i][jj] = *reinterpret_cast<const float4*>(p.relu_src + (int64_t)rowv[i] * p.relu_ld + colv[jj]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < NJW; ++jj) {
+        f32x4 v = acc[i][jj];
+        if constexpr (FMT == 1) v = hx_scale4(v, ex[jj], accE[i] - 2 * HX_TOP);
+        if (p.accumulate) { v[0] += tc[i][jj].x; v[1] += tc[i][jj].y; v[2] += tc[i][jj].z; v[3] += tc[i][jj].w; }
+        if (p.bias) { v[0] = fmaf(bs[jj].x, rscale[i], v[0]); v[1] = fmaf(bs[jj].y, rscale[i], v[1]); v[2] = fmaf(bs[jj].z, rscale[i], v[2]); v[3] = fmaf(bs[jj].w, rscale[i], v[3]); }
+        if (p.add_src) { v[0] += ta[i][jj].x; v[1] += ta[i][jj].y; v[2] += ta[i][jj].z; v[3] += ta[i][jj].w; }
+        if (zero[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (p.relu_src) {
+          v[0] = tr[i][jj].x > 0.f ? v[0] : 0.f; v[1] = tr[i][jj].y > 0.f ? v[1] : 0.f;
+          v[2] = tr[i][jj].z > 0.f ? v[2] : 0.f; v[3] = tr[i][jj].w > 0.f ? v[3] : 0.f;
+        }
+        acc[i][jj] = v;
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < NJW; ++jj)
+        if (okr[i] && okc[jj]) *reinterpret_cast<f32x4*>(Cb + (int64_t)rowv[i] * ldc + colv[jj]) = acc[i][jj];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = m0 + 16 * i + r;
@@ -2285,7 +2593,12 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
         const int tmr = (int)pfo_ceil_div(g.M, BM);
         dim3 grid((unsigned)tmr, tn, 1);
         if (xcd && tn > 1) { d.xcd_tm = tmr; d.xcd_tn = (int)tn; grid = dim3((unsigned)(pfo_ceil_div(tmr, 8) * 8 * tn), 1, 1); }
-        if (pfo_bx_fmt()) PFO_KLAUNCH(gemm_bx_areg_kernel<1>, grid, dim3(GEMM_THREADS), 0, stream, d);
+        // (eight single-strip wavefronts from PFO_AREG8 workgroups on: 0 = never; below one workgroup per slot the four-wavefront form's
+        //  fewer barriers win - QX / GRU shapes at 470 workgroups: 32.0 against 35.7 us)
+        static const int areg8_min = getenv("PFO_AREG8") ? atoi(getenv("PFO_AREG8")) : PFO_DEFAULT_AREG8;      // A/B switch
+        const bool areg8 = areg8_min > 0 && big_tiles >= areg8_min;
+        if (pfo_bx_fmt() && areg8) PFO_KLAUNCH(gemm_bx_areg8_kernel<1>, grid, dim3(512), 0, stream, d);
+        else if (pfo_bx_fmt()) PFO_KLAUNCH(gemm_bx_areg_kernel<1>, grid, dim3(GEMM_THREADS), 0, stream, d);
         else PFO_KLAUNCH(gemm_bx_areg_kernel<0>, grid, dim3(GEMM_THREADS), 0, stream, d);
       }
       else {
