@@ -76,6 +76,9 @@ static bool aligned4(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 #ifndef BXA_STAGGER
 #define BXA_STAGGER 0    // A/B: the second workgroup of every CU's first round starts BXA_STAGGER x 3.4 us late (phases of the two differ)
 #endif
+#ifndef PFO_DEFAULT_ASTAT
+#define PFO_DEFAULT_ASTAT 1
+#endif
 #ifndef PFO_DEFAULT_AREG8
 #define PFO_DEFAULT_AREG8 512 // the image kernel's large form as eight single-strip wavefronts (gemm_bx_areg8_kernel) from this many workgroups on
 #endif
@@ -1237,6 +1240,265 @@ __global__ __launch_bounds__(512, 2) void gemm_bx_areg8_kernel(const GemmDev p) 
   bx_areg_body<8, FMT, 1>(p, lds);
 }
 // ---------------------------------------------------------------------------------------------
+// A-STATIONARY form of the image kernel for SHORT contractions with MANY output columns (the d ctx' contraction: K = 172,
+// N = 704): a wavefront loads its 32 rows ONCE, finds each row's scale from the whole row (no running maximum, no rescaling),
+// splits them into the fp16 fragments of ALL k-tiles (<= 6 tiles: 96 registers) and keeps them; the image of B then streams
+// through an LDS ring, two 16-column tiles per slot, and every pair of column tiles is multiplied, scaled and STORED while the
+// next ones arrive.  Against gemm_bx_areg_kernel on this shape (in-kernel stamps, profiles/r5_areg_stamps.txt): the rows are
+// read and split once instead of once per 176-column block (4 x), the 3 us of load latency in front of a workgroup's first MFMA
+// is paid once per 128 x 704 instead of per 128 x 176 output, and the stores leave evenly over the workgroup's life instead of
+// in a burst behind its last k-tile (workgroups of one launch run in lockstep: everyone stored at once, nobody multiplied).
+// Plain stores only (no bias / addend / ReLU epilogue), N a multiple of 32, K <= 192, fp16x2 format; a workgroup whose 128 rows
+// are not all inside M takes conservative waits (the exact vmcnt bookkeeping below assumes no store is skipped).
+#define AS_TMAX 6
+#define AS_RING 3
+template <bool FULL, int T>
+__device__ __forceinline__ void bx_astat_body(const GemmDev& p, char* lds) {
+  constexpr int NP = 2;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * 128;
+  int Mlim = p.M;
+  if (p.m_dev) Mlim = min(Mlim, *p.m_dev);
+  const int wrow = 32 * wave;
+  const int K = p.K[0];
+  const int NS = p.N >> 5;                                         // slots: pairs of column tiles
+  const int64_t img_piece = (int64_t)p.b_img_rows * 64;
+  const char* img = reinterpret_cast<const char*>(p.b_img);
+  const int slot_bytes = 4 * T * 1024;                             // [column tile 0 | 1][k-tile][piece] x (16 image rows x 64 B)
+  char* ring = lds;
+  const int32_t* bexp = reinterpret_cast<const int32_t*>(img + (int64_t)T * NP * img_piece);   // the image rows' exponents
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // chunk c of a slot = (column tile jj, k-tile t, piece q), c = (jj * T + t) * 2 + q: 1 KB, contiguous in the image; wavefront w
+  // moves the chunks w, w + 4, ... (T of them)
+  auto dma_slot = [&](int s) {
+    char* dst = ring + (s % AS_RING) * (4 * AS_TMAX * 1024);
+    bx_for<T>([&](auto uc) {                                        // exactly T instructions per wavefront (the vmcnt bookkeeping counts them)
+      const int c = wave + 4 * decltype(uc)::value;
+      const int q = c & 1, h = c >> 1, jj = h >= T ? 1 : 0, t = h - jj * T;
+      const char* src = img + ((int64_t)t * NP + q) * img_piece + (int64_t)(32 * s + 16 * jj) * 64;
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + lane * 16), (lptr_t)(dst + c * 1024), 16, 0, 0);
+    });
+  };
+  // ---- the rows: loaded once, scaled by the row's own maximum, split for every k-tile
+  u32x4 a[AS_TMAX][2][NP];
+  int rowE[2];
+  {
+    float4 raw[AS_TMAX][2][2];
+    const float* a_row[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int gm = m0 + wrow + 16 * i + r;
+      int64_t ridx = (FULL || gm < Mlim) ? gm : m0;
+      if (p.a_idx[0]) ridx = p.a_idx[0][ridx];
+      a_row[i] = p.A[0] + ridx * p.lda[0] + 8 * g;
+    }
+#pragma unroll
+    for (int t = 0; t < AS_TMAX; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int k = t * BK + 8 * g + 4 * h;
+          raw[t][i][h] = (t < T && k < K) ? *reinterpret_cast<const float4*>(a_row[i] + t * BK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    // (behind the row loads in program order: the first MFMA needs both, and the rows come from HBM)
+    dma_slot(0);
+    if (NS > 1) dma_slot(1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float mx = 0.f;
+#pragma unroll
+      for (int t = 0; t < AS_TMAX; ++t) mx = fmaxf(mx, hx_absmax8(raw[t][i][0], raw[t][i][1]));
+      rowE[i] = hx_exp_of_bits(hx_max_over_g(__float_as_uint(mx)));
+      const int se = HX_TOP - rowE[i];
+#pragma unroll
+      for (int t = 0; t < AS_TMAX; ++t) {
+        uint2 h0, l0, h1, l1;
+        hx_split4(raw[t][i][0], se, h0, l0);
+        hx_split4(raw[t][i][1], se, h1, l1);
+        a[t][i][0] = u32x4{h0.x, h0.y, h1.x, h1.y};
+        a[t][i][1] = u32x4{l0.x, l0.y, l1.x, l1.y};
+      }
+    }
+  }
+  const int frag_off = r * 64 + ((g ^ bx_swz(r)) << 4);
+  float* crow[2];
+  bool ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = m0 + wrow + 16 * i + r;
+    ok[i] = FULL || row < Mlim;
+    crow[i] = p.C + (int64_t)(ok[i] ? row : m0) * p.ldc + 4 * g;
+  }
+  f32x4 prev[2][2];                                                // the pair of column tiles multiplied one slot ago, stored in this one
+  int4 pexp[2];                                                    // ... and its columns' exponents, fetched one slot ahead (2 loads)
+  // vmcnt bookkeeping of one wavefront, oldest first, at the top of slot s:
+  //   ... DMA(s) [T] | stores(s-2) [4] | exponents(s-1) [2] | DMA(s+1) [T]
+  // (iteration s-2 ended with DMA(s); iteration s-1 issued stores(s-2), the exponent loads of slot s-1, DMA(s+1)): DMA(s) has
+  // landed when at most 4 + 2 + T younger operations are outstanding.  Members that do not exist (no stores before slot 2, no
+  // DMA behind the last slot) are not counted: counting something that was never issued would make the wait too lax.
+  auto wait_vm = [&](auto nc) {
+    constexpr int n = (FULL && BXA_ABL == 0) ? decltype(nc)::value : 0;
+    static_assert(n <= 12, "vmcnt");
+    if constexpr (n == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (n == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    else if constexpr (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+#if BXA_STAMPS
+  uint32_t st_acc[4] = {0, 0, 0, 0};
+  BXA_STAMP(1);
+  const uint64_t st_loop0 = __builtin_amdgcn_s_memtime();
+#endif
+  // One slot: wait, barrier, then ONE straight-line block in which the 12 memory instructions of the slot (4 stores of the pair
+  // multiplied one slot ago, 2 exponent loads, T DMA chunks of slot s+2) are spread between the k-tiles' MFMAs.  Issued in a
+  // burst behind the barrier - by all four wavefronts at once - they queued in the CU's one texture-address unit for 1 430
+  // cycles per slot while no wavefront multiplied (in-kernel stamps, profiles/r5_areg_stamps.txt).
+  auto slot_body = [&](int s, auto hsc, auto hdc, auto nc) {
+    constexpr bool HS = decltype(hsc)::value, HD = decltype(hdc)::value;
+#if BXA_STAMPS
+    const uint64_t c0 = __builtin_amdgcn_s_memtime();
+#endif
+    wait_vm(nc);
+#if BXA_STAMPS
+    const uint64_t c1 = __builtin_amdgcn_s_memtime();
+#endif
+    __syncthreads();                                               // DMA(s) of every wavefront has landed; slot (s-1) % RING is free
+#if BXA_STAMPS
+    const uint64_t c2 = __builtin_amdgcn_s_memtime();
+    const uint64_t c3 = c2;
+#endif
+    const char* Bs = ring + (s % AS_RING) * (4 * AS_TMAX * 1024);
+    char* dst = ring + ((s + 2) % AS_RING) * (4 * AS_TMAX * 1024);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[jj][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 b0[2][NP], b1[2][NP];
+    auto ldb = [&](u32x4 (&b)[2][NP], int t) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) b[jj][q] = *reinterpret_cast<const u32x4*>(Bs + ((jj * T + t) * 2 + q) * 1024 + frag_off);
+    };
+    auto mma = [&](const u32x4 (&b)[2][NP], auto tc) {
+      constexpr int t = decltype(tc)::value;
+      // four independent accumulators, product by product: a dependent MFMA never follows its predecessor directly
+      bx_for<3>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[jj][i] = bx_mma_q<1, Q>(b[jj], a[t][i], acc[jj][i]);
+      });
+    };
+    // memory instruction m of the slot, in the order the bookkeeping above assumes: 0..3 stores (jj, i) | 4, 5 exponents | 6.. DMA
+    int4 nexp[2];
+    auto mem_op = [&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      if constexpr (m < 4) {
+        if constexpr (HS) {
+          constexpr int jj = m >> 1, i = m & 1;
+          const f32x4 v = hx_scale4(prev[jj][i], pexp[jj], rowE[i] - 2 * HX_TOP);
+          if ((FULL || ok[i]) && !((BXA_ABL & 2) && K > 0)) *reinterpret_cast<f32x4*>(crow[i] + 32 * (s - 1) + 16 * jj) = v;
+        }
+      } else if constexpr (m < 6) {
+        nexp[m - 4] = *reinterpret_cast<const int4*>(bexp + 32 * s + 16 * (m - 4) + 4 * g);
+      } else if constexpr (m - 6 < T) {
+        if constexpr (HD) {
+          if (!((BXA_ABL & 8) && K > 0)) {
+            const int c = wave + 4 * (m - 6);
+            const int q = c & 1, h = c >> 1, jj = h >= T ? 1 : 0, t = h - jj * T;
+            const char* src = img + ((int64_t)t * NP + q) * img_piece + (int64_t)(32 * (s + 2) + 16 * jj) * 64;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + lane * 16), (lptr_t)(dst + c * 1024), 16, 0, 0);
+          }
+        }
+      }
+    };
+    constexpr int NMEM = 6 + T, PER = (NMEM + T - 1) / T;         // memory instructions per k-tile
+    ldb(b0, 0);
+    bx_for<T>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      if constexpr ((t & 1) == 0) { if constexpr (t + 1 < T) ldb(b1, t + 1); mma(b0, tc); }
+      else                        { if constexpr (t + 1 < T) ldb(b0, t + 1); mma(b1, tc); }
+      bx_for<PER>([&](auto kc) { mem_op(std::integral_constant<int, t * PER + decltype(kc)::value>{}); });
+    });
+    // (the order the scheduler must keep: per k-tile the fragment reads of the next tile, 12 MFMAs, PER memory instructions)
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    bx_for<T>([&](auto tc) {
+      if constexpr (decltype(tc)::value + 1 < T) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, PER, 0);
+    });
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      pexp[jj] = nexp[jj];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) prev[jj][i] = acc[jj][i];
+    }
+#if BXA_STAMPS
+    asm volatile("s_nop 0" :: "v"(prev[0][0]), "v"(prev[1][1]) : "memory");
+    const uint64_t c4 = __builtin_amdgcn_s_memtime();
+    st_acc[0] += (uint32_t)(c1 - c0); st_acc[1] += (uint32_t)(c2 - c1); st_acc[2] += (uint32_t)(c3 - c2); st_acc[3] += (uint32_t)(c4 - c3);
+#endif
+  };
+  using TT_ = std::true_type; using FF_ = std::false_type;
+  // NS >= 4 (launcher: N >= 352).  Slot 0: nothing to store; slot 1: no stores are outstanding yet; the last two: no DMA
+  slot_body(0, FF_{}, TT_{}, std::integral_constant<int, T>{});                       // (both first DMAs came from the prologue)
+  slot_body(1, TT_{}, TT_{}, std::integral_constant<int, 2 + T>{});
+  for (int s = 2; s < NS - 2; ++s) slot_body(s, TT_{}, TT_{}, std::integral_constant<int, 4 + 2 + T>{});
+  slot_body(NS - 2, TT_{}, FF_{}, std::integral_constant<int, 4 + 2 + T>{});
+  slot_body(NS - 1, TT_{}, FF_{}, std::integral_constant<int, 4 + 2>{});
+  {                                                                // the last pair
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f32x4 v = hx_scale4(prev[jj][i], pexp[jj], rowE[i] - 2 * HX_TOP);
+        if (FULL || ok[i]) *reinterpret_cast<f32x4*>(crow[i] + 32 * (NS - 1) + 16 * jj) = v;
+      }
+  }
+#if BXA_STAMPS
+  BXA_STAMP(2);
+  if (threadIdx.x == 0 && blockIdx.x < 4096) {
+    g_bxa_stamps[blockIdx.x * 8 + 5] = ((uint64_t)st_acc[1] << 32) | st_acc[0];
+    g_bxa_stamps[blockIdx.x * 8 + 6] = ((uint64_t)st_acc[3] << 32) | st_acc[2];
+    g_bxa_stamps[blockIdx.x * 8 + 3] = (uint64_t)NS;
+    g_bxa_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - st_loop0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BXA_STAMP(4);
+#endif
+}
+#define AS_NMAX 1024
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bx_astat_kernel(const GemmDev p) {
+  __shared__ __attribute__((aligned(16))) char lds_dyn[AS_RING * 4 * AS_TMAX * 1024];      // 72 KB: two workgroups per CU
+  int Mlim = p.M;
+  if (p.m_dev) Mlim = min(Mlim, *p.m_dev);
+  const int m0 = blockIdx.x * 128;
+  if (m0 >= Mlim) return;
+  BXA_STAMP(0);
+  const int T = (p.K[0] + BK - 1) / BK;                             // 1 .. AS_TMAX (launcher)
+  const bool full = m0 + 128 <= Mlim;
+  bx_for<AS_TMAX>([&](auto tc) {
+    constexpr int TT = decltype(tc)::value + 1;
+    if (T == TT) { if (full) bx_astat_body<true, TT>(p, lds_dyn); else bx_astat_body<false, TT>(p, lds_dyn); }
+  });
+}
+// ---------------------------------------------------------------------------------------------
 // The lazy GRU of the touched rows in ONE launch (memory_updater.py:18-61: torch.nn.GRUCell on [message | memory]): both
 // contractions - message rows x W_ih^T (K = 3D + Ef) and memory rows x W_hh^T (K = D), K-concatenated - with the gate math in
 // the epilogue, so the pre-activations gi / gh (2 x 3D floats per row) never go to HBM.  What makes that possible is the ORDER
@@ -1959,19 +2221,58 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
     }
   };
   if (T > 0) {
+#if BXA_STAMPS
+    uint32_t st_acc[5] = {0, 0, 0, 0, 0};      // shader cycles of wavefront 0 per phase of a k-tile step (tools/probes/tn_stamps.py)
+    BXA_STAMP(0);
+#endif
     load_tile(0);
     if constexpr (FMT == 1) { publish_max(); __syncthreads(); }
     store_tile(true);
     __syncthreads();
+#if BXA_STAMPS
+    BXA_STAMP(1);
+    const uint64_t st_loop0 = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = 0; t < T; ++t) {
       const bool more = (BX_EXP == 1) ? false : (t + 1 < T);
+#if BXA_STAMPS
+      const uint64_t c0 = __builtin_amdgcn_s_memtime();
+#endif
       if (more) load_tile(t + 1);
+#if BXA_STAMPS
+      asm volatile("s_nop 0" ::: "memory");
+      const uint64_t c1 = __builtin_amdgcn_s_memtime();
+#endif
       if (BX_EXP != 2) compute_tile();
+#if BXA_STAMPS
+      asm volatile("s_nop 0" ::: "memory");
+      const uint64_t c2 = __builtin_amdgcn_s_memtime();
+#endif
       if constexpr (FMT == 1) { if (more) publish_max(); }
+#if BXA_STAMPS
+      asm volatile("s_nop 0" ::: "memory");
+      const uint64_t c3 = __builtin_amdgcn_s_memtime();
+#endif
       __syncthreads();
+#if BXA_STAMPS
+      const uint64_t c4 = __builtin_amdgcn_s_memtime();
+#endif
       if (more && BX_EXP != 3) store_tile(false);
       __syncthreads();
+#if BXA_STAMPS
+      const uint64_t c5 = __builtin_amdgcn_s_memtime();
+      st_acc[0] += (uint32_t)(c1 - c0); st_acc[1] += (uint32_t)(c2 - c1); st_acc[2] += (uint32_t)(c3 - c2); st_acc[3] += (uint32_t)(c4 - c3); st_acc[4] += (uint32_t)(c5 - c4);
+#endif
     }
+#if BXA_STAMPS
+    BXA_STAMP(2);
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
+      g_bxa_stamps[blockIdx.x * 8 + 5] = ((uint64_t)st_acc[1] << 32) | st_acc[0];
+      g_bxa_stamps[blockIdx.x * 8 + 6] = ((uint64_t)st_acc[3] << 32) | st_acc[2];
+      g_bxa_stamps[blockIdx.x * 8 + 3] = ((uint64_t)st_acc[4] << 32) | (uint32_t)T;
+      g_bxa_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - st_loop0;
+    }
+#endif
   }
   float* Cb = p.slab_base + (int64_t)split * (int64_t)p.M * p.N;
 #pragma unroll
@@ -1986,6 +2287,10 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
         if (col < p.N) Cb[(int64_t)row * p.N + col] = FMT == 1 ? __builtin_amdgcn_ldexpf(acc[i][j][reg], eA + eB - 2 * HX_TOP) : acc[i][j][reg];
       }
     }
+#if BXA_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BXA_STAMP(4);
+#endif
 }
 
 // Pre-split image of a weight operand for gemm_bf16x3_kernel<true>: [k-tile][piece][row n, padded to BN][64 B],
@@ -2595,9 +2900,21 @@ int pfo_gemm_launch(const PfoGemm& g, hipStream_t stream) {
         if (xcd && tn > 1) { d.xcd_tm = tmr; d.xcd_tn = (int)tn; grid = dim3((unsigned)(pfo_ceil_div(tmr, 8) * 8 * tn), 1, 1); }
         // (eight single-strip wavefronts from PFO_AREG8 workgroups on: 0 = never; below one workgroup per slot the four-wavefront form's
         //  fewer barriers win - QX / GRU shapes at 470 workgroups: 32.0 against 35.7 us)
+        // short contraction, many columns, plain stores: the A-stationary form (gemm_bx_astat_kernel)
+        bool as_done = false;
+        static const int astat = getenv("PFO_ASTAT") ? atoi(getenv("PFO_ASTAT")) : PFO_DEFAULT_ASTAT;           // A/B switch
+        if (astat && pfo_bx_fmt() && g.K[1] == 0 && g.K[0] <= AS_TMAX * BK && (g.N % 32) == 0 && g.N >= 352 && (g.ldc % 4) == 0 &&
+            aligned4(g.C) && !g.bias && !g.relu && !g.relu_src && !g.add_src && !g.accumulate && !g.row_scale && !g.row_zero &&
+            !g.gg_gates && g.M >= 128 * 256) {
+          if (g.N <= AS_NMAX) {
+            PFO_KLAUNCH(gemm_bx_astat_kernel, dim3((unsigned)pfo_ceil_div(g.M, 128)), dim3(GEMM_THREADS), 0, stream, d);
+            as_done = true;
+          }
+        }
         static const int areg8_min = getenv("PFO_AREG8") ? atoi(getenv("PFO_AREG8")) : PFO_DEFAULT_AREG8;      // A/B switch
         const bool areg8 = areg8_min > 0 && big_tiles >= areg8_min;
-        if (pfo_bx_fmt() && areg8) PFO_KLAUNCH(gemm_bx_areg8_kernel<1>, grid, dim3(512), 0, stream, d);
+        if (as_done) { }
+        else if (pfo_bx_fmt() && areg8) PFO_KLAUNCH(gemm_bx_areg8_kernel<1>, grid, dim3(512), 0, stream, d);
         else if (pfo_bx_fmt()) PFO_KLAUNCH(gemm_bx_areg_kernel<1>, grid, dim3(GEMM_THREADS), 0, stream, d);
         else PFO_KLAUNCH(gemm_bx_areg_kernel<0>, grid, dim3(GEMM_THREADS), 0, stream, d);
       }

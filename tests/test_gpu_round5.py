@@ -284,3 +284,38 @@ np.savez(sys.argv[1], *out)
             assert relerr(y, x) < 2e-5, (i, relerr(y, x))
         else:                                   # embeddings, loss: the forward is untouched
             assert np.array_equal(x, y)
+
+
+# ------------------------------------------------------------------ the image GEMM kernels reworked this round
+@pytest.mark.parametrize("M,N,K", [(128 * 256, 704, 172),       # the d ctx' shape class: every workgroup full (exact vmcnt bookkeeping)
+                                   (128 * 256 + 77, 704, 172),  # + a last workgroup with 77 rows (conservative waits, masked stores)
+                                   (128 * 256 + 128, 352, 148), # smallest column count taken, K not a multiple of the 32-deep tile
+                                   (128 * 260, 384, 36)])       # two k-tiles only
+def test_a_stationary_image_gemm_against_fp64(M, N, K):
+    """gemm_bx_astat_kernel (short contraction, many columns, plain stores: rows loaded and split once, the image of B streamed
+    through an LDS ring, stores spread over the workgroup's life): against an fp64 product on rows with a wide dynamic range,
+    error measured against sum |a||b| per element like the other image kernels (tests/test_gpu_kernels.py), and bit-identical
+    between two launches."""
+    torch.manual_seed(5)
+    A = torch.randn(M, K, device=DEV) * torch.exp(2 * torch.randn(M, K, device=DEV))
+    B = torch.randn(N, K, device=DEV) * torch.exp(2 * torch.randn(N, K, device=DEV))
+    C = torch.full((M, N), float("nan"), device=DEV)
+    lib = _lib.load()
+    nbytes = lib.pfo_gemm_bf16x3_workspace_bytes(N, K)
+    iws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+
+    def run(out):
+        _lib.call("pfo_gemm_bf16x3", A.data_ptr(), K, B.data_ptr(), K, 0, out.data_ptr(), N, None, M, N, K, 0, iws.data_ptr(), nbytes,
+                  _lib.stream_ptr())
+    run(C)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(C).all())                      # every element written (the NaN fill is gone)
+    for rows in (slice(0, 2048), slice(M - 2048, M)):
+        ref = A[rows].double() @ B.double().T
+        mag = A[rows].double().abs() @ B.double().abs().T
+        err = ((C[rows].double() - ref).abs() / mag).max().item()
+        assert err < 4e-6, err                                 # (two fp16 pieces: ~22 significant bits per operand)
+    C2 = torch.empty_like(C)
+    run(C2)
+    torch.cuda.synchronize()
+    assert torch.equal(C, C2)
