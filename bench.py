@@ -150,6 +150,8 @@ def _family_has(family, kernel_name):
     base = _kernel_base(kernel_name)
     if family == "attn_bwd":
         return base.startswith("attn_bwd_kernel")
+    if family == "gemm_bx":      # three forms behind PFO_PROF_GEMM_BX: four / eight wavefronts per workgroup, A-stationary
+        return base in ("gemm_bx_areg_kernel", "gemm_bx_areg8_kernel", "gemm_bx_astat_kernel")
     return base == FAMILY_KERNEL.get(family, family)
 
 

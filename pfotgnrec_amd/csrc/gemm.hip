@@ -1568,10 +1568,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
   // FMT 1: exponents of the image rows of this block, behind the tiles of each image
   const int32_t* bexp[2] = {reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.img0) + (int64_t)T0 * NP * img_piece) + n0,
                             reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.img1) + (int64_t)T1 * NP * img_piece) + n0};
-  float4 a_raw[2][2];
+  // the rows of tile t live in register set t & 1 and are fetched TWO tiles ahead (as in bx_areg_body: with one set the loads of
+  // tile t+1 had the 36 MFMAs of tile t to arrive in and every k-tile ended in a wait; 67-69 -> 60-65 us at C2)
+  float4 a_raw[2][2][2];
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  auto load_global = [&](int t, int buf) {
+  auto load_a = [&](int t, auto setc) {
+    constexpr int set = decltype(setc)::value;
     const int src = t < T0 ? 0 : 1;
     const int ts = src == 0 ? t : t - T0;
     const int k = ts * BK + 8 * g;
@@ -1580,7 +1583,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
-        a_raw[i][h] = ld4<true>(a_row[src][i] + ts * BK + 4 * h, a_ok[i] ? Ks - (k + 4 * h) : 0, safe);
+        a_raw[set][i][h] = ld4<true>(a_row[src][i] + ts * BK + 4 * h, a_ok[i] ? Ks - (k + 4 * h) : 0, safe);
+  };
+  auto load_b = [&](int t, int buf) {
+    const int src = t < T0 ? 0 : 1;
+    const int ts = src == 0 ? t : t - T0;
     const char* tile = img[src] + (int64_t)ts * NP * img_piece;
     char* Bs = lds + buf * NP * GF_B_PIECE;
     bx_for<2 * NP>([&](auto uc) {                              // NP pieces x 512 units of 16 bytes = 2 NP rounds of 256 threads
@@ -1593,7 +1600,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
   };
   u32x4 a[2][NP];
   int rowE[2] = {HX_EMIN, HX_EMIN};
-  auto split_a = [&](bool first) { bx_split_rows<FMT, GF_NJ>(a_raw, a, rowE, acc, first); };
+  auto split_a = [&](auto setc, bool first) { bx_split_rows<FMT, GF_NJ>(a_raw[decltype(setc)::value], a, rowE, acc, first); };
   const int frag_off = r * 64 + ((g ^ bx_swz(r)) << 4);
   // tiles that take source SRC: the message part feeds r, z, n_i (tiles 0 1 2 | 4 5 6), the memory part r, z, n_h (0 1 3 | 4 5 7)
   auto compute_tile = [&](int buf, auto src_c) {
@@ -1618,13 +1625,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
       mma(b1, act[q + 1]);
     }
   };
-  load_global(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  split_a(true);
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  load_a(0, C0{});
+  load_b(0, 0);
+  if (T > 1) { load_a(1, C1{}); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  split_a(C0{}, true);
   __syncthreads();
-  for (int t = 0; t < T; ++t) {
-    const bool more = t + 1 < T;
-    if (more) load_global(t + 1, (t + 1) & 1);
+  auto step = [&](int t, auto curc) {
+    constexpr int cur = decltype(curc)::value;                 // t & 1
+    const bool more = t + 1 < T, more2 = t + 2 < T;
+    if (more) load_b(t + 1, (t + 1) & 1);
+    if (more2) load_a(t + 2, curc);                            // (the rows of tile t were split before this call)
     if constexpr (FMT == 1) {
       if (t == T0) {                                // the memory part: the r and z tiles move from W_ih's row scales to W_hh's
 #pragma unroll
@@ -1642,10 +1655,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gru_fused_kernel(const GruFus
     }
     if (t < T0) compute_tile(t & 1, std::integral_constant<int, 0>{}); else compute_tile(t & 1, std::integral_constant<int, 1>{});
     if (more) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      split_a(false);
+      // (the DMA is ordered only by the issuing wavefront's vmcnt + the barrier; the four row loads of tile t+2 were issued last)
+      if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      split_a(std::integral_constant<int, 1 - cur>{}, false);
     }
     __syncthreads();
+  };
+  for (int t = 0; t < T; t += 2) {
+    step(t, C0{});
+    if (t + 1 < T) step(t + 1, C1{});
   }
   // gates.  lane (r, g), strip i: row m0 + wrow + 16 i + r; group q: hidden units u0 .. u0 + 3, u0 = 32 by + 16 q + 4 g
   // Two passes: every load and the gate math of all four (strip, group) pairs first, the 24 stores after them - a load may not
