@@ -6,6 +6,8 @@
 #                                                   "lib:<tag>" (pfotgnrec_amd/lib/libpfotgn_<tag>.so) or "VAR=1,VAR2=x" (environment)
 #   tools/gpu.sh stamps <out>                       in-kernel cycle stamps of the layer-1 attention backward (libpfotgn_stamps.so)
 #   tools/gpu.sh marks <out> [bench args]           milestone timeline of the step (bench.py --marks)
+#   tools/gpu.sh gemm_stamps <out>                  in-kernel stamps of the image / A-stationary / weight-gradient GEMM kernels
+#                                                   (build first, here: python -m pfotgnrec_amd.build -DBXA_STAMPS=2 --tag=stamps_bxa)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mode=$1; out=gpurun_out/$2; shift 2; mkdir -p "$out"
 line() { python -c "
@@ -31,6 +33,12 @@ case $mode in
     done; done 2>&1 | tee $out/ab.txt ;;
   stamps)
     PFOTGN_LIB=$GRAFT_REPO_ROOT/pfotgnrec_amd/lib/libpfotgn_stamps.so timeout -k 10 300 python tools/probes/runs_stamps.py "$@" 2>&1 | grep -v amdgpu.ids | tee $out/stamps.txt ;;
+  gemm_stamps)
+    export PFOTGN_LIB=$GRAFT_REPO_ROOT/pfotgnrec_amd/lib/libpfotgn_stamps_bxa.so
+    { PFO_ASTAT=0 STAMPS2=1 timeout -k 10 200 python tools/probes/areg_stamps.py 53760 704 172 &&
+      STAMPS2=1 timeout -k 10 200 python tools/probes/areg_stamps.py 53760 172 704 &&
+      ASTAT_SHAPE=1 timeout -k 10 200 python tools/probes/tn_stamps.py &&
+      timeout -k 10 200 python tools/probes/tn_stamps.py 704 172 53760; } 2>&1 | grep -v amdgpu.ids | tee $out/gemm_stamps.txt ;;
   marks)
     timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-prof --no-drop-in --min-seconds 1.0 --marks 100 "$@" > $out/marks.txt 2>&1; tail -80 $out/marks.txt ;;
   *) echo "unknown mode $mode"; exit 2 ;;
