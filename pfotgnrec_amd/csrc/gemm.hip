@@ -76,6 +76,9 @@ static bool aligned4(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 #ifndef BXA_STAGGER
 #define BXA_STAGGER 0    // A/B: the second workgroup of every CU's first round starts BXA_STAGGER x 3.4 us late (phases of the two differ)
 #endif
+#ifndef PFO_DEFAULT_TN8
+#define PFO_DEFAULT_TN8 500      // weight-gradient launches whose problems all have >= this many rows take 256-row tiles (0 = never)
+#endif
 #ifndef PFO_DEFAULT_ASTAT
 #define PFO_DEFAULT_ASTAT 1
 #endif
@@ -2074,16 +2077,22 @@ __device__ __forceinline__ uint32_t tx_wave_max_u32(uint32_t u) {
   u = max(u, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x124, 0xF, 0xF, false));
   return max(u, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x128, 0xF, 0xF, false));
 }
-template <int FMT>
+// W wavefronts per workgroup, 32 rows of the tile each: 4 (128 x 176, two workgroups per CU) or 8 (256 x 176, one per CU): the
+// second form stages the B tile once per 256 rows instead of once per 128 - the launch's L2-level traffic (A once, B once per row
+// tile) is what its time follows (profiles/r5_tn_stamps.txt).
+template <int FMT, int W = 4>
 __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by, int split, char* lds) {
   constexpr int NP = BxFmt<FMT>::NP;
+  constexpr int NT = 64 * W, TBM = 32 * W;                     // threads, rows of the tile
+  constexpr int TXA_ROW = 2 * TBM, TXA_PIECE = BK * TXA_ROW, TXA_MASK = TBM / 16 - 1;
+  constexpr int NA = BK * (TBM / 4) / NT, NB = (BK * 44 + NT - 1) / NT;      // float4 of the A / B tile per thread
   char* const As = lds;
-  char* const Bs = lds + NP * TX_A_PIECE;
-  uint32_t* const wmax = reinterpret_cast<uint32_t*>(lds + NP * TX_A_PIECE + NP * TX_B_PIECE);     // [4 wavefronts: A | 4: B]
+  char* const Bs = lds + NP * TXA_PIECE;
+  uint32_t* const wmax = reinterpret_cast<uint32_t*>(lds + NP * TXA_PIECE + NP * TX_B_PIECE);     // [W wavefronts: A | W: B]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int m0 = bx * BM, n0 = by * BN;
+  const int m0 = bx * TBM, n0 = by * BN;
   int Kext = p.K[0];
   if (p.m_dev) Kext = min(Kext, *p.m_dev);
   const int chunk = p.dyn_chunk ? ((Kext + p.nsplit - 1) / p.nsplit + BK - 1) / BK * BK : p.split_chunk;
@@ -2101,24 +2110,24 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
   const int64_t lda = p.lda[0], ldb = p.ldb[0];
   // per-thread invariants of the staging pass: which (k-row, column quad) of the tile each of the 4 + 6 float4 covers,
   // where it lands in LDS, and whether it holds the bias column
-  float4 a_reg[4], b_reg[6];
-  const float* a_ptr[4];          // row kbeg + kr of A at this thread's columns; advanced by BK rows per tile
-  int a_kr[4], a_off[4];
-  bool a_col_ok[4];
+  float4 a_reg[NA], b_reg[NB];
+  const float* a_ptr[NA];         // row kbeg + kr of A at this thread's columns; advanced by BK rows per tile
+  int a_kr[NA], a_off[NA];
+  bool a_col_ok[NA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int f = tid + 256 * i;
-    a_kr[i] = f >> 5;
-    const int mc = 4 * (f & 31);
+  for (int i = 0; i < NA; ++i) {
+    const int f = tid + NT * i;
+    a_kr[i] = f / (TBM / 4);
+    const int mc = 4 * (f % (TBM / 4));
     a_col_ok[i] = m0 + mc < p.M;                        // M % 4 == 0 (VEC): a quad is all in or all out
     a_ptr[i] = p.A[0] + (int64_t)(kbeg + a_kr[i]) * lda + m0 + mc;
-    a_off[i] = tx_off(TX_A_ROW, 7, a_kr[i], mc);
+    a_off[i] = tx_off(TXA_ROW, TXA_MASK, a_kr[i], mc);
   }
-  int b_kr[6], b_off[6], b_n[6], b_bias_e[6];
-  bool b_live[6];
+  int b_kr[NB], b_off[NB], b_n[NB], b_bias_e[NB];
+  bool b_live[NB];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int f = tid + 256 * i;
+  for (int i = 0; i < NB; ++i) {
+    const int f = tid + NT * i;
     b_kr[i] = f / 44;
     const int nc = 4 * (f - b_kr[i] * 44);
     b_live[i] = f < BK * 44;
@@ -2134,11 +2143,11 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
   const int k_last = max(Ks - 1, 0);
   // gathered B rows: the row indices of tile t+1 are fetched while tile t is staged, so the row loads of a tile never
   // wait for an index load issued just before them
-  int b_row_next[6];
+  int b_row_next[NB];
   auto fetch_rows = [&](int t) {
     const int k0 = kbeg + t * BK;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < NB; ++i) {
       const int kc = min(k0 + b_kr[i], k_last);
       b_row_next[i] = p.b_idx ? p.b_idx[kc] : kc;                       // wave-uniform test, unconditional load
     }
@@ -2147,12 +2156,12 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
   auto load_tile = [&](int t) {
     const int k0 = kbeg + t * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const bool ok = a_col_ok[i] && (k0 + a_kr[i] < Ks);
       a_reg[i] = ld4<true>(a_ptr[i] + (int64_t)t * BK * lda, ok ? 4 : 0, safe);
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < NB; ++i) {
       const int k = k0 + b_kr[i];
       const bool ok = b_live[i] && k < Ks && b_n[i] < p.N;
       b_reg[i] = ld4<true>(p.B[0] + (int64_t)b_row_next[i] * ldb + b_n[i], ok ? p.n_real - b_n[i] : 0, safe);
@@ -2168,11 +2177,11 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
   auto publish_max = [&]() {
     float ma = 0.f, mb = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ma = fmaxf(fmaxf(ma, fmaxf(fabsf(a_reg[i].x), fabsf(a_reg[i].y))), fmaxf(fabsf(a_reg[i].z), fabsf(a_reg[i].w)));
+    for (int i = 0; i < NA; ++i) ma = fmaxf(fmaxf(ma, fmaxf(fabsf(a_reg[i].x), fabsf(a_reg[i].y))), fmaxf(fabsf(a_reg[i].z), fabsf(a_reg[i].w)));
 #pragma unroll
-    for (int i = 0; i < 6; ++i) mb = fmaxf(fmaxf(mb, fmaxf(fabsf(b_reg[i].x), fabsf(b_reg[i].y))), fmaxf(fabsf(b_reg[i].z), fabsf(b_reg[i].w)));
+    for (int i = 0; i < NB; ++i) mb = fmaxf(fmaxf(mb, fmaxf(fabsf(b_reg[i].x), fabsf(b_reg[i].y))), fmaxf(fabsf(b_reg[i].z), fabsf(b_reg[i].w)));
     const uint32_t ua = tx_wave_max_u32(__float_as_uint(ma)), ub = tx_wave_max_u32(__float_as_uint(mb));
-    if (lane == 0) { wmax[wave] = ua; wmax[4 + wave] = ub; }
+    if (lane == 0) { wmax[wave] = ua; wmax[W + wave] = ub; }
   };
   auto hstore = [&](char* base, int piece_bytes, int off, const float4 v, const int se) {
     uint2 oh, ol;
@@ -2183,13 +2192,18 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
   auto store_tile = [&](bool first) {
     if constexpr (FMT == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) tx_split_store(As, TX_A_PIECE, a_off[i], a_reg[i]);
+      for (int i = 0; i < NA; ++i) tx_split_store(As, TXA_PIECE, a_off[i], a_reg[i]);
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
+      for (int i = 0; i < NB; ++i)
         if (b_live[i]) tx_split_store(Bs, TX_B_PIECE, b_off[i], b_reg[i]);
     } else {
-      const uint4 wa = *reinterpret_cast<const uint4*>(wmax), wb = *reinterpret_cast<const uint4*>(wmax + 4);
-      const int ta = hx_exp_of_bits(max(max(wa.x, wa.y), max(wa.z, wa.w))), tb = hx_exp_of_bits(max(max(wb.x, wb.y), max(wb.z, wb.w)));
+      uint32_t mwa = 0, mwb = 0;
+#pragma unroll
+      for (int q4 = 0; q4 < W / 4; ++q4) {
+        const uint4 wa = *reinterpret_cast<const uint4*>(wmax + 4 * q4), wb = *reinterpret_cast<const uint4*>(wmax + W + 4 * q4);
+        mwa = max(mwa, max(max(wa.x, wa.y), max(wa.z, wa.w))); mwb = max(mwb, max(max(wb.x, wb.y), max(wb.z, wb.w)));
+      }
+      const int ta = hx_exp_of_bits(mwa), tb = hx_exp_of_bits(mwb);
       const int nA = ta > eA ? min(ta + HX_GROW, HX_EMAX) : eA, nB = tb > eB ? min(tb + HX_GROW, HX_EMAX) : eB;
       if (nA != eA || nB != eB) {                              // a scale moves (the same decision in every thread): the sums follow
         if (!first) {
@@ -2205,9 +2219,9 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
       }
       const int sa = HX_TOP - eA, sb = HX_TOP - eB;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) hstore(As, TX_A_PIECE, a_off[i], a_reg[i], sa);
+      for (int i = 0; i < NA; ++i) hstore(As, TXA_PIECE, a_off[i], a_reg[i], sa);
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
+      for (int i = 0; i < NB; ++i)
         if (b_live[i]) hstore(Bs, TX_B_PIECE, b_off[i], b_reg[i], sb);
     }
   };
@@ -2217,7 +2231,7 @@ __device__ __forceinline__ void gemm_tile_tn_bx(const GemmDev& p, int bx, int by
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int q = 0; q < NP; ++q) a[i][q] = __builtin_bit_cast(u32x4, tx_read(As + q * TX_A_PIECE, TX_A_ROW, 7, 2 * wave + i, g, r));
+      for (int q = 0; q < NP; ++q) a[i][q] = __builtin_bit_cast(u32x4, tx_read(As + q * TXA_PIECE, TXA_ROW, TXA_MASK, 2 * wave + i, g, r));
     auto ldb = [&](u32x4 (&b)[NP], int j) {
 #pragma unroll
       for (int q = 0; q < NP; ++q) b[q] = __builtin_bit_cast(u32x4, tx_read(Bs + q * TX_B_PIECE, TX_B_ROW, 15, j, g, r));
@@ -2632,9 +2646,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_group_kernel(const TnGro
 }
 
 // the same grouped launch on the bf16 matrix cores (3-way split, transposed LDS reads)
-template <int FMT>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_group_bx_kernel(const TnGroupDev g) {
-  __shared__ __attribute__((aligned(16))) char lds[BxFmt<FMT>::NP * (TX_A_PIECE + TX_B_PIECE) + 32];
+template <int FMT, int W = 4>
+__global__ __launch_bounds__(64 * W, 2) void gemm_tn_group_bx_kernel(const TnGroupDev g) {
+  __shared__ __attribute__((aligned(16))) char lds[BxFmt<FMT>::NP * (BK * 64 * W + TX_B_PIECE) + 64];
   // Workgroups go to the XCDs round-robin by linear id.  All tiles of one K split read the same rows of A and B (a tile
   // takes 128 of A's columns and all of B's 172): with the (tile, split) grid the six tiles of dW1ovT's split sat on six
   // different L2s and B came from HBM six times (FETCH 188 MB per launch on average where the operands are 83 MB).  The
@@ -2662,7 +2676,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_group_bx_kernel(const
   d.slab_base = g.slabs + pr.slab_off;
   d.nsplit = g.nsplit;
   d.dyn_chunk = (g.k_dev != nullptr && g.nsplit > 1) ? 1 : 0;
-  gemm_tile_tn_bx<FMT>(d, t / pr.tn, t % pr.tn, split, lds);
+  gemm_tile_tn_bx<FMT, W>(d, t / pr.tn, t % pr.tn, split, lds);
 }
 __global__ __launch_bounds__(256) void tn_group_reduce_kernel(const TnGroupDev g) {
   int K = g.K;
@@ -2707,6 +2721,16 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
   memset(&g, 0, sizeof(g));
   bool vec = true;
   int tiles = 0;
+  // 256-row tiles of eight wavefronts (one workgroup per CU) when every problem is at least that tall: 0 = never  (A/B switch)
+  static const int tn8_env = getenv("PFO_TN8") ? atoi(getenv("PFO_TN8")) : PFO_DEFAULT_TN8;
+  static const int tn_fmt0 = getenv("PFO_TN_FMT") ? atoi(getenv("PFO_TN_FMT")) : PFO_DEFAULT_TN_FMT;
+  static const int bx0 = getenv("PFO_GEMM_BF16X3") ? atoi(getenv("PFO_GEMM_BF16X3")) : PFO_DEFAULT_BF16X3;
+  bool tn8 = tn8_env != 0 && tn_fmt0 != 0 && bx0 >= 1;
+  for (int i = 0; i < n; ++i) {
+    const PfoTnProblem& q = probs[i];
+    tn8 = tn8 && q.M >= tn8_env && aligned4(q.A) && aligned4(q.B) && (q.lda % 4) == 0 && (q.ldb % 4) == 0 && (q.M % 4) == 0 && (q.N % 4) == 0;
+  }
+  const int tbm = tn8 ? 256 : BM, slots = tn8 ? 256 : 512;
   int64_t per_split = 0;
   for (int i = 0; i < n; ++i) {
     const PfoTnProblem& s = probs[i];
@@ -2718,13 +2742,13 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
     d.M = s.M; d.N_real = s.N; d.N = s.N + (s.bias_out ? 1 : 0);
     d.tn = (int)pfo_ceil_div(d.N, BN);
     d.tile_begin = tiles;
-    tiles += (int)pfo_ceil_div(d.M, BM) * d.tn;
+    tiles += (int)pfo_ceil_div(d.M, tbm) * d.tn;
     d.slab_off = per_split;            // scaled by nsplit below
     per_split += (int64_t)d.M * d.N;
     vec = vec && aligned4(s.A) && aligned4(s.B) && (s.lda % 4) == 0 && (s.ldb % 4) == 0 && (s.M % 4) == 0 && (s.N % 4) == 0;
   }
   // one full round of resident workgroups (2 per CU x 256 CUs), never a nearly empty second one
-  int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(512 / std::max(1, tiles), pfo_ceil_div(K, 4 * BK)));
+  int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(slots / std::max(1, tiles), pfo_ceil_div(K, 4 * BK)));
   int chunk = (int)pfo_align_up(pfo_ceil_div(K, nsplit), BK);
   nsplit = (int)pfo_ceil_div(K, chunk);
   PFO_REQUIRE(slab_floats >= per_split * nsplit, "split-K workspace too small");
@@ -2739,7 +2763,8 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
   static const int xcd_map = getenv("PFO_TN_XCD") ? atoi(getenv("PFO_TN_XCD")) : 1;                      // A/B switch
   g.xcd_map = use_bx && xcd_map && nsplit > 1;
   const dim3 grid_bx = g.xcd_map ? dim3(tiles * nsplit, 1) : dim3(tiles, nsplit);
-  if (use_bx && tn_fmt) PFO_KLAUNCH(gemm_tn_group_bx_kernel<1>, grid_bx, dim3(GEMM_THREADS), 0, stream, g);
+  if (use_bx && tn_fmt && tn8) PFO_KLAUNCH((gemm_tn_group_bx_kernel<1, 8>), grid_bx, dim3(512), 0, stream, g);
+  else if (use_bx && tn_fmt) PFO_KLAUNCH(gemm_tn_group_bx_kernel<1>, grid_bx, dim3(GEMM_THREADS), 0, stream, g);
   else if (use_bx) PFO_KLAUNCH(gemm_tn_group_bx_kernel<0>, grid_bx, dim3(GEMM_THREADS), 0, stream, g);
   else if (vec) PFO_KLAUNCH(gemm_tn_group_kernel<true>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   else PFO_KLAUNCH(gemm_tn_group_kernel<false>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
