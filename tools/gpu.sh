@@ -7,7 +7,7 @@
 #   tools/gpu.sh stamps <out>                       in-kernel cycle stamps of the layer-1 attention backward (libpfotgn_stamps.so)
 #   tools/gpu.sh marks <out> [bench args]           milestone timeline of the step (bench.py --marks)
 #   tools/gpu.sh gemm_stamps <out>                  in-kernel stamps of the image / A-stationary / weight-gradient GEMM kernels
-#                                                   (build first, here: python -m pfotgnrec_amd.build -DBXA_STAMPS=2 --tag=stamps_bxa)
+#                                                   (build first, here: tools/probes/mkvariant.sh stamps_bxa -DBXA_STAMPS=2)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mode=$1; out=gpurun_out/$2; shift 2; mkdir -p "$out"
 line() { python -c "

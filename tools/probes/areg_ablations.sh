@@ -1,6 +1,6 @@
 #!/bin/bash
 # timing-only ablations / A-B builds of gemm_bx_areg_kernel at the h1 / dctx' shapes (GPU box): VARIANTS="abl1 abl2 nt ..." name
-# pfotgnrec_amd/lib/libpfotgn_<tag>.so builds (gemm.hip compiled with -DBXA_ABL=<bits> / -DBXA_NT=1 / -DBXA_STAGGER=n)
+# pfotgnrec_amd/lib/libpfotgn_<tag>.so builds (tools/probes/mkvariant.sh <tag> -DBXA_ABL=<bits> | -DBXA_NT=1 | -DBXA_STAGGER=n)
 cd "$GRAFT_REPO_ROOT"
 for v in "" ${VARIANTS:-abl1 abl2 abl4 abl8 abl3 abl12 abl31}; do
   lib=$GRAFT_REPO_ROOT/pfotgnrec_amd/lib/libpfotgn${v:+_$v}.so
