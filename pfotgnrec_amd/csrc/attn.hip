@@ -10,6 +10,7 @@
 #include "attn.hpp"
 #include <algorithm>
 #include <type_traits>
+#include <string.h>
 
 struct AttnDev {
   int N, K, D, Ef, H, Cp;
@@ -243,6 +244,672 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD_WAVES(N
     // bias), C+1 = 1 on head 0 (multiplies the folded out_proj bias; absent on rows without a valid neighbour)
     if (lane < Cp - C) ctx[h * Cp + C + lane] = lane == 0 ? ld[h] * il : ((lane == 1 && h == 0) ? 1.f : 0.f);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// KEY RING (round 6).  The kernel above keeps two register sets of KC_FWD keys: with five wavefronts per SIMD that is ten gathered
+// rows in flight per SIMD, and a wavefront waits out one L2 round trip per pair of keys (ten per instance: its ~13 us life is
+// mostly that).  Here the gathered rows never pass through registers: ONE global_load_lds_dwordx4 per key moves [row | edge
+// feature] (lanes < D/4 read the row, the next Ef/4 lanes the edge feature - the source address of an LDS-DMA load is per lane)
+// into a wavefront-private ring of FWD_RING slots in LDS, FWD_RING - 2 keys ahead of the pair being scored; the pair is read
+// back with three ds_read_b32 per key.  No registers are held by data in flight, so the depth is set by LDS, not by the
+// register file.  Node and edge columns are one contiguous [0, D + Ef) vector on both sides (key slot and qk' row), the time
+// half is formed in registers as before.  vmcnt counts the DMAs exactly: pairs are issued two at a time (an odd tail re-reads
+// its last key), so the pair at the head of the ring has landed when at most 2 (pairs issued behind it) are outstanding.
+#ifndef FWD_RING
+#define FWD_RING 4      // keys per wavefront's ring (even; 8 and 6 measure the same: the depth is not what binds)
+#endif
+#ifndef FWD_RING_WAVES
+#define FWD_RING_WAVES 6
+#endif
+#ifndef FWD_Q_DMA
+#define FWD_Q_DMA 0    // the qk' row by LDS-DMA (1: 0.176 ms per step) or by register-bound loads in front of the ring's DMAs (0: 0.168)
+#endif
+template <int N> __device__ __forceinline__ void pfo_wait_vm() {
+  static_assert(N >= 0 && N <= 48, "vmcnt");
+  if constexpr (N == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+  else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// wait until at most 2 * pairs_behind DMAs are outstanding (pairs_behind <= FWD_RING / 2 - 1, wave-uniform)
+template <int P = FWD_RING / 2 - 1>
+__device__ __forceinline__ void pfo_wait_pairs(int pairs_behind) {
+  if constexpr (P <= 0) { pfo_wait_vm<0>(); }
+  else {
+    if (pairs_behind >= P) pfo_wait_vm<2 * P>();
+    else pfo_wait_pairs<P - 1>(pairs_behind);
+  }
+}
+// FWD_STAMPS (diagnostic build only, -DFWD_STAMPS=1): shader cycles a wavefront spends per section of attn_fwd_ring_kernel, summed
+// over the launch into pfo_fwd_stamps: 0 whole wavefront, 1 prologue up to the barrier, 2 query row + first DMAs issued, 3 waiting
+// for a pair's DMA, 4 LDS reads + time encoding + scores (up to the reduced scalars), 5 softmax + context update, 6 epilogue,
+// 7 wavefronts, 8 pairs
+#ifndef FWD_STAMPS
+#define FWD_STAMPS 0
+#endif
+#if FWD_STAMPS
+// (one private row per wavefront, summed on the host: atomics of every wavefront into one row serialise in one L2 line and
+//  stretch exactly the sections that touch memory)
+#define FWD_STAMP_ROWS 65536
+__device__ unsigned long long pfo_fwd_stamps[FWD_STAMP_ROWS * 10];
+extern "C" int pfo_attn_fwd_stamps(unsigned long long* out, int reset) {
+  static unsigned long long host[FWD_STAMP_ROWS * 10];
+  if (out) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(pfo_fwd_stamps), sizeof(host)) != hipSuccess) return PFO_ERR_HIP;
+    for (int i = 0; i < 10; ++i) out[i] = 0;
+    for (int r = 0; r < FWD_STAMP_ROWS; ++r) for (int i = 0; i < 10; ++i) out[i] += host[r * 10 + i];
+  }
+  if (reset) { memset(host, 0, sizeof(host)); if (hipMemcpyToSymbol(HIP_SYMBOL(pfo_fwd_stamps), host, sizeof(host)) != hipSuccess) return PFO_ERR_HIP; }
+  return PFO_OK;
+}
+#define FWD_STAMP_BEGIN() unsigned long long fst_[10] = {}; const unsigned long long fst_begin = __builtin_amdgcn_s_memtime(); unsigned long long fst_last = fst_begin
+#define FWD_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); fst_[i] += t_ - fst_last; fst_last = t_; } while (0)
+#define FWD_STAMP_COUNT(i) do { fst_[i] += 1; } while (0)
+#define FWD_STAMP_END(row, nw) do { fst_[0] = __builtin_amdgcn_s_memtime() - fst_begin; fst_[7] = (nw); if (lane < 10) { unsigned long long v_ = 0; for (int i_ = 0; i_ < 10; ++i_) v_ = lane == i_ ? fst_[i_] : v_; pfo_fwd_stamps[((row) % FWD_STAMP_ROWS) * 10 + lane] += v_; } } while (0)
+#else
+#define FWD_STAMP_BEGIN() do {} while (0)
+#define FWD_STAMP(i) do {} while (0)
+#define FWD_STAMP_COUNT(i) do {} while (0)
+#define FWD_STAMP_END(row, nw) do {} while (0)
+#endif
+template <int NR, int H>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD_RING_WAVES))) void attn_fwd_ring_kernel(const AttnDev a) {
+  constexpr int SLOTF = NR * 64, RP = FWD_RING / 2;      // floats per ring slot; pairs the ring holds
+  static_assert(FWD_RING % 2 == 0 && FWD_RING >= 2, "ring");
+  __shared__ float s_tw[NR * 64], s_tb[NR * 64];
+  __shared__ __align__(16) float s_ring[4][FWD_RING][SLOTF];
+  extern __shared__ __align__(16) unsigned char s_q[];   // [4 wavefronts][H Cp floats]: the instance's qk' row (LDS-DMA)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = a.D, Ef = a.Ef, K = a.K, DE = D + Ef, C = 2 * D + Ef, Cp = a.Cp;
+  const uint32_t q_bytes = (uint32_t)(H * Cp) * 4u;
+  FWD_STAMP_BEGIN();
+  // Every first-level load of the wavefront leaves before the barrier - the time-encoder parameters for the workgroup's LDS
+  // copy, this instance's slot metadata and its query row's index (clamped instance for the wavefronts behind N): ONE round
+  // trip where the barrier used to separate two.
+  const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nc = n < a.N ? n : (int64_t)a.N - 1;
+  const int64_t slot0 = nc * K;
+  const bool inK = lane < K;
+  // (clamped addresses, not predicated loads: a predicated load is its own basic block with the wait for its result at the
+  //  end - the six loads then queue as six dependent round trips; straight-line, they leave together)
+  const int64_t si = slot0 + min(lane, K - 1);
+  const int tcol = min((int)threadIdx.x, D - 1);
+  const float twr = a.tw[tcol], tbr = a.tb[tcol];
+  const int id_r = a.nbr_ids[si];
+  // (an optional array is read through a pointer select - any valid address when it is absent - and its value selected away
+  //  behind the loads: a load under a pointer test is a basic block of its own, too)
+  const int row_l = (a.nbr_row ? a.nbr_row : a.nbr_ids)[si];
+  const int e_r = a.eidx[si];
+  const float dt_r = a.dt[si];
+  const int qrow_l = (a.qk_row ? a.qk_row : a.nbr_ids)[nc];
+  const uint32_t* const offp = a.offset_dev ? reinterpret_cast<const uint32_t*>(a.offset_dev) : reinterpret_cast<const uint32_t*>(a.tw);
+  const uint32_t off_lo = offp[0], off_hi = offp[1];
+  const int row_r = a.nbr_row ? row_l : (int)(a.nbr_row_base + si);
+  const int qrow = a.qk_row ? qrow_l : (int)nc;
+  const uint64_t rng_off = a.offset + (a.offset_dev ? (((uint64_t)off_hi << 32) | off_lo) : 0ull);
+  int my_id = inK ? id_r : 0, my_row = inK ? row_r : 0, my_e = inK ? e_r : 0;
+  float my_dt = inK ? dt_r : 0.f;
+  if (threadIdx.x < NR * 64) { const bool on = (int)threadIdx.x < D; s_tw[threadIdx.x] = on ? twr : 0.f; s_tb[threadIdx.x] = on ? tbr : 0.f; }
+  // columns [D + Ef, 64 NR) of a slot are never written by a DMA (lanes behind the row's end are off): cleared once, they
+  // read as zero and the dot products need no select
+  float* const ring = &s_ring[wave][0][0];
+  if (lane + 64 * (NR - 1) >= DE)
+#pragma unroll
+    for (int s = 0; s < FWD_RING; ++s) ring[s * SLOTF + lane + 64 * (NR - 1)] = 0.f;
+  __syncthreads();
+  if (n >= a.N) return;
+  FWD_STAMP(1);
+  // one range test per instance (as in the run-merged backward): |fma(dt, w, b)| <= max|dt| max|w| + max|b| < 2e7 -> the fp32
+  // range reduction holds for every key of the instance
+  float wmax = 0.f, bmax = 0.f;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) { wmax = fmaxf(wmax, fabsf(s_tw[lane + 64 * r])); bmax = fmaxf(bmax, fabsf(s_tb[lane + 64 * r])); }
+  wmax = pfo_wave_max(wmax); bmax = pfo_wave_max(bmax);
+
+  const unsigned long long valid = __ballot(inK && my_id != 0);
+  float* ctx = a.ctx + n * H * Cp;
+  if (valid == 0ull) {
+    if (lane == 0) a.inv[n] = 1;
+    for (int c = lane; c < H * Cp; c += 64) ctx[c] = 0.f;
+    for (int c = lane; c < H * K; c += 64) a.attw[n * H * K + c] = 0.f;
+    return;
+  }
+  const bool fast = fmaf(pfo_wave_max(fabsf(my_dt)), wmax, bmax) < 2.0e7f;     // (every register-bound load is consumed before the first DMA)
+  // ---- round trip 2, all of it LDS-DMA: the instance's qk' row (no register-bound load is in flight beside the ring: the
+  // compiler waits for vmcnt(0) at the first use of such a load, i.e. for every DMA behind it) and the first pairs of keys.
+  // Pair p = valid keys 2p, 2p + 1 in slot order; slots (2p) % RING, (2p + 1) % RING.
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  unsigned char* const qb = s_q + (size_t)wave * q_bytes;
+  // (every value that came from a register-bound load is pinned HERE: sunk behind the first DMA, its use would wait for vmcnt(0))
+  asm volatile("" : "+v"(my_row), "+v"(my_e), "+v"(my_dt), "+v"(my_id));
+#if FWD_Q_DMA
+  {
+    const char* src = reinterpret_cast<const char*>(a.QK + (int64_t)qrow * a.qk_ld);
+    const uint32_t lo = (uint32_t)lane * 16u;
+    for (uint32_t k = 0; k * 1024u < q_bytes; ++k)
+      if (k * 1024u + lo < q_bytes) __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 1024u + lo), (lptr_t)(qb + k * 1024u), 16, 0, 0);
+  }
+#else
+  // (register-bound loads of the qk' row in front of the DMAs, clamped columns: the compiler's vmcnt(0) at their first use -
+  //  the top of the walk - is the wait for the first pair anyway)
+  float r1[H][NR], rt[H][NR];
+  {
+    const float* qk = a.QK + (int64_t)qrow * a.qk_ld;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int c1 = min(lane + 64 * r, DE - 1), ct = min(lane + 64 * r, D - 1);
+#pragma unroll
+      for (int h = 0; h < H; ++h) { r1[h][r] = qk[h * Cp + c1]; rt[h][r] = qk[h * Cp + DE + ct]; }
+    }
+  }
+#endif
+  const int D4 = D >> 2, DE4 = DE >> 2;
+  // per lane: the table it reads (row table or edge features), its row stride in bytes and its 16-byte piece of the row; the
+  // per-key address is then ONE 64-bit multiply-add (base + index * stride) on a select of two wave-uniform indices
+  const bool is_node = lane < D4;
+  const uint64_t base_l = (is_node ? (uint64_t)(uintptr_t)a.nbr_tab : (uint64_t)(uintptr_t)a.edge_feat) + (uint64_t)((is_node ? lane : lane - D4) * 16);
+  const uint32_t mul_l = is_node ? (uint32_t)a.nbr_ld * 4u : (uint32_t)Ef * 4u;
+  const uint32_t node_mask = is_node ? 0xFFFFFFFFu : 0u;        // index select without a branch: e + ((row - e) & mask)
+  unsigned long long vm = valid;                               // keys not yet issued
+  const int nv = __popcll(valid);
+  const int n_pairs = (nv + 1) >> 1;
+  int issued = 0;                                              // pairs issued
+  auto issue_pair = [&]() {
+    int j0 = __ffsll((long long)vm) - 1;
+    vm &= vm - 1ull;
+    int j1 = vm ? (__ffsll((long long)vm) - 1) : j0;           // an odd tail re-reads its last key (its weight is forced to zero)
+    vm &= vm - 1ull;
+    const int sl = (2 * issued) % FWD_RING;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = c ? j1 : j0;
+      const uint32_t e_s = (uint32_t)rl_i(my_e, j);
+      const uint32_t idx = e_s + (((uint32_t)rl_i(my_row, j) - e_s) & node_mask);
+      const uint64_t src = base_l + (uint64_t)idx * (uint64_t)mul_l;
+      if (lane < DE4) __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)src, (lptr_t)(ring + (sl + c) * SLOTF), 16, 0, 0);
+    }
+    issued += 1;
+  };
+#pragma unroll
+  for (int p = 0; p < RP; ++p)
+    if (p < n_pairs) issue_pair();
+  FWD_STAMP(2);
+  const unsigned keep = attn_keep_for(a, rng_off, n, lane);
+  const float keep_scale = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
+  // the first pair has landed, and with it (older) the qk' row: [node | edge] columns as one vector, the time columns as
+  // another, both pre-multiplied by scale * log2(e) - a score then leaves the reduction ready for v_exp_f32 (2^x)
+  pfo_wait_pairs(issued - 1);
+  float q1[H][NR], qt[H][NR];
+  {
+    const float* qk = reinterpret_cast<const float*>(qb);
+    const float qs = a.scale * 1.44269504088896340736f;
+#if FWD_Q_DMA
+    // (clamped columns + a select behind the reads: predicated, each of the 4 NR H reads waited for its own LDS round trip)
+    float r1[H][NR], rt[H][NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int c1 = min(lane + 64 * r, DE - 1), ct = min(lane + 64 * r, D - 1);
+#pragma unroll
+      for (int h = 0; h < H; ++h) { r1[h][r] = qk[h * Cp + c1]; rt[h][r] = qk[h * Cp + DE + ct]; }
+    }
+#else
+    (void)qk;
+#endif
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int c = lane + 64 * r;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        q1[h][r] = c < DE ? r1[h][r] * qs : 0.f;
+        qt[h][r] = c < D ? rt[h][r] * qs : 0.f;
+      }
+    }
+  }
+
+  float m[H], l[H], ld[H], my_s[H];                            // m, my_s: scores in log2 units
+  float a1[H][NR], at[H][NR];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    m[h] = -INFINITY; l[h] = 0.f; ld[h] = 0.f; my_s[h] = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { a1[h][r] = 0.f; at[h][r] = 0.f; }
+  }
+  auto walk = [&](auto fast_c) {
+  constexpr bool FAST = decltype(fast_c)::value;
+  unsigned long long wm = valid;                               // keys not yet scored
+  for (int p = 0; p < n_pairs; ++p) {
+    const int js0 = __ffsll((long long)wm) - 1;
+    wm &= wm - 1ull;
+    const bool has1 = wm != 0ull;
+    const int js1 = has1 ? (__ffsll((long long)wm) - 1) : js0;
+    wm &= wm - 1ull;
+    const bool more = p + RP < n_pairs;                        // the pair RP ahead exists: RP - 1 pairs stay in flight behind this one
+    FWD_STAMP_COUNT(8);
+    if (more) pfo_wait_vm<2 * (RP - 1)>(); else pfo_wait_vm<0>();
+    FWD_STAMP(3);
+    const float* sl = ring + ((2 * p) % FWD_RING) * SLOTF;
+    float kn[2][NR], kt[2][NR], dtv[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) kn[c][r] = sl[c * SLOTF + lane + 64 * r];
+    dtv[0] = rl_f(my_dt, js0); dtv[1] = rl_f(my_dt, js1);
+    float part[2 * H];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        // (lanes beyond D carry w = b = 0: cos(0) = 1 there, against a zero query column - no select)
+        const float arg = pfo_time_arg(dtv[c], s_tw[lane + 64 * r], s_tb[lane + 64 * r]);
+        kt[c][r] = __builtin_amdgcn_cosf(FAST ? pfo_revolutions_fast(arg) : pfo_revolutions(arg));
+      }
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float pp = 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) pp = fmaf(kn[c][r], q1[h][r], fmaf(kt[c][r], qt[h][r], pp));
+        part[c * H + h] = pp;
+      }
+    }
+    // the slots are free again (their values sit in registers): the pair RP ahead starts its trip
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (more) issue_pair();
+    pfo_wave_sum_scalar_n<2 * H>(part);
+    FWD_STAMP(4);
+    // an absent second key (odd tail) scores -inf: weight 0 in every sum, no branch
+    float sc[2][H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) { sc[0][h] = part[h]; sc[1][h] = has1 ? part[H + h] : -INFINITY; }
+    // The scores are wave-uniform: the running sums are rescaled only when a maximum actually moves - ONE scalar branch per
+    // pair (taken for the first pairs of a row), all heads inside it
+    bool up = false;
+#pragma unroll
+    for (int h = 0; h < H; ++h) up = up || sc[0][h] > m[h] || sc[1][h] > m[h];
+    if (up) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float mn = fmaxf(m[h], fmaxf(sc[0][h], sc[1][h]));
+        const float corr = __builtin_amdgcn_exp2f(m[h] - mn);     // (first pair: 2^-inf = 0 against zero sums)
+        l[h] *= corr; ld[h] *= corr;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { a1[h][r] *= corr; at[h][r] *= corr; }
+        m[h] = mn;
+      }
+    }
+    const unsigned kb0 = (unsigned)rl_i((int)keep, js0), kb1 = (unsigned)rl_i((int)keep, js1);
+    const int js1c = has1 ? js1 : -1;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const unsigned kb = c ? kb1 : kb0;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        if (lane == (c ? js1c : js0)) my_s[h] = sc[c][h];
+        const float pr = __builtin_amdgcn_exp2f(sc[c][h] - m[h]);
+        const float pd = ((kb >> h) & 1u) ? pr * keep_scale : 0.f;
+        l[h] += pr;
+        ld[h] += pd;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          a1[h][r] = fmaf(pd, kn[c][r], a1[h][r]);
+          at[h][r] = fmaf(pd, kt[c][r], at[h][r]);
+        }
+      }
+    }
+#if FWD_STAMPS
+    asm volatile("s_nop 0" :: "v"(a1[0][0]), "v"(at[H - 1][NR - 1]) : "memory");
+#endif
+    FWD_STAMP(5);
+  }
+  };
+  if (fast) walk(std::true_type{}); else walk(std::false_type{});
+  if (lane == 0) a.inv[n] = 0;       // (here, not in front of the DMAs: the compiler drains a store before the first LDS-DMA load)
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const float il = 1.f / l[h];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int c = lane + 64 * r;
+      if (c < DE) ctx[h * Cp + c] = a1[h][r] * il;
+      if (c < D) ctx[h * Cp + DE + c] = at[h][r] * il;
+    }
+    if (lane < K) a.attw[(n * H + h) * K + lane] = ((valid >> lane) & 1ull) ? __builtin_amdgcn_exp2f(my_s[h] - m[h]) * il : 0.f;
+    if (lane < Cp - C) ctx[h * Cp + C + lane] = lane == 0 ? ld[h] * il : ((lane == 1 && h == 0) ? 1.f : 0.f);
+  }
+  FWD_STAMP(6);
+  FWD_STAMP_END(n, 1);
+}
+// ---------------------------------------------------------------------------------------------
+// INSTANCE PIPELINE (round 6).  In-kernel stamps of the ring form (tools/probes/fwd_stamps.py, profiles/r6_fwd_stamps.txt) show
+// where a wavefront's life goes: 14 % waiting for its first-level loads (slot metadata, query row index), 24 % for the query row
+// behind them, 14 % for the first pair of keys behind THAT, 40 % scoring, 8 % storing - three dependent round trips per instance
+// in front of ~12 k cycles of arithmetic, with every wavefront of a SIMD in the same phases.  Here a wavefront takes FWD_IPW
+// consecutive instances and nothing it needs is loaded into registers: the metadata of all its instances arrives by LDS-DMA in
+// ONE round trip at the start; query rows and key pairs then flow through LDS in consumption order - the query row of instance
+// i + 1 and its first key pairs are requested while instance i is scored (the key ring is one FIFO across instances).  Every
+// later round trip hides behind the arithmetic of the instance before.  vmcnt is kept exact by a software sequence counter:
+// `seq` counts the vector-memory instructions issued so far (DMAs and the epilogue's stores, each statement one instruction
+// that always has active lanes), every FIFO unit remembers seq at its last DMA, and the consumer waits for
+// vmcnt(seq - unit's seq) - the operations issued behind the unit may stay in flight.  Counting too few younger operations only
+// makes a wait stricter; nothing is counted that might not be issued (the zero-neighbour path's stores are not).
+#ifndef FWD_IPW
+#define FWD_IPW 4       // instances per wavefront
+#endif
+#ifndef FWD_PIPE_RING
+#define FWD_PIPE_RING 4 // key slots per wavefront (even)
+#endif
+#ifndef FWD_PIPE_WAVES
+#define FWD_PIPE_WAVES 5
+#endif
+__device__ __forceinline__ void pfo_wait_allowed(int allowed) {   // wave-uniform: wait until at most `allowed` vector-memory operations are outstanding
+  if (allowed >= 48) pfo_wait_vm<48>();
+  else if (allowed >= 32) pfo_wait_vm<32>();
+  else if (allowed >= 24) pfo_wait_vm<24>();
+  else if (allowed >= 16) pfo_wait_vm<16>();
+  else if (allowed >= 12) pfo_wait_vm<12>();
+  else if (allowed >= 8) pfo_wait_vm<8>();
+  else if (allowed >= 6) pfo_wait_vm<6>();
+  else if (allowed >= 4) pfo_wait_vm<4>();
+  else if (allowed >= 3) pfo_wait_vm<3>();
+  else if (allowed >= 2) pfo_wait_vm<2>();
+  else if (allowed >= 1) pfo_wait_vm<1>();
+  else pfo_wait_vm<0>();
+}
+static size_t attn_fwd_pipe_wave_bytes(int NR, int H, int Cp, int K) {
+  return (size_t)FWD_PIPE_RING * NR * 64 * 4 + (size_t)H * Cp * 4 + (size_t)pfo_align_up(5 * FWD_IPW * K * 4, 16);
+}
+template <int NR, int H>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD_PIPE_WAVES))) void attn_fwd_pipe_kernel(const AttnDev a) {
+  constexpr int SLOTF = NR * 64, R = FWD_PIPE_RING, P = FWD_IPW, RP = R / 2;
+  static_assert(R % 2 == 0 && R >= 2, "ring");
+  __shared__ float s_tw[NR * 64], s_tb[NR * 64];
+  __shared__ float s_sc[4][H][64];                       // per wavefront: the raw scores of the instance being walked, by slot
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = a.D, Ef = a.Ef, K = a.K, DE = D + Ef, C = 2 * D + Ef, Cp = a.Cp, PK = P * K;
+  const uint32_t q_bytes = (uint32_t)(H * Cp) * 4u;
+  const uint32_t meta_bytes = (uint32_t)((5 * PK * 4 + 15) & ~15);
+  unsigned char* const wbase = s_dyn + (size_t)wave * ((size_t)R * SLOTF * 4 + q_bytes + meta_bytes);
+  float* const ring = reinterpret_cast<float*>(wbase);
+  const float* const qbuf = reinterpret_cast<const float*>(wbase + R * SLOTF * 4);
+  int* const meta = reinterpret_cast<int*>(wbase + R * SLOTF * 4 + q_bytes);     // [ids | rows | edge ids | dt | query rows][P K]
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * P;
+  const int cnt = (int)min((int64_t)P, (int64_t)a.N - n0);                        // this wavefront's instances (<= 0: none)
+  FWD_STAMP_BEGIN();
+  // ---- round trip 1: the metadata of all the wavefront's instances, one dword per lane and instruction
+  if (cnt > 0) {
+    const int live = cnt * K;
+    const int64_t s0 = n0 * K;
+    for (int k = 0; k * 64 < live; ++k) {
+      const int i = k * 64 + lane;
+      if (i < live) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(a.nbr_ids + s0 + i), (lptr_t)(meta + 0 * PK + k * 64), 4, 0, 0);
+        if (a.nbr_row) __builtin_amdgcn_global_load_lds((gptr_t)(a.nbr_row + s0 + i), (lptr_t)(meta + 1 * PK + k * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(a.eidx + s0 + i), (lptr_t)(meta + 2 * PK + k * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(a.dt + s0 + i), (lptr_t)(meta + 3 * PK + k * 64), 4, 0, 0);
+      }
+    }
+    if (a.qk_row && lane < cnt) __builtin_amdgcn_global_load_lds((gptr_t)(a.qk_row + n0 + lane), (lptr_t)(meta + 4 * PK), 4, 0, 0);
+  }
+  {
+    float twv = 0.f, tbv = 0.f;
+    if (threadIdx.x < NR * 64 && (int)threadIdx.x < D) { twv = a.tw[threadIdx.x]; tbv = a.tb[threadIdx.x]; }
+    if (threadIdx.x < NR * 64) { s_tw[threadIdx.x] = twv; s_tb[threadIdx.x] = tbv; }
+  }
+  if (lane + 64 * (NR - 1) >= DE)
+#pragma unroll
+    for (int s = 0; s < R; ++s) ring[s * SLOTF + lane + 64 * (NR - 1)] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (cnt <= 0) return;
+  float wmax = 0.f, bmax = 0.f;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) { wmax = fmaxf(wmax, fabsf(s_tw[lane + 64 * r])); bmax = fmaxf(bmax, fabsf(s_tb[lane + 64 * r])); }
+  // (wave-uniform bounds, kept as scalars)
+  const float wmax_s = rl_f(pfo_wave_max(wmax), 0), bmax_s = rl_f(pfo_wave_max(bmax), 0);
+  const int D4 = D >> 2, DE4 = DE >> 2;
+  const uint64_t rng_off = a.offset + (a.offset_dev ? *a.offset_dev : 0ull);
+  const float keep_scale = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
+
+  int seq = 0;                        // vector-memory instructions issued since the barrier (those that are counted)
+  int q_seq = 0;                      // seq at the last DMA of the query row in flight
+  int ring_seq = 0;                   // lane s: seq at the last DMA of the pair in ring position s
+  int pairs_issued = 0, pairs_consumed = 0;
+  // ---- the issue cursor: instance iss_i, its slots' table rows / edge ids, the keys not yet requested
+  int iss_i = 0, is_row = 0, is_e = 0;
+  unsigned long long is_vm = 0ull;
+  auto load_issue_meta = [&](int i) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));      // (opaque: no per-lane LDS address of this rarely executed block is kept across the walk)
+    const bool ok = ln < K;
+    const int id = ok ? meta[0 * PK + i * K + ln] : 0;
+    is_row = ok ? (a.nbr_row ? meta[1 * PK + i * K + ln] : (int)(a.nbr_row_base + (n0 + i) * K + ln)) : 0;
+    is_e = ok ? meta[2 * PK + i * K + ln] : 0;
+    is_vm = __ballot(ok && id != 0);
+  };
+  auto issue_q = [&](int i) {
+    const int64_t qrow = a.qk_row ? (int64_t)__builtin_amdgcn_readfirstlane(meta[4 * PK + i]) : n0 + i;
+    const char* src = reinterpret_cast<const char*>(a.QK + qrow * a.qk_ld);
+    uint32_t lo = (uint32_t)lane * 16u;
+    asm volatile("" : "+v"(lo));
+    for (uint32_t k = 0; k * 1024u < q_bytes; ++k) {
+      if (k * 1024u + lo < q_bytes) __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 1024u + lo), (lptr_t)(wbase + R * SLOTF * 4 + k * 1024u), 16, 0, 0);
+      seq += 1;
+    }
+    q_seq = seq;
+  };
+  auto try_issue = [&]() {
+    if (pairs_issued - pairs_consumed >= RP) return;
+    while (is_vm == 0ull && iss_i + 1 < cnt) { iss_i += 1; load_issue_meta(iss_i); }
+    if (is_vm == 0ull) return;
+    const int j0 = __ffsll((long long)is_vm) - 1;
+    is_vm &= is_vm - 1ull;
+    const int j1 = is_vm ? (__ffsll((long long)is_vm) - 1) : j0;     // an odd tail re-reads its last key (its score is never used)
+    is_vm &= is_vm - 1ull;
+    const int pos = pairs_issued % RP;
+    // per lane: the table it reads (rows: lanes < D / 4, edge features: the next Ef / 4), its stride and its 16-byte piece -
+    // recomputed per pair from the lane id (a handful of vector instructions) instead of held across the walk
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const bool is_node = ln < D4;
+    const uint64_t base_l = (is_node ? (uint64_t)(uintptr_t)a.nbr_tab : (uint64_t)(uintptr_t)a.edge_feat) + (uint64_t)((is_node ? ln : ln - D4) * 16);
+    const uint32_t mul_l = is_node ? (uint32_t)a.nbr_ld * 4u : (uint32_t)Ef * 4u;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int j = c ? j1 : j0;
+      const uint32_t e_s = (uint32_t)rl_i(is_e, j), r_s = (uint32_t)rl_i(is_row, j);
+      const uint32_t idx = is_node ? r_s : e_s;
+      const uint64_t src = base_l + (uint64_t)idx * (uint64_t)mul_l;
+      if (ln < DE4) __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)src, (lptr_t)(ring + (2 * pos + c) * SLOTF), 16, 0, 0);
+    }
+    seq += 2;
+    ring_seq = ln == pos ? seq : ring_seq;
+    pairs_issued += 1;
+  };
+  load_issue_meta(0);
+  issue_q(0);
+#pragma unroll 1
+  for (int p = 0; p < RP; ++p) try_issue();
+  FWD_STAMP(1);
+
+#pragma unroll 1
+  for (int ci = 0; ci < cnt; ++ci) {
+    const int64_t n = n0 + ci;
+    int li = lane;
+    asm volatile("" : "+v"(li));                                 // (per-instance addresses are formed per instance, not hoisted)
+    const bool inK = li < K;
+    const int c_id = inK ? meta[0 * PK + ci * K + li] : 0;
+    const float my_dt = inK ? __int_as_float(meta[3 * PK + ci * K + li]) : 0.f;
+    const unsigned long long valid = __ballot(inK && c_id != 0);
+    float* ctx = a.ctx + n * H * Cp;
+    if (valid == 0ull) {
+      // no valid neighbour (temporal_attention.py:60-65,84): zero rows; the query row in flight is dropped, the next one follows it
+      if (li == 0) a.inv[n] = 1;
+      for (int c = li; c < H * Cp; c += 64) ctx[c] = 0.f;
+      for (int c = li; c < H * K; c += 64) a.attw[n * H * K + c] = 0.f;
+      if (ci + 1 < cnt) issue_q(ci + 1);
+      continue;
+    }
+    // ---- this instance's qk' row: landed behind everything issued before it; the buffer then takes the next instance's
+    pfo_wait_allowed(seq - q_seq);
+    float q1[H][NR], qt[H][NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int c = li + 64 * r;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        q1[h][r] = c < DE ? qbuf[h * Cp + c] : 0.f;
+        qt[h][r] = c < D ? qbuf[h * Cp + DE + c] : 0.f;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (ci + 1 < cnt) issue_q(ci + 1);
+    FWD_STAMP(2);
+    const unsigned keep = attn_keep_for(a, rng_off, n, li);
+    float m[H], l[H], ld[H];
+    float a1[H][NR], at[H][NR];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      m[h] = -INFINITY; l[h] = 0.f; ld[h] = 0.f;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) { a1[h][r] = 0.f; at[h][r] = 0.f; }
+    }
+    const int n_pairs = (__popcll(valid) + 1) >> 1;
+    const bool fast = fmaf(rl_f(pfo_wave_max(fabsf(my_dt)), 0), wmax_s, bmax_s) < 2.0e7f;
+    unsigned long long wm = valid;
+#pragma unroll 1
+    for (int p = 0; p < n_pairs; ++p) {
+      int js[2];
+      js[0] = __ffsll((long long)wm) - 1;
+      wm &= wm - 1ull;
+      js[1] = wm ? (__ffsll((long long)wm) - 1) : -1;
+      wm &= wm - 1ull;
+      const int pos = pairs_consumed % RP;
+      FWD_STAMP_COUNT(8);
+      pfo_wait_allowed(seq - rl_i(ring_seq, pos));             // the pair at the head of the FIFO has landed
+      FWD_STAMP(3);
+      int lp = li;
+      asm volatile("" : "+v"(lp));
+      const float* sl = ring + (2 * pos) * SLOTF + lp;
+      float kn[2][NR], kt[2][NR], dtv[2], arg[2][NR];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) kn[c][r] = sl[c * SLOTF + 64 * r];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) dtv[c] = rl_f(my_dt, js[c] < 0 ? js[0] : js[c]);
+      float part[2 * H];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          arg[c][r] = pfo_time_arg(dtv[c], s_tw[lp + 64 * r], s_tb[lp + 64 * r]);
+          kt[c][r] = pfo_revolutions_fast(arg[c][r]);
+        }
+      // the two slots are free (their values sit in registers): the FIFO takes its next pair - of this instance or the next
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      pairs_consumed += 1;
+      try_issue();
+      if (__builtin_expect(!fast, 0)) {
+        // some argument of this instance may leave the range of the fp32 reduction: those lanes take the fp64 one
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int r = 0; r < NR; ++r)
+            if (!(fabsf(arg[c][r]) < 2.0e7f)) kt[c][r] = pfo_revolutions_f64(arg[c][r]);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) kt[c][r] = __builtin_amdgcn_cosf(kt[c][r]);   // (lanes beyond D: w = b = 0, cos(0) against a zero query column)
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          float pp = 0.f;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) pp = fmaf(kn[c][r], q1[h][r], fmaf(kt[c][r], qt[h][r], pp));
+          part[c * H + h] = pp;
+        }
+      }
+      pfo_wave_sum_scalar_n<2 * H>(part);
+      FWD_STAMP(4);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (js[c] < 0) continue;
+        const unsigned kb = (unsigned)rl_i((int)keep, js[c]);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const float sc = part[c * H + h] * a.scale;
+          if (lp == 0) s_sc[wave][h][js[c]] = sc;
+          if (sc > m[h]) {
+            const float corr = pfo_exp_neg(m[h] - sc);
+            l[h] *= corr; ld[h] *= corr;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { a1[h][r] *= corr; at[h][r] *= corr; }
+            m[h] = sc;
+          }
+          const float pr = pfo_exp_neg(sc - m[h]);
+          const float pd = ((kb >> h) & 1u) ? pr * keep_scale : 0.f;
+          l[h] += pr;
+          ld[h] += pd;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            a1[h][r] = fmaf(pd, kn[c][r], a1[h][r]);
+            at[h][r] = fmaf(pd, kt[c][r], at[h][r]);
+          }
+        }
+      }
+#if FWD_STAMPS
+      asm volatile("s_nop 0" :: "v"(a1[0][0]), "v"(at[H - 1][NR - 1]) : "memory");
+#endif
+      FWD_STAMP(5);
+    }
+    // ---- the instance's rows: H (2 NR + 2) + 1 store instructions, every one with active lanes (64 (NR - 1) < D, K >= 1, Cp - C >= 2)
+    if (li == 0) a.inv[n] = 0;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float il = 1.f / l[h];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int c = li + 64 * r;
+        if (c < DE) ctx[h * Cp + c] = a1[h][r] * il;
+        if (c < D) ctx[h * Cp + DE + c] = at[h][r] * il;
+      }
+      if (li < K) a.attw[(n * H + h) * K + li] = ((valid >> li) & 1ull) ? pfo_exp_neg(s_sc[wave][h][li] - m[h]) * il : 0.f;
+      if (li < Cp - C) ctx[h * Cp + C + li] = li == 0 ? ld[h] * il : ((li == 1 && h == 0) ? 1.f : 0.f);
+    }
+    seq += H * (2 * NR + 2) + 1;
+    FWD_STAMP(6);
+  }
+  FWD_STAMP_END(n0 / P, cnt);
+}
+static bool attn_fwd_pipe_ok(const PfoAttn& a) {
+  static const int on = getenv("PFO_ATTN_FWD_PIPE") ? atoi(getenv("PFO_ATTN_FWD_PIPE")) : 0;      // A/B switch; off: measured 0.245-0.263 ms per step against 0.172 for the ring form (profiles/r6_experiments.txt)
+  static const int min_n = getenv("PFO_ATTN_FWD_PIPE_MIN") ? atoi(getenv("PFO_ATTN_FWD_PIPE_MIN")) : 16384;
+  const int64_t qk_ld = a.qk_ld > 0 ? a.qk_ld : (int64_t)a.H * a.Cp;
+  // (query rows travel 16 bytes per lane; metadata as FWD_IPW K dwords per array; small launches keep one instance per wavefront)
+  return on && a.N >= min_n && (qk_ld % 4) == 0 && (((uintptr_t)a.QK) & 15u) == 0 && FWD_IPW * a.K <= 1024 && FWD_IPW <= 64;
+}
+
+// the ring form takes rows it can move 16 bytes at a time, with [node | edge] inside NR column groups and one DMA per key
+static bool attn_fwd_ring_ok(const PfoAttn& a) {
+  static const int on = getenv("PFO_ATTN_FWD_RING") ? atoi(getenv("PFO_ATTN_FWD_RING")) : 1;     // A/B switch
+  const int NRv = (a.D + 63) / 64;
+  return on && (a.D % 4) == 0 && (a.Ef % 4) == 0 && a.D + a.Ef <= 64 * NRv && a.D + a.Ef <= 256 && (a.nbr_ld % 4) == 0 &&
+         (((uintptr_t)a.nbr_tab | (uintptr_t)a.edge_feat | (uintptr_t)a.QK) & 15u) == 0 && NRv * a.H <= 6 &&
+         ((a.qk_ld > 0 ? a.qk_ld : (int64_t)a.H * a.Cp) % 4) == 0;
 }
 
 #ifndef ATTN_BWD_MAX_BLOCKS
@@ -487,6 +1154,9 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
 #ifndef KC_RUNS
 #define KC_RUNS 2      // keys in flight per wavefront
 #endif
+#ifndef RUNS_CW
+#define RUNS_CW 0      // counted vmcnt at a member's start (attn_bwd_runs_kernel)
+#endif
 #ifndef RUNS_WAVES
 #define RUNS_WAVES(NR, H) ((NR) * (H) <= 6 ? 3 : 2)
 #endif
@@ -518,10 +1188,18 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
 #define RUNS_STAMPS 0
 #endif
 #if RUNS_STAMPS
-__device__ unsigned long long pfo_runs_stamps[8];
+// (one private row per workgroup, summed on the host - round 6: the round-5 form added every wavefront's sums into ONE row
+//  with atomics, which serialise in one L2 line and stretch the sections that touch memory)
+#define RUNS_STAMP_ROWS 16384
+__device__ unsigned long long pfo_runs_stamps[RUNS_STAMP_ROWS * 8];
 extern "C" int pfo_attn_runs_stamps(unsigned long long* out, int reset) {
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pfo_runs_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return PFO_ERR_HIP;
-  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pfo_runs_stamps), z, sizeof(z)) != hipSuccess) return PFO_ERR_HIP; }
+  static unsigned long long host[RUNS_STAMP_ROWS * 8];
+  if (out) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(pfo_runs_stamps), sizeof(host)) != hipSuccess) return PFO_ERR_HIP;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (int r = 0; r < RUNS_STAMP_ROWS; ++r) for (int i = 0; i < 8; ++i) out[i] += host[r * 8 + i];
+  }
+  if (reset) { memset(host, 0, sizeof(host)); if (hipMemcpyToSymbol(HIP_SYMBOL(pfo_runs_stamps), host, sizeof(host)) != hipSuccess) return PFO_ERR_HIP; }
   return PFO_OK;
 }
 #define STAMP() ((unsigned long long)__builtin_amdgcn_s_memtime())
@@ -592,6 +1270,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
   const float* const st_cx = reinterpret_cast<const float*>(s_stage + row_bytes);
   const float* const st_qk = reinterpret_cast<const float*>(s_stage + 2 * row_bytes);
   unsigned char* const st_meta = s_stage + 3 * row_bytes;        // (4 + H) arrays of K words: ids, table rows, edge ids, dt, weights
+  // COUNTED WAIT (round 6): vmcnt retires in issue order, so "this member's image has landed" needs only the operations issued
+  // BEFORE its DMAs to be done; the row atomics and row-sum stores of a flush behind them (an atomic stays in vmcnt for ~3 000
+  // cycles with every CU adding) may stay in flight across the next member's set-up and walk.  since_stage counts them - only
+  // statements that surely issue one instruction each; too low a count only makes the wait stricter.
+  int since_stage = 0;
   auto stage = [&](int64_t n, int slot) {
     const char* g_dc = reinterpret_cast<const char*>(a.dctx + n * H * Cp);
     const char* g_cx = reinterpret_cast<const char*>(a.ctx + n * H * Cp);
@@ -620,6 +1303,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
       for (int h = 0; h < H; ++h)
         __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.attw + (n * H + h) * K) + lo), (lptr_t)(st_meta + (4 + h) * kb), 4, 0, 0);
     }
+    since_stage = 0;
   };
 
   // Workgroups go to the XCDs round-robin by their id.  Consecutive chunks hold members of the same table row or of
@@ -693,6 +1377,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
           }
           if (lo < (uint32_t)Ef * 4u) atomicAdd(reinterpret_cast<float*>(out + (uint32_t)(h * Cp + D) * 4u + lo), dqe[h]);
         }
+        since_stage += H * 2 * NR + (Ef > 0 ? H : 0);
       } else if (acc_m >= 0) {
         char* out = reinterpret_cast<char*>(a.dQK + (int64_t)acc_m * H * Cp);      // row m, not n: the per-row sums then stream contiguous rows
         uint32_t lo = (uint32_t)lane * 4u;
@@ -710,6 +1395,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
           if (lo < (uint32_t)(Cp - C) * 4u) *reinterpret_cast<float*>(out + (uint32_t)(h * Cp + C) * 4u + lo) = 0.f;
         }
         if (lane == 0) a.dqk_live[acc_m] = 1;
+        since_stage += H * (2 * NR + 1) + (Ef > 0 ? H : 0) + 1;
       }
       acc_m = -1;
       acc_reset();
@@ -770,6 +1456,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
               if (DET) det_add(a.d_nbr, drow + lane + 64 * r, row[r]); else atomicAdd(reinterpret_cast<float*>(dst + (uint32_t)(256 * r) + lo), row[r]);
             }
           }
+          if (a.abl != 2) since_stage += NR;
         }
       }
 #pragma unroll
@@ -788,7 +1475,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
       const int64_t n = ch_get(0, m - u0);
       const int slot = ch_get(1, m - u0);
       const int cnt_n = ch_get(2, m - u0);
+#if RUNS_CW
+      pfo_wait_allowed(min(since_stage, 48));                    // this member's staging image has landed (counted wait, above)
+#else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this member's staging image has landed
+#endif
       const bool inK = lane < K;
       const int* const mi = reinterpret_cast<const int*>(st_meta);
       const int my_id = inK ? mi[lane] : 0;
@@ -1013,10 +1704,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
     for (int chunk = (int)blockIdx.x * RUN_CPW; chunk < ((int)blockIdx.x + 1) * RUN_CPW; ++chunk)
       for (int c = lane; c < 2 * D; c += 64) a.dtime_slab[(int64_t)chunk * 2 * D + c] = 0.0;
 #if RUNS_STAMPS
-  if (lane == 0) {
-    atomicAdd(&pfo_runs_stamps[0], STAMP() - st_begin);
-    atomicAdd(&pfo_runs_stamps[1], st_setup); atomicAdd(&pfo_runs_stamps[2], st_walk); atomicAdd(&pfo_runs_stamps[3], st_flush);
-    atomicAdd(&pfo_runs_stamps[4], st_store); atomicAdd(&pfo_runs_stamps[5], st_members); atomicAdd(&pfo_runs_stamps[6], st_chunks);
+  if (lane < 7) {
+    const unsigned long long tot_ = STAMP() - st_begin;
+    const unsigned long long v_ = lane == 0 ? tot_ : lane == 1 ? st_setup : lane == 2 ? st_walk : lane == 3 ? st_flush : lane == 4 ? st_store : lane == 5 ? st_members : st_chunks;
+    pfo_runs_stamps[(blockIdx.x % RUNS_STAMP_ROWS) * 8 + lane] += v_;
   }
 #endif
 }
@@ -1095,7 +1786,34 @@ int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream) {
   const double C = 2.0 * a.D + a.Ef;
   const double bytes = (double)a.N * (a.K * (4.0 * a.D + 4.0 * a.Ef + 12.0) + 2.0 * a.H * C * 4.0 + 4.0 * a.H * a.K);
   pfo_prof_begin(stream);
-  ATTN_DISPATCH(attn_fwd_kernel, pfo_ceil_div(a.N, 4));
+  if (attn_fwd_ring_ok(a) && attn_fwd_pipe_ok(a)) {
+    const int NRp = (a.D + 63) / 64;
+    const dim3 g((unsigned)pfo_ceil_div(a.N, 4 * FWD_IPW)), b(256);
+    const size_t lds = 4 * attn_fwd_pipe_wave_bytes(NRp, a.H, a.Cp, a.K);
+    switch (NRp * 8 + a.H) {
+      case 1 * 8 + 1: PFO_KLAUNCH((attn_fwd_pipe_kernel<1, 1>), g, b, lds, stream, d); break;
+      case 1 * 8 + 2: PFO_KLAUNCH((attn_fwd_pipe_kernel<1, 2>), g, b, lds, stream, d); break;
+      case 1 * 8 + 4: PFO_KLAUNCH((attn_fwd_pipe_kernel<1, 4>), g, b, lds, stream, d); break;
+      case 2 * 8 + 1: PFO_KLAUNCH((attn_fwd_pipe_kernel<2, 1>), g, b, lds, stream, d); break;
+      case 2 * 8 + 2: PFO_KLAUNCH((attn_fwd_pipe_kernel<2, 2>), g, b, lds, stream, d); break;
+      case 3 * 8 + 1: PFO_KLAUNCH((attn_fwd_pipe_kernel<3, 1>), g, b, lds, stream, d); break;
+      default: PFO_KLAUNCH((attn_fwd_pipe_kernel<3, 2>), g, b, lds, stream, d); break;
+    }
+  } else if (attn_fwd_ring_ok(a)) {
+    const dim3 g((unsigned)pfo_ceil_div(a.N, 4)), b(256);
+    const size_t qlds = FWD_Q_DMA ? 4 * (size_t)a.H * a.Cp * 4 : 0;   // the four wavefronts' qk' rows
+    switch (((a.D + 63) / 64) * 8 + a.H) {
+      case 1 * 8 + 1: PFO_KLAUNCH((attn_fwd_ring_kernel<1, 1>), g, b, qlds, stream, d); break;
+      case 1 * 8 + 2: PFO_KLAUNCH((attn_fwd_ring_kernel<1, 2>), g, b, qlds, stream, d); break;
+      case 1 * 8 + 4: PFO_KLAUNCH((attn_fwd_ring_kernel<1, 4>), g, b, qlds, stream, d); break;
+      case 2 * 8 + 1: PFO_KLAUNCH((attn_fwd_ring_kernel<2, 1>), g, b, qlds, stream, d); break;
+      case 2 * 8 + 2: PFO_KLAUNCH((attn_fwd_ring_kernel<2, 2>), g, b, qlds, stream, d); break;
+      case 3 * 8 + 1: PFO_KLAUNCH((attn_fwd_ring_kernel<3, 1>), g, b, qlds, stream, d); break;
+      default: PFO_KLAUNCH((attn_fwd_ring_kernel<3, 2>), g, b, qlds, stream, d); break;      // (3, 2): attn_fwd_ring_ok admits NR H <= 6
+    }
+  } else {
+    ATTN_DISPATCH(attn_fwd_kernel, pfo_ceil_div(a.N, 4));
+  }
   PFO_LAUNCH_CHECK();
   pfo_prof_end(PFO_PROF_ATTN_FWD, bytes, stream);
   return PFO_OK;

@@ -5,7 +5,7 @@
 # Usage: tools/profile_round.sh <tag> <key> [bench args]     e.g.  tools/profile_round.sh r5 C3@512 --config C3
 # Outputs land in gpurun_out/<tag>_<key>/; tools/summarize_profile.py <tag> <key> turns them into
 # profiles/<tag>_kernel_stats_bench_<key>.csv and profiles/<tag>_summary_<key>.json (bench.py reads those by key).
-tag=${1:-r5}; key=${2:-C2@512}; shift 2
+tag=${1:-r6}; key=${2:-C2@512}; shift $(( $# < 2 ? $# : 2 ))
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
 out=gpurun_out/${tag}_${key}
