@@ -73,8 +73,13 @@ def parse():
                     help="replay the step from a captured HIP graph (one launch per step instead of ~85).  auto (one GPU, per-GPU "
                          "batch <= 256): capture, time ten steps either way during set-up and keep the faster form - the graph "
                          "wins where the host's launch rate bounds the step (C1), the eager queue where the GPU does")
-    ap.add_argument("--allreduce", default="fused", choices=["single", "buckets", "fused", "fused_buckets"],
-                    help="N > 1: 'fused' (default): backward + all-reduce + Adam as one call whose end - the collective included - "
+    ap.add_argument("--allreduce", default="fused", choices=["single", "buckets", "fused", "fused_buckets", "fused_ordered"],
+                    help="N > 1: 'fused_ordered': the fused call with exchange and optimizer cut in two buckets in order of first use - "
+                         "the top layer's block reduced beside the backward and stepped last, [time encoder | GRU | layer 1] reduced and "
+                         "stepped first behind the backward's end: the next forward's caller's stream waits for that kernel alone (rehearsed "
+                         "with stub collectives: the same step time as 'fused' - what is exposed behind the exchange is the side stream's "
+                         "composite-weight chain, which needs every bucket: profiles/r6_experiments.txt 9); "
+                         "'fused' (default): backward + all-reduce + Adam as one call whose end - the collective included - "
                          "stays on the library's side stream while the caller's stream starts the next batch "
                          "(bpr_step(..., optimizer=, collective=)): the exchange of step n runs beside step n+1's sampling; "
                          "'single': one all-reduce of the flat gradient on the caller's stream after the backward; 'buckets': two "
@@ -129,7 +134,7 @@ VALU_ISSUE_PEAK_GINST = 1024 * 2.4 / 2
 
 # family (one PFO_PROF_* kind) -> the kernel(s) of that kind as named in the rocprofv3 summaries of profiles/ (template
 # arguments differ between configurations: matched by the name in front of them)
-FAMILY_KERNEL = {"gemm_bx": "gemm_bx_areg_kernel", "gemm_tn_bx": "gemm_tn_group_bx_kernel", "gru_fused": "gru_fused_kernel",
+FAMILY_KERNEL = {"gemm_bx": "gemm_bx_areg_kernel", "gemm_tn_bx": "gemm_tn_group_bx_kernel", "gemm_tn_bx8": "gemm_tn_group_bx_kernel", "gru_fused": "gru_fused_kernel",
                  "gemm_bx_skinny": "gemm_bx_skinny_kernel", "gemm_nt": "gemm_f32_kernel", "gemm_nn": "gemm_f32_kernel",
                  "gemm_devm": "gemm_f32_kernel", "gemm_tn": "gemm_tn_group_kernel", "gemm_multi": "gemm_multi_kernel",
                  "attn_fwd": "attn_fwd_kernel", "attn_bwd": "attn_bwd_kernel", "attn_bwd_runs": "attn_bwd_runs_kernel",
@@ -152,17 +157,38 @@ def _family_has(family, kernel_name):
         return base.startswith("attn_bwd_kernel")
     if family == "gemm_bx":      # three forms behind PFO_PROF_GEMM_BX: four / eight wavefronts per workgroup, A-stationary
         return base in ("gemm_bx_areg_kernel", "gemm_bx_areg8_kernel", "gemm_bx_astat_kernel")
+    if family in ("gemm_tn_bx", "gemm_tn_bx8"):   # two template instances = two kernels of the trace: <FMT, 8> is the 256-row form
+        eight = kernel_name.split("(")[0].replace(" ", "").endswith(",8>")
+        return base == "gemm_tn_group_bx_kernel" and eight == (family == "gemm_tn_bx8")
+    if family == "attn_fwd":     # the per-instance register form and the LDS key-ring / pipeline forms (PFO_PROF_ATTN_FWD)
+        return base in ("attn_fwd_kernel", "attn_fwd_ring_kernel", "attn_fwd_pipe_kernel")
     return base == FAMILY_KERNEL.get(family, family)
 
 
-def _summary_for(key):
-    """The newest committed profile summary of this workload: profiles/r*_summary_<key>.json (tools/profile_round.sh +
-    tools/summarize_profile.py); C2@512 also accepts the unkeyed files of rounds 1-4."""
+PROFILE_ROUND = "r6"       # the committed counter passes / kernel traces this line is priced from: profiles/<round>_*; a workload
+                           # without files of THIS round falls back to the newest older round and says so (``profiles_round``)
+
+
+def _profile_file(pattern, key):
+    """profiles/<PROFILE_ROUND>_<pattern % key> if it exists, else the newest older round's file of the same name."""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_summary_%s.json" % key)))
-    if not files and key == "C2@512":
-        files = sorted(glob.glob(os.path.join(REPO, "profiles", "r?_summary.json")))
+    if not key:
+        return None
+    f = os.path.join(REPO, "profiles", ("%s_" + pattern) % (PROFILE_ROUND, key))
+    if os.path.exists(f):
+        return f
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", ("r*_" + pattern) % key)))
     return files[-1] if files else None
+
+
+def _summary_for(key):
+    """The committed profile summary of this workload: profiles/<round>_summary_<key>.json (tools/profile_round.sh +
+    tools/summarize_profile.py), the CURRENT round's when it exists."""
+    return _profile_file("summary_%s.json", key)
+
+
+def _trace_for(key):
+    return _profile_file("kernel_stats_bench_%s.csv", key)
 
 
 def pmc_counters(family):
@@ -201,9 +227,8 @@ def trace_dominant(prof, n_prof_steps):
     import csv
     import glob
     key = WORKLOAD_KEY[0]
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_kernel_stats_bench_%s.csv" % key))) if key else []
-    if not files and key == "C2@512":
-        files = sorted(glob.glob(os.path.join(REPO, "profiles", "r?_kernel_stats_bench_C2.csv")))
+    tf = _trace_for(key)
+    files = [tf] if tf else []
     if not files:
         return None
     try:
@@ -220,13 +245,25 @@ def trace_dominant(prof, n_prof_steps):
                "ms_per_step_resident": round(float(r["TotalDurationNs"]) / steps / 1e6, 4),
                "share_of_kernel_time": round(float(r["TotalDurationNs"]) / tot, 4), "from": os.path.basename(files[-1])}
         if fam:
+            # (a family is ONE kernel of the trace - the two tile forms of the grouped weight gradients are families of their
+            #  own, PFO_PROF_GEMM_TN_BX / _BX8 - so this kernel's live work over this kernel's resident time is one division)
             v = prof[fam]
             unit = 1e12 if (fam.startswith("gemm") or fam == "gru_fused") else 1e9
             work_per_step = v["work"] / max(1, n_prof_steps)
             out["family"] = fam
+            out["work_per_step"] = round(work_per_step / unit, 4)
+            out["work_unit"] = "TFLOP" if unit == 1e12 else "GB"
             out["co_scheduled_rate"] = round(work_per_step / (out["ms_per_step_resident"] * 1e-3) / unit, 2)
             out["co_scheduled_rate_unit"] = "TFLOP/s" if unit == 1e12 else "GB/s"
             out["alone_rate"] = round(v["work"] / max(1e-12, v["ms"] * 1e-3) / unit, 2)
+            out["alone_avg_launch_us"] = round(v["ms"] / max(1, v["count"]) * 1e3, 2)
+            if fam in ("gemm_tn_bx", "gemm_tn_bx8"):
+                # both tile forms together (the four grouped weight-gradient launches of a step), same two views
+                both = [prof[k] for k in ("gemm_tn_bx", "gemm_tn_bx8") if k in prof and prof[k]["count"] > 0]
+                res = sum(float(q["TotalDurationNs"]) for q in rows if _kernel_base(q["Name"]) == "gemm_tn_group_bx_kernel") / steps / 1e6
+                w = sum(b["work"] for b in both) / max(1, n_prof_steps)
+                out["tile_forms_together"] = {"ms_per_step_resident": round(res, 4), "co_scheduled_rate": round(w / max(1e-12, res * 1e-3) / unit, 2),
+                                              "alone_rate": round(sum(b["work"] for b in both) / max(1e-12, sum(b["ms"] for b in both) * 1e-3) / unit, 2)}
         return out
     except Exception as e:
         return {"error": repr(e)[:200]}
@@ -386,7 +423,8 @@ class Workload:
                                message_function="identity", n_neighbors=cfg.n_neighbors)
         tgn.set_data_parallel(rank, world)
         tgn.deterministic = bool(args.deterministic)
-        tgn.dp_bucketed = (world > 1 or os.environ.get("PFO_DIST_FORCE") == "1") and args.allreduce in ("buckets", "fused_buckets")
+        tgn.dp_bucketed = (world > 1 or os.environ.get("PFO_DIST_FORCE") == "1" or emulate) and args.allreduce in ("buckets", "fused_buckets", "fused_ordered")
+        tgn.dp_ordered = tgn.dp_bucketed and args.allreduce == "fused_ordered"
         self.emulate = emulate                                # --emulate-ranks: a rank's compute without the collective
         import torch.distributed as _dist
         self.dist_on = (not emulate) and _dist.is_available() and _dist.is_initialized()   # world 1 with PFO_DIST_FORCE=1: the rank path on one GPU
@@ -459,7 +497,7 @@ class Workload:
         self.tgn.set_data_parallel(rank, world)
 
     def step(self, i):
-        from pfotgnrec_amd.distributed import allreduce_flat_grad, allreduce_flat_grad_buckets
+        from pfotgnrec_amd.distributed import allreduce_flat_grad, allreduce_flat_grad_buckets, allreduce_flat_grad_ordered
         P, torch, tgn, cfg, B, n_neg = self.P, self.torch, self.tgn, self.cfg, self.B, self.n_neg
         lo = self.start + (i * B) % self.span
         sl = slice(lo, lo + B)
@@ -499,15 +537,23 @@ class Workload:
         # the TGN backward (P.bpr_loss(...).backward() is the autograd spelling of the same thing, tests/test_gpu_round2.py)
         _lm.mark("step.embedded")
         ranks = self.dist_on and (self.world > 1 or self.force_dist)
-        fused_coll = ranks and self.allreduce_mode in ("fused", "fused_buckets") and self.overlap_tail and not self.prefetch
+        fused_coll = ranks and self.allreduce_mode in ("fused", "fused_buckets", "fused_ordered") and self.overlap_tail and not self.prefetch
         fused_opt = self.overlap_tail and (not ranks or fused_coll) and not self.prefetch
         coll = None
-        if self.emulate and self.world > 1 and fused_opt and self.allreduce_mode in ("fused", "fused_buckets"):
+        if self.emulate and self.world > 1 and fused_opt and self.allreduce_mode in ("fused", "fused_buckets", "fused_ordered"):
             # an emulated rank keeps the ranks' step schedule: the collective is a stub that holds the side stream for the
-            # predicted ring time (--emulate-sleep 0: returns at once)
-            if getattr(self, "sleep_coll", None) is None or self.sleep_coll_world != self.world:
-                us = predicted_ring_allreduce_us(tgn.flat_parameters.numel() * 4, self.world) if getattr(self.args, "emulate_sleep", 1) else 0.0
-                self.sleep_coll, self.sleep_coll_world = SleepCollective(us), self.world
+            # predicted ring time (--emulate-sleep 0: returns at once).  The bucketed forms hold the communication stream for the
+            # top block's time from the "top layer final" event on, and the side stream for the rest's.
+            if getattr(self, "sleep_coll", None) is None or self.sleep_coll_world != self.world or self.sleep_coll_mode != self.allreduce_mode:
+                sleep = getattr(self.args, "emulate_sleep", 1)
+                total, split = tgn.flat_parameters.numel(), tgn.grad_split
+                if self.allreduce_mode == "fused" or not (0 < split < total):
+                    self.sleep_coll = SleepCollective(predicted_ring_allreduce_us(total * 4, self.world) if sleep else 0.0)
+                else:
+                    self.sleep_coll = SleepCollectiveBuckets(tgn, predicted_ring_allreduce_us((total - split) * 4, self.world) if sleep else 0.0,
+                                                             predicted_ring_allreduce_us(split * 4, self.world) if sleep else 0.0,
+                                                             ordered=self.allreduce_mode == "fused_ordered")
+                self.sleep_coll_world, self.sleep_coll_mode = self.world, self.allreduce_mode
             coll = self.sleep_coll
         if fused_coll:
             def coll():                                           # runs on the library's side stream (bpr_step): bracketed THERE
@@ -515,7 +561,9 @@ class Workload:
                 if self.time_collective:
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record()
-                if self.allreduce_mode == "fused_buckets":
+                if self.allreduce_mode == "fused_ordered":
+                    allreduce_flat_grad_ordered(tgn, self.world, force=True)    # (no join of the communication stream: FusedAdam steps per bucket)
+                elif self.allreduce_mode == "fused_buckets":
                     allreduce_flat_grad_buckets(tgn, self.world, force=True)    # (the caller's stream of that call = the side stream)
                 else:
                     allreduce_flat_grad(tgn.flat_grad, self.world, force=True)
@@ -767,7 +815,8 @@ def trace_family_ms(prof):
     import csv
     import glob
     key = WORKLOAD_KEY[0]
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_kernel_stats_bench_%s.csv" % key))) if key else []
+    tf = _trace_for(key)
+    files = [tf] if tf else []
     if not files:
         return {}, None
     try:
@@ -826,6 +875,28 @@ def roofline_of(prof, n_prof_steps, profiled_workload=True):
     td = trace_dominant(prof, n_prof_steps) if profiled_workload else None
     if td:
         roof["trace_dominant"] = td
+    # The peaks above are priced at the 2.4 GHz of MI355X_MICROARCH.md; the shader clock the product kernels actually hold is
+    # stamped in three of them on every launch (pfo_shader_clock: s_memtime against the 100 MHz counter).  A second fraction at
+    # the measured clock rides along for the compute-bound families - the first one is never switched silently.
+    try:
+        from pfotgnrec_amd import _lib as _l
+        clk = {k: round(v, 3) for k, v in _l.shader_clock().items() if v > 0}
+        if clk:
+            roof["shader_clock_ghz_measured"] = clk
+            roof["shader_clock_ghz_priced"] = 2.4
+            own = clk.get({"gemm_tn_bx8": "gemm_tn_bx"}.get(dom, dom)) or (clk.get("gemm_tn_bx") if dom.startswith("gemm") else None)
+            if own and roof.get("bound") in ("mfma", "valu") and roof.get("frac") is not None:
+                roof["frac_at_measured_clock"] = round(roof["frac"] * 2.4 / own, 4)
+                roof["frac_at_measured_clock_note"] = "frac x 2.4 / %.3f GHz (the clock stamped inside %s)" % (own, "this kernel" if dom in clk or dom == "gemm_tn_bx8" else "gemm_tn_bx")
+    except Exception as e:
+        roof["shader_clock_ghz_measured"] = {"error": repr(e)[:120]}
+    sf = _summary_for(WORKLOAD_KEY[0]) if profiled_workload else None
+    roof["profiles_round"] = os.path.basename(sf).split("_")[0] if sf else None
+    if sf:
+        try:
+            roof["profiles_same_build_bench_line"] = json.load(open(sf)).get("bench_line_same_build")
+        except Exception:
+            pass
     return roof
 
 
@@ -834,7 +905,7 @@ def cfg_layers(cfg_name):
     return CONFIGS[cfg_name].n_layers
 
 
-BX_FAMILIES = ("gemm_bx", "gemm_tn_bx", "gemm_bx_skinny", "gru_fused")
+BX_FAMILIES = ("gemm_bx", "gemm_tn_bx", "gemm_tn_bx8", "gemm_bx_skinny", "gru_fused")
 
 
 def bx_products(family):
@@ -842,7 +913,7 @@ def bx_products(family):
     two-piece fp16 format (3 products) unless PFO_BX_FMT=0 keeps them on bf16x3; the weight-gradient tile likewise (PFO_TN_FMT)."""
     if family not in BX_FAMILIES:
         return 0
-    if family == "gemm_tn_bx":
+    if family in ("gemm_tn_bx", "gemm_tn_bx8"):
         return 6 if os.environ.get("PFO_TN_FMT", "1") == "0" else 3
     return 6 if os.environ.get("PFO_BX_FMT", "1") == "0" else 3
 
@@ -878,6 +949,45 @@ class SleepCollective:
         import torch
         if self.us > 0:
             torch.cuda._sleep(int(self.us * self.cycles_per_us))     # (runs on the current stream = the side stream inside bpr_step)
+        self.calls += 1
+
+
+class SleepCollectiveBuckets(SleepCollective):
+    """The two-piece exchange rehearsed: the top layer's block holds a communication stream for its predicted ring time from the
+    backward's "top layer final" event on (beside the rest of the backward), the rest holds the side stream behind the
+    backward's end.  ``ordered``: the communication stream is not joined here - FusedAdam steps the first-use bucket at once and
+    joins in front of the top block's step (distributed.allreduce_flat_grad_ordered); otherwise as allreduce_flat_grad_buckets."""
+
+    def __init__(self, tgn, us_top, us_rest, ordered):
+        super().__init__(us_rest)
+        import torch
+        self.tgn, self.us_top, self.ordered = tgn, float(us_top), ordered
+        # ONE communication stream per device for the life of the process (the one the real exchange uses): every further
+        # stream of the normal priority class ends up sharing a hardware queue with the caller's stream (DESIGN 6)
+        from pfotgnrec_amd.distributed import _COMM_STREAMS
+        dev = tgn.flat_parameters.device
+        if _COMM_STREAMS.get(dev) is None:
+            _COMM_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        self.comm = _COMM_STREAMS[dev]
+
+    def __call__(self):
+        import torch
+        tgn = self.tgn
+        main = torch.cuda.current_stream()
+        fresh, tgn._bucket_event_fresh = tgn._bucket_event_fresh, False
+        if fresh:
+            self.comm.wait_event(tgn._bucket_event)
+        else:
+            self.comm.wait_stream(main)
+        with torch.cuda.stream(self.comm):
+            if self.us_top > 0:
+                torch.cuda._sleep(int(self.us_top * self.cycles_per_us))
+        if self.us > 0:
+            torch.cuda._sleep(int(self.us * self.cycles_per_us))
+        if self.ordered:
+            tgn._comm_pending = self.comm
+        else:
+            main.wait_stream(self.comm)
         self.calls += 1
 
 
@@ -936,6 +1046,7 @@ def emulate_ranks(args, dev):
             ms = 1e3 * el / nt
             rows.append({"world": n, "rank": 0, "local_batch": wl.per_gpu, "global_batch": wl.B, "ms_per_step": round(ms, 4),
                          "stub_collective_us_on_side_stream": round(getattr(wl, "sleep_coll", None).us, 1) if getattr(wl, "sleep_coll", None) else 0.0,
+                         "stub_collective_us_on_comm_stream": round(getattr(getattr(wl, "sleep_coll", None), "us_top", 0.0), 1),
                          "interactions_per_s_if_all_ranks_like_this": round(wl.B / (ms * 1e-3), 1),
                          "host_enqueue_ms_per_step": round(float(np.median(wl.host_ms)), 4)})
             desc = wl.describe()
@@ -952,12 +1063,11 @@ def emulate_ranks(args, dev):
             torch.cuda.empty_cache()
         for r in rows:
             r["compute_scaling_efficiency_vs_first"] = round(rows[0]["ms_per_step"] / r["ms_per_step"], 4)
-        print(json.dumps({"emulated_ranks": True, "scaling": "weak", "workload": desc, "collective": "stub: a device-side spin of the predicted ring time on the library's side stream (fused schedule)" if args.emulate_sleep else "none (stubbed)",
+        print(json.dumps({"emulated_ranks": True, "scaling": "weak", "workload": desc, "collective": ("stub: device-side spins of the predicted ring times, form '%s' (buckets: the top block on a communication stream from the 'top layer final' event on, the rest on the library's side stream)" % args.allreduce) if args.emulate_sleep else "none (stubbed)",
                           "device": torch.cuda.get_device_name(dev), "table": rows}), flush=True)
         return
     cfg_name = args.config or "C4"
-    wl = Workload(args, cfg_name, dev, 0, 1, "strong")
-    wl.emulate = True
+    wl = Workload(args, cfg_name, dev, 0, 1, "strong", emulate=True)
     rows = []
     for n in worlds:
         wl.set_world(0, n)
@@ -1057,17 +1167,17 @@ def main():
         try:
             # (0) the same workload with the OTHER all-reduce form (one piece after the backward / two pieces, the top layer's
             #     block on a communication stream beside the backward): single vs. bucketed decided by data
-            for other in [m for m in ("single", "buckets", "fused", "fused_buckets") if m != wl.allreduce_mode]:
-                if other.endswith("buckets") and cfg_layers(cfg_name) < 2:
+            for other in [m for m in ("single", "buckets", "fused", "fused_buckets", "fused_ordered") if m != wl.allreduce_mode]:
+                if (other.endswith("buckets") or other.endswith("ordered")) and cfg_layers(cfg_name) < 2:
                     continue
-                wl.allreduce_mode, wl.tgn.dp_bucketed = other, other.endswith("buckets")
+                wl.allreduce_mode, wl.tgn.dp_bucketed, wl.tgn.dp_ordered = other, other.endswith("buckets") or other.endswith("ordered"), other.endswith("ordered")
                 el, nb, _, _, _ = wl.timed(args.steps, 5, min(args.min_seconds, 1.0), 0, first_step=50000)
                 cms, cn = wl.collective_ms()
                 sec["allreduce_" + other] = {"n_gpus": world, "value": round(nb * B / el, 1), "ms_per_step": round(1e3 * el / nb, 4),
                                             "collective_ms_per_step": None if cms is None else round(cms, 4),
                                             "workload": "the main line's workload, all-reduce form '%s'" % other}
                 wl.tgn.join()
-                wl.allreduce_mode, wl.tgn.dp_bucketed = args.allreduce, args.allreduce.endswith("buckets")
+                wl.allreduce_mode, wl.tgn.dp_bucketed, wl.tgn.dp_ordered = args.allreduce, args.allreduce.endswith("buckets") or args.allreduce.endswith("ordered"), args.allreduce.endswith("ordered")
             want_other_case = world > 1 and (args.secondary or world == 8)
             # (1) the same workload on ONE of these GPUs (rank 0 alone, the others wait): the denominator of the strong-scaling
             #     figure.  (2) the other scaling case.
@@ -1143,8 +1253,13 @@ def main():
                                              "(oracle/tgn_oracle.py: numpy fp32 + BLAS + C fmaf/cosf helper; the attention layers' "
                                              "53 760-instance calls run as 2 048-row chunks on a thread pool of min(64, cores) "
                                              "workers with single-threaded BLAS inside, everything else on %d BLAS threads; "
-                                             "steady-state memory), median step, %.1f s timed"
-                                             % (args.cpu_steps, args.cpu_batch, threads, spent),
+                                             "steady-state memory), median step, %.1f s timed.  Per thread: %.2f interactions/s - SURVEY 8(d)'s "
+                                             "anchor is the REFERENCE itself at 34-39 interactions/s on 8 vCPU = 4.3-4.9 per core (torch CPU, build "
+                                             "container); this port is faster in absolute terms but does not scale with the box's threads (numpy "
+                                             "gathers and the Python glue are serial), so per core it sits well below the anchor: a stated baseline, "
+                                             "not a tuned one"
+                                             % (args.cpu_steps, args.cpu_batch, threads, spent, v / max(1, threads)),
+                                   "per_thread": round(v / max(1, threads), 3), "survey_anchor_reference_per_core": [4.3, 4.9],
                                    "phases_median_s": getattr(cpu_baseline, "phases", None)}
         except Exception as e:  # the baseline never blocks the measurement
             out["cpu_baseline"] = {"value": None, "unit": "interactions/s", "cores": os.cpu_count(), "kind": "port",

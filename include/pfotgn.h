@@ -410,6 +410,14 @@ int pfo_tgn_debug_views(const pfo_tgn_config* cfg, void* workspace, pfo_tgn_debu
  * pfo_tgn_join(stream) makes any other stream wait (no-op when nothing is pending). */
 int pfo_tgn_adam_side(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
                       const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1, float beta2, float eps);
+/* The same step in BUCKETS ordered by first use in the next forward (data-parallel ranks: reduce + step per bucket).
+ * bucket 1: the ranges the next pfo_tgn_forward reads on the CALLER's stream (time encoder, GRU, layer 1: everything below
+ * pfo_tgn_grad_split) - an event behind this kernel is all that forward's caller's stream waits for; bucket 2: a later bucket of
+ * the same step (the top layer's block, whose all-reduce ran beside the backward) - the forward meets it through the side
+ * stream's own order (composite weights, fc2 fold); bucket 0: pfo_tgn_adam_side.  Models with n_layers >= 2. */
+int pfo_tgn_adam_side_bucket(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
+                             const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1, float beta2, float eps,
+                             int32_t bucket);
 int pfo_tgn_join(void* stream);
 /* The library's first side stream (hipStream_t; null on failure): the stream a deferred backward end is left on and
  * pfo_tgn_adam_side runs on.  A data-parallel caller queues its gradient all-reduce THERE, between pfo_tgn_backward
@@ -441,7 +449,8 @@ int pfo_tgn_refresh(const pfo_tgn_config* cfg, const pfo_tgn_state* state, void*
 #define PFO_PROF_SEGSUM 13     /* segsum_*_kernel: per-table-row sums of the layer-1 gradient rows (bytes: every member row once + the sums) */
 #define PFO_PROF_TN_REDUCE 14  /* tn_group_reduce_kernel: the split-K slabs of a grouped weight-gradient launch folded (bytes: slabs in, matrices out) */
 #define PFO_PROF_GRU_GATES_BWD 15 /* gru_gates_bwd_*_kernel: GRU gate backward (bytes: gates, h, d h in; dgi, dgh out) */
-#define PFO_PROF_KINDS 16
+#define PFO_PROF_GEMM_TN_BX8 16   /* the same grouped weight gradients on 256-row tiles of eight wavefronts (gemm_tn_group_bx_kernel<1, 8>): a kernel of its own in the traces */
+#define PFO_PROF_KINDS 17
 /* Milestones: while enabled (pfo_marks_enable(1)) the step's native calls record a timing event on the CALLER's stream at
  * named points of the critical path (sampling done, lazy GRU done, every large launch of every layer ...; callers may add
  * their own with pfo_mark).  pfo_marks_dump waits for them and writes one line per consecutive pair "from -> to  mean_us  n"
@@ -452,6 +461,12 @@ int pfo_mark(const char* name /* static string */, void* stream);
 int64_t pfo_marks_dump(char* out, int64_t cap); /* HOST buffer; returns the bytes written (0-terminated), clears the records */
 int pfo_prof_enable(int32_t on);
 int pfo_prof_collect(double* ms, double* work, int64_t* count); /* HOST arrays of PFO_PROF_KINDS entries */
+/* Shader clock under the product kernels [GHz]: the first wavefront of three large kernels stamps the shader cycle counter
+ * against the constant 100 MHz counter on every launch (two scalar reads, two atomics per launch).  out[0] attention forward
+ * (ring form), out[1] run-merged attention backward, out[2] grouped weight-gradient kernel; 0 where the kernel has not run since
+ * the last reset.  The peaks of MI355X_MICROARCH.md are priced at 2.4 GHz: bench.py prints both. */
+#define PFO_CLOCK_KERNELS 3
+int pfo_shader_clock(double* ghz_out /* HOST, PFO_CLOCK_KERNELS entries */, int32_t reset);
 
 #ifdef __cplusplus
 }

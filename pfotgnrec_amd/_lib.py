@@ -94,6 +94,8 @@ PROTOTYPES = {
     "pfo_tgn_workspace_bytes": (C.c_int64, [C.POINTER(TgnConfig)]),
     "pfo_tgn_adam_side": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int32), C.c_float, C.c_float, C.c_float, C.c_float]),
+    "pfo_tgn_adam_side_bucket": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int32), C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32]),
     "pfo_tgn_side_stream": (_VP, []),
     "pfo_tgn_join": (C.c_int, [_VP]),
     "pfo_tgn_pcache_bytes": (C.c_int64, [C.POINTER(TgnConfig)]),
@@ -112,10 +114,11 @@ PROTOTYPES = {
     "pfo_mark": (C.c_int, [C.c_char_p, _VP]),
     "pfo_marks_dump": (C.c_int64, [C.c_char_p, C.c_int64]),
     "pfo_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "pfo_shader_clock": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
 }
 
 PROF_KINDS = ["gemm_nt", "gemm_nn", "gemm_tn", "gemm_devm", "attn_fwd", "attn_bwd", "sampler", "gemm_bx", "gemm_tn_bx", "gemm_bx_skinny",
-              "attn_bwd_runs", "gru_fused", "gemm_multi", "segsum", "tn_reduce", "gru_gates_bwd"]
+              "attn_bwd_runs", "gru_fused", "gemm_multi", "segsum", "tn_reduce", "gru_gates_bwd", "gemm_tn_bx8"]
 
 
 _MARK_NAMES = {}
@@ -150,6 +153,16 @@ def prof_enable(on):
 
 def prof_is_on():
     return _PROF_ON[0]
+
+
+CLOCK_KERNELS = ["attn_fwd", "attn_bwd_runs", "gemm_tn_bx"]
+
+
+def shader_clock(reset=False):
+    """GHz the first wavefront of the three stamped kernels ran at since the last reset (0.0: not launched)."""
+    out = (C.c_double * len(CLOCK_KERNELS))()
+    call("pfo_shader_clock", out, 1 if reset else 0)
+    return {k: out[i] for i, k in enumerate(CLOCK_KERNELS)}
 
 
 def prof_collect():

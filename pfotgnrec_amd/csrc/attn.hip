@@ -30,6 +30,16 @@ struct AttnDev {
   int abl;      // timing-only ablation switch (PFO_ATTN_ABL): 1 = spread the atomic destinations (wrong results)
 };
 
+// shader-clock pairs (common.hpp pfo_clock_*): 0 = attention forward (ring form), 1 = run-merged backward
+__device__ unsigned long long g_attn_clock[2][2];
+int pfo_attn_clock_read(double* out, int reset) {
+  unsigned long long h[2][2];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_attn_clock), sizeof(h)) != hipSuccess) return PFO_ERR_HIP;
+  for (int i = 0; i < 2; ++i) { out[2 * i] = (double)h[i][0]; out[2 * i + 1] = (double)h[i][1]; }
+  if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_clock), h, sizeof(h)) != hipSuccess) return PFO_ERR_HIP; }
+  return PFO_OK;
+}
+
 // deterministic mode: a gradient element is added as 2^-40 fixed point - integer addition does not depend on the order
 __device__ __forceinline__ void det_add(float* table, int64_t idx, float v) {
   atomicAdd(reinterpret_cast<unsigned long long*>(table) + idx, (unsigned long long)__double2ll_rn((double)v * PFO_DET_SCALE));
@@ -334,6 +344,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD_RING_WA
   const int D = a.D, Ef = a.Ef, K = a.K, DE = D + Ef, C = 2 * D + Ef, Cp = a.Cp;
   const uint32_t q_bytes = (uint32_t)(H * Cp) * 4u;
   FWD_STAMP_BEGIN();
+  const bool clk_on = blockIdx.x == 0 && threadIdx.x < 64;       // (wave-uniform)
+  PfoClockStamp clk;
+  if (clk_on) clk = pfo_clock_begin();
   // Every first-level load of the wavefront leaves before the barrier - the time-encoder parameters for the workgroup's LDS
   // copy, this instance's slot metadata and its query row's index (clamped instance for the wavefronts behind N): ONE round
   // trip where the barrier used to separate two.
@@ -589,6 +602,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD_RING_WA
   }
   FWD_STAMP(6);
   FWD_STAMP_END(n, 1);
+  if (clk_on && lane == 0) pfo_clock_end(clk, g_attn_clock[0]);
 }
 // ---------------------------------------------------------------------------------------------
 // INSTANCE PIPELINE (round 6).  In-kernel stamps of the ring form (tools/probes/fwd_stamps.py, profiles/r6_fwd_stamps.txt) show
@@ -1218,6 +1232,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
   extern __shared__ __align__(16) unsigned char s_stage[];
   const int lane = threadIdx.x;
   const int D = a.D, Ef = a.Ef, K = a.K, C = 2 * D + Ef, Cp = a.Cp;
+  const bool clk_on = blockIdx.x == 0;
+  PfoClockStamp clk;
+  if (clk_on) clk = pfo_clock_begin();
   // Two chains of dependent loads open a wavefront's life: (A) *n_rows -> seg_ptr[.] = the members' count M, (B) the
   // wavefront's member ids -> their query rows / history counts.  (B) is issued speculatively - clamped indices, no dependence
   // on M - so the two chains overlap instead of queueing (a wavefront lives ~35 us: every round trip is 3-4 % of it).
@@ -1703,6 +1720,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
   if (DET && (int)blockIdx.x >= n_units)
     for (int chunk = (int)blockIdx.x * RUN_CPW; chunk < ((int)blockIdx.x + 1) * RUN_CPW; ++chunk)
       for (int c = lane; c < 2 * D; c += 64) a.dtime_slab[(int64_t)chunk * 2 * D + c] = 0.0;
+  if (clk_on && lane == 0) pfo_clock_end(clk, g_attn_clock[1]);
 #if RUNS_STAMPS
   if (lane < 7) {
     const unsigned long long tot_ = STAMP() - st_begin;

@@ -78,6 +78,10 @@ struct PfoRange {
   PfoRange& operator=(const PfoRange&) = delete;
 };
 
+// per-TU clock accumulators (attn.hip, gemm.hip), read by misc.hip's pfo_shader_clock
+int pfo_attn_clock_read(double* cycles_ticks /* [2 kernels][2] */, int reset);
+int pfo_gemm_clock_read(double* cycles_ticks /* [1 kernel][2] */, int reset);
+
 static inline int64_t pfo_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t pfo_align_up(int64_t a, int64_t b) { return pfo_ceil_div(a, b) * b; }
 
@@ -251,5 +255,23 @@ __device__ __forceinline__ float pfo_wave_max(float v) {
   v = pfo_dpp_max<0x4E>(v);
   v = pfo_dpp_max<0x124>(v);
   return pfo_dpp_max<0x128>(v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shader clock as the product kernels see it (include/pfotgn.h pfo_shader_clock): the first wavefront of workgroup 0 of a few
+// large kernels reads the shader cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) at its start and its
+// end and adds both differences to a per-kernel pair - two scalar reads and two atomics per LAUNCH.  cycles / (ticks * 10 ns)
+// = the clock that wavefront ran at, under that kernel's own power draw.
+struct PfoClockStamp { unsigned long long c0, r0; };
+__device__ __forceinline__ PfoClockStamp pfo_clock_begin() {
+  PfoClockStamp s;
+  s.c0 = __builtin_amdgcn_s_memtime();
+  s.r0 = __builtin_amdgcn_s_memrealtime();
+  return s;
+}
+__device__ __forceinline__ void pfo_clock_end(const PfoClockStamp& s, unsigned long long* acc /* [2]: cycles, ticks */) {
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  atomicAdd(acc, c1 - s.c0);
+  atomicAdd(acc + 1, r1 - s.r0);
 }
 #endif  // __HIPCC__

@@ -2645,10 +2645,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_tn_group_kernel(const TnGro
   gemm_tile<true, true, 0, VEC>(d, t / pr.tn, t % pr.tn, 0, blockIdx.y, lds_a, lds_b);
 }
 
+// shader-clock pair of the grouped weight-gradient kernel (common.hpp pfo_clock_*)
+__device__ unsigned long long g_gemm_clock[1][2];
+int pfo_gemm_clock_read(double* out, int reset) {
+  unsigned long long h[1][2];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_clock), sizeof(h)) != hipSuccess) return PFO_ERR_HIP;
+  out[0] = (double)h[0][0]; out[1] = (double)h[0][1];
+  if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_clock), h, sizeof(h)) != hipSuccess) return PFO_ERR_HIP; }
+  return PFO_OK;
+}
 // the same grouped launch on the bf16 matrix cores (3-way split, transposed LDS reads)
 template <int FMT, int W = 4>
 __global__ __launch_bounds__(64 * W, 2) void gemm_tn_group_bx_kernel(const TnGroupDev g) {
   __shared__ __attribute__((aligned(16))) char lds[BxFmt<FMT>::NP * (BK * 64 * W + TX_B_PIECE) + 64];
+  const bool clk_on = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64;
+  PfoClockStamp clk;
+  if (clk_on) clk = pfo_clock_begin();
   // Workgroups go to the XCDs round-robin by linear id.  All tiles of one K split read the same rows of A and B (a tile
   // takes 128 of A's columns and all of B's 172): with the (tile, split) grid the six tiles of dW1ovT's split sat on six
   // different L2s and B came from HBM six times (FETCH 188 MB per launch on average where the operands are 83 MB).  The
@@ -2677,6 +2689,7 @@ __global__ __launch_bounds__(64 * W, 2) void gemm_tn_group_bx_kernel(const TnGro
   d.nsplit = g.nsplit;
   d.dyn_chunk = (g.k_dev != nullptr && g.nsplit > 1) ? 1 : 0;
   gemm_tile_tn_bx<FMT, W>(d, t / pr.tn, t % pr.tn, split, lds);
+  if (clk_on && threadIdx.x == 0) pfo_clock_end(clk, g_gemm_clock[0]);
 }
 __global__ __launch_bounds__(256) void tn_group_reduce_kernel(const TnGroupDev g) {
   int K = g.K;
@@ -2770,7 +2783,7 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
   else PFO_KLAUNCH(gemm_tn_group_kernel<false>, dim3(tiles, nsplit), dim3(GEMM_THREADS), 0, stream, g);
   PFO_LAUNCH_CHECK();
   // the GEMM kernel alone; with a device-side K bound the work is (flops per k-row) x the count read back at collect time
-  if (use_bx) pfo_prof_end_dev(PFO_PROF_GEMM_TN_BX, flops / (double)K, k_dev, K, stream);
+  if (use_bx) pfo_prof_end_dev((tn_fmt && tn8) ? PFO_PROF_GEMM_TN_BX8 : PFO_PROF_GEMM_TN_BX, flops / (double)K, k_dev, K, stream);
   if (use_bx) pfo_prof_begin(stream);                           // the slab fold is a family of its own: slabs in, matrices out
   PFO_KLAUNCH(tn_group_reduce_kernel, dim3((unsigned)std::min<int64_t>(1024, pfo_ceil_div(per_split, 256))), dim3(256), 0,
                      stream, g);

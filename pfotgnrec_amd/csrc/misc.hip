@@ -189,7 +189,15 @@ extern "C" int64_t pfo_marks_dump(char* out, int64_t cap) {
   return n;
 }
 
-extern "C" int pfo_abi_version(void) { return 5; }   // 3: pfo_tgn_batch.dropout_keep, pfo_attn_dropout_mask, PFO_PROF_GRU_FUSED; 4: pfo_segment_sum, pfo_tgn_side_stream, defer_join / pcache fields; 5: PFO_PROF_KINDS 12 -> 16 (pfo_prof_collect arrays)
+extern "C" int pfo_shader_clock(double* ghz_out, int32_t reset) {
+  PFO_REQUIRE(ghz_out != nullptr, "null output");
+  double ct[2 * PFO_CLOCK_KERNELS] = {0};
+  if (int rc = pfo_attn_clock_read(ct, reset)) return rc;
+  if (int rc = pfo_gemm_clock_read(ct + 4, reset)) return rc;
+  for (int i = 0; i < PFO_CLOCK_KERNELS; ++i) ghz_out[i] = ct[2 * i + 1] > 0 ? ct[2 * i] / (ct[2 * i + 1] * 10.0) : 0.0;   // cycles per ns
+  return PFO_OK;
+}
+extern "C" int pfo_abi_version(void) { return 6; }   // 3: pfo_tgn_batch.dropout_keep, pfo_attn_dropout_mask, PFO_PROF_GRU_FUSED; 4: pfo_segment_sum, pfo_tgn_side_stream, defer_join / pcache fields; 5: PFO_PROF_KINDS 12 -> 16 (pfo_prof_collect arrays); 6: PFO_PROF_GEMM_TN_BX8 (17 kinds), pfo_shader_clock
 
 // ---------------------------------------------------------------------------------------------
 // roctx ranges (common.hpp)

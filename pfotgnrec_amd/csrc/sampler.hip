@@ -187,7 +187,7 @@ int pfo_tnbr_sample_dev(const int64_t* indptr, const int32_t* adj_nbr, const int
 #undef LAUNCH
   PFO_LAUNCH_CHECK();
   // per query K*(4+4+8) adjacency bytes read + K*12 written (+8 per frontier slot) + ~11 probes + row bounds
-  pfo_prof_end(PFO_PROF_SAMPLER, (double)n_q * (K * 36.0 + 112.0), s);
+  pfo_prof_end(PFO_PROF_SAMPLER, (double)n_q * (K * 36.0 + 112.0) + (clear_ptr ? 4.0 * (double)clear_ints : 0.0), s);   // (+ the flags this launch clears)
   return PFO_OK;
 }
 

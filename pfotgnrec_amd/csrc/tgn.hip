@@ -335,6 +335,13 @@ struct Side {
   // state_dict() and the next backward on the caller's stream then read parameters the side stream was still writing.)
   uint64_t side_gen = 0, recorded_gen = 0;
   bool last_backward_deferred = false;                           // pfo_tgn_adam_side may only follow such a backward
+  hipStream_t deferred_from = nullptr;                           // the caller's stream of that backward (the only stream the side stream is already ordered behind)
+  // Buckets of a side-stream optimizer step in order of FIRST USE (pfo_tgn_adam_side_bucket): early_done fires behind the
+  // kernel that finishes the parameters the next forward reads on the caller's stream (time encoder, GRU, layer 1's biases);
+  // it stands for the whole side stream as long as nothing but later buckets of the same step was queued behind it.
+  hipEvent_t early_done = nullptr;
+  uint64_t early_gen = 0;
+  bool early_ok = false;
   struct Joined { hipStream_t s; uint64_t gen; } joined[8] = {};
   int n_joined = 0;
   bool pending_for(hipStream_t s) const {
@@ -384,6 +391,7 @@ Side& side() {
     good = good && hipEventCreateWithFlags(&sd.pc_b, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.main_done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.side_done, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.early_done, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; l <= PFO_MAX_LAYERS; ++l) good = good && hipEventCreateWithFlags(&sd.layer[l], hipEventDisableTiming) == hipSuccess;
     sd.ok = good;
   }
@@ -391,8 +399,19 @@ Side& side() {
 }
 #define HIPOK(expr, msg) PFO_REQUIRE((expr) == hipSuccess, msg)
 // `s` waits for whatever a deferred backward end / side-stream optimizer step left in flight (pfo_tgn_batch.defer_join)
-int side_join(Side& sd, hipStream_t s) {
+// allow_early (pfo_tgn_forward only): when the side stream's tail is a bucketed optimizer step, the caller's stream waits for
+// the first-use bucket alone and is NOT marked joined - everything else the forward takes from the side streams arrives
+// through events recorded there behind the later buckets (composite weights, weight images, the fc2 fold), and the next full
+// join (the backward's) still waits for all of it.
+int side_join(Side& sd, hipStream_t s, bool allow_early = false) {
   if (!sd.pending_for(s)) return PFO_OK;
+  if (allow_early && sd.early_ok && sd.early_gen == sd.side_gen) {
+    hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap0) == hipSuccess && cap0 == hipStreamCaptureStatusNone) {
+      HIPOK(hipStreamWaitEvent(s, sd.early_done, 0), "event wait failed");
+      return PFO_OK;
+    }
+  }
   // A capturing stream does not join: a capture starts from a synchronised device (torch.cuda.graph, GraphedTrainStep.capture),
   // so nothing deferred is still in flight, and the calls below would be captured - by the time a forward joins, the side stream
   // belongs to the capture (it waited for the fork event), a record on it would turn side_done into a capture-only event and
@@ -543,7 +562,10 @@ static int prepare_sample(const pfo_tgn_config* c, const pfo_tgn_state* st, cons
   // (fwd.begin -> fwd.sampled 40.4 -> 35.6 us).  Both levels of most-recent sampling in ONE launch (a workgroup per root: its
   // own query, then the 1 + K queries that depend on it) was built and measured too: it marks, so the memset comes back, and
   // the step does not move (1.302 / 1.308 against 1.297 / 1.305 ms, round 5) - removed again.
-  const bool clear_in_sampler = L >= 2 && (w.mark_bytes % 4) == 0;
+  // (only while the clear stays a small share of that launch: it runs on ceil(n * 16 / 256) workgroups, a memset on the
+  //  whole chip - beyond ~4 K ints per workgroup (large node tables under small batches) the memset is the faster head)
+  const int64_t clear_blocks = std::max<int64_t>(1, pfo_ceil_div(n[L] * 16, 256));
+  const bool clear_in_sampler = L >= 2 && (w.mark_bytes % 4) == 0 && (int64_t)(w.mark_bytes / 4) <= 4096 * clear_blocks;
   if (!clear_in_sampler) HIPOK(hipMemsetAsync(w.mark, 0, w.mark_bytes, s), "memset failed");
   // ---- frontier expansion: K1 per level (utils.py:163-219 called from embedding_module.py:125).  Enqueued before the
   // side-stream work below: it depends on nothing else, and the GPU samples while the host is still enqueueing
@@ -822,7 +844,9 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   // (with a deferred backward end in flight the side stream already waits for the caller's stream's last launch of that
   //  backward, and everything this call gives it either reads parameters only or sits behind an event of this call: no fork)
   static const int skip_fork = getenv("PFO_SKIP_FORK") ? atoi(getenv("PFO_SKIP_FORK")) : 1;      // A/B switch
-  if (!(skip_fork && sd.pending_for(s) && bind_events)) {
+  // (only for the stream that queued the deferred backward: the side stream waits for THAT stream's last launch; a writer of
+  //  the parameters on any other stream - a native optimizer step there, a graph replay - is ordered by the fork below)
+  if (!(skip_fork && sd.pending_for(s) && sd.deferred_from == s && bind_events)) {
     HIPOK(hipEventRecord(sd.fork, s), "event record failed");
     HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
   }
@@ -830,7 +854,10 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   PFO_MARK("fwd.sampled", s);
   // a deferred backward end + optimizer step of the previous step may still be running on the side stream: the sampling above
   // reads neither its buffers nor the parameters; everything below does (compaction counts, the GRU's weights ...)
-  RUN(side_join(sd, s));
+  static const int early_join = getenv("PFO_EARLY_JOIN") ? atoi(getenv("PFO_EARLY_JOIN")) : 1;      // A/B switch
+  // (early: needs the fused state update's ordering - persist / message store run on the side stream behind every bucket -
+  //  and layers >= 2 wait for fold_done, recorded there too; the top layer's raw b2 is the only late-bucket value this stream reads)
+  RUN(side_join(sd, s, early_join != 0 && c->n_layers >= 2));
   PFO_MARK("fwd.side_joined", s);
   const bool fused_state = b->upd_src != nullptr && c->use_memory && L >= 2;
   PFO_REQUIRE(!fused_state || (b->upd_dst && b->upd_ts && b->upd_eidx && b->upd_B >= 1), "bad state-update arguments");
@@ -1521,8 +1548,10 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     HIPOK(hipStreamWaitEvent(ss, sd.main_done, 0), "event wait failed");
     sd.side_gen += 1;
     sd.last_backward_deferred = true;
+    sd.deferred_from = s;
   } else {
     sd.last_backward_deferred = false;
+    sd.deferred_from = nullptr;
     HIPOK(hipEventRecord(sd.done, ss), "event record failed");
     HIPOK(hipStreamWaitEvent(s, sd.done, 0), "event wait failed");
   }
@@ -1540,6 +1569,24 @@ extern "C" int pfo_tgn_adam_side(float* param, const float* grad, float* exp_avg
   sd.side_gen += 1;                                              // (a stream that joined between the backward and this call joins again)
   PFO_MARK("@side1.adam.end", sd.s);
   return rc;
+}
+
+extern "C" int pfo_tgn_adam_side_bucket(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
+                                        const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1, float beta2,
+                                        float eps, int32_t bucket) {
+  Side& sd = side();
+  PFO_REQUIRE(sd.ok, "could not create the side stream");
+  PFO_REQUIRE(bucket >= 0 && bucket <= 2, "bucket must be 0 (plain), 1 (first use) or 2 (later bucket of the same step)");
+  PFO_REQUIRE(bucket != 2 || sd.early_ok, "a later bucket follows a first-use bucket of the same step");
+  const int rc = pfo_tgn_adam_side(param, grad, exp_avg, exp_avg_sq, n_ranges, lo, hi, step, lr, beta1, beta2, eps);
+  if (rc != PFO_OK) { sd.early_ok = false; return rc; }
+  if (bucket == 1) {
+    HIPOK(hipEventRecord(sd.early_done, sd.s), "event record failed");
+    sd.early_ok = true;
+  }
+  if (bucket == 0) sd.early_ok = false;
+  sd.early_gen = sd.side_gen;                                    // (bucket 2: the event of bucket 1 still stands for the stream's tail)
+  return PFO_OK;
 }
 
 extern "C" void* pfo_tgn_side_stream(void) {

@@ -99,6 +99,42 @@ def allreduce_flat_grad_buckets(tgn, world, force=False):
     return g
 
 
+def allreduce_flat_grad_ordered(tgn, world, force=False):
+    """The two pieces of ``allreduce_flat_grad_buckets`` for a FUSED step whose optimizer runs per bucket in order of first use
+    (``tgn.dp_ordered``; ``FusedAdam.step(side=True)``).  Called on the library's side stream (``bpr_step``): the top layer's
+    block is reduced on the communication stream as soon as its gradients are final - beside the rest of the backward - and
+    this stream reduces ``flat_grad[:split]`` (time encoder, GRU, layer 1: what the next forward reads FIRST) behind the
+    backward's end.  Unlike the two-bucket form it does not join the communication stream: the optimizer steps the first-use
+    block at once, the next forward waits for that kernel alone, and the top block's step follows behind
+    ``tgn.wait_comm_stream()``.  Same collectives, same sizes, same order on every rank (also one with an empty shard)."""
+    g = tgn.flat_grad
+    tgn._comm_pending = None
+    if g is None or (world <= 1 and not force):
+        return g
+    split = tgn.grad_split
+    if not (tgn.dp_bucketed and 0 < split < g.numel()):
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        return g
+    fresh, tgn._bucket_event_fresh = tgn._bucket_event_fresh, False
+    if g.device.type != "cuda":
+        dist.all_reduce(g[split:], op=dist.ReduceOp.SUM)
+        dist.all_reduce(g[:split], op=dist.ReduceOp.SUM)
+        return g
+    main = torch.cuda.current_stream(g.device)
+    side = _COMM_STREAMS.get(g.device)
+    if side is None:
+        side = _COMM_STREAMS[g.device] = torch.cuda.Stream(device=g.device)
+    if fresh:
+        side.wait_event(tgn._bucket_event)
+    else:
+        side.wait_stream(main)
+    with torch.cuda.stream(side):
+        dist.all_reduce(g[split:], op=dist.ReduceOp.SUM)
+    dist.all_reduce(g[:split], op=dist.ReduceOp.SUM)
+    tgn._comm_pending = side                               # joined by the optimizer in front of the top block's step
+    return g
+
+
 def broadcast_parameters(flat_params, world, src=0):
     if world > 1:
         dist.broadcast(flat_params, src=src)

@@ -54,6 +54,10 @@ class FusedAdam(torch.optim.Optimizer):
             side = False            # the moments are allocated (and cleared) on the caller's stream below: this one step runs there
         if not side:
             tgn.join()
+            comm = getattr(tgn, "_comm_pending", None)
+            if comm is not None:                     # (a serial step behind allreduce_flat_grad_ordered: an empty shard's route)
+                tgn._comm_pending = None
+                torch.cuda.current_stream(tgn.flat_parameters.device).wait_stream(comm)
         if tgn.flat_grad is None:
             return None
         _lib.require_gpu(tgn.flat_parameters.device)
@@ -73,6 +77,39 @@ class FusedAdam(torch.optim.Optimizer):
             else:
                 lo.append(off); hi.append(off + n); st.append(t)
         MAXR = 16
+        ordered = side and getattr(tgn, "dp_ordered", False) and step_dev is None and 0 < tgn.grad_split < tgn.flat_parameters.numel()
+        if ordered:
+            # Two buckets in order of first use: [0, split) = time encoder, GRU, layer 1 - the next forward reads them on the
+            # caller's stream ~70 us into the step and waits for THIS kernel alone; [split, total) = the top layer's block, whose
+            # all-reduce ran beside the backward - stepped behind it, met by the next forward through the side stream's order.
+            split = tgn.grad_split
+            cut_lo, cut_hi, cut_st = [], [], []
+            for a, b, t in zip(lo, hi, st):
+                if a < split < b:
+                    cut_lo += [a, split]; cut_hi += [split, b]; cut_st += [t, t]
+                else:
+                    cut_lo.append(a); cut_hi.append(b); cut_st.append(t)
+            first = [j for j in range(len(cut_lo)) if cut_hi[j] <= split]
+            later = [j for j in range(len(cut_lo)) if cut_lo[j] >= split]
+            args = (tgn.flat_parameters.data_ptr(), tgn.flat_grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr())
+            hyp = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
+
+            def run(idx, last_bucket):
+                for i in range(0, len(idx), MAXR):
+                    part = idx[i:i + MAXR]
+                    k = len(part)
+                    bucket = last_bucket if i + MAXR >= len(idx) else (0 if last_bucket == 1 else 2)
+                    _lib.call("pfo_tgn_adam_side_bucket", *args, k, (ctypes.c_int64 * k)(*[cut_lo[j] for j in part]),
+                              (ctypes.c_int64 * k)(*[cut_hi[j] for j in part]), (ctypes.c_int32 * k)(*[cut_st[j] for j in part]), *hyp, bucket)
+            if first and later:
+                run(first, 1)
+                tgn.wait_comm_stream()
+                run(later, 2)
+                tgn.parameters_changed(refresh=False)
+                return None
+            tgn.wait_comm_stream()                    # (nothing to cut: the plain side step below, behind the top block's all-reduce)
+        elif side and getattr(tgn, "_comm_pending", None) is not None:
+            tgn.wait_comm_stream()
         for i in range(0, len(lo), MAXR):
             k = min(MAXR, len(lo) - i)
             if step_dev is not None:

@@ -54,6 +54,20 @@ def pack_portfolios(portfolio_list, map_item_id, width=None):
 
 
 _PORT_CACHE = []          # [(base object array, map_item_id, packed idx, packed lens, raw list lengths)] - at most one entry
+_PORT_BAD = []            # [(base, map_item_id)] whose whole-array pack failed (a code outside the map somewhere): batches of it
+                          # are packed directly, the base is not re-packed per batch
+_PORT_MAX_WIDTH = 256     # a base with a longer portfolio is not cached (the packed form is [N, widest] int32)
+
+
+def _spot_check(a, idx_rows, lens_rows, map_item_id, k=3):
+    """A few rows of the batch packed directly against the cached rows: an in-place edit of the dataset that keeps every
+    list's length (codes swapped) is caught with probability ~k / rows-changed per batch instead of never."""
+    n = a.shape[0]
+    for r in {0, n // 2, n - 1} if n >= k else range(n):
+        row = [map_item_id[c] for c in a[r] if c]
+        if len(row) != int(lens_rows[r]) or any(int(x) != y for x, y in zip(idx_rows[r][:len(row)], row)):
+            return False
+    return True
 
 
 def packed_portfolios_of(portfolio_list, map_item_id):
@@ -76,12 +90,22 @@ def packed_portfolios_of(portfolio_list, map_item_id):
         n = a.shape[0]
         if start < 0 or start + n > base.shape[0]:
             return pack_portfolios(a, map_item_id)
+        if _PORT_BAD and _PORT_BAD[0][0] is base and _PORT_BAD[0][1] is map_item_id:
+            return pack_portfolios(a, map_item_id)
         hit = _PORT_CACHE and _PORT_CACHE[0][0] is base and _PORT_CACHE[0][1] is map_item_id
         if not hit:
-            idx, lens = pack_portfolios(base, map_item_id)
+            try:
+                idx, lens = pack_portfolios(base, map_item_id)
+            except Exception:
+                _PORT_BAD[:] = [(base, map_item_id)]         # remembered: the fallback stays O(batch)
+                return pack_portfolios(a, map_item_id)
+            if idx.shape[1] > _PORT_MAX_WIDTH:
+                _PORT_BAD[:] = [(base, map_item_id)]
+                return pack_portfolios(a, map_item_id)
             _PORT_CACHE[:] = [(base, map_item_id, idx, lens, np.fromiter(map(len, base), np.int64, base.shape[0]))]
         _, _, idx, lens, raw = _PORT_CACHE[0]
-        if not np.array_equal(np.fromiter(map(len, a), np.int64, n), raw[start:start + n]):   # the dataset changed under the cache: repack
+        if (not np.array_equal(np.fromiter(map(len, a), np.int64, n), raw[start:start + n])
+                or not _spot_check(a, idx[start:start + n], lens[start:start + n], map_item_id)):   # the dataset changed under the cache: repack
             _PORT_CACHE[:] = []
             return pack_portfolios(a, map_item_id)
         return idx[start:start + n], lens[start:start + n]

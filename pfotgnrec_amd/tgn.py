@@ -153,6 +153,8 @@ class TGN(nn.Module):
         self.dp_rank, self.dp_world = 0, 1
         self.deterministic = False        # bitwise run-to-run reproducible backward (pfo_tgn_batch.deterministic), ~4 % slower
         self.dp_bucketed = False          # ask the backward for the "top layer's gradients are final" event (two-bucket all-reduce)
+        self.dp_ordered = False           # fused step: reduce + optimizer step per bucket, first-use bucket first (distributed.allreduce_flat_grad_ordered)
+        self._comm_pending = None         # the communication stream the top block's all-reduce of this step is in flight on
         self._bucket_event, self._bucket_event_fresh, self._grad_split = None, False, None
         self._mid_event, self._mid_event_fresh = None, False   # recorded by the native backward in front of layer 1's attention backward
         self.seg_in_forward_dp = os.environ.get("PFO_SEG_FWD_DP", "1") != "0"   # ... also on a data-parallel rank (A/B switch; emulated rank 0 of 8: 1.4465 -> 1.439 ms)
@@ -519,6 +521,12 @@ class TGN(nn.Module):
             self._side_stream = torch.cuda.ExternalStream(ptr, device=self.device)
         return self._side_stream
 
+    def wait_comm_stream(self):
+        """The library's side stream waits for the top block's all-reduce (``allreduce_flat_grad_ordered``), once per step."""
+        comm, self._comm_pending = self._comm_pending, None
+        if comm is not None:
+            self.side_stream().wait_stream(comm)
+
     def join(self):
         """Makes the current stream wait for a backward end / optimizer step that ``bpr_step(..., optimizer=...)`` left on the
         library's side stream (no-op when nothing is pending)."""
@@ -868,7 +876,10 @@ class TGN(nn.Module):
     def train(self, mode=True):
         # main.py calls ``tgn = tgn.train()`` in front of EVERY batch (main.py:308,354): nn.Module.train walks all submodules and
         # sets an attribute on each - 0.1 ms per batch on the drop-in loop for a mode that does not change
-        if self.training == bool(mode):
+        # (short-circuit only while EVERY submodule already is in that mode: a child toggled on its own - tgn.child.eval() - or
+        #  attached after the last call is reset exactly as nn.Module.train would; the walk without the attribute writes is 5 us)
+        mode = bool(mode)
+        if self.training == mode and all(m.training == mode for m in self.modules()):
             return self
         return super().train(mode)
 

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
         assert name in _lib.PROTOTYPES, "no ctypes prototype for %s" % name
-    assert lib.pfo_abi_version() == 5
+    assert lib.pfo_abi_version() == 6
 
 
 def test_param_layout_matches_reference_inventory():

@@ -106,6 +106,48 @@ def test_bucketed_allreduce_issues_the_same_collectives_on_a_rank_with_an_empty_
     assert ret[0][2] is False and ret[1][2] is False
 
 
+def _ordered_worker(rank, world, port, ret):
+    """allreduce_flat_grad_ordered: same two pieces, same order, on a rank whose shard was empty."""
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from pfotgnrec_amd.distributed import init_from_env, allreduce_flat_grad_ordered
+    init_from_env(backend="gloo")
+    sizes = []
+    real = dist.all_reduce
+
+    def counting(t, op=dist.ReduceOp.SUM, **kw):
+        sizes.append(int(t.numel()))
+        return real(t, op=op, **kw)
+    dist.all_reduce = counting
+
+    class Stub:
+        flat_grad = torch.full((100,), float(rank + 1)) if rank == 0 else torch.zeros(100)
+        grad_split = 60
+        dp_bucketed = True
+        dp_ordered = True
+        _bucket_event_fresh = rank == 0
+        _bucket_event = None
+        _comm_pending = "stale"
+    allreduce_flat_grad_ordered(Stub, world)
+    ret[rank] = (sizes, Stub.flat_grad.tolist(), Stub._bucket_event_fresh, Stub._comm_pending)
+    dist.all_reduce = real
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ordered_allreduce_issues_the_same_collectives_on_a_rank_with_an_empty_shard():
+    """Round 6: the first-use-ordered exchange cuts the buffer at the same rank-invariant place as the two-bucket form and
+    issues top block, then the rest, on every rank - also the one whose shard was empty; host tensors leave no stream pending."""
+    port = 29250 + (os.getpid() % 100)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ordered_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret[0][0] == ret[1][0] == [40, 60]
+    assert ret[0][1] == ret[1][1] == [1.0] * 100
+    assert ret[0][2] is False and ret[1][2] is False
+    assert ret[0][3] is None and ret[1][3] is None
+
+
 def test_shard_bounds_cover_batch_exactly():
     from pfotgnrec_amd.distributed import shard_bounds
     for B in (1, 7, 512, 4096):

@@ -14,12 +14,13 @@ from conftest import REPO, has_gpu
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")]
 
 
-def _run(rank, world, port, out_dir, n_steps, B=48, buckets=False, det=False, fused=False):
+def _run(rank, world, port, out_dir, n_steps, B=48, buckets=False, det=False, fused=False, ordered=False):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import torch.distributed as dist
     import pfotgnrec_amd as P
-    from pfotgnrec_amd.distributed import init_from_env, allreduce_flat_grad, allreduce_flat_grad_buckets, broadcast_parameters
+    from pfotgnrec_amd.distributed import (init_from_env, allreduce_flat_grad, allreduce_flat_grad_buckets, allreduce_flat_grad_ordered,
+                                           broadcast_parameters)
     from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
     init_from_env(backend="gloo")
     dev = torch.device("cuda:0")
@@ -30,7 +31,8 @@ def _run(rank, world, port, out_dir, n_steps, B=48, buckets=False, det=False, fu
     tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, dev, n_layers=2, n_heads=2, dropout=0.0,
                 use_memory=True, memory_dimension=32, message_function="identity")
     tgn.set_data_parallel(rank, world)
-    tgn.dp_bucketed = buckets
+    tgn.dp_bucketed = buckets or ordered
+    tgn.dp_ordered = ordered                                    # reduce + optimizer step per bucket, first-use bucket first (round 6)
     tgn.deterministic = det                                     # bitwise run-to-run reproducible backward (round 3)
     broadcast_parameters(tgn.flat_parameters, world)
     opt = P.FusedAdam(tgn, lr=1e-3)
@@ -48,7 +50,8 @@ def _run(rank, world, port, out_dir, n_steps, B=48, buckets=False, det=False, fu
             # backward + all-reduce + Adam as ONE call: the end of the backward, the collective and the optimizer's kernel stay
             # on the library's side stream (functional.bpr_step); an empty shard takes the serial order inside the same call
             P.bpr_step(tgn, emb, b, 3, optimizer=opt,
-                       collective=(lambda: allreduce_flat_grad_buckets(tgn, world)) if buckets else (lambda: allreduce_flat_grad(tgn.flat_grad, world)))
+                       collective=(lambda: allreduce_flat_grad_ordered(tgn, world)) if ordered else
+                                  ((lambda: allreduce_flat_grad_buckets(tgn, world)) if buckets else (lambda: allreduce_flat_grad(tgn.flat_grad, world))))
             if step == 0:
                 tgn.join()
                 grad0 = tgn.flat_grad.cpu().numpy().copy()
@@ -69,7 +72,7 @@ def _run(rank, world, port, out_dir, n_steps, B=48, buckets=False, det=False, fu
         opt.zero_grad(set_to_none=True)
     tgn.join()
     torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, "w%d_r%d_B%d%s.npz" % (world, rank, B, ("_buckets" if buckets else "") + ("_fused" if fused else ""))), params=tgn.flat_parameters.cpu().numpy(), grad0=grad0, mem0=mem0,
+    np.savez(os.path.join(out_dir, "w%d_r%d_B%d%s.npz" % (world, rank, B, ("_buckets" if buckets else "") + ("_ordered" if ordered else "") + ("_fused" if fused else ""))), params=tgn.flat_parameters.cpu().numpy(), grad0=grad0, mem0=mem0,
              memory=tgn.memory.memory.cpu().numpy(), last_update=tgn.memory.last_update.cpu().numpy(),
              msg=tgn.memory.msg_table.cpu().numpy(), msg_t=tgn.memory.msg_time.cpu().numpy(), has=tgn.memory.has_msg.cpu().numpy())
     if world > 1:
@@ -77,9 +80,9 @@ def _run(rank, world, port, out_dir, n_steps, B=48, buckets=False, det=False, fu
         dist.destroy_process_group()
 
 
-def _spawn(world, port, tmp_path, n_steps, B, buckets=False, det=False, fused=False):
+def _spawn(world, port, tmp_path, n_steps, B, buckets=False, det=False, fused=False, ordered=False):
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_run, args=(r, world, port, str(tmp_path), n_steps, B, buckets, det, fused)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, str(tmp_path), n_steps, B, buckets, det, fused, ordered)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -186,5 +189,22 @@ def test_fused_step_on_three_ranks_with_uneven_shards(tmp_path):
     _spawn(3, port + 1, tmp_path, 3, 7, det=True, fused=True)
     for r in range(3):
         one, two = np.load(tmp_path / ("w3_r%d_B7.npz" % r)), np.load(tmp_path / ("w3_r%d_B7_fused.npz" % r))
+        for k in one.files:
+            assert np.array_equal(one[k], two[k]), (r, k)
+
+
+@pytest.mark.parametrize("B", [48, 1])
+def test_fused_step_with_buckets_in_order_of_first_use_equals_the_serial_order(tmp_path, B):
+    """Round 6: the fused call with the exchange AND the optimizer cut in two - the top layer's block reduced
+    beside the backward, [time encoder | GRU | layer 1] reduced and stepped first behind its end (the next forward waits for that
+    kernel alone), the top block stepped behind it.  Same arithmetic per element as backward -> all-reduce -> step: gradients
+    of step 1, parameters after three steps, memory and message tables BIT-identical on both ranks (gloo, one GPU,
+    deterministic backward); B = 1: rank 1's shard is empty - same two collectives through the serial route."""
+    port = 29330 + (os.getpid() % 40) + 2 * B
+    _spawn(2, port, tmp_path, 3, B, det=True)
+    _spawn(2, port + 1, tmp_path, 3, B, det=True, fused=True, ordered=True)
+    for r in (0, 1):
+        one = np.load(tmp_path / ("w2_r%d_B%d.npz" % (r, B)))
+        two = np.load(tmp_path / ("w2_r%d_B%d_ordered_fused.npz" % (r, B)))
         for k in one.files:
             assert np.array_equal(one[k], two[k]), (r, k)
