@@ -626,6 +626,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD_RING_WA
 #ifndef FWD_PIPE_WAVES
 #define FWD_PIPE_WAVES 5
 #endif
+// ... with the counts the run-merged backward meets exact at its benchmark shapes (one pair's gathers: 8 or 6, the staging
+// DMAs: 15 / 16, both: 23 / 24) and the nearest lower count otherwise - waiting for fewer outstanding operations is always safe
+__device__ __forceinline__ void pfo_wait_allowed_exact(int allowed) {
+#define PFO_WVM(n) if (allowed >= n) { asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); return; }
+  PFO_WVM(24) PFO_WVM(23) PFO_WVM(22) PFO_WVM(21) PFO_WVM(16) PFO_WVM(15) PFO_WVM(14) PFO_WVM(13) PFO_WVM(8) PFO_WVM(6) PFO_WVM(4) PFO_WVM(2)
+#undef PFO_WVM
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 __device__ __forceinline__ void pfo_wait_allowed(int allowed) {   // wave-uniform: wait until at most `allowed` vector-memory operations are outstanding
   if (allowed >= 48) pfo_wait_vm<48>();
   else if (allowed >= 32) pfo_wait_vm<32>();
@@ -1168,6 +1176,9 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
 #ifndef KC_RUNS
 #define KC_RUNS 2      // keys in flight per wavefront
 #endif
+#ifndef RUNS_ASM_GATHER
+#define RUNS_ASM_GATHER 0   // 1: key gathers by inline asm + counted vmcnt, staging behind the first two pairs (attn_bwd_runs_kernel) - measured 0.297 against 0.267 ms per step (profiles/r6_experiments.txt 10), off
+#endif
 #ifndef RUNS_CW
 #define RUNS_CW 0      // counted vmcnt at a member's start (attn_bwd_runs_kernel)
 #endif
@@ -1292,6 +1303,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
   // cycles with every CU adding) may stay in flight across the next member's set-up and walk.  since_stage counts them - only
   // statements that surely issue one instruction each; too low a count only makes the wait stricter.
   int since_stage = 0;
+  int stage_count = 0;          // DMA instructions issued by stage() so far (every one has active lanes)
+  const bool inject = a.keep_inject != nullptr && a.dropout_p > 0.f;
   auto stage = [&](int64_t n, int slot) {
     const char* g_dc = reinterpret_cast<const char*>(a.dctx + n * H * Cp);
     const char* g_cx = reinterpret_cast<const char*>(a.ctx + n * H * Cp);
@@ -1307,6 +1320,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         __builtin_amdgcn_global_load_lds((gptr_t)(g_cx + off), (lptr_t)(s_stage + row_bytes + k * 1024u), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(g_qk + off), (lptr_t)(s_stage + 2 * row_bytes + k * 1024u), 16, 0, 0);
       }
+      stage_count += 3;                                          // (k * 1024 < row_bytes: lane 0 is on)
     }
     if (lane < K) {
       // wave-uniform row starts + ONE 32-bit lane offset (the scalar-base form of the load: no per-lane 64-bit pointers to keep)
@@ -1319,7 +1333,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
 #pragma unroll
       for (int h = 0; h < H; ++h)
         __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.attw + (n * H + h) * K) + lo), (lptr_t)(st_meta + (4 + h) * kb), 4, 0, 0);
+      // injected dropout decisions (parity tests) ride in the image too, one byte per slot (a dword of LDS each): a register-bound load of them in
+      // the member's set-up put the compiler's s_waitcnt vmcnt(0) for it - taken whether or not the load ran - right behind
+      // these DMAs: every member waited out the staging round trip it was meant to walk beside
+      if (inject) __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.keep_inject + s0) + (lo >> 2)), (lptr_t)(st_meta + (4 + H) * kb), 1, 0, 0);
     }
+    stage_count += 4 + H + (inject ? 1 : 0);                     // (K >= 1: lane 0 is on)
     since_stage = 0;
   };
 
@@ -1560,9 +1579,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         cxs[h] = st_cx[h * Cp + C];
         my_a[h] = inK ? __int_as_float(mi[(4 + h) * K + lane]) : 0.f;
       }
-      // the image is free again: the next member's rows start their trip now and land while this member is walked
+      // the image is free again: the next member's rows start their trip from inside the walk (RUNS_ASM_GATHER: behind the
+      // first two pairs' gathers) or right here, and land while this member is walked
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !RUNS_ASM_GATHER
       if (m + 1 < u_end) stage(ch_get(0, m + 1 - u0), ch_get(1, m + 1 - u0));
+#endif
       pfo_wave_sum_scalar_n<H>(reinterpret_cast<float(&)[H]>(tds));     // delta_h = dctx_h . ctx_h (+ the extra column below)
       float t[H];
 #pragma unroll
@@ -1576,7 +1598,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
       // ks with one v_readlane per head instead of unpacking a bit mask (scalar and / compare / select + a vector select)
       float my_ks[H];
       {
-        const unsigned keep = attn_keep_for(a, rng_off, n, lane);
+        // (a sub-dword LDS-DMA load writes one zero-extended DWORD per lane: the injected bytes sit at a stride of four)
+        const unsigned keep = inject ? (inK ? (unsigned)mi[(4 + H) * K + lane] & 0xFFu : 0xFu) : attn_keep_bits(a.seed, rng_off, n, lane, a.dropout_p);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
           my_ks[h] = ((keep >> h) & 1u) ? keep_scale : 0.f;
@@ -1598,6 +1621,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
           vm &= vm - 1ull;
         }
       };
+#if RUNS_ASM_GATHER
+      // ASM GATHERS (round 6).  While an LDS-DMA is in flight the compiler waits for vmcnt(0) at the first use of any
+      // register-bound load result - the first pair of every walk waited out the staging DMAs issued in front of it, i.e.
+      // the round trip the staging was built to hide (ISA of the round-5 kernel).  The key gathers are issued by inline
+      // asm instead, invisible to the compiler's counter, and waited for by a COUNTED vmcnt: vseq counts the gather loads
+      // and staging DMAs issued; a pair is ready when at most (vseq - its vseq) younger operations are outstanding.  The
+      // staging of the next member is issued BEHIND the first two pairs' gathers: vmcnt retires in order, so only pairs
+      // gathered behind it wait for it - two pairs of arithmetic later.
+      int vseq = 0;
+      const int L_pair = KC_RUNS * (NR + (Ef > 0 ? 1 : 0));
+      auto gather = [&](const int (&jj)[KC_RUNS], float (&kk)[KC_RUNS][NR], float (&ee)[KC_RUNS]) {
+#pragma unroll
+        for (int c = 0; c < KC_RUNS; ++c) {
+          const int j = jj[c] < 0 ? 0 : jj[c];                   // an absent key re-reads slot 0's row: never used
+          const float* src = nbr_tab + (uint32_t)rl_i(my_row, j) * nbr_ld;
+          const uint32_t e = (uint32_t)rl_i(my_e, j);
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const float* pr = src + colr[r];
+            asm volatile("global_load_dword %0, %1, off" : "=v"(kk[c][r]) : "v"(pr));
+          }
+          if (Ef > 0) {
+            const float* pe = edge_feat + e * (uint32_t)Ef + (uint32_t)cole;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(ee[c]) : "v"(pe));
+          } else {
+            ee[c] = 0.f;
+          }
+        }
+        vseq += L_pair;
+      };
+      // the pair gathered when vseq stood at `at` has landed; its registers are tied to the wait (no use is scheduled above it)
+      auto landed = [&](int at, float (&kk)[KC_RUNS][NR], float (&ee)[KC_RUNS]) {
+        pfo_wait_allowed_exact(vseq - at);
+#pragma unroll
+        for (int c = 0; c < KC_RUNS; ++c) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r) asm volatile("" : "+v"(kk[c][r]));
+          asm volatile("" : "+v"(ee[c]));
+        }
+      };
+#else
       auto gather = [&](const int (&jj)[KC_RUNS], float (&kk)[KC_RUNS][NR], float (&ee)[KC_RUNS]) {
 #pragma unroll
         for (int c = 0; c < KC_RUNS; ++c) {
@@ -1609,6 +1673,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
           ee[c] = Ef > 0 ? edge_feat[e * (uint32_t)Ef + (uint32_t)cole] : 0.f;
         }
       };
+#endif
       auto process = [&](const int (&js)[KC_RUNS], const float (&kn)[KC_RUNS][NR], const float (&ke)[KC_RUNS]) {
         float kt[KC_RUNS][NR], ks[KC_RUNS][NR], dtv[KC_RUNS], part[KC_RUNS * H];
 #pragma unroll
@@ -1662,6 +1727,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
           }
         }
       };
+#if RUNS_ASM_GATHER
+      pick(jsA);
+      gather(jsA, knA, keA);
+      int atA = vseq, atB = 0;
+      bool first = true;
+      while (true) {
+        pick(jsB);
+        if (jsB[0] >= 0) { gather(jsB, knB, keB); atB = vseq; }
+        if (first) {
+          // the next member's image, behind the gathers of this member's first two pairs (stage() counts its DMAs into vseq)
+          first = false;
+          if (m + 1 < u_end) { const int before = stage_count; stage(ch_get(0, m + 1 - u0), ch_get(1, m + 1 - u0)); vseq += stage_count - before; }
+        }
+        landed(atA, knA, keA);
+        process(jsA, knA, keA);
+        if (jsB[0] < 0) break;
+        pick(jsA);
+        if (jsA[0] >= 0) { gather(jsA, knA, keA); atA = vseq; }
+        landed(atB, knB, keB);
+        process(jsB, knB, keB);
+        if (jsA[0] < 0) break;
+      }
+#else
       pick(jsA);
       gather(jsA, knA, keA);
       while (true) {
@@ -1674,6 +1762,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         process(jsB, knB, keB);
         if (jsA[0] < 0) break;
       }
+#endif
       };
 #if RUNS_STAMPS
       const unsigned long long st1 = STAMP();
@@ -1892,7 +1981,7 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
   const int dmode = !a.d_nbr ? 0 : (a.nbr_row ? 1 : 2);
   static const int lds_pad = getenv("PFO_ATTN_RUNS_LDSPAD") ? atoi(getenv("PFO_ATTN_RUNS_LDSPAD")) : 0;   // occupancy probe
   // the run-merged kernel's staging image: three rows of H Cp floats + (4 + H) metadata arrays of K words (attn_bwd_runs_kernel)
-  const size_t run_lds = (size_t)lds_pad + 3 * (size_t)a.H * a.Cp * 4 + (size_t)(4 + a.H) * a.K * 4;
+  const size_t run_lds = (size_t)lds_pad + 3 * (size_t)a.H * a.Cp * 4 + (size_t)(4 + a.H) * a.K * 4 + (size_t)pfo_align_up(4 * a.K, 16);   // (+ K injected keep bytes, one dword each)
   if (pfo_attn_bwd_uses_runs(a)) {
     // run-merged form: single-wavefront workgroups, one chunk of members each (the grid-stride loop only matters when the
     // grid is capped for an experiment)

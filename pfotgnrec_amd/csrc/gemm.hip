@@ -3036,6 +3036,8 @@ int pfo_gemm_multi_launch(const PfoGemm* list, int n, hipStream_t stream) {
     double mflops = 0;
     for (int i = 0; i < cnt; ++i) mflops += 2.0 * list[base + i].M * list[base + i].N * (double)list[base + i].K[0] * list[base + i].batch;
     pfo_prof_begin(stream);
+    static const int abl_multi = getenv("PFO_ABL_MULTI") ? atoi(getenv("PFO_ABL_MULTI")) : 0;   // timing-only ablation (wrong results): 1 = a single tile per launch
+    if (abl_multi) tiles = 1;
     if (vec) PFO_KLAUNCH(gemm_multi_kernel<true>, dim3(tiles), dim3(GEMM_THREADS), 0, stream, g);
     else PFO_KLAUNCH(gemm_multi_kernel<false>, dim3(tiles), dim3(GEMM_THREADS), 0, stream, g);
     PFO_LAUNCH_CHECK();
