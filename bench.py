@@ -435,7 +435,8 @@ class Workload:
             broadcast_parameters(tgn.flat_parameters, world)
         if cfg.use_memory:
             steady_state_init(tgn, None)
-        self.opt = P.FusedAdam(tgn, lr=args.lr)
+        # (the loop below zeroes the gradients right after every step, as main.py:388-390 does: the optimizer's kernel does it)
+        self.opt = P.FusedAdam(tgn, lr=args.lr, zero_grads_in_step=os.environ.get("PFO_BENCH_ZERO_IN_STEP", "1") == "1")
         t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
         self.src_all, self.dst_all = t(d.sources, np.int32), t(d.destinations, np.int32)
         self.ts_all, self.eidx_all = t(d.timestamps, np.float64), t(d.edge_idxs, np.int32)

@@ -414,10 +414,12 @@ int pfo_tgn_adam_side(float* param, const float* grad, float* exp_avg, float* ex
  * bucket 1: the ranges the next pfo_tgn_forward reads on the CALLER's stream (time encoder, GRU, layer 1: everything below
  * pfo_tgn_grad_split) - an event behind this kernel is all that forward's caller's stream waits for; bucket 2: a later bucket of
  * the same step (the top layer's block, whose all-reduce ran beside the backward) - the forward meets it through the side
- * stream's own order (composite weights, fc2 fold); bucket 0: pfo_tgn_adam_side.  Models with n_layers >= 2. */
-int pfo_tgn_adam_side_bucket(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
+ * stream's own order (composite weights, fc2 fold); bucket 0: pfo_tgn_adam_side.  Buckets 1 / 2: models with n_layers >= 2. */
+int pfo_tgn_adam_side_bucket(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
                              const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1, float beta2, float eps,
-                             int32_t bucket);
+                             int32_t flags /* bits 0-1: the bucket; bit 2 (4): the kernel also CLEARS the gradient ranges it read -
+                                              optimizer.zero_grad() folded in, so that the next pfo_tgn_backward_ev may run with
+                                              zero_grad_first = 0 (no clear on its critical path) when the ranges cover the buffer */);
 int pfo_tgn_join(void* stream);
 /* The library's first side stream (hipStream_t; null on failure): the stream a deferred backward end is left on and
  * pfo_tgn_adam_side runs on.  A data-parallel caller queues its gradient all-reduce THERE, between pfo_tgn_backward

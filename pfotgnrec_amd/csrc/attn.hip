@@ -270,7 +270,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD_WAVES(N
 #define FWD_RING 4      // keys per wavefront's ring (even; 8 and 6 measure the same: the depth is not what binds)
 #endif
 #ifndef FWD_RING_WAVES
-#define FWD_RING_WAVES 6
+#define FWD_RING_WAVES(NR, H) ((NR) * (H) <= 6 ? 6 : ((NR) * (H) <= 8 ? 4 : ((NR) * (H) <= 12 ? 3 : 2)))   // wavefronts per SIMD the register budget is cut for
+#endif
+#ifndef FWD_RING_MAX_NRH
+#define FWD_RING_MAX_NRH 12   // column groups x heads the ring form takes (beyond: the register form)
 #endif
 #ifndef FWD_Q_DMA
 #define FWD_Q_DMA 0    // the qk' row by LDS-DMA (1: 0.176 ms per step) or by register-bound loads in front of the ring's DMAs (0: 0.168)
@@ -334,7 +337,7 @@ extern "C" int pfo_attn_fwd_stamps(unsigned long long* out, int reset) {
 #define FWD_STAMP_END(row, nw) do {} while (0)
 #endif
 template <int NR, int H>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD_RING_WAVES))) void attn_fwd_ring_kernel(const AttnDev a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FWD_RING_WAVES(NR, H)))) void attn_fwd_ring_kernel(const AttnDev a) {
   constexpr int SLOTF = NR * 64, RP = FWD_RING / 2;      // floats per ring slot; pairs the ring holds
   static_assert(FWD_RING % 2 == 0 && FWD_RING >= 2, "ring");
   __shared__ float s_tw[NR * 64], s_tb[NR * 64];
@@ -922,7 +925,8 @@ static bool attn_fwd_pipe_ok(const PfoAttn& a) {
   static const int min_n = getenv("PFO_ATTN_FWD_PIPE_MIN") ? atoi(getenv("PFO_ATTN_FWD_PIPE_MIN")) : 16384;
   const int64_t qk_ld = a.qk_ld > 0 ? a.qk_ld : (int64_t)a.H * a.Cp;
   // (query rows travel 16 bytes per lane; metadata as FWD_IPW K dwords per array; small launches keep one instance per wavefront)
-  return on && a.N >= min_n && (qk_ld % 4) == 0 && (((uintptr_t)a.QK) & 15u) == 0 && FWD_IPW * a.K <= 1024 && FWD_IPW <= 64;
+  return on && a.N >= min_n && (qk_ld % 4) == 0 && (((uintptr_t)a.QK) & 15u) == 0 && FWD_IPW * a.K <= 1024 && FWD_IPW <= 64 &&
+         ((a.D + 63) / 64) * a.H <= 6;                             // (the instantiations its launcher holds)
 }
 
 // the ring form takes rows it can move 16 bytes at a time, with [node | edge] inside NR column groups and one DMA per key
@@ -930,7 +934,7 @@ static bool attn_fwd_ring_ok(const PfoAttn& a) {
   static const int on = getenv("PFO_ATTN_FWD_RING") ? atoi(getenv("PFO_ATTN_FWD_RING")) : 1;     // A/B switch
   const int NRv = (a.D + 63) / 64;
   return on && (a.D % 4) == 0 && (a.Ef % 4) == 0 && a.D + a.Ef <= 64 * NRv && a.D + a.Ef <= 256 && (a.nbr_ld % 4) == 0 &&
-         (((uintptr_t)a.nbr_tab | (uintptr_t)a.edge_feat | (uintptr_t)a.QK) & 15u) == 0 && NRv * a.H <= 6 &&
+         (((uintptr_t)a.nbr_tab | (uintptr_t)a.edge_feat | (uintptr_t)a.QK) & 15u) == 0 && NRv * a.H <= FWD_RING_MAX_NRH &&
          ((a.qk_ld > 0 ? a.qk_ld : (int64_t)a.H * a.Cp) % 4) == 0;
 }
 
@@ -1916,7 +1920,12 @@ int pfo_attn_fwd_launch(const PfoAttn& a, hipStream_t stream) {
       case 2 * 8 + 1: PFO_KLAUNCH((attn_fwd_ring_kernel<2, 1>), g, b, qlds, stream, d); break;
       case 2 * 8 + 2: PFO_KLAUNCH((attn_fwd_ring_kernel<2, 2>), g, b, qlds, stream, d); break;
       case 3 * 8 + 1: PFO_KLAUNCH((attn_fwd_ring_kernel<3, 1>), g, b, qlds, stream, d); break;
-      default: PFO_KLAUNCH((attn_fwd_ring_kernel<3, 2>), g, b, qlds, stream, d); break;      // (3, 2): attn_fwd_ring_ok admits NR H <= 6
+      case 3 * 8 + 2: PFO_KLAUNCH((attn_fwd_ring_kernel<3, 2>), g, b, qlds, stream, d); break;
+      case 2 * 8 + 4: PFO_KLAUNCH((attn_fwd_ring_kernel<2, 4>), g, b, qlds, stream, d); break;
+      case 3 * 8 + 4: PFO_KLAUNCH((attn_fwd_ring_kernel<3, 4>), g, b, qlds, stream, d); break;
+      case 4 * 8 + 1: PFO_KLAUNCH((attn_fwd_ring_kernel<4, 1>), g, b, qlds, stream, d); break;
+      case 4 * 8 + 2: PFO_KLAUNCH((attn_fwd_ring_kernel<4, 2>), g, b, qlds, stream, d); break;
+      default: PFO_REQUIRE(false, "unsupported (D, H) combination");       // (attn_fwd_ring_ok admits NR H <= 12)
     }
   } else {
     ATTN_DISPATCH(attn_fwd_kernel, pfo_ceil_div(a.N, 4));

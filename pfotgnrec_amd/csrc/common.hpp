@@ -208,6 +208,15 @@ __device__ __forceinline__ void pfo_wave_sum_scalar_n(float (&v)[N]) {
     v[3] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
     return;
   }
+  if constexpr (N == 8) {
+    // two rounds of the four-sum form (20 vector instructions against 56 for eight interleaved DPP trees): four heads x two keys
+    float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+    pfo_wave_sum_scalar_n<4>(lo);
+    pfo_wave_sum_scalar_n<4>(hi);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = lo[i]; v[4 + i] = hi[i]; }
+    return;
+  }
   if constexpr (N == 2) {
     // rows 0-1: sum 0, rows 2-3: sum 1; the row pairs are folded by a second swap of the register with itself
     const float y = pfo_swap_add32(v[0], v[1]);

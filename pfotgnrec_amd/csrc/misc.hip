@@ -436,7 +436,8 @@ extern "C" int pfo_adam_step(float* param, const float* grad, float* exp_avg, fl
 }
 
 struct AdamRanges { int64_t lo[PFO_ADAM_MAX_RANGES], hi[PFO_ADAM_MAX_RANGES]; float lr_bc1[PFO_ADAM_MAX_RANGES], bc2_sqrt[PFO_ADAM_MAX_RANGES]; int n; };
-__global__ void adam_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+template <bool ZERO>
+__global__ void adam_ranges_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                    float* __restrict__ v, const AdamRanges r, float b1, float b2, float eps) {
   for (int q = 0; q < r.n; ++q) {
     const float step_size = r.lr_bc1[q], bc2s = r.bc2_sqrt[q];
@@ -447,12 +448,21 @@ __global__ void adam_ranges_kernel(float* __restrict__ p, const float* __restric
       m[i] = mi;
       v[i] = vi;
       p[i] -= step_size * (mi / (sqrtf(vi) / bc2s + eps));
+      if (ZERO) g[i] = 0.f;         // optimizer.zero_grad() folded in: the next backward clears nothing on its critical path
     }
   }
 }
+int pfo_adam_step_ranges_impl(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
+                              const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1,
+                              float beta2, float eps, bool zero_grad, void* stream);
 extern "C" int pfo_adam_step_ranges(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
                                     const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1,
                                     float beta2, float eps, void* stream) {
+  return pfo_adam_step_ranges_impl(param, const_cast<float*>(grad), exp_avg, exp_avg_sq, n_ranges, lo, hi, step, lr, beta1, beta2, eps, false, stream);
+}
+int pfo_adam_step_ranges_impl(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
+                              const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1,
+                              float beta2, float eps, bool zero_grad, void* stream) {
   PFO_REQUIRE(param && grad && exp_avg && exp_avg_sq, "null buffer");
   PFO_REQUIRE(n_ranges >= 0 && n_ranges <= PFO_ADAM_MAX_RANGES, "too many ranges");
   if (n_ranges == 0) return PFO_OK;
@@ -470,8 +480,8 @@ extern "C" int pfo_adam_step_ranges(float* param, const float* grad, float* exp_
     longest = std::max(longest, hi[q] - lo[q]);
   }
   const int nb = (int)std::min<int64_t>(2048, std::max<int64_t>(1, pfo_ceil_div(longest, 256)));
-  PFO_KLAUNCH(adam_ranges_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, r,
-                     beta1, beta2, eps);
+  if (zero_grad) PFO_KLAUNCH(adam_ranges_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, r, beta1, beta2, eps);
+  else PFO_KLAUNCH(adam_ranges_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, r, beta1, beta2, eps);
   PFO_LAUNCH_CHECK();
   return PFO_OK;
 }

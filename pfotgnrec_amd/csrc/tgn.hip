@@ -1559,26 +1559,34 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
   return PFO_OK;
 }
 
-extern "C" int pfo_tgn_adam_side(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
-                                 const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1, float beta2,
-                                 float eps) {
+int pfo_adam_step_ranges_impl(float*, float*, float*, float*, int32_t, const int64_t*, const int64_t*, const int32_t*, float, float, float,
+                              float, bool, void*);
+static int adam_side_impl(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
+                          const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1, float beta2,
+                          float eps, bool zero_grad) {
   Side& sd = side();
   PFO_REQUIRE(sd.ok, "could not create the side stream");
   PFO_REQUIRE(sd.last_backward_deferred, "pfo_tgn_adam_side follows a backward that ran with pfo_tgn_batch.defer_join");
-  const int rc = pfo_adam_step_ranges(param, grad, exp_avg, exp_avg_sq, n_ranges, lo, hi, step, lr, beta1, beta2, eps, (void*)sd.s);
+  const int rc = pfo_adam_step_ranges_impl(param, grad, exp_avg, exp_avg_sq, n_ranges, lo, hi, step, lr, beta1, beta2, eps, zero_grad, (void*)sd.s);
   sd.side_gen += 1;                                              // (a stream that joined between the backward and this call joins again)
   PFO_MARK("@side1.adam.end", sd.s);
   return rc;
 }
+extern "C" int pfo_tgn_adam_side(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
+                                 const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1, float beta2,
+                                 float eps) {
+  return adam_side_impl(param, const_cast<float*>(grad), exp_avg, exp_avg_sq, n_ranges, lo, hi, step, lr, beta1, beta2, eps, false);
+}
 
-extern "C" int pfo_tgn_adam_side_bucket(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
+extern "C" int pfo_tgn_adam_side_bucket(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int32_t n_ranges,
                                         const int64_t* lo, const int64_t* hi, const int32_t* step, float lr, float beta1, float beta2,
-                                        float eps, int32_t bucket) {
+                                        float eps, int32_t flags) {
   Side& sd = side();
   PFO_REQUIRE(sd.ok, "could not create the side stream");
-  PFO_REQUIRE(bucket >= 0 && bucket <= 2, "bucket must be 0 (plain), 1 (first use) or 2 (later bucket of the same step)");
+  const int bucket = flags & 3;
+  PFO_REQUIRE(flags >= 0 && flags < 8 && bucket <= 2, "flags: bucket 0 (plain), 1 (first use) or 2 (later bucket of the same step), + 4 = clear the gradient ranges");
   PFO_REQUIRE(bucket != 2 || sd.early_ok, "a later bucket follows a first-use bucket of the same step");
-  const int rc = pfo_tgn_adam_side(param, grad, exp_avg, exp_avg_sq, n_ranges, lo, hi, step, lr, beta1, beta2, eps);
+  const int rc = adam_side_impl(param, grad, exp_avg, exp_avg_sq, n_ranges, lo, hi, step, lr, beta1, beta2, eps, (flags & 4) != 0);
   if (rc != PFO_OK) { sd.early_ok = false; return rc; }
   if (bucket == 1) {
     HIPOK(hipEventRecord(sd.early_done, sd.s), "event record failed");

@@ -14,8 +14,13 @@ from . import _lib
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, tgn, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, tgn, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, zero_grads_in_step=False):
+        """``zero_grads_in_step``: a side-stream step (``step(side=True)``, i.e. ``bpr_step(..., optimizer=)``) also CLEARS the
+        gradients it consumed - ``optimizer.zero_grad()`` folded into the optimizer's kernel, for loops that zero the gradients
+        right after the step anyway (main.py:388-390 does): the next native backward then clears nothing on its critical path.
+        ``.grad`` reads zero after such a step."""
         self.tgn = tgn
+        self.zero_grads_in_step = bool(zero_grads_in_step)
         super().__init__(list(tgn.parameters()), dict(lr=lr, betas=betas, eps=eps))
         self._m = None
         self._v = None
@@ -77,6 +82,9 @@ class FusedAdam(torch.optim.Optimizer):
             else:
                 lo.append(off); hi.append(off + n); st.append(t)
         MAXR = 16
+        # the kernel may clear what it read when the ranges cover the whole flat buffer (every tensor has a gradient)
+        covered = bool(lo) and lo[0] == 0 and hi[-1] == tgn.flat_parameters.numel() and all(hi[j] == lo[j + 1] for j in range(len(lo) - 1))
+        zero_all = bool(side and self.zero_grads_in_step and step_dev is None and covered and len(lo) <= MAXR)
         ordered = side and getattr(tgn, "dp_ordered", False) and step_dev is None and 0 < tgn.grad_split < tgn.flat_parameters.numel()
         if ordered:
             # Two buckets in order of first use: [0, split) = time encoder, GRU, layer 1 - the next forward reads them on the
@@ -94,18 +102,21 @@ class FusedAdam(torch.optim.Optimizer):
             args = (tgn.flat_parameters.data_ptr(), tgn.flat_grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr())
             hyp = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
 
+            zflag = 4 if zero_all else 0
+
             def run(idx, last_bucket):
                 for i in range(0, len(idx), MAXR):
                     part = idx[i:i + MAXR]
                     k = len(part)
                     bucket = last_bucket if i + MAXR >= len(idx) else (0 if last_bucket == 1 else 2)
                     _lib.call("pfo_tgn_adam_side_bucket", *args, k, (ctypes.c_int64 * k)(*[cut_lo[j] for j in part]),
-                              (ctypes.c_int64 * k)(*[cut_hi[j] for j in part]), (ctypes.c_int32 * k)(*[cut_st[j] for j in part]), *hyp, bucket)
+                              (ctypes.c_int64 * k)(*[cut_hi[j] for j in part]), (ctypes.c_int32 * k)(*[cut_st[j] for j in part]), *hyp, bucket | zflag)
             if first and later:
                 run(first, 1)
                 tgn.wait_comm_stream()
                 run(later, 2)
                 tgn.parameters_changed(refresh=False)
+                tgn._grad_zeroed = zero_all
                 return None
             tgn.wait_comm_stream()                    # (nothing to cut: the plain side step below, behind the top block's all-reduce)
         elif side and getattr(tgn, "_comm_pending", None) is not None:
@@ -117,6 +128,13 @@ class FusedAdam(torch.optim.Optimizer):
                           self._v.data_ptr(), k, (ctypes.c_int64 * k)(*lo[i:i + k]), (ctypes.c_int64 * k)(*hi[i:i + k]),
                           (ctypes.c_int32 * k)(*st[i:i + k]), step_dev.data_ptr(), float(g["lr"]), float(g["betas"][0]),
                           float(g["betas"][1]), float(g["eps"]), _lib.stream_ptr())
+                continue
+            if side and zero_all:
+                _lib.call("pfo_tgn_adam_side_bucket", tgn.flat_parameters.data_ptr(), tgn.flat_grad.data_ptr(), self._m.data_ptr(),
+                          self._v.data_ptr(), k, (ctypes.c_int64 * k)(*lo[i:i + k]), (ctypes.c_int64 * k)(*hi[i:i + k]),
+                          (ctypes.c_int32 * k)(*st[i:i + k]), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                          float(g["eps"]), 4)
+                tgn._grad_zeroed = True
                 continue
             if side:
                 _lib.call("pfo_tgn_adam_side", tgn.flat_parameters.data_ptr(), tgn.flat_grad.data_ptr(), self._m.data_ptr(),

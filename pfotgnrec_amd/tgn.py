@@ -162,6 +162,7 @@ class TGN(nn.Module):
         self.record_mid_event = False     # ... only on request: an event record on the caller's stream costs the step a launch gap
         self.mid_event_late = False       # record it behind the attention backward instead of in front of it
         self._zero_next = False
+        self._grad_zeroed = False         # the optimizer's kernel cleared the flat gradient buffer (FusedAdam(zero_grads_in_step=True))
         self.eval_chunk_roots = 16384     # roots per forward-only pass (evaluation.py scores B*(2+N_ITEMS) roots per batch)
         self.eval_dedup = True            # forward-only passes embed every distinct (node, time) root once
         # memory_updater.py:25,41 assert that no pending message is older than its node's last update; the check reads
@@ -549,6 +550,9 @@ class TGN(nn.Module):
         """``mean`` = (src f32[n], out f32[1]): a mean the backward takes on its side stream (the BPR loss value)."""
         zero_first = self._attach_grads(call.gru_applied, defer_zero=True) or self._zero_next
         self._zero_next = False
+        if self._grad_zeroed:             # (the buffer IS clear: the optimizer's side-stream kernel wrote the zeros behind its reads)
+            zero_first = False
+        self._grad_zeroed = False         # this backward accumulates into it
         st = self._state_struct()
         pkey = getattr(call, "pkey", None)
         if pkey is not None and not torch.cuda.is_current_stream_capturing() and pkey != self._param_key():

@@ -1,0 +1,150 @@
+"""Round-6 GPU tests: the three forms of the attention forward (register form, LDS key ring, instance pipeline) against each
+other and the oracle at ragged shapes, the optimizer step that clears the gradients it read, the shader-clock stamps."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")]
+
+if has_gpu():
+    import pfotgnrec_amd as P
+    from pfotgnrec_amd import _lib
+    DEV = torch.device("cuda:0")
+
+RTOL_EMB = 1e-4            # north_star: embeddings within 1e-4 relative (max-norm: max|a - b| / max|b|)
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+_FWD_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[2])
+import pfotgnrec_amd as P
+from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+D, H, K, L, B, Ef = [int(x) for x in sys.argv[3:9]]
+cfg = SyntheticConfig("f6", 400, 30, 8000, D, L, K, H, edge_dim=Ef) if Ef != 4 else SyntheticConfig("f6", 400, 30, 8000, D, L, K, H)
+g = make_graph(cfg, with_prices=False)
+d = g.data
+torch.manual_seed(11)
+tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, torch.device("cuda:0"), n_layers=L, n_heads=H,
+            dropout=0.0, use_memory=True, memory_dimension=D, message_function="identity", n_neighbors=K)
+tgn.deterministic = True
+rs = np.random.RandomState(2)
+out = {}
+for step in range(2):
+    s = 300 + step * 3000                     # early in the timeline: many instances with fewer than K (or no) neighbours
+    neg = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * 3)
+    tgn.train()
+    emb = torch.cat(tgn.compute_temporal_embeddings(d.sources[s:s + B], d.destinations[s:s + B], neg, d.timestamps[s:s + B],
+                                                    d.edge_idxs[s:s + B], K))
+    P.bpr_loss(emb, B, 3).backward()
+    out["emb%d" % step] = emb.detach().cpu().numpy()
+    out["grad%d" % step] = tgn.flat_grad.detach().cpu().numpy().copy()
+    for p in tgn.parameters():
+        p.grad = None
+np.savez(sys.argv[1], **out)
+"""
+
+
+@pytest.mark.parametrize("D,H,K,L,B", [(172, 2, 20, 2, 96), (64, 4, 7, 2, 40), (32, 1, 10, 1, 64), (172, 4, 20, 2, 24), (256, 2, 5, 1, 16)])
+def test_attention_forward_forms_agree(tmp_path, D, H, K, L, B):
+    """The LDS key-ring forward (default; one LDS-DMA per key, [node | edge] columns as one vector, scores in log2 units with
+    the scale folded into the query), the round-5 register form (PFO_ATTN_FWD_RING=0) and the instance pipeline
+    (PFO_ATTN_FWD_PIPE=1 with its launch threshold at 0) on the same two steps: embeddings within 1e-6 of each other (the
+    forms differ only in rounding: pre-scaled query, exp2), gradients within 1e-5 (the backward reads ctx' / weights the
+    forward wrote).  Shapes: C2's, four heads (NR H = 12: four wavefronts per SIMD), one column group, D = 256 (four groups),
+    K < and > the ring; batches early in the timeline hold instances with 0 .. K neighbours (odd counts: the pair tail)."""
+    res = {}
+    for name, env in (("ring", {}), ("reg", {"PFO_ATTN_FWD_RING": "0"}), ("pipe", {"PFO_ATTN_FWD_PIPE": "1", "PFO_ATTN_FWD_PIPE_MIN": "0"})):
+        path = str(tmp_path / (name + ".npz"))
+        r = subprocess.run(["timeout", "-k", "10", "300", sys.executable, "-c", _FWD_CHILD, path, REPO, str(D), str(H), str(K), str(L), str(B), "4"],
+                           env=dict(os.environ, **env), capture_output=True)
+        assert r.returncode == 0, (name, r.stderr.decode()[-2000:])
+        res[name] = np.load(path)
+    for k in res["reg"].files:
+        tol = 1e-6 if k.startswith("emb") else 2e-5
+        assert relerr(res["ring"][k], res["reg"][k]) < tol, ("ring", k, relerr(res["ring"][k], res["reg"][k]))
+        assert relerr(res["pipe"][k], res["reg"][k]) < tol, ("pipe", k, relerr(res["pipe"][k], res["reg"][k]))
+    assert np.abs(res["ring"]["emb0"]).max() > 0 and np.isfinite(res["ring"]["grad1"]).all()
+
+
+def test_optimizer_step_that_clears_the_gradients_equals_the_plain_one():
+    """FusedAdam(zero_grads_in_step=True): the side-stream optimizer kernel of bpr_step(..., optimizer=) writes zeros behind the
+    gradients it read, and the next native backward runs without clearing the flat buffer first.  Four steps bit-identical
+    to the plain order (deterministic backward), .grad reads zero after such a step, and a step whose ranges do not cover the
+    buffer (the GRU tensors without a gradient: first batch, no pending message) falls back to the plain kernel."""
+    from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+    cfg = SyntheticConfig("z6", 300, 25, 6000, 64, 2, 8, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    B, K = 48, 8
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(DEV)
+
+    def run(zero_in_step):
+        torch.manual_seed(9)
+        tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=2, dropout=0.0,
+                    use_memory=True, memory_dimension=64, message_function="identity", n_neighbors=K)
+        tgn.deterministic = True
+        opt = P.FusedAdam(tgn, lr=1e-3, zero_grads_in_step=zero_in_step)
+        rs = np.random.RandomState(1)
+        tgn.train()
+        zero_seen = []
+        for step in range(4):
+            s = 2500 + step * B
+            neg = t(rs.randint(301, 326, size=B * 3), np.int32)
+            emb, b = tgn.embed_device(t(d.sources[s:s + B], np.int32), t(d.destinations[s:s + B], np.int32), [neg], [3],
+                                      t(d.timestamps[s:s + B], np.float64), t(d.edge_idxs[s:s + B], np.int32), K)
+            P.bpr_step(tgn, emb, b, 3, optimizer=opt)
+            tgn.join()
+            zero_seen.append(bool((tgn.flat_grad == 0).all()))
+            opt.zero_grad(set_to_none=True)
+        tgn.join()
+        torch.cuda.synchronize()
+        return tgn.flat_parameters.detach().cpu().numpy().copy(), tgn.memory.memory.detach().cpu().numpy().copy(), zero_seen
+
+    p0, m0, z0 = run(False)
+    p1, m1, z1 = run(True)
+    assert np.array_equal(p0, p1) and np.array_equal(m0, m1)
+    assert not any(z0)                       # the plain step leaves the gradients in place
+    assert all(z1[1:])                       # (step 0: no pending messages -> the GRU tensors have no gradient -> plain kernel)
+    assert np.isfinite(p1).all()
+
+
+def test_shader_clock_stamps_read_a_plausible_clock():
+    """pfo_shader_clock: the first wavefront of the attention forward / run-merged backward / grouped weight-gradient kernel stamps
+    s_memtime against the 100 MHz counter on every launch.  After two C2-shaped steps every ratio lies in (0.5, 3.0) GHz and a
+    reset clears the sums."""
+    from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+    cfg = SyntheticConfig("c6", 3000, 60, 60000, 172, 2, 20, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    B = 256
+    tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=2, dropout=0.0,
+                use_memory=True, memory_dimension=172, message_function="identity", n_neighbors=20)
+    rs = np.random.RandomState(0)
+    _lib.shader_clock(reset=True)
+    tgn.train()
+    for step in range(2):
+        s = 40000 + step * B
+        neg = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=B * 3)
+        emb = torch.cat(tgn.compute_temporal_embeddings(d.sources[s:s + B], d.destinations[s:s + B], neg, d.timestamps[s:s + B],
+                                                        d.edge_idxs[s:s + B], 20))
+        P.bpr_loss(emb, B, 3).backward()
+        for p in tgn.parameters():
+            p.grad = None
+    torch.cuda.synchronize()
+    clk = _lib.shader_clock(reset=True)
+    assert set(clk) == {"attn_fwd", "attn_bwd_runs", "gemm_tn_bx"}
+    for k, v in clk.items():
+        assert 0.5 < v < 3.0, (k, v)
+    torch.cuda.synchronize()
+    assert all(v == 0.0 for v in _lib.shader_clock().values())
