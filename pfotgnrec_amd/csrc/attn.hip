@@ -1152,6 +1152,267 @@ __device__ __forceinline__ void attn_bwd_body(const AttnDev& a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// KEY RING for the per-instance backward (round 6): the form above gathers a pair of keys into registers and uses them at once -
+// one exposed round trip per pair, ten per instance - and its predicated first-level loads queue as dependent round trips
+// (ISA notes at attn_fwd_ring_kernel).  Here, as in the ring forward: every first-level load clamped and in one batch, one
+// LDS-DMA per key into a wavefront-private ring BWD_RING - 2 keys ahead of the pair being differentiated, [node | edge] columns
+// as one vector on every side (key slot, qk' row, d ctx' row, d qk' row), counted vmcnt.  DMODE 0 (no key-side gradients:
+// layer 1 without memory - C5) and 2 (plain stores: layers >= 2); the atomic forms keep the register kernel (layer 1 with
+// memory takes the run-merged kernel anyway).  Same arithmetic per element as attn_bwd_body.
+#ifndef BWD_RING
+#define BWD_RING 4
+#endif
+template <int NR, int H, int DMODE>
+__device__ __forceinline__ void attn_bwd_ring_body(const AttnDev& a) {
+  static_assert(DMODE == 0 || DMODE == 2, "ring form: no key-side gradients, or plain stores");
+  constexpr int SLOTF = NR * 64, RP = BWD_RING / 2;
+  __shared__ double s_red[4][2][NR * 64];
+  __shared__ __align__(16) float s_ring[4][BWD_RING][SLOTF];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = a.D, Ef = a.Ef, K = a.K, DE = D + Ef, C = 2 * D + Ef, Cp = a.Cp;
+  const bool direct = (a.nbr_row == nullptr);
+  float tw[NR], tb[NR];
+  double dw[NR], db[NR];     // sums of terms scaled by dt ~ 1e7 with heavy cancellation: accumulate in fp64
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int c = min(lane + 64 * r, D - 1);
+    const float w = a.tw[c], b = a.tb[c];
+    tw[r] = lane + 64 * r < D ? w : 0.f;
+    tb[r] = lane + 64 * r < D ? b : 0.f;
+    dw[r] = 0.0; db[r] = 0.0;
+  }
+  float* const ring = &s_ring[wave][0][0];
+  if (lane + 64 * (NR - 1) >= DE)
+#pragma unroll
+    for (int s = 0; s < BWD_RING; ++s) ring[s * SLOTF + lane + 64 * (NR - 1)] = 0.f;     // (columns no DMA writes read as zero)
+  const float keep_scale = a.dropout_p > 0.f ? 1.f / (1.f - a.dropout_p) : 1.f;
+  const uint64_t rng_off = a.offset + (a.offset_dev ? *a.offset_dev : 0ull);
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int D4 = D >> 2, DE4 = DE >> 2;
+  const bool is_node = lane < D4;
+  const uint64_t base_l = (is_node ? (uint64_t)(uintptr_t)a.nbr_tab : (uint64_t)(uintptr_t)a.edge_feat) + (uint64_t)((is_node ? lane : lane - D4) * 16);
+  const uint32_t mul_l = is_node ? (uint32_t)a.nbr_ld * 4u : (uint32_t)Ef * 4u;
+  const uint32_t node_mask = is_node ? 0xFFFFFFFFu : 0u;
+  const bool inK = lane < K;
+
+  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < a.N; n += (int64_t)gridDim.x * 4) {
+    float* dqk_out = a.dQK + n * H * Cp;
+    const int64_t slot0 = n * K;
+    // ---- first-level loads, clamped, one batch
+    const int64_t si = slot0 + min(lane, K - 1);
+    const int id_r = a.nbr_ids[si];
+    const int row_l = (direct ? a.nbr_ids : a.nbr_row)[si];
+    const int e_r = a.eidx[si];
+    const float dt_r = a.dt[si];
+    const int qrow_l = (a.qk_row ? a.qk_row : a.nbr_ids)[n];
+    float a_r[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) a_r[h] = a.attw[(n * H + h) * K + min(lane, K - 1)];
+    int my_id = inK ? id_r : 0, my_row = inK ? (direct ? (int)(a.nbr_row_base + si) : row_l) : 0, my_e = inK ? e_r : 0;
+    float my_dt = inK ? dt_r : 0.f;
+    float my_a[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) my_a[h] = inK ? a_r[h] : 0.f;
+    const int qrow = a.qk_row ? qrow_l : (int)n;
+    const unsigned long long valid = __ballot(inK && my_id != 0);
+    if (DMODE == 2) {
+      // padded slots own a gradient row too (the buffer is reused every step): zero it
+      unsigned long long im = ~valid & (K >= 64 ? ~0ull : ((1ull << K) - 1ull));
+      while (im) {
+        const int j = __ffsll((long long)im) - 1;
+        im &= im - 1ull;
+        float* dst = a.d_nbr + (a.nbr_row_base + slot0 + j) * a.d_nbr_ld;
+        for (int c = lane; c < D; c += 64) dst[c] = 0.f;
+      }
+    }
+    if (valid == 0ull) {
+      for (int c = lane; c < H * Cp; c += 64) dqk_out[c] = 0.f;
+      continue;
+    }
+    // ---- second level: the instance's qk', d ctx' and ctx' rows (register-bound, clamped, in front of the DMAs)
+    float q1[H][NR], qt[H][NR], g1[H][NR], gt[H][NR], t[H], dsb[H];
+    {
+      const float* qk = a.QK + (int64_t)qrow * a.qk_ld;
+      const float* dc = a.dctx + n * H * Cp;
+      const float* cx = a.ctx + n * H * Cp;
+      float c1[H][NR], ct[H][NR], cs[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int k1 = min(lane + 64 * r, DE - 1), kt_ = min(lane + 64 * r, D - 1);
+          q1[h][r] = qk[h * Cp + k1]; qt[h][r] = qk[h * Cp + DE + kt_];
+          g1[h][r] = dc[h * Cp + k1]; gt[h][r] = dc[h * Cp + DE + kt_];
+          c1[h][r] = cx[h * Cp + k1]; ct[h][r] = cx[h * Cp + DE + kt_];
+        }
+        dsb[h] = dc[h * Cp + C];          // d loss / d (sum_j a'_jh): the gradient of the context's extra column
+        cs[h] = cx[h * Cp + C];
+      }
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int c = lane + 64 * r;
+          if (!(c < DE)) { q1[h][r] = 0.f; g1[h][r] = 0.f; c1[h][r] = 0.f; }
+          if (!(c < D)) { qt[h][r] = 0.f; gt[h][r] = 0.f; ct[h][r] = 0.f; }
+          part = fmaf(g1[h][r], c1[h][r], fmaf(gt[h][r], ct[h][r], part));
+        }
+        t[h] = part;
+      }
+      // delta_h = sum_j a_jh da_jh = d ctx'_h . ctx'_h + d(sum a')_h (sum a')_h
+      pfo_wave_sum_scalar_n<H>(t);
+#pragma unroll
+      for (int h = 0; h < H; ++h) t[h] = fmaf(dsb[h], cs[h], t[h]);
+    }
+    const unsigned keep = attn_keep_for(a, rng_off, n, lane);
+    // (every register-bound value is pinned in front of the first DMA: the compiler's wait for it must not sit behind one)
+    asm volatile("" : "+v"(my_row), "+v"(my_e), "+v"(my_dt), "+v"(my_id));
+#pragma unroll
+    for (int h = 0; h < H; ++h) { asm volatile("" : "+v"(my_a[h]), "+v"(t[h]), "+v"(dsb[h])); }
+    unsigned kp = keep;
+    asm volatile("" : "+v"(kp));
+    // ---- the ring: pair p = valid keys 2p, 2p + 1
+    unsigned long long vm = valid;
+    const int n_pairs = (__popcll(valid) + 1) >> 1;
+    int issued = 0;
+    auto issue_pair = [&]() {
+      int j0 = __ffsll((long long)vm) - 1;
+      vm &= vm - 1ull;
+      int j1 = vm ? (__ffsll((long long)vm) - 1) : j0;
+      vm &= vm - 1ull;
+      const int sl = (2 * issued) % BWD_RING;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int j = c ? j1 : j0;
+        const uint32_t e_s = (uint32_t)rl_i(my_e, j);
+        const uint32_t idx = e_s + (((uint32_t)rl_i(my_row, j) - e_s) & node_mask);
+        const uint64_t src = base_l + (uint64_t)idx * (uint64_t)mul_l;
+        if (lane < DE4) __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)src, (lptr_t)(ring + (sl + c) * SLOTF), 16, 0, 0);
+      }
+      issued += 1;
+    };
+#pragma unroll
+    for (int p = 0; p < RP; ++p)
+      if (p < n_pairs) issue_pair();
+    float dq1[H][NR], dqt[H][NR];
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) { dq1[h][r] = 0.f; dqt[h][r] = 0.f; }
+    unsigned long long wm = valid;
+    for (int p = 0; p < n_pairs; ++p) {
+      int js[2];
+      js[0] = __ffsll((long long)wm) - 1;
+      wm &= wm - 1ull;
+      js[1] = wm ? (__ffsll((long long)wm) - 1) : -1;
+      wm &= wm - 1ull;
+      const bool more = p + RP < n_pairs;
+      if (more) pfo_wait_vm<2 * (RP - 1)>(); else pfo_wait_vm<0>();
+      const float* sl = ring + ((2 * p) % BWD_RING) * SLOTF;
+      float kn[2][NR], kt[2][NR], ks[2][NR], dtv[2];
+      int rows[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int j = js[c] < 0 ? js[0] : js[c];
+        rows[c] = rl_i(my_row, j);
+        dtv[c] = rl_f(my_dt, j);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) kn[c][r] = sl[c * SLOTF + lane + 64 * r];
+      }
+      float part[2 * H];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          float sv, cv;
+          pfo_sincosf(pfo_time_arg(dtv[c], tw[r], tb[r]), sv, cv);
+          const bool on = r < NR - 1 || lane + 64 * r < D;
+          kt[c][r] = on ? cv : 0.f;
+          ks[c][r] = on ? sv : 0.f;
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          float pp = 0.f;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) pp = fmaf(kn[c][r], g1[h][r], fmaf(kt[c][r], gt[h][r], pp));
+          part[c * H + h] = pp;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the slots' values sit in registers: the pair RP ahead starts its trip
+      if (more) issue_pair();
+      pfo_wave_sum_scalar_n<2 * H>(part);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (js[c] < 0) continue;
+        const unsigned kb = (unsigned)rl_i((int)kp, js[c]);
+        float cA[H], cB[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const float ks_h = ((kb >> h) & 1u) ? keep_scale : 0.f;
+          const float da = (part[c * H + h] + dsb[h]) * ks_h;            // d loss / d a_jh (through dropout)
+          const float aj = rl_f(my_a[h], js[c]);
+          const float dscore = aj * (da - t[h]);                         // softmax backward
+          cA[h] = aj * ks_h;                                             // a'_jh multiplies d ctx'_h
+          cB[h] = dscore * a.scale;                                      // multiplies qk'_h
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            dq1[h][r] = fmaf(cB[h], kn[c][r], dq1[h][r]);
+            dqt[h][r] = fmaf(cB[h], kt[c][r], dqt[h][r]);
+          }
+        }
+        float* dst = (DMODE == 2) ? a.d_nbr + (int64_t)rows[c] * a.d_nbr_ld : nullptr;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int cc = lane + 64 * r;
+          float dkn = 0.f, dkt = 0.f;
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            dkn = fmaf(cA[h], g1[h][r], fmaf(cB[h], q1[h][r], dkn));
+            dkt = fmaf(cA[h], gt[h][r], fmaf(cB[h], qt[h][r], dkt));
+          }
+          if (DMODE == 2 && cc < D) dst[cc] = (a.nbr_relu && !(kn[c][r] > 0.f)) ? 0.f : dkn;   // the row is a ReLU output of the layer below
+          const float gsin = -ks[c][r] * dkt;            // d/d(arg) cos(arg) = -sin(arg); ks = 0 on lanes beyond D
+          dw[r] += (double)gsin * (double)dtv[c];
+          db[r] += (double)gsin;
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int c = lane + 64 * r;
+        if (c < DE) dqk_out[h * Cp + c] = dq1[h][r];
+        if (c < D) dqk_out[h * Cp + DE + c] = dqt[h][r];
+      }
+      if (lane < Cp - C) dqk_out[h * Cp + C + lane] = 0.f;      // padding columns feed GEMMs: keep them finite
+    }
+    // (the stores above are drained before the next instance's DMAs by the compiler: a store round trip per instance, behind ~20 keys of arithmetic)
+  }
+  // time-encoder partials: fold the four wavefronts, one slab row per workgroup (deterministic)
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    s_red[wave][0][lane + 64 * r] = dw[r];
+    s_red[wave][1][lane + 64 * r] = db[r];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += 256) {
+    const int which = c / D, cc = c - which * D;
+    const double v = s_red[0][which][cc] + s_red[1][which][cc] + s_red[2][which][cc] + s_red[3][which][cc];
+    if (a.det) a.dtime_slab[(int64_t)blockIdx.x * 2 * D + c] = v;
+    else atomicAdd(&a.dtime_part[(int64_t)(blockIdx.x & (ATTN_TIME_BINS - 1)) * 2 * D + c], v);
+  }
+}
+static bool attn_bwd_ring_ok(const PfoAttn& a, int dmode) {
+  static const int on = getenv("PFO_ATTN_BWD_RING") ? atoi(getenv("PFO_ATTN_BWD_RING")) : 1;      // A/B switch
+  const int NRv = (a.D + 63) / 64;
+  return on && (dmode == 0 || dmode == 2) && (a.D % 4) == 0 && (a.Ef % 4) == 0 && a.D + a.Ef <= 64 * NRv && a.D + a.Ef <= 256 &&
+         (a.nbr_ld % 4) == 0 && (((uintptr_t)a.nbr_tab | (uintptr_t)a.edge_feat) & 15u) == 0 && NRv * a.H <= 12;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Layer-1 backward with SHIFT MERGING.  The level-0 gradient scatter is bound by the float-atomic rate of the part (~1.3 TB/s of
 // added bytes chip-wide, MI355X_MICROARCH.md: one 256-byte wave instruction per ~50 ns per CU); everything else in this kernel
 // hides behind it.  Instances arrive ordered by (touched-table row, entries of the row's history before the instance's time) -
@@ -1583,6 +1844,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         cxs[h] = st_cx[h * Cp + C];
         my_a[h] = inK ? __int_as_float(mi[(4 + h) * K + lane]) : 0.f;
       }
+      // injected dropout decisions: read HERE, with the rest of the image, in front of the next member's staging (a sub-dword
+      // LDS-DMA load writes one zero-extended DWORD per lane: the bytes sit at a stride of four)
+      const unsigned keep_img = (inject && inK) ? ((unsigned)mi[(4 + H) * K + lane] & 0xFFu) : 0xFu;
       // the image is free again: the next member's rows start their trip from inside the walk (RUNS_ASM_GATHER: behind the
       // first two pairs' gathers) or right here, and land while this member is walked
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1602,8 +1866,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
       // ks with one v_readlane per head instead of unpacking a bit mask (scalar and / compare / select + a vector select)
       float my_ks[H];
       {
-        // (a sub-dword LDS-DMA load writes one zero-extended DWORD per lane: the injected bytes sit at a stride of four)
-        const unsigned keep = inject ? (inK ? (unsigned)mi[(4 + H) * K + lane] & 0xFFu : 0xFu) : attn_keep_bits(a.seed, rng_off, n, lane, a.dropout_p);
+        const unsigned keep = inject ? keep_img : attn_keep_bits(a.seed, rng_off, n, lane, a.dropout_p);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
           my_ks[h] = ((keep >> h) & 1u) ? keep_scale : 0.f;
@@ -1881,10 +2144,35 @@ static int check_common(const PfoAttn& a) {
     PFO_REQUIRE(done, "unsupported (D, H) combination");                                                      \
   }
 
+// the ring forms: NR H <= 12 (attn_bwd_ring_ok)
+#define ATTN_DISPATCH_RING(KERNEL, grid)                                                                      \
+  {                                                                                                           \
+    const int NRv = (a.D + 63) / 64;                                                                          \
+    const dim3 g((unsigned)(grid)), b(256);                                                                   \
+    bool done = true;                                                                                         \
+    switch (NRv * 8 + a.H) {                                                                                  \
+      case 1 * 8 + 1: PFO_KLAUNCH((KERNEL<1, 1>), g, b, 0, stream, d); break;                          \
+      case 1 * 8 + 2: PFO_KLAUNCH((KERNEL<1, 2>), g, b, 0, stream, d); break;                          \
+      case 1 * 8 + 4: PFO_KLAUNCH((KERNEL<1, 4>), g, b, 0, stream, d); break;                          \
+      case 2 * 8 + 1: PFO_KLAUNCH((KERNEL<2, 1>), g, b, 0, stream, d); break;                          \
+      case 2 * 8 + 2: PFO_KLAUNCH((KERNEL<2, 2>), g, b, 0, stream, d); break;                          \
+      case 2 * 8 + 4: PFO_KLAUNCH((KERNEL<2, 4>), g, b, 0, stream, d); break;                          \
+      case 3 * 8 + 1: PFO_KLAUNCH((KERNEL<3, 1>), g, b, 0, stream, d); break;                          \
+      case 3 * 8 + 2: PFO_KLAUNCH((KERNEL<3, 2>), g, b, 0, stream, d); break;                          \
+      case 3 * 8 + 4: PFO_KLAUNCH((KERNEL<3, 4>), g, b, 0, stream, d); break;                          \
+      case 4 * 8 + 1: PFO_KLAUNCH((KERNEL<4, 1>), g, b, 0, stream, d); break;                          \
+      case 4 * 8 + 2: PFO_KLAUNCH((KERNEL<4, 2>), g, b, 0, stream, d); break;                          \
+      default: done = false;                                                                                  \
+    }                                                                                                         \
+    PFO_REQUIRE(done, "unsupported (D, H) combination");                                                      \
+  }
+
 // minimum wavefronts per SIMD the register allocation must allow: 3 where the kernel fits 168 VGPRs without spilling
 #ifndef BWD_WAVES
 #define BWD_WAVES(NR, H, DMODE) (((H) <= 2 && (NR) <= 3) ? ((DMODE) == 1 ? 2 : 3) : (((H) == 4 && (NR) == 4) ? 1 : 2))
 #endif
+template <int NR, int H> __global__ __launch_bounds__(256, BWD_WAVES(NR, H, 0)) void attn_bwd_ring_kernel_none(const AttnDev a) { attn_bwd_ring_body<NR, H, 0>(a); }
+template <int NR, int H> __global__ __launch_bounds__(256, BWD_WAVES(NR, H, 2)) void attn_bwd_ring_kernel_direct(const AttnDev a) { attn_bwd_ring_body<NR, H, 2>(a); }
 template <int NR, int H> __global__ __launch_bounds__(256, BWD_WAVES(NR, H, 0)) void attn_bwd_kernel_none(const AttnDev a) { attn_bwd_body<NR, H, 0>(a); }
 template <int NR, int H> __global__ __launch_bounds__(256, BWD_WAVES(NR, H, 1)) void attn_bwd_kernel(const AttnDev a) { attn_bwd_body<NR, H, 1>(a); }
 template <int NR, int H> __global__ __launch_bounds__(256, BWD_WAVES(NR, H, 2)) void attn_bwd_kernel_direct(const AttnDev a) { attn_bwd_body<NR, H, 2>(a); }
@@ -2022,7 +2310,9 @@ int pfo_attn_bwd_launch(const PfoAttn& a, int* n_parts, hipStream_t stream) {
     return PFO_OK;
   }
   pfo_prof_begin(stream);
-  if (dmode == 0) { ATTN_DISPATCH(attn_bwd_kernel_none, grid); }
+  if (attn_bwd_ring_ok(a, dmode) && dmode == 0) { ATTN_DISPATCH_RING(attn_bwd_ring_kernel_none, grid); }
+  else if (attn_bwd_ring_ok(a, dmode)) { ATTN_DISPATCH_RING(attn_bwd_ring_kernel_direct, grid); }
+  else if (dmode == 0) { ATTN_DISPATCH(attn_bwd_kernel_none, grid); }
   else if (dmode == 1 && a.det) { ATTN_DISPATCH(attn_bwd_kernel_det, grid); }
   else if (dmode == 1) { ATTN_DISPATCH(attn_bwd_kernel, grid); }
   else { ATTN_DISPATCH(attn_bwd_kernel_direct, grid); }

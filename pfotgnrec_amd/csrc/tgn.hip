@@ -1176,7 +1176,8 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
     // better than next to the attention backward alone, whose single-wavefront workgroups starved a 74 KB-LDS kernel of slots);
     // the fp16 tile (49 KB, half the matrix work) does better behind d ctx', beside the attention backward: 1.4495 against
     // 1.4532 ms over four interleaved pairs.  (Behind the attention backward, beside the serial tail: +2 % per step.)
-    static const int tna_mode = getenv("PFO_TNA_MODE") ? atoi(getenv("PFO_TNA_MODE")) : 0;   // A/B: 0 fork behind the d ctx' contraction (beside the attention backward), 2 beside d ctx', 1 main stream
+    static const int tna_mode = getenv("PFO_TNA_MODE") ? atoi(getenv("PFO_TNA_MODE")) : 0;
+    const int tna_mode_g = tna_mode;   // A/B: 0 fork behind the d ctx' contraction (beside the attention backward), 2 beside d ctx', 1 main stream
     bool tn_a_bound = false;                                   // tn_a already rides on the d ctx' launch
     const bool dq_atomic = l == 1 && dq_atomic_mode(c, b);
     bool dh1_summed = false;
@@ -1355,6 +1356,10 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       // (on the second side stream: the first one must stay free for layer 1's weight gradients over the instances)
       hipStream_t sf = sd.s2;
       HIPOK(hipStreamWaitEvent(sf, sd.layer[l], 0), "event wait failed");
+      // (A/B, PFO_L2_CHAIN_LATE=1: layer 2's weight gradients and chain wait for layer 1's d ctx' contraction too - they then
+      //  run beside the attention backward instead of taking workgroup slots from the contraction the caller's stream waits for)
+      static const int chain_late = getenv("PFO_L2_CHAIN_LATE") ? atoi(getenv("PFO_L2_CHAIN_LATE")) : 0;
+      if (chain_late && l == 2 && !pfo_prof_on() && tna_mode_g == 0) HIPOK(hipStreamWaitEvent(sf, sd.tn_a, 0), "event wait failed");
       if (pfo_prof_on()) {
         // event-bracketed step (bench.py's roofline sample): on the caller's stream, so that the bracket times the kernel alone
         RUN(pfo_gemm_tn_group_launch(tn, ntn, N, nullptr, w.slabs, w.slab_floats, s));
