@@ -850,11 +850,22 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     HIPOK(hipEventRecord(sd.fork, s), "event record failed");
     HIPOK(hipStreamWaitEvent(ss, sd.fork, 0), "event wait failed");
   }
+  // The GRU's two weight images depend on the parameters alone.  With a deferred backward end + optimizer step in flight on
+  // the side stream they are made THERE, right behind that step's kernel (this call is queued while the device still runs the
+  // backward) - the join below covers them - instead of on the caller's stream between the join and the lazy GRU (6 us + a
+  // launch gap of the step's serial head).  PFO_GRU_IMG_SIDE=1: A/B (off: +6 us, as round 4 found for the refresh path).
+  static const int early_join = getenv("PFO_EARLY_JOIN") ? atoi(getenv("PFO_EARLY_JOIN")) : 1;      // A/B switch
+  static const int gru_img_side = getenv("PFO_GRU_IMG_SIDE") ? atoi(getenv("PFO_GRU_IMG_SIDE")) : 0;   // (measured: 1.2238 with, 1.2173 without - off)
+  const bool early_path = early_join != 0 && c->n_layers >= 2 && sd.early_ok && sd.early_gen == sd.side_gen;
+  bool gru_img_done = false;
+  if (gru_img_side && c->use_memory && build && bind_events && sd.pending_for(s) && sd.deferred_from == s && !early_path) {
+    RUN(build_gru_images(c, d, w, P, ss));
+    gru_img_done = true;
+  }
   if (!b->prepared) RUN(prepare_sample(c, st, b, w, n, s));
   PFO_MARK("fwd.sampled", s);
   // a deferred backward end + optimizer step of the previous step may still be running on the side stream: the sampling above
   // reads neither its buffers nor the parameters; everything below does (compaction counts, the GRU's weights ...)
-  static const int early_join = getenv("PFO_EARLY_JOIN") ? atoi(getenv("PFO_EARLY_JOIN")) : 1;      // A/B switch
   // (early: needs the fused state update's ordering - persist / message store run on the side stream behind every bucket -
   //  and layers >= 2 wait for fold_done, recorded there too; the top layer's raw b2 is the only late-bucket value this stream reads)
   RUN(side_join(sd, s, early_join != 0 && c->n_layers >= 2));
@@ -863,7 +874,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   PFO_REQUIRE(!fused_state || (b->upd_dst && b->upd_ts && b->upd_eidx && b->upd_B >= 1), "bad state-update arguments");
 
   // the GRU contractions come first on the main stream: their two weight images are made there too (one 4 us launch)
-  if (c->use_memory && build) RUN(build_gru_images(c, d, w, P, s));
+  if (c->use_memory && build && !gru_img_done) RUN(build_gru_images(c, d, w, P, s));
   bool composites_awaited = false;
 
   // ---- the nodes this step reads, compacted, and their level-0 rows packed (prepare_compact_pack; a prepared batch has them)
