@@ -2743,7 +2743,8 @@ int pfo_gemm_tn_group_launch(const PfoTnProblem* probs, int n, int K, const int3
     const PfoTnProblem& q = probs[i];
     tn8 = tn8 && q.M >= tn8_env && aligned4(q.A) && aligned4(q.B) && (q.lda % 4) == 0 && (q.ldb % 4) == 0 && (q.M % 4) == 0 && (q.N % 4) == 0;
   }
-  const int tbm = tn8 ? 256 : BM, slots = tn8 ? 256 : 512;
+  static const int slots4_env = getenv("PFO_TN_SLOTS") ? atoi(getenv("PFO_TN_SLOTS")) : 512;      // A/B: workgroups of the 128-row form the split count is sized for (2 per CU; 768 = 3: LDS 3 x 49.6 KB and 3 x 120 registers fit)
+  const int tbm = tn8 ? 256 : BM, slots = tn8 ? 256 : slots4_env;
   int64_t per_split = 0;
   for (int i = 0; i < n; ++i) {
     const PfoTnProblem& s = probs[i];

@@ -11,7 +11,12 @@ export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
 out=gpurun_out/${tag}_${key}
 mkdir -p $out
 CMD="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-prof --no-drop-in --min-seconds 0 $*"
+# the bench line of the SAME build on the same box (no tracer), embedded in the summary (bench_line_same_build)
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-drop-in $* 2>/dev/null | tail -1 > $out/bench_line.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- $CMD > $out/bench_under_trace.log 2>&1
+# one step kernel by kernel (before the raw per-dispatch table is dropped below)
+mkdir -p gpurun_out/profiles_out
+python3 tools/step_timeline.py "$(find $out/trace -name '*kernel_trace.csv' | head -1)" > gpurun_out/profiles_out/${tag}_step_timeline_${key}.txt 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o p -- $CMD > $out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o p -- $CMD > $out/pmc_write.log 2>&1
 # SQ instruction counts of the same command (their own passes): the vector-issue roofline of the attention kernels and the

@@ -65,6 +65,13 @@ for sub, names in (("pmc_sq1", ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"
             if k in pmc:
                 pmc[k].setdefault("sq", {})[name] = round(v, 1)
 bench_line = None
+try:
+    bl = json.loads(open(os.path.join(src, "bench_line.json")).read().strip().splitlines()[-1])
+    bench_line = {"value": bl["value"], "unit": bl["unit"], "ms_per_step": bl["ms_per_step"], "timed_steps": bl["config"].get("timed_steps"),
+                  "block_ms_per_step": bl["config"].get("block_ms_per_step"),
+                  "note": "python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-drop-in %s on the box and build of these passes, no tracer" % bench_args}
+except Exception:
+    pass
 out = {"workload": key,
        "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 "
                   "--no-cpu-baseline --no-prof --min-seconds 0 %s  (+ separate --pmc passes: FETCH_SIZE; WRITE_SIZE; "
