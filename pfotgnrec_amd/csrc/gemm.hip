@@ -2524,6 +2524,114 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_multi_kernel(const MultiDev
   }
 }
 
+// DIRECT form of the same grouped launch (round 6).  These products (composite weights, their gradient chains: M, N, K <= 704,
+// operands L2-resident weights) are chains of k-tiles, each a global -> LDS -> barrier -> fragment round trip: 10-57 us per
+// launch for ~40 MFLOP, 0.32 ms per step of side-stream residency.  Here a wavefront owns ONE 16 x 16 output tile and takes
+// its MFMA fragments straight from global memory - no LDS, no barrier: lane (r, g) holds A[row r][16 q + 4 g + j] and
+// B[16 q + 4 g + j][col r], j = 0..3, as one float4 (or four dwords on a k-major operand) per 16 k; MFMA step j multiplies the
+// j-th elements, so every k of the block is taken exactly once (a permutation of the k order inside a block of 16 - the sum
+// does not care).  Loads run MULTI_PD blocks ahead; four times the workgroups (16 x 64 per workgroup instead of 32 x 64).
+#ifndef MULTI_PD
+#define MULTI_PD 4
+#endif
+template <bool A_KM, bool B_KM, bool VEC>
+__device__ __forceinline__ void gemm_direct_tile(const GemmDev& p, const int bx, const int by, const int zb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int m0 = bx * 16, n0 = by * 64 + 16 * wave;
+  if (n0 >= p.N) return;                                    // (no barrier in this kernel: a wavefront may leave)
+  const int K = p.K[0];
+  const float* Ab = p.A[0] + zb * p.a_bs[0];
+  const float* Bb = p.B[0] + zb * p.b_bs[0];
+  const int64_t lda = p.lda[0], ldb = p.ldb[0];
+  const int mr = min(m0 + r, p.M - 1), nr = min(n0 + r, p.N - 1);       // clamped: rows / columns beyond the edge only feed outputs that are not stored
+  const int T = (K + 15) >> 4;
+  float a[MULTI_PD][4], b[MULTI_PD][4];
+  auto load = [&](int q, float (&av)[4], float (&bv)[4]) {
+    const int k0 = 16 * q + 4 * g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { av[j] = 0.f; bv[j] = 0.f; }
+    if (!A_KM) {
+      const float* src = Ab + (int64_t)mr * lda + min(k0, max(K - 4, 0));
+      if (VEC) { const float4 v = *reinterpret_cast<const float4*>(src); av[0] = v.x; av[1] = v.y; av[2] = v.z; av[3] = v.w; }
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) av[j] = Ab[(int64_t)mr * lda + min(k0 + j, K - 1)];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) av[j] = Ab[(int64_t)min(k0 + j, K - 1) * lda + mr];
+    }
+    if (!B_KM) {
+      const float* src = Bb + (int64_t)nr * ldb + min(k0, max(K - 4, 0));
+      if (VEC) { const float4 v = *reinterpret_cast<const float4*>(src); bv[0] = v.x; bv[1] = v.y; bv[2] = v.z; bv[3] = v.w; }
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = Bb[(int64_t)nr * ldb + min(k0 + j, K - 1)];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = Bb[(int64_t)min(k0 + j, K - 1) * ldb + nr];
+    }
+    // beyond K both operands are zero (selects behind the unconditional loads)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool in = k0 + j < K;
+      av[j] = in ? av[j] : 0.f;
+      bv[j] = in ? bv[j] : 0.f;
+    }
+  };
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int d = 0; d < MULTI_PD; ++d)
+    if (d < T) load(d, a[d], b[d]);
+  for (int q0 = 0; q0 < T; q0 += MULTI_PD) {
+#pragma unroll
+    for (int d = 0; d < MULTI_PD; ++d) {
+      if (q0 + d < T) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][j], b[d][j], acc, 0, 0, 0);
+        if (q0 + d + MULTI_PD < T) load(q0 + d + MULTI_PD, a[d], b[d]);
+      }
+    }
+  }
+  // C/D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
+  float* Cb = p.C + zb * p.c_bs;
+  const float* bias = p.bias ? p.bias + zb * p.bias_bs : nullptr;
+  const int col = n0 + r;
+  if (col < p.N) {
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = m0 + 4 * g + reg;
+      if (row < p.M) {
+        float v = acc[reg];
+        if (p.accumulate) v += Cb[(int64_t)row * p.ldc + col];
+        Cb[(int64_t)row * p.ldc + col] = v + bv;
+      }
+    }
+  }
+}
+template <bool VEC>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_multi_direct_kernel(const MultiDev g) {
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < MULTI_MAX; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.tile_begin[i]) q = i;
+  int t = blockIdx.x - g.tile_begin[q];
+  const int per_batch = g.tm[q] * g.tn[q];
+  const int zb = t / per_batch;
+  t -= zb * per_batch;
+  const int bx = t / g.tn[q], by = t % g.tn[q];
+  const GemmDev p = g.p[q];
+  switch (g.layout[q]) {
+    case 0: gemm_direct_tile<false, false, VEC>(p, bx, by, zb); break;
+    case 1: gemm_direct_tile<false, true, VEC>(p, bx, by, zb); break;
+    case 2: gemm_direct_tile<true, false, VEC>(p, bx, by, zb); break;
+    default: gemm_direct_tile<true, true, VEC>(p, bx, by, zb); break;
+  }
+}
+
 // out[m, n] += sum_r u_r[m] * v_r[n], several independent updates in one launch (blockIdx.y = the update)
 struct Rank1Dev {
   const float* u[PFO_RANK1_MAX]; const float* v[PFO_RANK1_MAX]; float* out[PFO_RANK1_MAX];
@@ -3021,14 +3129,22 @@ int pfo_gemm_multi_launch(const PfoGemm* list, int n, hipStream_t stream) {
     memset(&g, 0, sizeof(g));
     bool vec = true;
     int tiles = 0;
+    // the direct form (gemm_multi_direct_kernel): plain problems of one source - everything these launches are used for
+    static const int direct_env = getenv("PFO_MULTI_DIRECT") ? atoi(getenv("PFO_MULTI_DIRECT")) : 0;      // A/B switch (off: 1.223-1.239 against 1.216-1.220 ms per step, profiles/r6_experiments.txt 17)
+    bool direct = direct_env != 0;
+    for (int i = 0; i < cnt; ++i) {
+      const PfoGemm& s = list[base + i];
+      direct = direct && s.K[1] == 0 && !s.a_idx[0] && !s.b_idx && !s.relu && !s.relu_src && !s.row_scale && !s.row_zero && !s.add_src &&
+               !s.b_img && !s.gg_gates;
+    }
     for (int i = 0; i < cnt; ++i) {
       const PfoGemm& s = list[base + i];
       PFO_REQUIRE(s.M > 0 && s.N > 0 && s.K[0] > 0 && s.A[0] && s.B[0] && s.C, "bad problem");
       PFO_REQUIRE(!s.m_dev && !s.slabs, "multi launch takes plain problems only");
       to_dev(s, g.p[i]);
       g.layout[i] = (s.a_kmajor ? 2 : 0) + (s.b_kmajor ? 1 : 0);
-      g.tm[i] = (int)pfo_ceil_div(s.M, 32);
-      g.tn[i] = (int)pfo_ceil_div(s.N, 64);            // gemm_tile's TINY shape: 32 x 64
+      g.tm[i] = (int)pfo_ceil_div(s.M, direct ? 16 : 32);
+      g.tn[i] = (int)pfo_ceil_div(s.N, 64);            // gemm_tile's TINY shape: 32 x 64; the direct form: 16 x 64 (four 16 x 16 tiles)
       g.tile_begin[i] = tiles;
       tiles += g.tm[i] * g.tn[i] * s.batch;
       vec = vec && gemm_vec_ok(s);
@@ -3039,7 +3155,9 @@ int pfo_gemm_multi_launch(const PfoGemm* list, int n, hipStream_t stream) {
     pfo_prof_begin(stream);
     static const int abl_multi = getenv("PFO_ABL_MULTI") ? atoi(getenv("PFO_ABL_MULTI")) : 0;   // timing-only ablation (wrong results): 1 = a single tile per launch
     if (abl_multi) tiles = 1;
-    if (vec) PFO_KLAUNCH(gemm_multi_kernel<true>, dim3(tiles), dim3(GEMM_THREADS), 0, stream, g);
+    if (direct && vec) PFO_KLAUNCH(gemm_multi_direct_kernel<true>, dim3(tiles), dim3(GEMM_THREADS), 0, stream, g);
+    else if (direct) PFO_KLAUNCH(gemm_multi_direct_kernel<false>, dim3(tiles), dim3(GEMM_THREADS), 0, stream, g);
+    else if (vec) PFO_KLAUNCH(gemm_multi_kernel<true>, dim3(tiles), dim3(GEMM_THREADS), 0, stream, g);
     else PFO_KLAUNCH(gemm_multi_kernel<false>, dim3(tiles), dim3(GEMM_THREADS), 0, stream, g);
     PFO_LAUNCH_CHECK();
     pfo_prof_end(PFO_PROF_GEMM_MULTI, mflops, stream);
