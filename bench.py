@@ -153,8 +153,8 @@ def _family_has(family, kernel_name):
     """Is this kernel (a name of the rocprofv3 tables) one of the family's?  The per-instance attention backward has three
     entry points (attn_bwd_kernel, _none, _direct, _det) behind one PFO_PROF kind; the run-merged kernel is a family of its own."""
     base = _kernel_base(kernel_name)
-    if family == "attn_bwd":
-        return base.startswith("attn_bwd_kernel")
+    if family == "attn_bwd":     # per-instance backward: register form (four entry points) and LDS key-ring form (two)
+        return base.startswith("attn_bwd_kernel") or base.startswith("attn_bwd_ring_kernel")
     if family == "gemm_bx":      # three forms behind PFO_PROF_GEMM_BX: four / eight wavefronts per workgroup, A-stationary
         return base in ("gemm_bx_areg_kernel", "gemm_bx_areg8_kernel", "gemm_bx_astat_kernel")
     if family in ("gemm_tn_bx", "gemm_tn_bx8"):   # two template instances = two kernels of the trace: <FMT, 8> is the 256-row form
