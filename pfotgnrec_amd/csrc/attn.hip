@@ -1441,6 +1441,18 @@ static bool attn_bwd_ring_ok(const PfoAttn& a, int dmode) {
 #ifndef KC_RUNS
 #define KC_RUNS 2      // keys in flight per wavefront
 #endif
+// RUNS_LATE (round 6): the rarely executed blocks of attn_bwd_runs_kernel (staging, row-sum store, flush) read their pointers and
+// strides from the kernel-argument segment WHERE THEY USE THEM, through a pointer the optimiser cannot see through - hoisted to the
+// kernel's entry, two dozen scalar pairs lived across the key walk and were parked in vector lanes (149 SGPR spills: a v_readlane /
+// v_writelane per access on a kernel that is short of vector issue slots).
+#ifndef RUNS_LATE
+#define RUNS_LATE 0      // (measured: 0.329-0.333 against 0.269 ms per step - scalar loads on the flush / staging paths wait on lgkmcnt with the LDS traffic; off)
+#endif
+#if RUNS_LATE && defined(__HIP_DEVICE_COMPILE__)      // (the host pass of this file only parses the kernel)
+#define RUNS_LATE_ARGS(ka) const AttnDev* ka = reinterpret_cast<const AttnDev*>(__builtin_amdgcn_kernarg_segment_ptr()); asm volatile("" : "+s"(ka))
+#else
+#define RUNS_LATE_ARGS(ka) const AttnDev* const ka = &a
+#endif
 #ifndef RUNS_ASM_GATHER
 #define RUNS_ASM_GATHER 0   // 1: key gathers by inline asm + counted vmcnt, staging behind the first two pairs (attn_bwd_runs_kernel) - measured 0.297 against 0.267 ms per step (profiles/r6_experiments.txt 10), off
 #endif
@@ -1571,9 +1583,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
   int stage_count = 0;          // DMA instructions issued by stage() so far (every one has active lanes)
   const bool inject = a.keep_inject != nullptr && a.dropout_p > 0.f;
   auto stage = [&](int64_t n, int slot) {
-    const char* g_dc = reinterpret_cast<const char*>(a.dctx + n * H * Cp);
-    const char* g_cx = reinterpret_cast<const char*>(a.ctx + n * H * Cp);
-    const char* g_qk = reinterpret_cast<const char*>(a.QK + (int64_t)slot * a.qk_ld);
+    RUNS_LATE_ARGS(ka);
+    const char* g_dc = reinterpret_cast<const char*>(ka->dctx + n * H * Cp);
+    const char* g_cx = reinterpret_cast<const char*>(ka->ctx + n * H * Cp);
+    const char* g_qk = reinterpret_cast<const char*>(ka->QK + (int64_t)slot * ka->qk_ld);
     // (the lane offset is made opaque: hoisted out of the member loop, the per-lane addresses of nine loads would be kept alive
     // as 64-bit register pairs across the key walk - the kernel sits at its register limit, they went to scratch)
     uint32_t lo = (uint32_t)lane * 4u;
@@ -1591,17 +1604,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
       // wave-uniform row starts + ONE 32-bit lane offset (the scalar-base form of the load: no per-lane 64-bit pointers to keep)
       const uint32_t kb = (uint32_t)K * 4u;
       const int64_t s0 = n * K;
-      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.nbr_ids + s0) + lo), (lptr_t)(st_meta), 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.nbr_row + s0) + lo), (lptr_t)(st_meta + kb), 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.eidx + s0) + lo), (lptr_t)(st_meta + 2 * kb), 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.dt + s0) + lo), (lptr_t)(st_meta + 3 * kb), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(ka->nbr_ids + s0) + lo), (lptr_t)(st_meta), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(ka->nbr_row + s0) + lo), (lptr_t)(st_meta + kb), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(ka->eidx + s0) + lo), (lptr_t)(st_meta + 2 * kb), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(ka->dt + s0) + lo), (lptr_t)(st_meta + 3 * kb), 4, 0, 0);
 #pragma unroll
       for (int h = 0; h < H; ++h)
-        __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.attw + (n * H + h) * K) + lo), (lptr_t)(st_meta + (4 + h) * kb), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(ka->attw + (n * H + h) * K) + lo), (lptr_t)(st_meta + (4 + h) * kb), 4, 0, 0);
       // injected dropout decisions (parity tests) ride in the image too, one byte per slot (a dword of LDS each): a register-bound load of them in
       // the member's set-up put the compiler's s_waitcnt vmcnt(0) for it - taken whether or not the load ran - right behind
       // these DMAs: every member waited out the staging round trip it was meant to walk beside
-      if (inject) __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.keep_inject + s0) + (lo >> 2)), (lptr_t)(st_meta + (4 + H) * kb), 1, 0, 0);
+      if (inject) __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(ka->keep_inject + s0) + (lo >> 2)), (lptr_t)(st_meta + (4 + H) * kb), 1, 0, 0);
     }
     stage_count += 4 + H + (inject ? 1 : 0);                     // (K >= 1: lane 0 is on)
     since_stage = 0;
@@ -1661,10 +1674,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
     // optimiser: hoisted out of the member loop, their per-lane 64-bit element offsets lived across the key walk - a dozen
     // register pairs at a kernel that sits on its register limit, i.e. scratch reloads in front of every store)
     auto acc_store = [&]() {
-      if (acc_m >= 0 && !DET && a.dq_rows) {
+      RUNS_LATE_ARGS(ka);
+      if (acc_m >= 0 && !DET && ka->dq_rows) {
         // added straight into the table row's sum (the members of a row sit in several chunks: float atomics, ~20 k rows of
         // H Cp floats per launch at C2 beside the ~275 k neighbour rows)
-        char* out = reinterpret_cast<char*>(a.dq_rows + (int64_t)run_slot * a.dq_ld);
+        char* out = reinterpret_cast<char*>(ka->dq_rows + (int64_t)run_slot * ka->dq_ld);
         uint32_t lo = (uint32_t)lane * 4u;
         asm volatile("" : "+v"(lo));
 #pragma unroll
@@ -1680,7 +1694,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         }
         since_stage += H * 2 * NR + (Ef > 0 ? H : 0);
       } else if (acc_m >= 0) {
-        char* out = reinterpret_cast<char*>(a.dQK + (int64_t)acc_m * H * Cp);      // row m, not n: the per-row sums then stream contiguous rows
+        char* out = reinterpret_cast<char*>(ka->dQK + (int64_t)acc_m * H * Cp);      // row m, not n: the per-row sums then stream contiguous rows
         uint32_t lo = (uint32_t)lane * 4u;
         asm volatile("" : "+v"(lo));
 #pragma unroll
@@ -1695,7 +1709,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
           if (lo < (uint32_t)Ef * 4u) *reinterpret_cast<float*>(out + (uint32_t)(h * Cp + D) * 4u + lo) = dqe[h];
           if (lo < (uint32_t)(Cp - C) * 4u) *reinterpret_cast<float*>(out + (uint32_t)(h * Cp + C) * 4u + lo) = 0.f;
         }
-        if (lane == 0) a.dqk_live[acc_m] = 1;
+        if (lane == 0) ka->dqk_live[acc_m] = 1;
         since_stage += H * (2 * NR + 1) + (Ef > 0 ? H : 0) + 1;
       }
       acc_m = -1;
@@ -1707,7 +1721,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
     for (int h = 0; h < H; ++h) sBr[h] = 0.f;
     auto flush = [&]() {                                           // the run's rows: one float atomic per element
       if (run_valid != 0ull && run_len > 0) {
-        const char* qk = reinterpret_cast<const char*>(a.QK + (int64_t)run_slot * a.qk_ld);
+        RUNS_LATE_ARGS(ka);
+        const char* qk = reinterpret_cast<const char*>(ka->QK + (int64_t)run_slot * ka->qk_ld);
         uint32_t lo = (uint32_t)lane * 4u;
         asm volatile("" : "+v"(lo));
         float qn[H][NR], g[RUN_CHUNK][H][NR];
@@ -1720,7 +1735,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
 #pragma unroll
         for (int i = 0; i < RUN_CHUNK; ++i) {
           const bool on = i < run_len;                             // wave-uniform
-          const char* dc = reinterpret_cast<const char*>(a.dctx + (int64_t)ch_get(0, (on ? run_first + i : run_first) - u0) * H * Cp);
+          const char* dc = reinterpret_cast<const char*>(ka->dctx + (int64_t)ch_get(0, (on ? run_first + i : run_first) - u0) * H * Cp);
           const int sl = lane - (on ? s_delta[i] : 0);             // the instance's slot on this lane (may lie outside [0, K): zero)
 #pragma unroll
           for (int h = 0; h < H; ++h) {
@@ -1734,7 +1749,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
         while (vmask) {
           const int j = __ffsll((long long)vmask) - 1;
           vmask &= vmask - 1ull;
-          const int64_t drow = (int64_t)rl_i(run_rows, j) * a.d_nbr_ld;
+          const int64_t drow = (int64_t)rl_i(run_rows, j) * ka->d_nbr_ld;
           char* dst = reinterpret_cast<char*>(d_nbr_x + drow);
           float row[NR];
 #pragma unroll
@@ -1754,7 +1769,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RUNS_WAVES(N
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
             if ((r < NR - 1 || lo < (uint32_t)(D - 64 * r) * 4u) && a.abl != 2) {
-              if (DET) det_add(a.d_nbr, drow + lane + 64 * r, row[r]); else atomicAdd(reinterpret_cast<float*>(dst + (uint32_t)(256 * r) + lo), row[r]);
+              if (DET) det_add(ka->d_nbr, drow + lane + 64 * r, row[r]); else atomicAdd(reinterpret_cast<float*>(dst + (uint32_t)(256 * r) + lo), row[r]);
             }
           }
           if (a.abl != 2) since_stage += NR;
