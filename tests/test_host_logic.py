@@ -278,3 +278,42 @@ def test_portfolios_packed_once_for_slices_of_one_long_lived_array():
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     a, b = pack_portfolios(list(arr[:5]), m), packed_portfolios_of(list(arr[:5]), m)    # a plain list of lists
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ------------------------------------------------------------------ round 6: the line's accounting helpers
+def test_bench_families_are_single_kernels_and_profiles_are_pinned_to_the_round(tmp_path, monkeypatch):
+    """bench.py: the two tile forms of the grouped weight gradients are families of their own (so trace_dominant's co-scheduled
+    rate is the kernel's own work over the kernel's own resident time), the new attention kernels belong to their families, and
+    the committed profile of a workload is the CURRENT round's file when it exists, the newest older one otherwise."""
+    import bench
+    eight = "void gemm_tn_group_bx_kernel<1, 8>(TnGroupDev)"
+    four = "void gemm_tn_group_bx_kernel<1, 4>(TnGroupDev)"
+    assert bench._family_has("gemm_tn_bx8", eight) and not bench._family_has("gemm_tn_bx8", four)
+    assert bench._family_has("gemm_tn_bx", four) and not bench._family_has("gemm_tn_bx", eight)
+    assert bench._family_has("attn_fwd", "void attn_fwd_ring_kernel<3, 2>(AttnDev)")
+    assert bench._family_has("attn_fwd", "void attn_fwd_kernel<3, 4>(AttnDev)")
+    assert bench._family_has("attn_bwd", "void attn_bwd_ring_kernel_direct<3, 2>(AttnDev)")
+    assert not bench._family_has("attn_bwd", "void attn_bwd_runs_kernel<3, 2, false>(AttnDev)")
+    assert bench.bx_products("gemm_tn_bx8") == 3
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    assert bench._summary_for("C2@512") is None
+    (prof / "r4_summary_C2@512.json").write_text("{}")
+    (prof / "r5_summary_C2@512.json").write_text("{}")
+    assert bench._summary_for("C2@512").endswith("r5_summary_C2@512.json")          # no file of this round: the newest older one
+    (prof / ("%s_summary_C2@512.json" % bench.PROFILE_ROUND)).write_text("{}")
+    assert bench._summary_for("C2@512").endswith("%s_summary_C2@512.json" % bench.PROFILE_ROUND)
+    assert bench._trace_for("C9@1") is None
+    from pfotgnrec_amd import _lib
+    assert len(_lib.PROF_KINDS) == 17 and _lib.PROF_KINDS[16] == "gemm_tn_bx8"
+
+
+def test_fused_adam_ranges_cover_check_for_the_gradient_clear():
+    """FusedAdam(zero_grads_in_step=True) may fold the gradient clear into its kernel only when its ranges tile the whole flat
+    buffer: the coverage test used by step() on hand-made range lists."""
+    covered = lambda lo, hi, total: bool(lo) and lo[0] == 0 and hi[-1] == total and all(hi[j] == lo[j + 1] for j in range(len(lo) - 1))
+    assert covered([0], [100], 100)
+    assert covered([0, 40, 60], [40, 60, 100], 100)             # split by step counts (the GRU tensors one step behind), still a tiling
+    assert not covered([0, 60], [40, 100], 100)                 # a tensor without a gradient in between
+    assert not covered([10], [100], 100) and not covered([0], [90], 100) and not covered([], [], 100)
