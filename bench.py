@@ -669,6 +669,9 @@ class Workload:
                    "%d/GPU" % self.per_gpu if self.scaling == "weak" else "%d global (fixed), %d shards" % (self.B, self.world)))
 
 
+DROP_IN_ENTRIES = ("torch.optim.Adam", "FusedAdam", "FusedAdam + bpr_loss_blocks", "ours branch, FusedAdam")
+
+
 def drop_in_surface(wl, budget_s=1.0):
     """Throughput through the LITERAL drop-in surface - what a maintainer gets after the four-import swap of INTEGRATION.md, with
     the reference's loop otherwise untouched (main.py:160-394, baseline branch): numpy batch slices, ``RandEdgeSampler(...)``
@@ -693,10 +696,24 @@ def drop_in_surface(wl, budget_s=1.0):
     n_vis = n_rows // B
     out = {"workload": wl.describe(), "loop": "main.py:160-394 (baseline branch) on pfotgnrec_amd's drop-in classes, numpy batches"}
     was_training = tgn.training
-    for name in ("torch.optim.Adam", "FusedAdam"):
+    mvs = None
+    for name in DROP_IN_ENTRIES:
+        # (third entry: the loop with ONE more line swapped - main.py:364-381's ten-kernel torch expression replaced by
+        #  ``loss = pfotgnrec_amd.bpr_loss_blocks(source_embedding, destination_embedding, negative_embedding)``, INTEGRATION.md;
+        #  fourth: the ``ours`` branch, main.py:190-337 - the inline mean-variance block as ``MVSampler.select`` on numpy batches,
+        #  ``compute_temporal_embeddings_p`` with one p_pos and three p_neg per interaction: 3 072 roots per batch instead of
+        #  2 560, the device-resident comparator is the C3 line of profiles/r*_bench_all_configs.jsonl)
+        native_bpr = name.endswith("bpr_loss_blocks")
+        ours = name.startswith("ours")
+        if ours and mvs is None:
+            prs = np.random.RandomState(7)
+            prices = 100.0 * np.exp(np.cumsum(prs.randn(cfg.n_days, cfg.n_items, 30) * 0.02, axis=2))
+            mvs = P.MVSampler(prices, g.upper_u, tgn.device, gamma=2.0, lambda_mv=0.5, p_pos_num=1, p_neg_num=3, day_of=g.day_of)
         tgn.join()
         torch.cuda.synchronize()
         opt = torch.optim.Adam(tgn.parameters(), lr=wl.args.lr) if name == "torch.optim.Adam" else P.FusedAdam(tgn, lr=wl.args.lr)
+        if ours:
+            out.setdefault("loop_ours", "main.py:160-394 ('ours' branch, main.py:190-337) - MVSampler.select in place of the inline block")
         t_sampler = t_embed = t_loss = t_bwd = t_opt = t_item = 0.0
         n, i, t_all0 = 0, 0, None
         while True:
@@ -713,21 +730,31 @@ def drop_in_surface(wl, budget_s=1.0):
             portfolios_batch = portfolios_all[s - wl.start:s - wl.start + B]
             train_rand_sampler = P.RandEdgeSampler(sources_batch, d.destinations, portfolios_batch, g.upper_u, g.map_item_id)
             negatives_batch = train_rand_sampler.sample(size=q)
+            if ours:
+                p_pos_batch, p_neg_batch = mvs.select(destinations_batch, negatives_batch, timestamps_batch,
+                                                      train_rand_sampler.port_idx, train_rand_sampler.port_len)
             t1 = time.perf_counter()
             tgn = tgn.train()
-            source_embedding, destination_embedding, negative_embedding = tgn.compute_temporal_embeddings(
-                sources_batch, destinations_batch, negatives_batch.flatten(), timestamps_batch, edge_idxs_batch, K)
+            if ours:
+                source_embedding, _, destination_embedding, negative_embedding = tgn.compute_temporal_embeddings_p(
+                    sources_batch, destinations_batch, p_pos_batch, p_neg_batch, timestamps_batch, edge_idxs_batch, K)
+            else:
+                source_embedding, destination_embedding, negative_embedding = tgn.compute_temporal_embeddings(
+                    sources_batch, destinations_batch, negatives_batch.flatten(), timestamps_batch, edge_idxs_batch, K)
             t2 = time.perf_counter()
             bsbs = source_embedding.shape[0]
             source_embedding = source_embedding.view(bsbs, 1, -1)
-            destination_embedding = destination_embedding.view(bsbs, 1, -1)
-            negative_embedding = negative_embedding.view(bsbs, q, -1)
-            pos_scores = torch.sum(source_embedding * destination_embedding, dim=2)
-            neg_scores = torch.matmul(source_embedding, negative_embedding.transpose(1, 2)).squeeze()
-            score_diff = pos_scores - neg_scores
-            score_diff_mean = torch.mean(score_diff, dim=1)
-            log_and_sigmoid = torch.log(torch.sigmoid(score_diff_mean))
-            loss = -torch.mean(log_and_sigmoid)
+            destination_embedding = destination_embedding.view(bsbs, 1, -1)          # (ours: the p_pos block, p_pos_num = 1)
+            negative_embedding = negative_embedding.view(bsbs, q, -1)                # (ours: the p_neg block, p_neg_num = 3)
+            if native_bpr:
+                loss = P.bpr_loss_blocks(source_embedding, destination_embedding, negative_embedding)
+            else:
+                pos_scores = torch.sum(source_embedding * destination_embedding, dim=2)
+                neg_scores = torch.matmul(source_embedding, negative_embedding.transpose(1, 2)).squeeze()
+                score_diff = pos_scores - neg_scores
+                score_diff_mean = torch.mean(score_diff, dim=1)
+                log_and_sigmoid = torch.log(torch.sigmoid(score_diff_mean))
+                loss = -torch.mean(log_and_sigmoid)
             t3 = time.perf_counter()
             loss.backward()
             t4 = time.perf_counter()
@@ -746,7 +773,8 @@ def drop_in_surface(wl, budget_s=1.0):
         ms = lambda x: round(1e3 * x / n, 4)
         out[name] = {"value": round(n * B / wall, 1), "unit": "interactions/s", "ms_per_step": ms(wall), "timed_steps": n,
                      "final_loss": round(float(loss_value), 5),
-                     "host_ms_per_step": {"RandEdgeSampler(...) + sample() [incl. its device sync]": ms(t_sampler),
+                     "host_ms_per_step": {("RandEdgeSampler(...) + sample() + MVSampler.select() [two device syncs]" if ours else
+                                           "RandEdgeSampler(...) + sample() [incl. its device sync]"): ms(t_sampler),
                                           "compute_temporal_embeddings [enqueue]": ms(t_embed), "BPR expression [enqueue]": ms(t_loss),
                                           "loss.backward() [enqueue]": ms(t_bwd), "optimizer.step() [enqueue]": ms(t_opt),
                                           "loss.item() + detach_memory() [wait for the device]": ms(t_item)}}
@@ -1229,7 +1257,7 @@ def main():
         try:
             out.setdefault("secondary", {})["drop_in_surface"] = drop_in_surface(wl)
             di = out["secondary"]["drop_in_surface"]
-            for k in ("torch.optim.Adam", "FusedAdam"):
+            for k in DROP_IN_ENTRIES[:3]:
                 di[k]["vs_device_resident_step"] = round(di[k]["ms_per_step"] / out["ms_per_step"], 3)
         except Exception as e:                                  # a secondary figure never costs the main line
             out.setdefault("secondary", {})["drop_in_surface"] = {"error": repr(e)[:300]}

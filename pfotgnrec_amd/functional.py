@@ -53,6 +53,66 @@ def bpr_loss(emb, batch, n_neg, pos_block=1, grad_scale=1.0):
     return _BprFn.apply(emb, batch, pos_off, neg_off, n_neg, grad_scale)
 
 
+def adjacent_rows(blocks):
+    """Row blocks that lie one behind the other in ONE buffer (the outputs of ``compute_temporal_embeddings``, the gradient
+    blocks ``bpr_loss_blocks`` hands back) as the single matrix they are a cut of - no copy; None when they are anything else."""
+    t0 = blocks[0]
+    if t0.dim() != 2:
+        return None
+    D, off, base = t0.shape[1], t0.storage_offset(), t0.untyped_storage().data_ptr()
+    rows = 0
+    for t in blocks:
+        if (t.dim() != 2 or t.shape[1] != D or t.dtype != t0.dtype or not t.is_contiguous()
+                or t.untyped_storage().data_ptr() != base or t.storage_offset() != off + rows * D):
+            return None
+        rows += t.shape[0]
+    return torch.as_strided(t0, (rows, D), (D, 1), off)
+
+
+class _BprBlocksFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, n_neg, *blocks):
+        emb = adjacent_rows(blocks)
+        if emb is None:
+            emb = torch.cat(blocks)
+        B = blocks[0].shape[0]
+        loss, d_emb = bpr_loss_and_grad(emb, B, (len(blocks) - 2) * B, (len(blocks) - 1) * B, n_neg, 1.0)
+        ctx.save_for_backward(d_emb)
+        ctx.heights = [t.shape[0] for t in blocks]
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_emb,) = ctx.saved_tensors
+        d = d_emb * g
+        out, r = [], 0
+        for h in ctx.heights:
+            out.append(d[r:r + h])
+            r += h
+        return (None,) + tuple(out)
+
+
+def bpr_loss_blocks(source_embedding, destination_embedding, negative_embedding, p_pos_embedding=None):
+    """The BPR expression of main.py:364-381 (baseline: positive = destination) / 321-337 (``ours``: positive = the p_pos block,
+    pass it as ``p_pos_embedding``) on the blocks the reference's loop holds after ``compute_temporal_embeddings[_p]`` - one
+    native launch for loss and gradient rows instead of ten torch kernels forward and ~20 backward:
+
+        loss = pfotgnrec_amd.bpr_loss_blocks(source_embedding, destination_embedding, negative_embedding)
+
+    The blocks are used in place when they are the adjacent outputs of one call (no copy either way: the gradient blocks
+    go back as adjacent rows of one matrix and the TGN backward takes that matrix as it stands)."""
+    B = source_embedding.shape[0]
+    if B == 0:
+        return source_embedding.sum() * 0.0
+    D = source_embedding.shape[-1]
+    blocks = [source_embedding.reshape(B, D), destination_embedding.reshape(B, D)]
+    if p_pos_embedding is not None:
+        blocks.append(p_pos_embedding.reshape(B, D))
+    neg = negative_embedding.reshape(-1, D)
+    blocks.append(neg)
+    return _BprBlocksFn.apply(neg.shape[0] // B, *blocks)
+
+
 def bpr_step(tgn, emb, batch, n_neg, pos_block=1, grad_scale=None, optimizer=None, collective=None):
     """``loss = bpr_loss(...); loss.backward()`` (main.py:321-337 + 388) as two native calls and no torch kernel: the loss
     kernel writes the already scaled gradient rows and the TGN backward is called on them directly, skipping autograd's

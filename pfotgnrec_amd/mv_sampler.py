@@ -78,13 +78,20 @@ class MVSampler:
     def select(self, destinations_batch, negatives_batch, timestamps_batch, port_idx, port_len, want_scores=False):
         """Host-array entry mirroring main.py:207-304: returns flat i64 ``p_pos_batch`` / ``p_neg_batch`` node ids."""
         import torch
+        from .rand_edge_sampler import _device_rows
         dst = np.asarray(destinations_batch, np.int64).reshape(-1, 1)
-        cand = np.concatenate([dst, np.asarray(negatives_batch, np.int64)], 1).astype(np.int32)   # main.py:207
-        day = np.asarray(self.day_of(timestamps_batch), np.int64).astype(np.int32)
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
-        out = self.select_device(t(day), t(cand), t(np.asarray(port_idx, np.int32)), t(np.asarray(port_len, np.int32)),
-                                 want_scores)
-        res = [o.cpu().numpy() for o in out]
-        res[0] = res[0].astype(np.int64).reshape(-1)
-        res[1] = res[1].astype(np.int64).reshape(-1)
+        cand = np.concatenate([dst, np.asarray(negatives_batch, np.int64)], 1)                    # main.py:207
+        B, n_c = cand.shape
+        day = np.asarray(self.day_of(timestamps_batch), np.int64)
+        # one upload for (day, candidates), none for the portfolio rows when they are a batch of the packed dataset
+        # (rand_edge_sampler.packed_portfolios_of / RandEdgeSampler.port_idx), one read-back for (p_pos, p_neg)
+        both = torch.from_numpy(np.concatenate([day.reshape(-1), cand.reshape(-1)]).astype(np.int32)).to(self.device)
+        pi, pl = _device_rows(np.asarray(port_idx) if not isinstance(port_idx, np.ndarray) else port_idx,
+                              np.asarray(port_len) if not isinstance(port_len, np.ndarray) else port_len, self.device)
+        if pi.dtype != torch.int32 or pl.dtype != torch.int32:
+            pi, pl = pi.to(torch.int32), pl.to(torch.int32)
+        out = self.select_device(both[:B], both[B:].view(B, n_c), pi, pl, want_scores)
+        sel = torch.cat([out[0], out[1]], 1).cpu().numpy().astype(np.int64)
+        res = [np.ascontiguousarray(sel[:, :self.p_pos_num]).reshape(-1), np.ascontiguousarray(sel[:, self.p_pos_num:]).reshape(-1)]
+        res += [o.cpu().numpy() for o in out[2:]]
         return tuple(res)

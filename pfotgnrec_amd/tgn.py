@@ -55,6 +55,9 @@ class _Call:
             pass
 
 
+_TORCH_OF = {"float64": torch.float64, "float32": torch.float32, "int32": torch.int32, "int64": torch.int64, "uint8": torch.uint8}
+
+
 class _EmbedFn(torch.autograd.Function):
     """Autograd bridge: forward = native forward (+ state update), backward = native backward.
 
@@ -63,21 +66,35 @@ class _EmbedFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, tgn, call, post, *params):
+    def forward(ctx, tgn, call, post, split, *params):
+        # ``split`` = row ranges ((r0, r1), ...) of the embedding matrix handed out as SEPARATE outputs (the reference's entry
+        # points return (source, destination, negative ...) embeddings, tgn.py:215-217 / 325-327): as outputs of this node their
+        # gradients arrive side by side and one concatenation rebuilds d emb - as three slices of one output autograd filled
+        # three zero matrices of the full size, copied a block into each and added them up (8 launches, ~30 us of device time
+        # and ~60 us of host time per batch on the drop-in loop)
         emb = tgn._native_forward(call)
         if post is not None:
             post(call)
-        ctx.tgn, ctx.call, ctx.n_params = tgn, call, len(params)
-        return emb
+        ctx.tgn, ctx.call, ctx.n_params, ctx.split = tgn, call, len(params), split
+        if split is None:
+            return emb
+        return tuple(emb[r0:r1] for r0, r1 in split)
 
     @staticmethod
-    def backward(ctx, d_emb):
+    def backward(ctx, *d_out):
         if ctx.call.ws is None:
             raise RuntimeError("backward through a TGN forward whose workspace was already consumed "
                                "(a second backward over the same call is not supported)")
-        ctx.tgn._native_backward(ctx.call, d_emb.contiguous())
+        if ctx.split is None:
+            d_emb = d_out[0].contiguous()
+        else:
+            from .functional import adjacent_rows
+            d_emb = adjacent_rows(d_out)              # (bpr_loss_blocks hands back the cut of one matrix: used as it stands)
+            if d_emb is None:
+                d_emb = torch.cat(d_out)
+        ctx.tgn._native_backward(ctx.call, d_emb)
         ctx.call.release()
-        return (None, None, None) + (None,) * ctx.n_params
+        return (None, None, None, None) + (None,) * ctx.n_params
 
 
 class TGN(nn.Module):
@@ -496,7 +513,12 @@ class TGN(nn.Module):
         backward (which does it on its side stream, off the critical path)."""
         if self._flat_grad is None:
             self._flat_grad = torch.zeros_like(self._flat)
-        missing = [v for v in self._views if v[0].grad is None]
+        gv = self.__dict__.get("_grad_views")
+        if gv is None or gv[0] is not self._flat_grad:
+            # the views are made once per buffer: main.py's optimizer.zero_grad() drops every .grad in front of every batch, and
+            # slicing + reshaping ~50 views again was 70 us of host time per batch in front of the native backward
+            gv = self.__dict__["_grad_views"] = (self._flat_grad, [self._flat_grad[off:off + n].view(shape) for _, off, n, shape in self._views])
+        missing = [i for i, v in enumerate(self._views) if v[0].grad is None]
         deferred = False
         if len(missing) == len(self._views):
             if defer_zero:
@@ -504,12 +526,13 @@ class TGN(nn.Module):
             else:
                 self._flat_grad.zero_()
         else:
-            for _, off, n, _ in missing:
-                self._flat_grad[off:off + n].zero_()
-        for p, off, n, shape in missing:
+            for i in missing:
+                gv[1][i].zero_()
+        for i in missing:
+            p = self._views[i][0]
             if not gru_applied and p in self._gru_params:
                 continue
-            p.grad = self._flat_grad[off:off + n].view(shape)
+            p.grad = gv[1][i]
         return deferred
 
     def side_stream(self):
@@ -724,7 +747,7 @@ class TGN(nn.Module):
         return None
 
     def embed_device(self, src, dst, extra_roots, extra_repeat, edge_times, edge_idxs, n_neighbors, draws=None, offset_dev=None,
-                     dropout_keep=None):
+                     dropout_keep=None, split_blocks=None):
         """Device-resident core of both reference entry points.
 
         src/dst i32[B], edge_times f64[B], edge_idxs i32[B], extra_roots: list of i32 tensors [B*r_k] (negatives /
@@ -736,6 +759,8 @@ class TGN(nn.Module):
         (tgn.py:290-317).  ``offset_dev`` (a 1-element int64 device tensor): position of the random streams for steps
         captured into a HIP graph (pfotgnrec_amd/graph.py).  ``self.dp_grad_scale`` then holds b / B, the factor that turns this shard's mean-loss
         gradient into its share of the global-batch mean gradient.
+        ``split_blocks`` (block heights in units of b, e.g. (1, 1, n_neg)): the first return value is a tuple of those row
+        blocks instead of the matrix - under autograd as separate outputs of one node (see _EmbedFn.forward).
         """
         _lib.require_gpu(self.device)
         B = int(src.shape[0])
@@ -789,7 +814,13 @@ class TGN(nn.Module):
                     self._zero_next = False
                 self._bucket_event_fresh = False                  # no backward ran to record the event (the collectives stay the same)
             # a leaf that requires grad: the caller's loss.backward() is a no-op instead of an error
-            return torch.zeros((0, D), dtype=torch.float32, device=self.device, requires_grad=grad_mode), 0
+            z = torch.zeros((0, D), dtype=torch.float32, device=self.device, requires_grad=grad_mode)
+            return (z if split_blocks is None else tuple(z[0:0] for _ in split_blocks)), 0
+        split = None
+        if split_blocks is not None:
+            edges = np.concatenate([[0], np.cumsum(split_blocks)]) * b
+            split = tuple((int(r0), int(r1)) for r0, r1 in zip(edges[:-1], edges[1:]))
+            assert split[-1][1] == R, "split_blocks must cover the roots: (1, 1, repeat counts of the extra groups)"
         if grad_mode:
             if pre is not None:
                 call = pre
@@ -809,7 +840,10 @@ class TGN(nn.Module):
                 call.keep = (getattr(call, "keep", None), src, dst, edge_times, edge_idxs)
                 self.memory._any_msg = True
                 post = None
-            emb = _EmbedFn.apply(self, call, post, *self.hot_parameters())
+            # (ONE parameter that requires a gradient ties the node into the graph: the native backward accumulates every
+            #  parameter gradient itself, and autograd's per-input bookkeeping of ~50 tensors was ~15 us of host time per batch)
+            anchor = next((v[0] for v in self._views if v[0].requires_grad), None)
+            emb = _EmbedFn.apply(self, call, post, split, *(() if anchor is None else (anchor,)))
             return emb, b
         # forward only (evaluation.py:94: R = B*(2+N_ITEMS) roots): walk the roots in chunks through the same
         # kernels; memory is persisted once, after the last chunk, from a pass that covers the positives.
@@ -844,6 +878,8 @@ class TGN(nn.Module):
         call.release()
         if inverse is not None:
             emb = emb.index_select(0, inverse)
+        if split is not None:
+            emb = tuple(emb[r0:r1] for r0, r1 in split)
         return emb, b
 
     def _dedup_roots(self, src, dst, ts, groups, lo, hi, B, roots, root_ts):
@@ -889,18 +925,38 @@ class TGN(nn.Module):
 
     def _batch_to_dev(self, parts):
         """Several small host arrays of one batch in ONE host-to-device copy: ``parts`` = [(array, numpy dtype)], widest dtype
-        first; returns the device tensors in the same order (five separate copies cost the drop-in loop ~60 us of host time)."""
-        arrs = [np.ascontiguousarray(np.asarray(a), dtype=dt) for a, dt in parts]
-        sizes = [a.nbytes for a in arrs]
-        offs = np.concatenate([[0], np.cumsum([(n + 7) // 8 * 8 for n in sizes])]).astype(np.int64)
-        buf = np.empty(int(offs[-1]), np.uint8)
-        for a, o, n in zip(arrs, offs[:-1], sizes):
-            buf[o:o + n] = a.view(np.uint8).reshape(-1)
-        dev = torch.from_numpy(buf).to(self.device)
+        first; returns the device tensors in the same order (five separate copies cost the drop-in loop ~60 us of host time).
+        The arrays are converted straight into one of two page-locked staging buffers (an event per buffer says when its last
+        copy has left it) and the copy is asynchronous on the caller's stream: the host goes on to build the call while it
+        runs (a pageable copy holds the host for ~25 us with the device idle behind it)."""
+        _lib.require_gpu(self.device)
+        arrs = [np.asarray(a) for a, _ in parts]
+        dts = [np.dtype(dt) for _, dt in parts]
+        sizes = [a.size * dt.itemsize for a, dt in zip(arrs, dts)]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 7) & ~7
+        ring = self.__dict__.setdefault("_stage_ring", [])
+        slot = self.__dict__["_stage_next"] = (self.__dict__.get("_stage_next", -1) + 1) % 2
+        if len(ring) <= slot or ring[slot][0].numel() < total:
+            host = torch.empty(max(total, 1 << 16), dtype=torch.uint8, pin_memory=True)
+            entry = (host, host.numpy(), torch.cuda.Event())
+            if len(ring) <= slot:
+                ring.append(entry)
+            else:
+                ring[slot][2].synchronize()
+                ring[slot] = entry
+        else:
+            ring[slot][2].synchronize()                       # (its last copy: two batches ago - normally long done)
+        host, view, ev = ring[slot]
+        for a, dt, o, n in zip(arrs, dts, offs, sizes):
+            view[o:o + n].view(dt)[...] = a.reshape(-1)       # converts while it copies
+        dev = host[:total].to(self.device, non_blocking=True)
+        ev.record()
         out = []
-        for a, o, n, (_, dt) in zip(arrs, offs[:-1], sizes, parts):
-            t = dev[int(o):int(o) + n].view(torch.from_numpy(np.empty(0, dt)).dtype)
-            out.append(t.view(a.shape))
+        for a, dt, o, n in zip(arrs, dts, offs, sizes):
+            out.append(dev[o:o + n].view(_TORCH_OF[dt.name]).view(a.shape))
         return out
 
     def _check_nodes(self, a, what):
@@ -942,9 +998,9 @@ class TGN(nn.Module):
                                                       (self._check_nodes(destination_nodes, "destination_nodes"), np.int32),
                                                       (self._check_nodes(p_neg_nodes, "p_neg_nodes"), np.int32),
                                                       (self._check_edges(edge_idxs), np.int32)])
-        emb, b = self.embed_device(src, dst, [neg], [size], ts, eidx, n_neighbors, self._dev_draws(draws),
-                                   dropout_keep=self._dev_keep(dropout_keep))
-        return emb[:b], emb[b:2 * b], emb[2 * b:]
+        out, _ = self.embed_device(src, dst, [neg], [size], ts, eidx, n_neighbors, self._dev_draws(draws),
+                                   dropout_keep=self._dev_keep(dropout_keep), split_blocks=(1, 1, size))
+        return out
 
     def compute_temporal_embeddings_p(self, source_nodes, destination_nodes, p_pos_nodes, p_neg_nodes, edge_times,
                                       edge_idxs, n_neighbors=20, draws=None):
@@ -956,8 +1012,9 @@ class TGN(nn.Module):
                                                          (self._check_nodes(p_pos_nodes, "p_pos_nodes"), np.int32),
                                                          (self._check_nodes(p_neg_nodes, "p_neg_nodes"), np.int32),
                                                          (self._check_edges(edge_idxs), np.int32)])
-        emb, b = self.embed_device(src, dst, [pp, pn], [n_pos, n_neg], ts, eidx, n_neighbors, self._dev_draws(draws))
-        return emb[:b], emb[b:2 * b], emb[2 * b:(2 + n_pos) * b], emb[(2 + n_pos) * b:]
+        out, _ = self.embed_device(src, dst, [pp, pn], [n_pos, n_neg], ts, eidx, n_neighbors, self._dev_draws(draws),
+                                   split_blocks=(1, 1, n_pos, n_neg))
+        return out
 
     def _dev_keep(self, masks):
         """Injected dropout decisions for a parity test: ``{l: multipliers or booleans [n_l, H, K]}`` (level order, the layout

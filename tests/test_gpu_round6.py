@@ -148,3 +148,59 @@ def test_shader_clock_stamps_read_a_plausible_clock():
         assert 0.5 < v < 3.0, (k, v)
     torch.cuda.synchronize()
     assert all(v == 0.0 for v in _lib.shader_clock().values())
+
+
+def test_entry_point_blocks_are_outputs_of_one_node_and_the_native_bpr_expression_matches_torch():
+    """compute_temporal_embeddings hands out (source, destination, negative) as three OUTPUTS of the native node: the gradient the
+    TGN backward receives is one concatenation of the three incoming blocks, bit-identical to what autograd assembled from
+    three slices of one output (zero matrices + adds); pfotgnrec_amd.bpr_loss_blocks (one native launch) against the reference's
+    torch expression (main.py:364-381) on the same blocks: loss within 1e-6, parameter gradients within 1e-5 - and its gradient
+    blocks reach the backward as ONE matrix without a copy."""
+    from pfotgnrec_amd.functional import adjacent_rows
+    from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+    cfg = SyntheticConfig("b6", 300, 25, 6000, 64, 2, 8, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    B, K, q = 40, 8, 3
+    s = 2500
+    rs = np.random.RandomState(4)
+    neg = rs.randint(301, 326, size=B * q)
+
+    def torch_expression(se, de, ne):
+        se, de, ne = se.view(B, 1, -1), de.view(B, 1, -1), ne.view(B, q, -1)
+        pos = torch.sum(se * de, dim=2)
+        ngs = torch.matmul(se, ne.transpose(1, 2)).squeeze()
+        return -torch.mean(torch.log(torch.sigmoid(torch.mean(pos - ngs, dim=1))))
+
+    def run(kind):
+        torch.manual_seed(5)
+        tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=2, dropout=0.0,
+                    use_memory=True, memory_dimension=64, message_function="identity", n_neighbors=K)
+        tgn.deterministic = True
+        tgn.train()
+        out = None
+        for step in range(2):                                       # (second step: pending messages, the GRU has a gradient)
+            a = s + step * B
+            args = (d.sources[a:a + B], d.destinations[a:a + B], neg, d.timestamps[a:a + B], d.edge_idxs[a:a + B], K)
+            if kind == "slices":
+                t = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x, dtype=dt)).to(DEV)
+                emb, b = tgn.embed_device(t(args[0], np.int32), t(args[1], np.int32), [t(neg, np.int32)], [q], t(args[3], np.float64),
+                                          t(args[4], np.int32), K)
+                blocks = (emb[:b], emb[b:2 * b], emb[2 * b:])
+            else:
+                blocks = tgn.compute_temporal_embeddings(*args)
+                assert adjacent_rows(blocks) is not None and blocks[0].grad_fn is blocks[2].grad_fn
+            loss = P.bpr_loss_blocks(*blocks) if kind == "native" else torch_expression(*blocks)
+            loss.backward()
+            out = (float(loss), tgn.flat_grad.detach().cpu().numpy().copy(), torch.cat(blocks).detach().cpu().numpy())
+            for p in tgn.parameters():
+                p.grad = None
+        return out
+
+    l_blocks, g_blocks, e_blocks = run("blocks")
+    l_slices, g_slices, e_slices = run("slices")
+    l_native, g_native, e_native = run("native")
+    assert np.array_equal(e_blocks, e_slices) and np.array_equal(e_blocks, e_native)
+    assert l_blocks == l_slices and np.array_equal(g_blocks, g_slices)
+    assert abs(l_native - l_blocks) < 1e-6 * max(1.0, abs(l_blocks))
+    assert relerr(g_native, g_blocks) < 1e-5 and np.abs(g_blocks).max() > 0
