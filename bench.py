@@ -669,16 +669,18 @@ class Workload:
                    "%d/GPU" % self.per_gpu if self.scaling == "weak" else "%d global (fixed), %d shards" % (self.B, self.world)))
 
 
-DROP_IN_ENTRIES = ("torch.optim.Adam", "FusedAdam", "FusedAdam + bpr_loss_blocks", "ours branch, FusedAdam")
+DROP_IN_ENTRIES = ("torch.optim.Adam", "FusedAdam", "FusedAdam + bpr_loss_blocks", "FusedAdam(overlap_backward=True)",
+                   "FusedAdam(overlap_backward=True) + bpr_loss_blocks", "ours branch, FusedAdam(overlap_backward=True)")
 
 
-def drop_in_surface(wl, budget_s=1.0):
+def drop_in_surface(wl, budget_s=0.7):
     """Throughput through the LITERAL drop-in surface - what a maintainer gets after the four-import swap of INTEGRATION.md, with
     the reference's loop otherwise untouched (main.py:160-394, baseline branch): numpy batch slices, ``RandEdgeSampler(...)``
     constructed per batch (main.py:347-348), ``compute_temporal_embeddings`` on numpy arrays, the BPR loss as the reference's
     torch expression (main.py:364-381), ``loss.backward()``, ``optimizer.step()``, ``loss.item()`` (main.py:388-390: a device
     sync per batch), ``detach_memory()`` (main.py:394) - once with torch.optim.Adam (main.py:123), once with the package's
-    FusedAdam.  Wall time per step with the host part itemised (the host cannot run ahead: the loop synchronises twice per batch)."""
+    FusedAdam; then with the optional swaps of INTEGRATION.md (DROP_IN_ENTRIES).  Wall time per step with the host part itemised
+    (the host cannot run ahead: the loop synchronises twice per batch)."""
     import torch
     P, cfg, g, tgn = wl.P, wl.cfg, wl.graph, wl.tgn
     d = g.data
@@ -703,15 +705,19 @@ def drop_in_surface(wl, budget_s=1.0):
         #  fourth: the ``ours`` branch, main.py:190-337 - the inline mean-variance block as ``MVSampler.select`` on numpy batches,
         #  ``compute_temporal_embeddings_p`` with one p_pos and three p_neg per interaction: 3 072 roots per batch instead of
         #  2 560, the device-resident comparator is the C3 line of profiles/r*_bench_all_configs.jsonl)
+        #  ``overlap_backward``: the native backward and the optimizer's kernel on a stream of their own - the loop's
+        #  ``loss.item()`` waits for the forward only and the host prepares the next batch beside the backward)
         native_bpr = name.endswith("bpr_loss_blocks")
         ours = name.startswith("ours")
+        overlap = "overlap_backward=True" in name
         if ours and mvs is None:
             prs = np.random.RandomState(7)
             prices = 100.0 * np.exp(np.cumsum(prs.randn(cfg.n_days, cfg.n_items, 30) * 0.02, axis=2))
             mvs = P.MVSampler(prices, g.upper_u, tgn.device, gamma=2.0, lambda_mv=0.5, p_pos_num=1, p_neg_num=3, day_of=g.day_of)
         tgn.join()
         torch.cuda.synchronize()
-        opt = torch.optim.Adam(tgn.parameters(), lr=wl.args.lr) if name == "torch.optim.Adam" else P.FusedAdam(tgn, lr=wl.args.lr)
+        tgn.overlap_backward = False
+        opt = torch.optim.Adam(tgn.parameters(), lr=wl.args.lr) if name == "torch.optim.Adam" else P.FusedAdam(tgn, lr=wl.args.lr, overlap_backward=overlap)
         if ours:
             out.setdefault("loop_ours", "main.py:160-394 ('ours' branch, main.py:190-337) - MVSampler.select in place of the inline block")
         t_sampler = t_embed = t_loss = t_bwd = t_opt = t_item = 0.0
@@ -780,6 +786,8 @@ def drop_in_surface(wl, budget_s=1.0):
                                           "loss.item() + detach_memory() [wait for the device]": ms(t_item)}}
         if isinstance(opt, P.FusedAdam):
             opt.zero_grad(set_to_none=True)
+        tgn.join()
+        tgn.overlap_backward = False
     tgn.train(was_training)
     tgn.join()
     torch.cuda.synchronize()
@@ -1257,7 +1265,7 @@ def main():
         try:
             out.setdefault("secondary", {})["drop_in_surface"] = drop_in_surface(wl)
             di = out["secondary"]["drop_in_surface"]
-            for k in DROP_IN_ENTRIES[:3]:
+            for k in DROP_IN_ENTRIES[:5]:
                 di[k]["vs_device_resident_step"] = round(di[k]["ms_per_step"] / out["ms_per_step"], 3)
         except Exception as e:                                  # a secondary figure never costs the main line
             out.setdefault("secondary", {})["drop_in_surface"] = {"error": repr(e)[:300]}

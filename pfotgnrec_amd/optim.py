@@ -14,17 +14,30 @@ from . import _lib
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, tgn, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, zero_grads_in_step=False):
-        """``zero_grads_in_step``: a side-stream step (``step(side=True)``, i.e. ``bpr_step(..., optimizer=)``) also CLEARS the
+    def __init__(self, tgn, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, zero_grads_in_step=False, overlap_backward=False):
+        """``overlap_backward``: for the reference's own loop (main.py:160-394), which reads ``loss.item()`` after every batch.
+        ``loss.backward()`` leaves the native backward on a stream of its own and ``step()`` queues the optimizer's kernel behind
+        it there, so that ``loss.item()`` waits for the forward only and the host prepares the next batch (candidate draw,
+        uploads, launches) while the device is still differentiating; the next forward - and ``state_dict()``, ``tgn.join()`` -
+        wait for the step.  Gradients and parameters are IN FLIGHT after ``backward()`` / ``step()`` until then: read ``.grad`` or
+        a parameter only behind ``tgn.join()``.  One rank, eager mode; anything else takes the serial order.
+        ``zero_grads_in_step``: a side-stream step (``step(side=True)``, i.e. ``bpr_step(..., optimizer=)``) also CLEARS the
         gradients it consumed - ``optimizer.zero_grad()`` folded into the optimizer's kernel, for loops that zero the gradients
         right after the step anyway (main.py:388-390 does): the next native backward then clears nothing on its critical path.
         ``.grad`` reads zero after such a step."""
         self.tgn = tgn
         self.zero_grads_in_step = bool(zero_grads_in_step)
+        if overlap_backward:
+            tgn.overlap_backward = True
         super().__init__(list(tgn.parameters()), dict(lr=lr, betas=betas, eps=eps))
         self._m = None
         self._v = None
         self._steps = {}            # parameter -> steps taken (torch.optim.Adam's state[p]["step"])
+
+    def zero_grad(self, set_to_none=True):
+        if not set_to_none:
+            self.tgn.join()                  # (the clear is a torch kernel on the caller's stream)
+        return super().zero_grad(set_to_none=set_to_none)
 
     # tests / checkpoint restore: one step count for every tensor
     @property
@@ -55,6 +68,16 @@ class FusedAdam(torch.optim.Optimizer):
         ``side``: the kernel goes to the library's side stream, behind a backward that ran with ``defer_join``
         (``functional.bpr_step(..., optimizer=self)``); otherwise anything pending there is joined first."""
         tgn = self.tgn
+        if (not side and step_dev is None and getattr(tgn, "_bwd_event", None) is not None and tgn._overlap_ok()
+                and torch.cuda.current_stream(tgn.flat_parameters.device) != tgn._backward_stream()):
+            # behind the backward on ITS stream (overlap_backward); the event the next forward waits for moves behind the step
+            bwd = tgn._backward_stream()
+            with torch.cuda.stream(bwd):
+                out = self.step(closure)
+                ev = torch.cuda.Event()
+                ev.record(bwd)
+            tgn._bwd_event = ev
+            return out
         if side and (self._m is None or self._m.device != tgn.flat_parameters.device):
             side = False            # the moments are allocated (and cleared) on the caller's stream below: this one step runs there
         if not side:

@@ -92,7 +92,10 @@ class _EmbedFn(torch.autograd.Function):
             d_emb = adjacent_rows(d_out)              # (bpr_loss_blocks hands back the cut of one matrix: used as it stands)
             if d_emb is None:
                 d_emb = torch.cat(d_out)
-        ctx.tgn._native_backward(ctx.call, d_emb)
+        if ctx.tgn._overlap_ok():
+            ctx.tgn._backward_beside(ctx.call, d_emb)
+        else:
+            ctx.tgn._native_backward(ctx.call, d_emb)
         ctx.call.release()
         return (None, None, None, None) + (None,) * ctx.n_params
 
@@ -180,6 +183,10 @@ class TGN(nn.Module):
         self.mid_event_late = False       # record it behind the attention backward instead of in front of it
         self._zero_next = False
         self._grad_zeroed = False         # the optimizer's kernel cleared the flat gradient buffer (FusedAdam(zero_grads_in_step=True))
+        # FusedAdam(tgn, overlap_backward=True): loss.backward() leaves the native backward - and optimizer.step() its kernel - on
+        # a stream of their own, so that the loop's per-batch ``loss.item()`` (main.py:390) waits for the forward only
+        self.overlap_backward = False
+        self._bwd_stream, self._bwd_event, self._bwd_hold = None, None, []
         self.eval_chunk_roots = 16384     # roots per forward-only pass (evaluation.py scores B*(2+N_ITEMS) roots per batch)
         self.eval_dedup = True            # forward-only passes embed every distinct (node, time) root once
         # memory_updater.py:25,41 assert that no pending message is older than its node's last update; the check reads
@@ -478,6 +485,7 @@ class TGN(nn.Module):
 
     def _native_forward(self, call, out=None):
         _lib.require_gpu(self.device)
+        self._join_backward()
         # torch wrote the parameters on the caller's stream since the last native forward (p.copy_(), a torch optimizer ...):
         # that write is ordered against nothing the library left on its side stream, and the forward would not fork from
         # the caller's stream while a deferred step is pending there - join first (a no-op when nothing is pending)
@@ -553,9 +561,45 @@ class TGN(nn.Module):
 
     def join(self):
         """Makes the current stream wait for a backward end / optimizer step that ``bpr_step(..., optimizer=...)`` left on the
-        library's side stream (no-op when nothing is pending)."""
+        library's side stream, and for a whole backward + step that ``overlap_backward`` left on theirs (no-op when nothing is
+        pending)."""
         if self._flat.is_cuda:
+            self._join_backward()
             _lib.call("pfo_tgn_join", _lib.stream_ptr())
+
+    # ------------------------------------------------------------------ backward beside the host loop (overlap_backward)
+    def _overlap_ok(self):
+        return (self.overlap_backward and self.dp_world == 1 and self._flat.is_cuda and not self.record_mid_event
+                and not self.dp_bucketed and not torch.cuda.is_current_stream_capturing())
+
+    def _backward_stream(self):
+        if self._bwd_stream is None:
+            self._bwd_stream = torch.cuda.Stream(device=self.device)
+        return self._bwd_stream
+
+    def _join_backward(self):
+        """The current stream waits for what ``overlap_backward`` left in flight; the tensors that work reads (gradient rows,
+        the call's roots) are let go only now - the allocator may hand their memory to this stream, which has waited."""
+        ev = self._bwd_event
+        if ev is None:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if self._bwd_stream is not None and cur == self._bwd_stream:
+            return                                                # (the optimizer's kernel, queued behind the backward there)
+        cur.wait_event(ev)
+        self._bwd_event = None
+        self._bwd_hold = []
+
+    def _backward_beside(self, call, d_emb):
+        """``_native_backward`` on the backward stream, behind everything the current stream holds (the gradient rows)."""
+        cur, side = torch.cuda.current_stream(self.device), self._backward_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._native_backward(call, d_emb)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._bwd_hold.append((d_emb, call.roots, call.root_ts, call.extra, getattr(call, "keep", None), call.draws))
+        self._bwd_event = ev
 
     def state_dict(self, *args, **kwargs):
         self.join()
@@ -571,6 +615,7 @@ class TGN(nn.Module):
 
     def _native_backward(self, call, d_emb, mean=None, defer_join=False):
         """``mean`` = (src f32[n], out f32[1]): a mean the backward takes on its side stream (the BPR loss value)."""
+        self._join_backward()             # (a no-op on the backward stream itself and when nothing is in flight)
         zero_first = self._attach_grads(call.gru_applied, defer_zero=True) or self._zero_next
         self._zero_next = False
         if self._grad_zeroed:             # (the buffer IS clear: the optimizer's side-stream kernel wrote the zeros behind its reads)
@@ -618,6 +663,7 @@ class TGN(nn.Module):
         return self._grad_split
 
     def _native_update_state(self, call, src, dst, ts, eidx):
+        self._join_backward()
         self.memory._any_msg = True
         st = self._state_struct()
         _lib.call("pfo_tgn_update_state", ctypes.byref(call.cfg), ctypes.byref(st), src.data_ptr(), dst.data_ptr(),

@@ -204,3 +204,66 @@ def test_entry_point_blocks_are_outputs_of_one_node_and_the_native_bpr_expressio
     assert l_blocks == l_slices and np.array_equal(g_blocks, g_slices)
     assert abs(l_native - l_blocks) < 1e-6 * max(1.0, abs(l_blocks))
     assert relerr(g_native, g_blocks) < 1e-5 and np.abs(g_blocks).max() > 0
+
+
+def test_backward_beside_the_host_loop_equals_the_serial_order():
+    """FusedAdam(tgn, overlap_backward=True) on the reference's loop (main.py:160-394 in shape: numpy batches, torch BPR
+    expression, loss.backward(), optimizer.step(), loss.item(), optimizer.zero_grad()): the native backward and the optimizer's
+    kernel run on a stream of their own and the next forward waits for them.  Five steps bit-identical (losses, parameters,
+    memory) to the serial order with the deterministic backward; ``tgn.join()`` makes gradients readable; a validation forward
+    and ``state_dict()`` in between see the stepped parameters."""
+    from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+    cfg = SyntheticConfig("o6", 300, 25, 6000, 64, 2, 8, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    B, K, q = 48, 8, 3
+
+    def run(overlap):
+        torch.manual_seed(21)
+        tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=2, dropout=0.0,
+                    use_memory=True, memory_dimension=64, message_function="identity", n_neighbors=K)
+        tgn.deterministic = True
+        opt = P.FusedAdam(tgn, lr=1e-3, overlap_backward=overlap)
+        rs = np.random.RandomState(3)
+        losses, extra = [], []
+        for step in range(5):
+            s = 2500 + step * B
+            opt.zero_grad()
+            neg = rs.randint(301, 326, size=B * q)
+            tgn = tgn.train()
+            se, de, ne = tgn.compute_temporal_embeddings(d.sources[s:s + B], d.destinations[s:s + B], neg, d.timestamps[s:s + B],
+                                                          d.edge_idxs[s:s + B], K)
+            se, de, ne = se.view(B, 1, -1), de.view(B, 1, -1), ne.view(B, q, -1)
+            pos = torch.sum(se * de, dim=2)
+            ngs = torch.matmul(se, ne.transpose(1, 2)).squeeze()
+            loss = -torch.mean(torch.log(torch.sigmoid(torch.mean(pos - ngs, dim=1))))
+            loss.backward()
+            if overlap and step == 1:
+                assert tgn._bwd_event is not None                    # in flight: nothing on this stream waits for it yet
+            opt.step()
+            losses.append(loss.item())
+            tgn.memory.detach_memory()
+            if step == 2:                                            # a checkpoint and a validation forward between two steps
+                sd = tgn.state_dict()
+                extra.append(sd[sorted(k for k in sd if k.endswith("weight"))[0]].detach().cpu().numpy().copy())
+                with torch.no_grad():
+                    tgn.eval()
+                    bak = tgn.memory.backup_memory()
+                    ev = torch.cat(tgn.compute_temporal_embeddings(d.sources[100:120], d.destinations[100:120], neg[:60],
+                                                                   d.timestamps[100:120], d.edge_idxs[100:120], K))
+                    tgn.memory.restore_memory(bak)
+                    extra.append(ev.cpu().numpy())
+            if step == 3:
+                tgn.join()
+                extra.append(tgn.flat_grad.detach().cpu().numpy().copy())
+        tgn.join()
+        torch.cuda.synchronize()
+        return losses, tgn.flat_parameters.detach().cpu().numpy().copy(), tgn.memory.memory.detach().cpu().numpy().copy(), extra
+
+    l0, p0, m0, e0 = run(False)
+    l1, p1, m1, e1 = run(True)
+    assert l0 == l1
+    assert np.array_equal(p0, p1) and np.array_equal(m0, m1)
+    for a, b in zip(e0, e1):
+        assert np.array_equal(a, b)
+    assert np.isfinite(p1).all() and np.abs(e1[2]).max() > 0
