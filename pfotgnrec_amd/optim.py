@@ -13,6 +13,29 @@ import torch
 from . import _lib
 
 
+class _StepCounts(dict):
+    """parameter -> steps taken, stored under id(parameter) (hashing a tensor is a Python-level call: ~100 of them per step);
+    tensors and ids are both accepted as keys."""
+    @staticmethod
+    def _k(key):
+        return key if isinstance(key, int) else id(key)
+
+    def __getitem__(self, key):
+        return dict.__getitem__(self, self._k(key))
+
+    def __setitem__(self, key, value):
+        dict.__setitem__(self, self._k(key), value)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, self._k(key))
+
+    def get(self, key, default=None):
+        return dict.get(self, self._k(key), default)
+
+    def copy(self):
+        return _StepCounts(self)
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, tgn, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, zero_grads_in_step=False, overlap_backward=False):
         """``overlap_backward``: for the reference's own loop (main.py:160-394), which reads ``loss.item()`` after every batch.
@@ -32,7 +55,8 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(list(tgn.parameters()), dict(lr=lr, betas=betas, eps=eps))
         self._m = None
         self._v = None
-        self._steps = {}            # parameter -> steps taken (torch.optim.Adam's state[p]["step"])
+        self._steps = _StepCounts() # id(parameter) -> steps taken (torch.optim.Adam's state[p]["step"]; ids: hashing a tensor is a Python call)
+        self._sorted_views = None   # (the model's views in flat-buffer order, sorted once)
 
     def zero_grad(self, set_to_none=True):
         if not set_to_none:
@@ -46,19 +70,19 @@ class FusedAdam(torch.optim.Optimizer):
 
     @_t.setter
     def _t(self, value):
-        self._steps = {p: int(value) for p in self.tgn.hot_parameters()}
+        self._steps = _StepCounts({id(p): int(value) for p in self.tgn.hot_parameters()})
 
     def sync_steps(self, taken):
         """Adds ``taken`` steps to every tensor that has a gradient (after replaying a captured step ``taken`` times)."""
         for p in self.tgn.hot_parameters():
             if p.grad is not None:
-                self._steps[p] = self._steps.get(p, 0) + int(taken)
+                self._steps[id(p)] = self._steps.get(id(p), 0) + int(taken)
 
     def set_steps(self, steps_by_name):
         """Per-tensor step counts (``{parameter name: steps taken}``), e.g. from a torch.optim.Adam state dict."""
         names = dict(self.tgn.named_parameters())
         for k, t in steps_by_name.items():
-            self._steps[names[k]] = int(t)
+            self._steps[id(names[k])] = int(t)
 
     @torch.no_grad()
     def step(self, closure=None, step_dev=None, side=False):
@@ -94,12 +118,16 @@ class FusedAdam(torch.optim.Optimizer):
             self._v = torch.zeros_like(tgn.flat_parameters)
         g = self.param_groups[0]
         lo, hi, st = [], [], []
-        for p, off, n, _ in sorted(tgn._views, key=lambda v: v[1]):
+        sv = self._sorted_views
+        if sv is None or sv[0] is not tgn._views or len(sv[1]) != len(tgn._views):
+            sv = self._sorted_views = (tgn._views, [(p, off, n, id(p)) for p, off, n, _ in sorted(tgn._views, key=lambda v: v[1])])
+        steps, inc = self._steps, (1 if step_dev is None else 0)
+        for p, off, n, key in sv[1]:
             if p.grad is None:                       # torch.optim.Adam: skipped entirely (no moment decay, no step)
                 continue
-            t = self._steps.get(p, 0) + (1 if step_dev is None else 0)
-            if step_dev is None:
-                self._steps[p] = t
+            t = steps.get(key, 0) + inc
+            if inc:
+                steps[key] = t
             if lo and hi[-1] == off and st[-1] == t:
                 hi[-1] = off + n
             else:

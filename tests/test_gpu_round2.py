@@ -255,7 +255,7 @@ def test_literal_main_loop_with_torch_bpr_and_torch_adam():
         before = Bm.flat_parameters.clone()
         m_before = None if optB._m is None else optB._m.clone()
         v_before = None if optB._v is None else optB._v.clone()
-        steps_before = dict(optB._steps)
+        steps_before = optB._steps.copy()
         negatives_batch = rs.randint(cfg.n_users + 1, cfg.n_users + cfg.n_items + 1, size=(40, 3))
         la, ga = _main_loop_step(A, optA, d, cfg, k, negatives_batch, True)
         lb, gb = _main_loop_step(Bm, optB, d, cfg, k, negatives_batch, False)
