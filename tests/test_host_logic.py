@@ -317,3 +317,29 @@ def test_fused_adam_ranges_cover_check_for_the_gradient_clear():
     assert covered([0, 40, 60], [40, 60, 100], 100)             # split by step counts (the GRU tensors one step behind), still a tiling
     assert not covered([0, 60], [40, 100], 100)                 # a tensor without a gradient in between
     assert not covered([10], [100], 100) and not covered([0], [90], 100) and not covered([], [], 100)
+
+
+def test_adjacent_row_blocks_and_step_count_keys():
+    """functional.adjacent_rows: blocks that are a cut of one matrix come back as that matrix without a copy, anything else as
+    None; optim._StepCounts: per-tensor step counts stored under id(parameter), reachable by tensor and by id."""
+    import torch
+    from pfotgnrec_amd.functional import adjacent_rows
+    from pfotgnrec_amd.optim import _StepCounts
+    m = torch.arange(60.0).reshape(10, 6)
+    whole = adjacent_rows((m[0:2], m[2:4], m[4:10]))
+    assert whole is not None and whole.data_ptr() == m.data_ptr() and torch.equal(whole, m)
+    part = adjacent_rows((m[2:4], m[4:9]))
+    assert part.data_ptr() == m[2:].data_ptr() and torch.equal(part, m[2:9])
+    assert adjacent_rows((m[0:2], m[3:5])) is None                      # a gap
+    assert adjacent_rows((m[2:4], m[0:2])) is None                      # out of order
+    assert adjacent_rows((m[0:2], m[2:4].clone())) is None              # another buffer
+    assert adjacent_rows((m[0:2], m[2:4, :3])) is None                  # another width / not contiguous
+    assert adjacent_rows((m[0:2].reshape(2, 1, 6),)) is None            # not a matrix
+    assert torch.equal(adjacent_rows((m[0:0], m[0:3])), m[0:3])         # an empty block (no negatives) is fine
+    a, b = torch.zeros(3), torch.zeros(3)
+    c = _StepCounts()
+    c[a] = 4
+    assert a in c and id(a) in c and b not in c and c[a] == 4 and c.get(b, 0) == 0 and c.get(id(a)) == 4
+    d = c.copy()
+    d[b] = 1
+    assert isinstance(d, _StepCounts) and b not in c and d[b] == 1 and max(d.values()) == 4
