@@ -100,7 +100,7 @@ class FusedAdam(torch.optim.Optimizer):
                 out = self.step(closure)
                 ev = torch.cuda.Event()
                 ev.record(bwd)
-            tgn._bwd_event = ev
+            tgn._set_backward_event(ev)
             return out
         if side and (self._m is None or self._m.device != tgn.flat_parameters.device):
             side = False            # the moments are allocated (and cleared) on the caller's stream below: this one step runs there

@@ -186,7 +186,7 @@ class TGN(nn.Module):
         # FusedAdam(tgn, overlap_backward=True): loss.backward() leaves the native backward - and optimizer.step() its kernel - on
         # a stream of their own, so that the loop's per-batch ``loss.item()`` (main.py:390) waits for the forward only
         self.overlap_backward = False
-        self._bwd_stream, self._bwd_event, self._bwd_hold = None, None, []
+        self._bwd_stream, self._bwd_event, self._bwd_hold, self._bwd_joined, self._bwd_home = None, None, [], set(), None
         self.eval_chunk_roots = 16384     # roots per forward-only pass (evaluation.py scores B*(2+N_ITEMS) roots per batch)
         self.eval_dedup = True            # forward-only passes embed every distinct (node, time) root once
         # memory_updater.py:25,41 assert that no pending message is older than its node's last update; the check reads
@@ -578,17 +578,23 @@ class TGN(nn.Module):
         return self._bwd_stream
 
     def _join_backward(self):
-        """The current stream waits for what ``overlap_backward`` left in flight; the tensors that work reads (gradient rows,
-        the call's roots) are let go only now - the allocator may hand their memory to this stream, which has waited."""
+        """The current stream waits for what ``overlap_backward`` left in flight (once per stream and event).  The tensors that
+        work reads (gradient rows, the call's roots) are let go when the stream they were allocated on has waited: the
+        allocator may then hand their memory to that stream again."""
         ev = self._bwd_event
         if ev is None:
             return
         cur = torch.cuda.current_stream(self.device)
-        if self._bwd_stream is not None and cur == self._bwd_stream:
-            return                                                # (the optimizer's kernel, queued behind the backward there)
+        key = cur.cuda_stream
+        if key in self._bwd_joined or (self._bwd_stream is not None and key == self._bwd_stream.cuda_stream):
+            return                                                # (the backward stream itself: the optimizer's kernel behind the backward)
         cur.wait_event(ev)
-        self._bwd_event = None
-        self._bwd_hold = []
+        self._bwd_joined.add(key)
+        if key == self._bwd_home:
+            self._bwd_hold = []
+
+    def _set_backward_event(self, ev):
+        self._bwd_event, self._bwd_joined = ev, set()
 
     def _backward_beside(self, call, d_emb):
         """``_native_backward`` on the backward stream, behind everything the current stream holds (the gradient rows)."""
@@ -599,7 +605,8 @@ class TGN(nn.Module):
             ev = torch.cuda.Event()
             ev.record(side)
         self._bwd_hold.append((d_emb, call.roots, call.root_ts, call.extra, getattr(call, "keep", None), call.draws))
-        self._bwd_event = ev
+        self._bwd_home = cur.cuda_stream
+        self._set_backward_event(ev)
 
     def state_dict(self, *args, **kwargs):
         self.join()
@@ -732,6 +739,7 @@ class TGN(nn.Module):
         _lib.require_gpu(self.device)
         if bool(getattr(self.neighbor_finder, "uniform", False)) or not torch.is_grad_enabled():
             return False
+        self._join_backward()             # (overlap_backward: the workspace this call takes may be the one that backward reads)
         self._drop_prefetched()
         B, K = int(src.shape[0]), int(n_neighbors)
         lo, hi = 0, B
