@@ -267,3 +267,59 @@ def test_backward_beside_the_host_loop_equals_the_serial_order():
     for a, b in zip(e0, e1):
         assert np.array_equal(a, b)
     assert np.isfinite(p1).all() and np.abs(e1[2]).max() > 0
+
+
+def test_ours_branch_with_native_bpr_blocks_and_backward_overlap():
+    """The ``ours`` branch of the loop (main.py:190-337 in shape): compute_temporal_embeddings_p with one p_pos and three p_neg per
+    interaction, the BPR expression over (source, p_pos, p_neg) - once as the reference's torch expression in the serial order,
+    once as pfotgnrec_amd.bpr_loss_blocks(..., p_pos_embedding=) under FusedAdam(overlap_backward=True).  Four free-running
+    steps: step 0's loss and gradient are compared (identical state: 1e-6 / 1e-5), the parameters after four steps stay
+    within the optimizer's reach of each other, every workspace is handed back and state_dict() joins the last step."""
+    from pfotgnrec_amd.synthetic import SyntheticConfig, make_graph
+    cfg = SyntheticConfig("p6", 300, 25, 6000, 64, 2, 8, 2)
+    g = make_graph(cfg, with_prices=False)
+    d = g.data
+    B, K = 32, 8
+    rs = np.random.RandomState(8)
+    ppos = rs.randint(301, 326, size=(4, B * 1))
+    pneg = rs.randint(301, 326, size=(4, B * 3))
+
+    def run(native):
+        torch.manual_seed(31)
+        tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=2, dropout=0.0,
+                    use_memory=True, memory_dimension=64, message_function="identity", n_neighbors=K)
+        tgn.deterministic = True
+        opt = P.FusedAdam(tgn, lr=1e-3, overlap_backward=native)
+        first = None
+        for step in range(4):
+            s = 2500 + step * B
+            opt.zero_grad()
+            tgn = tgn.train()
+            se, de, pe, ne = tgn.compute_temporal_embeddings_p(d.sources[s:s + B], d.destinations[s:s + B], ppos[step], pneg[step],
+                                                                d.timestamps[s:s + B], d.edge_idxs[s:s + B], K)
+            if native:
+                loss = P.bpr_loss_blocks(se, de, ne, p_pos_embedding=pe)
+            else:
+                sv, pv, nv = se.view(B, 1, -1), pe.view(B, 1, -1), ne.view(B, 3, -1)
+                pos = torch.sum(sv * pv, dim=2)
+                ngs = torch.matmul(sv, nv.transpose(1, 2)).squeeze()
+                loss = -torch.mean(torch.log(torch.sigmoid(torch.mean(pos - ngs, dim=1))))
+            loss.backward()
+            if step == 0:
+                tgn.join()
+                first = (float(loss), tgn.flat_grad.detach().cpu().numpy().copy())
+            opt.step()
+            loss.item()
+            tgn.memory.detach_memory()
+        sd = tgn.state_dict()
+        torch.cuda.synchronize()
+        assert len(tgn._ws_pool) >= 1 and all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+        return first, tgn.flat_parameters.detach().cpu().numpy().copy()
+
+    (l0, g0), p0 = run(False)
+    (l1, g1), p1 = run(True)
+    assert abs(l0 - l1) < 1e-6 * max(1.0, abs(l0))
+    assert relerr(g1, g0) < 1e-5 and np.abs(g0).max() > 0
+    # four Adam steps of lr 1e-3 from rounding-level different gradients: a parameter whose gradient is noise moves +-lr per
+    # step either way (SURVEY 7 hard part 5) - the bound is the optimizer's reach, not a parity bar
+    assert np.abs(p1 - p0).max() <= 4 * 2 * 1e-3 * 1.01 and np.isfinite(p1).all()
