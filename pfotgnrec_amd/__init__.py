@@ -36,7 +36,7 @@ from .rand_edge_sampler import RandEdgeSampler, DeviceNegativeSampler  # noqa: F
 from .mv_sampler import MVSampler  # noqa: F401
 from .memory import Memory  # noqa: F401
 from .tgn import TGN  # noqa: F401
-from .optim import FusedAdam  # noqa: F401
+from .optim import FusedAdam, overlap_backward  # noqa: F401
 from .functional import bpr_loss, bpr_loss_blocks, bpr_step, time_encode, rank_metrics  # noqa: F401
 from .graph import GraphedTrainStep  # noqa: F401,E402
 from . import ops  # noqa: F401,E402  (registers torch.ops.pfotgn.*)

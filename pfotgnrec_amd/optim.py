@@ -203,3 +203,36 @@ class FusedAdam(torch.optim.Optimizer):
             # phase - so that the next forward launches none of it.  (A step being captured rebuilds inside its own forward.)
             tgn.parameters_changed(refresh=tgn.refresh_after_step and step_dev is None and not side)
         return None
+
+
+def overlap_backward(tgn, optimizer):
+    """``FusedAdam(tgn, overlap_backward=True)`` for ANY torch optimizer over ``tgn.parameters()`` (main.py:123 builds
+    ``torch.optim.Adam``): ``loss.backward()`` leaves the native backward on a stream of its own, and ``optimizer.step()`` -
+    wrapped here - runs its kernels on that stream behind it, so the loop's ``loss.item()`` (main.py:390) waits for the forward
+    only and the host prepares the next batch beside the backward.  The next forward, ``state_dict()`` and ``tgn.join()`` wait
+    for the step; read ``.grad`` or a parameter from torch only behind ``tgn.join()``.  ``optimizer.zero_grad(set_to_none=
+    False)`` joins first (its kernels run on the caller's stream).  Returns the optimizer."""
+    tgn.overlap_backward = True
+    if isinstance(optimizer, FusedAdam) or getattr(optimizer, "_pfo_overlap", None) is tgn:
+        return optimizer
+    plain_step, plain_zero = optimizer.step, optimizer.zero_grad
+
+    def step(*args, **kwargs):
+        if getattr(tgn, "_bwd_event", None) is None or not tgn._overlap_ok():
+            tgn.join()
+            return plain_step(*args, **kwargs)
+        bwd = tgn._backward_stream()
+        with torch.cuda.stream(bwd):
+            out = plain_step(*args, **kwargs)
+            ev = torch.cuda.Event()
+            ev.record(bwd)
+        tgn._set_backward_event(ev)
+        return out
+
+    def zero_grad(set_to_none=True):
+        if not set_to_none:
+            tgn.join()
+        return plain_zero(set_to_none=set_to_none)
+
+    optimizer.step, optimizer.zero_grad, optimizer._pfo_overlap = step, zero_grad, tgn
+    return optimizer

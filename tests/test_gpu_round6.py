@@ -206,8 +206,10 @@ def test_entry_point_blocks_are_outputs_of_one_node_and_the_native_bpr_expressio
     assert relerr(g_native, g_blocks) < 1e-5 and np.abs(g_blocks).max() > 0
 
 
-def test_backward_beside_the_host_loop_equals_the_serial_order():
-    """FusedAdam(tgn, overlap_backward=True) on the reference's loop (main.py:160-394 in shape: numpy batches, torch BPR
+@pytest.mark.parametrize("kind", ["fused", "torch"])
+def test_backward_beside_the_host_loop_equals_the_serial_order(kind):
+    """FusedAdam(tgn, overlap_backward=True) - and pfotgnrec_amd.overlap_backward(tgn, torch.optim.Adam(...)), whose step() is
+    wrapped to run behind the backward on its stream - on the reference's loop (main.py:160-394 in shape: numpy batches, torch BPR
     expression, loss.backward(), optimizer.step(), loss.item(), optimizer.zero_grad()): the native backward and the optimizer's
     kernel run on a stream of their own and the next forward waits for them.  Five steps bit-identical (losses, parameters,
     memory) to the serial order with the deterministic backward; ``tgn.join()`` makes gradients readable; a validation forward
@@ -223,7 +225,12 @@ def test_backward_beside_the_host_loop_equals_the_serial_order():
         tgn = P.TGN(P.get_neighbor_finder(d, False), g.node_features, g.edge_features, DEV, n_layers=2, n_heads=2, dropout=0.0,
                     use_memory=True, memory_dimension=64, message_function="identity", n_neighbors=K)
         tgn.deterministic = True
-        opt = P.FusedAdam(tgn, lr=1e-3, overlap_backward=overlap)
+        if kind == "fused":
+            opt = P.FusedAdam(tgn, lr=1e-3, overlap_backward=overlap)
+        else:
+            opt = torch.optim.Adam(tgn.parameters(), lr=1e-3)
+            if overlap:
+                assert P.overlap_backward(tgn, opt) is opt and P.overlap_backward(tgn, opt) is opt      # (idempotent)
         rs = np.random.RandomState(3)
         losses, extra = [], []
         for step in range(5):
