@@ -201,12 +201,23 @@ def call(name, *args):
         raise PfoError("%s failed (%d): %s" % (name, rc, lib.pfo_last_error().decode()))
 
 
+_GPU_SEEN = [False]
+
+
 def require_gpu(device=None):
-    import torch
-    if not torch.cuda.is_available():
-        raise PfoError("a HIP device (MI355X) is required: the hot path has no CPU implementation")
-    if device is not None and torch.device(device).type != "cuda":
-        raise PfoError("tensors must live on a HIP device, got %s" % device)
+    # (torch.cuda.is_available() reads the environment on every call: ~3 us, a dozen times per step - asked once)
+    if not _GPU_SEEN[0]:
+        import torch
+        if not torch.cuda.is_available():
+            raise PfoError("a HIP device (MI355X) is required: the hot path has no CPU implementation")
+        _GPU_SEEN[0] = True
+    if device is not None:
+        t = getattr(device, "type", None)
+        if t is None:
+            import torch
+            t = torch.device(device).type
+        if t != "cuda":
+            raise PfoError("tensors must live on a HIP device, got %s" % device)
 
 
 def ptr(t):
@@ -214,6 +225,57 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def stream_ptr():
+# torch.cuda.current_stream() builds a Stream object through several Python layers (~8 us); the step asks for the current
+# stream's handle a dozen times.  The raw handle comes from one C call; Stream OBJECTS (for Event.record / Stream.wait_event)
+# are kept per handle - torch's streams live in a pool and are never destroyed, an external stream is its handle.
+_RAW = [None, None]
+_STREAM_OBJECTS = {}
+
+
+def _raw_fns():
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    torch.cuda.current_stream()                         # (initialises the runtime the first time)
+    _RAW[0], _RAW[1] = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+    return _RAW[0]
+
+
+def stream_ptr():
+    get = _RAW[0] or _raw_fns()
+    return get(_RAW[1]())
+
+
+def current_stream():
+    """The current stream of the current device as a (cached) torch Stream object."""
+    raw = stream_ptr()
+    s = _STREAM_OBJECTS.get(raw)
+    if s is None:
+        import torch
+        s = _STREAM_OBJECTS[raw] = torch.cuda.current_stream()
+    return s
+
+
+class on_stream:
+    """``with torch.cuda.stream(s):`` for a stream of the CURRENT device, without the context manager's Python layers
+    (two C calls each way); another device's stream takes torch's own context."""
+    __slots__ = ("s", "prev", "ctx")
+
+    def __init__(self, stream):
+        self.s, self.prev, self.ctx = stream, None, None
+
+    def __enter__(self):
+        import torch
+        s = self.s
+        if (_RAW[1] or (_raw_fns() and _RAW[1]))() != s.device_index:
+            self.ctx = torch.cuda.stream(s)
+            return self.ctx.__enter__()
+        self.prev = torch._C._cuda_getCurrentStream(s.device_index)
+        torch._C._cuda_setStream(stream_id=s.stream_id, device_index=s.device_index, device_type=s.device_type)
+        return None
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        import torch
+        p = self.prev
+        torch._C._cuda_setStream(stream_id=p[0], device_index=p[1], device_type=p[2])
+        return False

@@ -79,6 +79,12 @@ class Memory(nn.Module):
         self._any_msg = False
         self._state_version += 1
 
+    def __setattr__(self, name, value):
+        if name[0] == "_" and not isinstance(value, (nn.Parameter, nn.Module)):      # plain bookkeeping, written every batch
+            object.__setattr__(self, name, value)
+            return
+        super().__setattr__(name, value)
+
     def detach_memory(self):
         """modules/memory.py:62-71.  Stored messages and memory never carry an autograd graph here."""
         return None

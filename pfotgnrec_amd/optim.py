@@ -93,15 +93,19 @@ class FusedAdam(torch.optim.Optimizer):
         (``functional.bpr_step(..., optimizer=self)``); otherwise anything pending there is joined first."""
         tgn = self.tgn
         if (not side and step_dev is None and getattr(tgn, "_bwd_event", None) is not None and tgn._overlap_ok()
-                and torch.cuda.current_stream(tgn.flat_parameters.device) != tgn._backward_stream()):
+                and _lib.stream_ptr() != tgn._backward_stream().cuda_stream):
             # behind the backward on ITS stream (overlap_backward); the event the next forward waits for moves behind the step
             bwd = tgn._backward_stream()
-            with torch.cuda.stream(bwd):
-                out = self.step(closure)
+            with _lib.on_stream(bwd):
+                out = self._step(closure, None, False)
                 ev = torch.cuda.Event()
                 ev.record(bwd)
             tgn._set_backward_event(ev)
             return out
+        return self._step(closure, step_dev, side)
+
+    def _step(self, closure, step_dev, side):
+        tgn = self.tgn
         if side and (self._m is None or self._m.device != tgn.flat_parameters.device):
             side = False            # the moments are allocated (and cleared) on the caller's stream below: this one step runs there
         if not side:
@@ -222,7 +226,7 @@ def overlap_backward(tgn, optimizer):
             tgn.join()
             return plain_step(*args, **kwargs)
         bwd = tgn._backward_stream()
-        with torch.cuda.stream(bwd):
+        with _lib.on_stream(bwd):
             out = plain_step(*args, **kwargs)
             ev = torch.cuda.Event()
             ev.record(bwd)

@@ -584,11 +584,10 @@ class TGN(nn.Module):
         ev = self._bwd_event
         if ev is None:
             return
-        cur = torch.cuda.current_stream(self.device)
-        key = cur.cuda_stream
+        key = _lib.stream_ptr()
         if key in self._bwd_joined or (self._bwd_stream is not None and key == self._bwd_stream.cuda_stream):
             return                                                # (the backward stream itself: the optimizer's kernel behind the backward)
-        cur.wait_event(ev)
+        _lib.current_stream().wait_event(ev)
         self._bwd_joined.add(key)
         if key == self._bwd_home:
             self._bwd_hold = []
@@ -598,9 +597,11 @@ class TGN(nn.Module):
 
     def _backward_beside(self, call, d_emb):
         """``_native_backward`` on the backward stream, behind everything the current stream holds (the gradient rows)."""
-        cur, side = torch.cuda.current_stream(self.device), self._backward_stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
+        cur, side = _lib.current_stream(), self._backward_stream()
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        side.wait_event(fork)
+        with _lib.on_stream(side):
             self._native_backward(call, d_emb)
             ev = torch.cuda.Event()
             ev.record(side)
@@ -973,9 +974,31 @@ class TGN(nn.Module):
         # (short-circuit only while EVERY submodule already is in that mode: a child toggled on its own - tgn.child.eval() - or
         #  attached after the last call is reset exactly as nn.Module.train would; the walk without the attribute writes is 5 us)
         mode = bool(mode)
-        if self.training == mode and all(m.training == mode for m in self.modules()):
-            return self
+        if self.training == mode:
+            # (the module LIST is kept: walking named_modules() is 25 us per batch; a module attached to this model later
+            #  drops it - __setattr__ / add_module below - and a tree edited underneath a child is caught by the count)
+            mods = self.__dict__.get("_module_list")
+            if mods is None or len(mods[0]._modules) != mods[1]:
+                ms = list(self.modules())
+                mods = self.__dict__["_module_list"] = (self, len(self._modules), ms, sum(len(m._modules) for m in ms))
+            if all(m.training == mode for m in mods[2]) and sum(len(m._modules) for m in mods[2]) == mods[3]:
+                return self
+            self.__dict__["_module_list"] = None
         return super().train(mode)
+
+    def __setattr__(self, name, value):
+        # plain private state (step counters, cache keys, events ...) is written a dozen times per step: nn.Module.__setattr__
+        # walks its parameter / buffer / module tables first (~3 us each).  Parameters and modules take the usual route.
+        if name[0] == "_" and not isinstance(value, (nn.Parameter, nn.Module)):
+            object.__setattr__(self, name, value)
+            return
+        if isinstance(value, nn.Module):
+            self.__dict__["_module_list"] = None
+        super().__setattr__(name, value)
+
+    def add_module(self, name, module):
+        self.__dict__["_module_list"] = None
+        return super().add_module(name, module)
 
     def _batch_to_dev(self, parts):
         """Several small host arrays of one batch in ONE host-to-device copy: ``parts`` = [(array, numpy dtype)], widest dtype
