@@ -246,11 +246,13 @@ def stream_ptr():
 
 def current_stream():
     """The current stream of the current device as a (cached) torch Stream object."""
-    raw = stream_ptr()
-    s = _STREAM_OBJECTS.get(raw)
+    get = _RAW[0] or _raw_fns()
+    dev = _RAW[1]()
+    key = (dev, get(dev))                               # (the default stream's handle is 0 on every device)
+    s = _STREAM_OBJECTS.get(key)
     if s is None:
         import torch
-        s = _STREAM_OBJECTS[raw] = torch.cuda.current_stream()
+        s = _STREAM_OBJECTS[key] = torch.cuda.current_stream()
     return s
 
 
