@@ -767,3 +767,50 @@ def test_full_size_evaluation_batch_slice_against_oracle(c2):
     tab, mt, has = ref.pending_table()
     assert relerr(tgn.memory.msg_table.cpu().numpy()[has], tab[has]) < RTOL_EMB
     assert np.array_equal(tgn.memory.msg_time.cpu().numpy()[has], mt[has])
+
+
+def test_full_size_reference_loop_with_the_backward_beside_the_host_loop(c2):
+    """C2 at batch 512 through the reference's loop (numpy batches, RandEdgeSampler per batch, compute_temporal_embeddings, torch
+    BPR expression, loss.item() per batch): FusedAdam(overlap_backward=True) - native backward + optimizer kernel on a stream
+    of their own, the next forward waits for them - against the serial order, three steps from the steady state with the
+    deterministic backward: losses, parameters and memory bit-identical; the candidate draws are the same seeded stream."""
+    cfg, g, nf = c2
+    d = g.data
+    B, K, q = 512, cfg.n_neighbors, 3
+    start = 600000
+    portfolios = np.empty(3 * B, dtype=object)
+    for r in range(3 * B):
+        n = int(g.portfolio_len[start + r])
+        portfolios[r] = [g.codes[j] for j in g.portfolio_idx[start + r, :n]] if n > 0 else [""]
+
+    def run(overlap):
+        tgn = _model(cfg, g, nf, seed=13)
+        tgn.deterministic = True
+        _steady_state(tgn, g, cfg, np.random.RandomState(5))
+        opt = P.FusedAdam(tgn, lr=1e-3, overlap_backward=overlap)
+        losses = []
+        for step in range(3):
+            s = start + step * B
+            opt.zero_grad()
+            sampler = P.RandEdgeSampler(d.sources[s:s + B], d.destinations, portfolios[step * B:(step + 1) * B], g.upper_u, g.map_item_id,
+                                        seed=100 + step)
+            negatives = sampler.sample(size=q)
+            tgn = tgn.train()
+            se, de, ne = tgn.compute_temporal_embeddings(d.sources[s:s + B], d.destinations[s:s + B], negatives.flatten(),
+                                                          d.timestamps[s:s + B], d.edge_idxs[s:s + B], K)
+            se, de, ne = se.view(B, 1, -1), de.view(B, 1, -1), ne.view(B, q, -1)
+            pos = torch.sum(se * de, dim=2)
+            ngs = torch.matmul(se, ne.transpose(1, 2)).squeeze()
+            loss = -torch.mean(torch.log(torch.sigmoid(torch.mean(pos - ngs, dim=1))))
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+            tgn.memory.detach_memory()
+        tgn.join()
+        torch.cuda.synchronize()
+        return losses, tgn.flat_parameters.detach().cpu().numpy().copy(), tgn.memory.memory.detach().cpu().numpy().copy()
+
+    l0, p0, m0 = run(False)
+    l1, p1, m1 = run(True)
+    assert l0 == l1 and all(np.isfinite(l0))
+    assert np.array_equal(p0, p1) and np.array_equal(m0, m1)
