@@ -339,7 +339,7 @@ struct Side {
   // Buckets of a side-stream optimizer step in order of FIRST USE (pfo_tgn_adam_side_bucket): early_done fires behind the
   // kernel that finishes the parameters the next forward reads on the caller's stream (time encoder, GRU, layer 1's biases);
   // it stands for the whole side stream as long as nothing but later buckets of the same step was queued behind it.
-  hipEvent_t early_done = nullptr;
+  hipEvent_t early_done = nullptr, late_done = nullptr;
   uint64_t early_gen = 0;
   bool early_ok = false;
   struct Joined { hipStream_t s; uint64_t gen; } joined[8] = {};
@@ -392,6 +392,7 @@ Side& side() {
     good = good && hipEventCreateWithFlags(&sd.main_done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.side_done, hipEventDisableTiming) == hipSuccess;
     good = good && hipEventCreateWithFlags(&sd.early_done, hipEventDisableTiming) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&sd.late_done, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; l <= PFO_MAX_LAYERS; ++l) good = good && hipEventCreateWithFlags(&sd.layer[l], hipEventDisableTiming) == hipSuccess;
     sd.ok = good;
   }
@@ -871,6 +872,8 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
   RUN(side_join(sd, s, early_join != 0 && c->n_layers >= 2));
   PFO_MARK("fwd.side_joined", s);
   const bool fused_state = b->upd_src != nullptr && c->use_memory && L >= 2;
+  static const int side_late_env = getenv("PFO_FWD_SIDE_LATE") ? atoi(getenv("PFO_FWD_SIDE_LATE")) : 0;   // EXPERIMENT switch
+  const bool side_late = side_late_env != 0 && bind_events;
   PFO_REQUIRE(!fused_state || (b->upd_dst && b->upd_ts && b->upd_eidx && b->upd_B >= 1), "bad state-update arguments");
 
   // the GRU contractions come first on the main stream: their two weight images are made there too (one 4 us launch)
@@ -934,7 +937,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     if (L >= 2) {
       if (build) RUN(build_stage_b(d, w, P, ss));
       else if (!capturing) HIPOK(hipStreamWaitEvent(ss, sd.pc_b, 0), "event wait failed");
-      if (fused_state) {
+      if (fused_state && !side_late) {
         // the batch's state update, here: behind the lazy GRU (whose rows it persists), beside layer 1, in front of the event
         // layer 2 waits for - persist + message store leave the critical path and are joined at no extra wait
         HIPOK(hipStreamWaitEvent(ss, sd.gru_done, 0), "event wait failed");
@@ -1013,6 +1016,15 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
     PFO_MARK(mk_qk[l], s);
     RUN(pfo_attn_fwd_launch(a, s));
     PFO_MARK(mk_at[l], s);
+    if (l == 1 && fused_state && side_late) {
+      // EXPERIMENT (PFO_FWD_SIDE_LATE=1): the state update and the instance groups behind layer 1's attention kernel instead of
+      // beside it (they are ~12 small launches that share the chip with the step's second-longest kernel)
+      HIPOK(hipEventRecord(sd.layer[1], s), "event record failed");
+      HIPOK(hipStreamWaitEvent(ss, sd.layer[1], 0), "event wait failed");
+      RUN(state_update(c, st, w, b->upd_src, b->upd_dst, b->upd_ts, b->upd_eidx, b->upd_B, ss));
+      if (b->seg_in_forward) RUN(seg_prologue(c, b, w, d, n, ss));
+      HIPOK(hipEventRecord(sd.late_done, ss), "event record failed");
+    }
     // ---- h1 = relu(ctx' W1ovT + x W1[:, E:]^T + b1)   (MergeLayer fc1 with out_proj and the value projection folded in)
     if (l == 1) {
       // the x term was projected with the table: it arrives as a row-gathered addend of the epilogue
@@ -1044,6 +1056,7 @@ extern "C" int pfo_tgn_forward(const pfo_tgn_config* c, const pfo_tgn_state* st,
       RUN(pfo_gemm_launch(g, s));
     }
   }
+  if (fused_state && side_late) HIPOK(hipStreamWaitEvent(s, sd.late_done, 0), "event wait failed");
   PFO_MARK("fwd.end", s);
   return PFO_OK;
 }
