@@ -620,6 +620,11 @@ class Workload:
         from pfotgnrec_amd import _lib
         torch = self.torch
         multi = collective and self.dist_on and (self.world > 1 or self.force_dist)
+        # what exists now (graph arrays, the model, a process group's set-up garbage) is collected once and taken out of the
+        # cycle collector's later passes: a full collection inside a timed block holds the host for tens of ms (experiment 22)
+        import gc
+        gc.collect()
+        gc.freeze()
         i = first_step
         for _ in range(warmup):
             self.step(i)
@@ -1077,6 +1082,7 @@ def release_workload_memory():
     whatever its configuration).  Collect here, then hand the cached blocks back."""
     import gc
     import torch
+    gc.unfreeze()                     # (Workload.timed froze what existed then: the dead workload is among it)
     gc.collect()
     torch.cuda.empty_cache()
 
