@@ -701,7 +701,6 @@ static int build_stage_b(const Dims& d, const Ws& w, const Params& P, hipStream_
     const auto& p = P.l[l];
     const float* A = P.l[l - 1].w2;
     const float* bv = P.l[l - 1].b2;
-    HIPOK(hipMemcpyAsync(lw.W1ovT_f, lw.W1ovT, HCpD * sizeof(float), hipMemcpyDeviceToDevice, ss), "copy failed");
     PfoGemm* a = f1 + m1;
     a[0] = g_nn(lw.Wqk, D, A, D, lw.T1, D, HCp, D, D);                                    // T1 = Q A (all heads' rows)
     a[1] = g_nt(bv, D, nullptr, lw.Wqk, D, lw.tq, HCp, 1, HCp, D, lw.cqk);               // t = Q b + cqk
@@ -714,8 +713,21 @@ static int build_stage_b(const Dims& d, const Ws& w, const Params& P, hipStream_
     const LayerWs& lw = w.layer[l];
     const float* A = P.l[l - 1].w2;
     const float* bv = P.l[l - 1].b2;
-    HIPOK(hipMemcpyAsync(lw.Wqk_f, lw.T1, HCpD * sizeof(float), hipMemcpyDeviceToDevice, ss), "copy failed");   // edge | time rows stay
-    HIPOK(hipMemcpyAsync(lw.cqk_f, lw.tq, (size_t)HCp * sizeof(float), hipMemcpyDeviceToDevice, ss), "copy failed");
+    static const int grouped_copy = getenv("PFO_GROUPED_COPY") ? atoi(getenv("PFO_GROUPED_COPY")) : 1;      // A/B switch
+    if (!grouped_copy) {
+      HIPOK(hipMemcpyAsync(lw.W1ovT_f, lw.W1ovT, HCpD * sizeof(float), hipMemcpyDeviceToDevice, ss), "copy failed");
+      HIPOK(hipMemcpyAsync(lw.Wqk_f, lw.T1, HCpD * sizeof(float), hipMemcpyDeviceToDevice, ss), "copy failed");   // edge | time rows stay
+      HIPOK(hipMemcpyAsync(lw.cqk_f, lw.tq, (size_t)HCp * sizeof(float), hipMemcpyDeviceToDevice, ss), "copy failed");
+    } else {
+      // the rows the fold does not touch (edge | time, the two bias rows) come over as they are - ONE grouped launch instead of
+      // three runtime blits (each a launch of its own in this chain of small dependent launches)
+      PfoSumSlabs cp[3];
+      cp[0].dst = lw.W1ovT_f; cp[0].src = lw.W1ovT; cp[0].count = HCpD;
+      cp[1].dst = lw.Wqk_f;   cp[1].src = lw.T1;    cp[1].count = HCpD;
+      cp[2].dst = lw.cqk_f;   cp[2].src = lw.tq;    cp[2].count = HCp;
+      for (int q = 0; q < 3; ++q) { cp[q].n_slabs = 1; cp[q].accumulate = 0; cp[q].stride = 0; }
+      RUN(pfo_sum_slabs_launch(cp, 3, ss));
+    }
     PfoGemm* a = f2 + m2;
     a[0] = g_nn(A, D, lw.T1, D, lw.Wqk_f, D, D, D, D);        a[0].a_kmajor = 1;          // Q_f,node = A^T T1_node
     a[0].batch = H; a[0].b_bs[0] = (int64_t)Cp * D; a[0].c_bs = (int64_t)Cp * D;
@@ -1392,9 +1404,19 @@ extern "C" int pfo_tgn_backward_ev(const pfo_tgn_config* c, const pfo_tgn_state*
       } else {
         RUN(pfo_gemm_tn_group_launch(tn, ntn, N, nullptr, w.slabs3, w.slab_floats, sf));
       }
-      HIPOK(hipMemcpyAsync(lw.dT1, lw.dWqk_f, HCpD * sizeof(float), hipMemcpyDeviceToDevice, sf), "copy failed");
-      HIPOK(hipMemcpyAsync(lw.gqk, lw.gqk_f, (size_t)HCp * sizeof(float), hipMemcpyDeviceToDevice, sf), "copy failed");
-      HIPOK(hipMemcpyAsync(lw.dW1ovT, lw.dW1ovT_f, HCpD * sizeof(float), hipMemcpyDeviceToDevice, sf), "copy failed");
+      static const int grouped_copy_b = getenv("PFO_GROUPED_COPY") ? atoi(getenv("PFO_GROUPED_COPY")) : 1;      // A/B switch
+      if (!grouped_copy_b) {
+        HIPOK(hipMemcpyAsync(lw.dT1, lw.dWqk_f, HCpD * sizeof(float), hipMemcpyDeviceToDevice, sf), "copy failed");
+        HIPOK(hipMemcpyAsync(lw.gqk, lw.gqk_f, (size_t)HCp * sizeof(float), hipMemcpyDeviceToDevice, sf), "copy failed");
+        HIPOK(hipMemcpyAsync(lw.dW1ovT, lw.dW1ovT_f, HCpD * sizeof(float), hipMemcpyDeviceToDevice, sf), "copy failed");
+      } else {
+        PfoSumSlabs cp[3];                        // (one grouped launch instead of three runtime blits, as in build_stage_b)
+        cp[0].dst = lw.dT1;    cp[0].src = lw.dWqk_f;   cp[0].count = HCpD;
+        cp[1].dst = lw.gqk;    cp[1].src = lw.gqk_f;    cp[1].count = HCp;
+        cp[2].dst = lw.dW1ovT; cp[2].src = lw.dW1ovT_f; cp[2].count = HCpD;
+        for (int q = 0; q < 3; ++q) { cp[q].n_slabs = 1; cp[q].accumulate = 0; cp[q].stride = 0; }
+        RUN(pfo_sum_slabs_launch(cp, 3, sf));
+      }
       float* sl = lw.fold_slabs;
       float* vs = lw.fold_vslabs;
       {
